@@ -1,0 +1,127 @@
+/*
+ * lnb.h -- C ABI of liblnb_hip.so: the MI355X-native replacement for the LlamaTransformer.Forward
+ * hot path of adalkiran/llama-nuts-and-bolts (reference file:line citations are relative to that repo).
+ *
+ * This is the drop-in boundary: the reference has no plugin registry, the seam is
+ * the Go method itself, so each entry point below is what the body of one Go function becomes through
+ * cgo (binding shown in INTEGRATION.md).  Plain pointers and sizes only; no torch / HIP types.
+ *
+ * Conventions: every function returns 0 on success, <0 on error; lnb_last_error() returns a
+ * thread-local message (the Go side wraps it in errors.New, mirroring the reference's fmt.Errorf paths).
+ * The library owns DEVICE memory only: host pointers are never retained after a call returns
+ * (the reference's weight tensors are sub-slices of an mmap, src/torch/types.go:51-55).
+ * Handles: lnb_model is immutable after lnb_model_finalize and may be shared by several lnb_ctx
+ * (reference: the transformer is read-only after construction, one InferenceContext per GenerateString
+ * call, src/inference/inference.go:174); an lnb_ctx must be used by one thread at a time.
+ */
+#ifndef LNB_H
+#define LNB_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct lnb_model lnb_model;
+typedef struct lnb_ctx lnb_ctx;
+
+/* mirrors model.ModelArgs (src/model/modelargs.go:12-27; defaults :29-44) */
+typedef struct lnb_model_args {
+    int32_t dim;                 /* 4096 */
+    int32_t n_layers;            /* 32 */
+    int32_t n_heads;             /* 32 */
+    int32_t n_kv_heads;          /* 8; <0 => n_heads (llamatransformer.go:73-75) */
+    int32_t vocab_size;          /* 128256 */
+    int32_t multiple_of;         /* 1024 */
+    double  ffn_dim_multiplier;  /* 1.3; <= -1 => unset (llamatransformer.go:573-575) */
+    float   norm_eps;            /* 1e-5 */
+    int32_t use_scaled_rope;     /* 1 */
+    double  rope_theta;          /* 500000; <=0 => 500000 (llamatransformer.go:80-82) */
+    int32_t max_seq_len;         /* 2048; RoPE table has 2*max_seq_len rows (llamatransformer.go:109) */
+} lnb_model_args;
+
+const char* lnb_last_error(void);
+int lnb_device_count(int* out_count);
+
+/* ---- model: replaces model.NewLlamaTransformer (src/model/llamatransformer.go:64-113) --------------
+ * A model handle owns the device copy of one pipeline STAGE: transformer blocks [layer_begin,layer_end),
+ * plus tok_embeddings when layer_begin == 0 and norm + output when layer_end == n_layers.
+ * layer_begin=0, layer_end=n_layers is the whole model on one GPU. */
+int lnb_model_create(const lnb_model_args* args, int device, int layer_begin, int layer_end, lnb_model** out);
+int lnb_model_destroy(lnb_model* m);
+
+/* FFN hidden size derivation (llamatransformer.go:569-577) */
+int lnb_model_ffn_hidden_dim(const lnb_model_args* args);
+
+/* Bind one checkpoint tensor by its Meta key (the names the reference binds with getTensor/getLayerTensor,
+ * llamatransformer.go:84,98,105,191,202,273-283,580-587; shape check = loader.go:183-192).
+ * host_bf16 is the reference layout: row-major [out_features,in_features] bf16 bits; it is copied to the
+ * device and re-tiled; the caller keeps ownership.  Tensors of layers outside this stage are rejected. */
+int lnb_model_set_tensor(lnb_model* m, const char* name, const uint16_t* host_bf16, const int64_t* shape, int rank);
+/* read a tensor back in the reference layout (tests / debugging) */
+int lnb_model_get_tensor(lnb_model* m, const char* name, uint16_t* host_bf16, int64_t nelem);
+/* random-init every tensor of this stage on the device with the counter-based generator of DESIGN.md
+ * ("Synthetic weights"): no checkpoint is needed for benchmarking */
+int lnb_model_fill_synthetic(lnb_model* m, uint64_t seed);
+/* builds PrecomputedFreqsCis (llamatransformer.go:109,694-751) and the SiLU table (src/ml/activations.go:15-20);
+ * rope_rows <= 0 selects the reference's 2*max_seq_len rows, a larger value extends the table by the same formula */
+int lnb_model_finalize(lnb_model* m, int rope_rows);
+/* LlamaTransformer.PrecomputedFreqsCis as [rows][head_dim/2][2] f32 (exported field, llamatransformer.go:24) */
+int lnb_model_rope_table(lnb_model* m, float* out, int64_t nfloats, int* rows_out);
+int64_t lnb_model_weight_bytes(lnb_model* m);
+
+/* ---- context: replaces model.NewInferenceContext (src/model/inferencecontext.go:17-46) ---------------
+ * device-resident, zero-filled CacheK/CacheV [seq_len, n_kv_heads, head_dim] bf16 per owned layer */
+int lnb_ctx_create(lnb_model* m, int seq_len, lnb_ctx** out);
+int lnb_ctx_destroy(lnb_ctx* c);
+int lnb_ctx_reset(lnb_ctx* c);                                       /* zero the caches again */
+/* InferenceContext.CacheK/CacheV[layer] (exported, poked by llamatransformer_simulated_test.go:527-538) */
+int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which /*0=K 1=V*/, uint16_t* host_bf16);
+/* optional per-layer progress hook = infContext.Logf("Transformer block layer %d / %d was run, took %.4f sec(s)")
+ * (llamatransformer.go:157-163); forces a per-layer stream sync, so it is off by default */
+typedef void (*lnb_layer_cb)(int layer_1based, int n_layers, double secs, void* user);
+int lnb_ctx_set_layer_callback(lnb_ctx* c, lnb_layer_cb cb, void* user);
+
+/* ---- forward: replaces (*LlamaTransformer).Forward (src/model/llamatransformer.go:145-180) -------------
+ * tokens: [seq] int32 (caller-owned, not retained, inference.go:195-202); start_pos as in the reference.
+ * logits_out: caller-allocated [seq, vocab_size] f32, bf16-representable values (llamatransformer.go:170-177);
+ *   NULL => only the last row is evaluated and only argmax_last_out is produced.
+ * argmax_last_out: ml.Argmax of the last row (first maximum wins, operations_impl.go:529-541); may be NULL.
+ * Errors (same conditions as the reference): seq == 0 "empty token array" (llamatransformer.go:146-148);
+ * start_pos+seq beyond the RoPE table or the KV cache (tensor.go:275-279; the reference silently drops the
+ * SetSlice error at llamatransformer.go:402-403 and then fails in Slice :409 -- here it fails up front);
+ * seq > 1 with (start_pos+seq) % seq != 0 "two tensor shapes cannot be broadcasted" (tensor.go:414-428).
+ * Requires a whole-model handle (layer_begin == 0 && layer_end == n_layers). */
+int lnb_forward(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, float* logits_out, int32_t* argmax_last_out);
+
+/* ---- greedy loop on the device: the decode half of InferenceEngine.generateTokensInternal
+ * (src/inference/inference.go:194-252).  Starting from `token` at position start_pos (its KV is computed by
+ * the first step), runs n_steps one-token Forward+Argmax steps as replays of one captured hipGraph without
+ * any host round trip; out_tokens[i] is the token generated by step i.  ms_out (optional) = device time of
+ * the n_steps measured with HIP events on the library's stream. */
+int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int32_t* out_tokens, float* ms_out);
+
+/* ---- pipeline-stage form (layer-sharded multi-GPU) -------------------------------
+ * hidden state buffers live on the device and are owned by the ctx: [seq_len, dim] bf16.
+ * which: 0 = stage input, 1 = stage output.  RCCL send/recv (done by the host layer) targets these pointers. */
+void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which);
+/* Runs this stage's layers.  tokens != NULL only on the first stage (embedding gather); otherwise the input
+ * hidden state must already be in hidden_ptr(0).  On the last stage logits_out/argmax_last_out behave as in
+ * lnb_forward; on other stages they must be NULL and the result is left in hidden_ptr(1). */
+int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, float* logits_out, int32_t* argmax_last_out);
+/* block the calling thread until everything enqueued for this ctx has finished */
+int lnb_ctx_synchronize(lnb_ctx* c);
+/* raw HIP stream (hipStream_t) the ctx enqueues on, for event timing by the caller */
+void* lnb_ctx_stream(lnb_ctx* c);
+
+/* ---- single-op entry points (the src/ml operators on the hot path), used by the parity tests --------
+ * y[rows,n] = trunc(sum_k x[rows,k]*w[n,k])  == ml.LinearTransformation (operations_impl.go:427-447);
+ * host buffers in the reference layout; rw in {0(auto),16,32,64} selects the tiling */
+int lnb_op_linear(int device, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int n_out, int k_in, int rw);
+/* RMSNorm.Forward (llamatransformer.go:633-639) followed by a linear layer, as the fused kernel computes it */
+int lnb_op_rmsnorm_linear(int device, const uint16_t* x, const uint16_t* norm_w, float eps, const uint16_t* w,
+                          uint16_t* y, int rows, int n_out, int k_in, int rw);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,568 @@
+// lnb_api.cpp -- C ABI (include/lnb.h) over the gfx950 kernels of lnb_kernels.hip.
+// Host-side orchestration of LlamaTransformer.Forward (reference: src/model/llamatransformer.go:145-180):
+// device-resident weights (re-tiled once), device-resident KV cache, 5 launches per transformer block,
+// and a hipGraph-replayed greedy decode loop whose position/token state lives on the device.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <chrono>
+#include <map>
+#include <string>
+#include <vector>
+#include "../../include/lnb.h"
+#include "lnb_device.h"
+
+extern "C" {
+hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, int n_blocks, hipStream_t st);
+hipError_t lnbk_attn(const AttnParams* p, hipStream_t st);
+hipError_t lnbk_embed(const uint16_t* emb, const int32_t* tokens, uint16_t* x, int S, int dim, int vocab, int* err, hipStream_t st);
+hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_token, StepState* state, int32_t* out_tokens, int out_cap, int advance, hipStream_t st);
+hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st);
+hipError_t lnbk_tile(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, int gather, hipStream_t st);
+hipError_t lnbk_synth_fill(uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, uint64_t seed, uint32_t tensor_id, int kind, float sigma, hipStream_t st);
+hipError_t lnbk_init(void);
+}
+
+static thread_local char g_err[1024] = "";
+static int fail(const char* fmt, ...) {
+    va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);
+    return -1;
+}
+extern "C" const char* lnb_last_error(void) { return g_err; }
+#define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
+
+static inline float bf_wide_h(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+static inline uint16_t bf_trunc_h(float f) { uint32_t u; memcpy(&u, &f, 4); return (uint16_t)(u >> 16); }
+
+// ---------------------------------------------------------------------------------------------------
+struct TensorRef {
+    int rows = 0, cols = 0;        // logical shape in the reference layout (1-D tensors: rows = 1)
+    bool tiled = false;
+    uint16_t* linear = nullptr;    // when !tiled
+    TiledDesc* td = nullptr;       // when tiled
+    int row_off = 0, chain = 0;
+    uint32_t synth_id = 0; int synth_kind = 0;
+    int rank = 2;
+};
+struct LayerW {
+    uint16_t* attn_norm = nullptr; uint16_t* ffn_norm = nullptr;
+    TiledDesc wqkv{}, wo{}, w13{}, w2{};
+};
+struct lnb_model {
+    lnb_model_args a{};
+    int device = 0, layer_begin = 0, layer_end = 0;
+    int head_dim = 0, n_rep = 0, ffn_hidden = 0, q_dim = 0, kv_dim = 0;
+    uint16_t* tok_embd = nullptr; uint16_t* norm = nullptr; TiledDesc output{};
+    std::vector<LayerW> layers;           // indexed by absolute layer id - layer_begin
+    std::map<std::string, TensorRef> tensors;
+    float* cis = nullptr; int cis_rows = 0; float* silu = nullptr;
+    std::vector<float> cis_host;
+    hipStream_t stream = nullptr;
+    bool finalized = false;
+    int64_t weight_bytes = 0;
+    bool first() const { return layer_begin == 0; }
+    bool last() const { return layer_end == a.n_layers; }
+};
+struct lnb_ctx {
+    lnb_model* m = nullptr; int seq_len = 0;
+    hipStream_t stream = nullptr;
+    std::vector<uint16_t*> ck, cv;
+    StepState* st = nullptr; int32_t* dtok = nullptr; int32_t* dnext = nullptr; int* derr = nullptr;
+    int32_t* dout = nullptr; int dout_cap = 0;
+    uint16_t *x = nullptr, *h = nullptr, *q = nullptr, *att = nullptr, *ffn = nullptr, *logits = nullptr;
+    int logits_rows = 0;
+    hipGraphExec_t graph = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    lnb_layer_cb cb = nullptr; void* cb_user = nullptr;
+};
+
+static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
+static int auto_rw(int lane_rows, const char* env) {
+    int v = env_int(env, 0);
+    if (v == 16 || v == 32 || v == 64) return v;
+    if (lane_rows <= 8192) return 16;       // thin: spread the rows over all 256 CUs
+    if (lane_rows <= 32768) return 32;
+    return 64;
+}
+static int alloc_tiled(TiledDesc& t, int n_rows, int K, int rw, int nch, int64_t& bytes) {
+    t.n_rows = n_rows; t.k = K; t.rw = rw; t.nch = nch; t.n_blocks = (n_rows + rw - 1) / rw;
+    size_t n = tiled_elems(n_rows, K, rw, nch) * 2;
+    HIPCHK(hipMalloc((void**)&t.w, n));
+    HIPCHK(hipMemset(t.w, 0, n));
+    bytes += (int64_t)n;
+    return 0;
+}
+static int alloc_linear(uint16_t** p, size_t elems, int64_t& bytes) {
+    HIPCHK(hipMalloc((void**)p, elems * 2)); HIPCHK(hipMemset(*p, 0, elems * 2)); bytes += (int64_t)elems * 2; return 0;
+}
+
+extern "C" int lnb_device_count(int* out) { int n = 0; HIPCHK(hipGetDeviceCount(&n)); *out = n; return 0; }
+
+extern "C" int lnb_model_ffn_hidden_dim(const lnb_model_args* a) {   // llamatransformer.go:569-577
+    int h = 4 * a->dim;
+    h = (int)(2 * h / 3);
+    if (a->ffn_dim_multiplier > -1) h = (int)(a->ffn_dim_multiplier * (double)h);
+    h = a->multiple_of * ((h + a->multiple_of - 1) / a->multiple_of);
+    return h;
+}
+
+static void reg_linear(lnb_model* m, const std::string& name, uint16_t* p, int cols, uint32_t sid, int kind, int rows = 1, int rank = 1) {
+    TensorRef r; r.rows = rows; r.cols = cols; r.tiled = false; r.linear = p; r.synth_id = sid; r.synth_kind = kind; r.rank = rank;
+    m->tensors[name] = r;
+}
+static void reg_tiled(lnb_model* m, const std::string& name, TiledDesc* td, int rows, int cols, int row_off, int chain, uint32_t sid) {
+    TensorRef r; r.rows = rows; r.cols = cols; r.tiled = true; r.td = td; r.row_off = row_off; r.chain = chain; r.synth_id = sid; r.rank = 2;
+    m->tensors[name] = r;
+}
+
+extern "C" int lnb_model_create(const lnb_model_args* args, int device, int layer_begin, int layer_end, lnb_model** out) {
+    if (!args || !out) return fail("null argument");
+    lnb_model_args a = *args;
+    if (a.n_kv_heads < 0) a.n_kv_heads = a.n_heads;                       // llamatransformer.go:73-75
+    if (a.rope_theta <= 0) a.rope_theta = 500000.0;                       // :80-82
+    if (a.dim <= 0 || a.n_heads <= 0 || a.dim % a.n_heads || a.n_heads % a.n_kv_heads) return fail("invalid head configuration");
+    if (layer_begin < 0 || layer_end > a.n_layers || layer_begin >= layer_end) return fail("invalid layer range [%d,%d)", layer_begin, layer_end);
+    int hd = a.dim / a.n_heads;
+    if (a.dim % 8 || hd % 8) return fail("dim and head_dim must be multiples of 8");
+    int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev == 0) return fail("no HIP device: liblnb_hip.so has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail("device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(lnbk_init());
+    lnb_model* m = new lnb_model();
+    m->a = a; m->device = device; m->layer_begin = layer_begin; m->layer_end = layer_end;
+    m->head_dim = hd; m->n_rep = a.n_heads / a.n_kv_heads; m->ffn_hidden = lnb_model_ffn_hidden_dim(&a);
+    if (m->ffn_hidden % 8) { delete m; return fail("ffn hidden dim must be a multiple of 8"); }
+    m->q_dim = a.n_heads * hd; m->kv_dim = a.n_kv_heads * hd;
+    HIPCHK(hipStreamCreate(&m->stream));
+    int64_t& wb = m->weight_bytes;
+    const int dim = a.dim, F = m->ffn_hidden;
+    if (m->first()) {
+        if (alloc_linear(&m->tok_embd, (size_t)a.vocab_size * dim, wb)) return -1;
+        reg_linear(m, "tok_embeddings.weight", m->tok_embd, dim, 0, 0, a.vocab_size, 2);
+    }
+    m->layers.resize(layer_end - layer_begin);
+    for (int l = layer_begin; l < layer_end; l++) {
+        LayerW& L = m->layers[l - layer_begin];
+        char nm[128]; uint32_t base = 16u * (uint32_t)(l + 1);
+        if (alloc_linear(&L.attn_norm, dim, wb) || alloc_linear(&L.ffn_norm, dim, wb)) return -1;
+        if (alloc_tiled(L.wqkv, m->q_dim + 2 * m->kv_dim, dim, auto_rw(m->q_dim + 2 * m->kv_dim, "LNB_RW_QKV"), 1, wb)) return -1;
+        if (alloc_tiled(L.wo, dim, m->q_dim, auto_rw(dim, "LNB_RW_WO"), 1, wb)) return -1;
+        if (alloc_tiled(L.w13, F, dim, auto_rw(2 * F, "LNB_RW_W13") > 32 ? 32 : auto_rw(2 * F, "LNB_RW_W13"), 2, wb)) return -1;
+        if (alloc_tiled(L.w2, dim, F, auto_rw(dim, "LNB_RW_W2"), 1, wb)) return -1;
+        snprintf(nm, sizeof nm, "layers.%d.attention_norm.weight", l); reg_linear(m, nm, L.attn_norm, dim, base + 0, 1);
+        snprintf(nm, sizeof nm, "layers.%d.attention.wq.weight", l); reg_tiled(m, nm, &L.wqkv, m->q_dim, dim, 0, 0, base + 1);
+        snprintf(nm, sizeof nm, "layers.%d.attention.wk.weight", l); reg_tiled(m, nm, &L.wqkv, m->kv_dim, dim, m->q_dim, 0, base + 2);
+        snprintf(nm, sizeof nm, "layers.%d.attention.wv.weight", l); reg_tiled(m, nm, &L.wqkv, m->kv_dim, dim, m->q_dim + m->kv_dim, 0, base + 3);
+        snprintf(nm, sizeof nm, "layers.%d.attention.wo.weight", l); reg_tiled(m, nm, &L.wo, dim, m->q_dim, 0, 0, base + 4);
+        snprintf(nm, sizeof nm, "layers.%d.ffn_norm.weight", l); reg_linear(m, nm, L.ffn_norm, dim, base + 5, 1);
+        snprintf(nm, sizeof nm, "layers.%d.feed_forward.w1.weight", l); reg_tiled(m, nm, &L.w13, F, dim, 0, 0, base + 6);
+        snprintf(nm, sizeof nm, "layers.%d.feed_forward.w2.weight", l); reg_tiled(m, nm, &L.w2, dim, F, 0, 0, base + 7);
+        snprintf(nm, sizeof nm, "layers.%d.feed_forward.w3.weight", l); reg_tiled(m, nm, &L.w13, F, dim, 0, 1, base + 8);
+    }
+    if (m->last()) {
+        if (alloc_linear(&m->norm, dim, wb)) return -1;
+        reg_linear(m, "norm.weight", m->norm, dim, 1, 1);
+        if (alloc_tiled(m->output, a.vocab_size, dim, auto_rw(a.vocab_size, "LNB_RW_OUT"), 1, wb)) return -1;
+        reg_tiled(m, "output.weight", &m->output, a.vocab_size, dim, 0, 0, 2);
+    }
+    *out = m;
+    return 0;
+}
+
+extern "C" int lnb_model_destroy(lnb_model* m) {
+    if (!m) return 0;
+    hipSetDevice(m->device);
+    if (m->tok_embd) hipFree(m->tok_embd);
+    if (m->norm) hipFree(m->norm);
+    if (m->output.w) hipFree(m->output.w);
+    for (auto& L : m->layers) {
+        hipFree(L.attn_norm); hipFree(L.ffn_norm); hipFree(L.wqkv.w); hipFree(L.wo.w); hipFree(L.w13.w); hipFree(L.w2.w);
+    }
+    if (m->cis) hipFree(m->cis);
+    if (m->silu) hipFree(m->silu);
+    if (m->stream) hipStreamDestroy(m->stream);
+    delete m;
+    return 0;
+}
+
+extern "C" int64_t lnb_model_weight_bytes(lnb_model* m) { return m ? m->weight_bytes : 0; }
+
+extern "C" int lnb_model_set_tensor(lnb_model* m, const char* name, const uint16_t* host, const int64_t* shape, int rank) {
+    if (!m || !name || !host || !shape) return fail("null argument");
+    HIPCHK(hipSetDevice(m->device));
+    auto it = m->tensors.find(name);
+    if (it == m->tensors.end()) return fail("tensor \"%s\" does not belong to this model stage", name);
+    TensorRef& r = it->second;
+    // shape check as loader.go:183-192
+    if (rank != r.rank || (rank == 1 && shape[0] != r.cols) || (rank == 2 && (shape[0] != r.rows || shape[1] != r.cols)))
+        return fail("tensor \"%s\": shape mismatch, expected [%d%s%d]", name, r.rank == 1 ? r.cols : r.rows, r.rank == 1 ? "" : " ", r.rank == 1 ? 0 : r.cols);
+    size_t n = (size_t)r.rows * r.cols;
+    if (!r.tiled) { HIPCHK(hipMemcpy(r.linear, host, n * 2, hipMemcpyHostToDevice)); return 0; }
+    uint16_t* stage = nullptr;
+    HIPCHK(hipMalloc((void**)&stage, n * 2));
+    HIPCHK(hipMemcpy(stage, host, n * 2, hipMemcpyHostToDevice));
+    hipError_t e = lnbk_tile(stage, r.td->w, r.rows, r.cols, r.row_off, r.chain, r.td->rw, r.td->nch, 0, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    hipFree(stage);
+    HIPCHK(e);
+    return 0;
+}
+
+extern "C" int lnb_model_get_tensor(lnb_model* m, const char* name, uint16_t* host, int64_t nelem) {
+    if (!m || !name || !host) return fail("null argument");
+    HIPCHK(hipSetDevice(m->device));
+    auto it = m->tensors.find(name);
+    if (it == m->tensors.end()) return fail("tensor \"%s\" does not belong to this model stage", name);
+    TensorRef& r = it->second;
+    size_t n = (size_t)r.rows * r.cols;
+    if ((int64_t)n != nelem) return fail("tensor \"%s\": expected %zu elements", name, n);
+    if (!r.tiled) { HIPCHK(hipMemcpy(host, r.linear, n * 2, hipMemcpyDeviceToHost)); return 0; }
+    uint16_t* stage = nullptr;
+    HIPCHK(hipMalloc((void**)&stage, n * 2));
+    hipError_t e = lnbk_tile(r.td->w, stage, r.rows, r.cols, r.row_off, r.chain, r.td->rw, r.td->nch, 1, m->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
+    if (e == hipSuccess) e = hipMemcpy(host, stage, n * 2, hipMemcpyDeviceToHost);
+    hipFree(stage);
+    HIPCHK(e);
+    return 0;
+}
+
+extern "C" int lnb_model_fill_synthetic(lnb_model* m, uint64_t seed) {
+    if (!m) return fail("null argument");
+    HIPCHK(hipSetDevice(m->device));
+    for (auto& kv : m->tensors) {
+        TensorRef& r = kv.second;
+        if (r.tiled) HIPCHK(lnbk_synth_fill(r.td->w, r.rows, r.cols, r.row_off, r.chain, r.td->rw, r.td->nch, seed, r.synth_id, 0, 0.02f, m->stream));
+        else HIPCHK(lnbk_synth_fill(r.linear, r.rows, r.cols, 0, 0, 0, 1, seed, r.synth_id, r.synth_kind, 0.02f, m->stream));
+    }
+    HIPCHK(hipStreamSynchronize(m->stream));
+    return 0;
+}
+
+// precomputeFreqsCis + applyScaling (llamatransformer.go:662-751): host-side, f32 arithmetic with bf16
+// truncation of freqs, positions and angles; cos/sin in f64.  (Independent restatement: the oracle has its own.)
+static void build_rope_table(int head_dim, int rows, double theta, bool scaled, std::vector<float>& cis) {
+    const int n = head_dim / 2;
+    std::vector<uint16_t> freqs(n);
+    const float dimf = (float)head_dim;
+    for (int i = 0; i < n; i++) {
+        float val = bf_wide_h(bf_trunc_h((float)(2 * i)));
+        freqs[i] = bf_trunc_h((float)(1.0 / std::pow(theta, (double)(val / dimf))));
+    }
+    if (scaled) {
+        const float scale_factor = 8.0f, low_freq_factor = 1.0f, high_freq_factor = 4.0f, old_context_len = 8192.0f;
+        const float low_freq_wavelen = old_context_len / low_freq_factor, high_freq_wavelen = old_context_len / high_freq_factor;
+        for (int i = 0; i < n; i++) {
+            volatile float freq = bf_wide_h(freqs[i]);
+            volatile float wavelen = (float)(2 * M_PI) / freq;
+            float nf;
+            if (wavelen < high_freq_wavelen) nf = freq;
+            else if (wavelen > low_freq_wavelen) nf = freq / scale_factor;
+            else {
+                volatile float smooth = (old_context_len / wavelen - low_freq_factor) / (high_freq_factor - low_freq_factor);
+                volatile float t1 = (1 - smooth) * freq; t1 = t1 / scale_factor;
+                volatile float t2 = smooth * freq;
+                nf = t1 + t2;
+            }
+            freqs[i] = bf_trunc_h(nf);
+        }
+    }
+    cis.resize((size_t)rows * n * 2);
+    for (int p = 0; p < rows; p++) {
+        const float t = bf_wide_h(bf_trunc_h((float)p));
+        for (int i = 0; i < n; i++) {
+            volatile float prod = t * bf_wide_h(freqs[i]);
+            const double ang = (double)bf_wide_h(bf_trunc_h(prod));
+            cis[((size_t)p * n + i) * 2 + 0] = (float)std::cos(ang);
+            cis[((size_t)p * n + i) * 2 + 1] = (float)std::sin(ang);
+        }
+    }
+}
+
+extern "C" int lnb_model_finalize(lnb_model* m, int rope_rows) {
+    if (!m) return fail("null argument");
+    HIPCHK(hipSetDevice(m->device));
+    m->cis_rows = rope_rows > 0 ? rope_rows : m->a.max_seq_len * 2;           // llamatransformer.go:109
+    build_rope_table(m->head_dim, m->cis_rows, m->a.rope_theta, m->a.use_scaled_rope != 0, m->cis_host);
+    if (m->cis) hipFree(m->cis);
+    HIPCHK(hipMalloc((void**)&m->cis, m->cis_host.size() * 4));
+    HIPCHK(hipMemcpy(m->cis, m->cis_host.data(), m->cis_host.size() * 4, hipMemcpyHostToDevice));
+    // TABLE_SILU (activations.go:15-25): f32(x / (1 + exp(-x))) in f64 for every bf16 bit pattern
+    std::vector<float> silu(1 << 16);
+    for (int i = 0; i < (1 << 16); i++) { double x = (double)bf_wide_h((uint16_t)i); silu[i] = (float)(x / (1.0 + std::exp(-x))); }
+    if (!m->silu) HIPCHK(hipMalloc((void**)&m->silu, silu.size() * 4));
+    HIPCHK(hipMemcpy(m->silu, silu.data(), silu.size() * 4, hipMemcpyHostToDevice));
+    m->finalized = true;
+    return 0;
+}
+
+extern "C" int lnb_model_rope_table(lnb_model* m, float* out, int64_t nfloats, int* rows_out) {
+    if (!m || !m->finalized) return fail("model not finalized");
+    if (rows_out) *rows_out = m->cis_rows;
+    if (out) {
+        if ((size_t)nfloats != m->cis_host.size()) return fail("rope table has %zu floats", m->cis_host.size());
+        memcpy(out, m->cis_host.data(), m->cis_host.size() * 4);
+    }
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------
+extern "C" int lnb_ctx_create(lnb_model* m, int seq_len, lnb_ctx** out) {
+    if (!m || !out) return fail("null argument");
+    if (!m->finalized) return fail("model not finalized");
+    HIPCHK(hipSetDevice(m->device));
+    lnb_ctx* c = new lnb_ctx();
+    c->m = m; c->seq_len = seq_len > 0 ? seq_len : m->a.max_seq_len;        // inferencecontext.go:22-26
+    if ((size_t)c->seq_len * 12 + 1024 > 150 * 1024) { delete c; return fail("seq_len %d exceeds the %d positions the attention kernel stages in LDS", c->seq_len, (150 * 1024 - 1024) / 12); }
+    HIPCHK(hipStreamCreate(&c->stream));
+    HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+    const size_t kvn = (size_t)c->seq_len * m->kv_dim;
+    for (size_t l = 0; l < m->layers.size(); l++) {
+        uint16_t *k = nullptr, *v = nullptr;
+        HIPCHK(hipMalloc((void**)&k, kvn * 2)); HIPCHK(hipMalloc((void**)&v, kvn * 2));
+        HIPCHK(hipMemset(k, 0, kvn * 2)); HIPCHK(hipMemset(v, 0, kvn * 2));     // ml.Zeros, inferencecontext.go:32-42
+        c->ck.push_back(k); c->cv.push_back(v);
+    }
+    HIPCHK(hipMalloc((void**)&c->st, sizeof(StepState))); HIPCHK(hipMemset(c->st, 0, sizeof(StepState)));
+    HIPCHK(hipMalloc((void**)&c->dtok, (size_t)c->seq_len * 4));
+    HIPCHK(hipMalloc((void**)&c->dnext, 16)); HIPCHK(hipMalloc((void**)&c->derr, 16)); HIPCHK(hipMemset(c->derr, 0, 16));
+    c->dout_cap = c->seq_len; HIPCHK(hipMalloc((void**)&c->dout, (size_t)c->dout_cap * 4));
+    const size_t S = c->seq_len;
+    HIPCHK(hipMalloc((void**)&c->x, S * m->a.dim * 2)); HIPCHK(hipMalloc((void**)&c->h, S * m->a.dim * 2));
+    HIPCHK(hipMalloc((void**)&c->q, S * m->q_dim * 2)); HIPCHK(hipMalloc((void**)&c->att, S * m->q_dim * 2));
+    HIPCHK(hipMalloc((void**)&c->ffn, S * m->ffn_hidden * 2));
+    if (m->last()) { HIPCHK(hipMalloc((void**)&c->logits, (size_t)m->a.vocab_size * 2)); c->logits_rows = 1; }
+    *out = c;
+    return 0;
+}
+
+extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
+    if (!c) return 0;
+    hipSetDevice(c->m->device);
+    hipStreamSynchronize(c->stream);
+    if (c->graph) hipGraphExecDestroy(c->graph);
+    for (auto p : c->ck) hipFree(p);
+    for (auto p : c->cv) hipFree(p);
+    hipFree(c->st); hipFree(c->dtok); hipFree(c->dnext); hipFree(c->derr); hipFree(c->dout);
+    hipFree(c->x); hipFree(c->h); hipFree(c->q); hipFree(c->att); hipFree(c->ffn); if (c->logits) hipFree(c->logits);
+    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
+    hipStreamDestroy(c->stream);
+    delete c;
+    return 0;
+}
+
+extern "C" int lnb_ctx_reset(lnb_ctx* c) {
+    if (!c) return fail("null argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    const size_t kvn = (size_t)c->seq_len * c->m->kv_dim;
+    for (size_t l = 0; l < c->ck.size(); l++) { HIPCHK(hipMemsetAsync(c->ck[l], 0, kvn * 2, c->stream)); HIPCHK(hipMemsetAsync(c->cv[l], 0, kvn * 2, c->stream)); }
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+
+extern "C" int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which, uint16_t* host) {
+    if (!c || !host) return fail("null argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    if (layer < c->m->layer_begin || layer >= c->m->layer_end) return fail("layer %d is not owned by this stage", layer);
+    const size_t kvn = (size_t)c->seq_len * c->m->kv_dim;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(host, (which ? c->cv : c->ck)[layer - c->m->layer_begin], kvn * 2, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+extern "C" int lnb_ctx_set_layer_callback(lnb_ctx* c, lnb_layer_cb cb, void* user) { if (!c) return fail("null argument"); c->cb = cb; c->cb_user = user; return 0; }
+extern "C" void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which) { (void)which; return c ? (void*)c->x : nullptr; }
+extern "C" void* lnb_ctx_stream(lnb_ctx* c) { return c ? (void*)c->stream : nullptr; }
+extern "C" int lnb_ctx_synchronize(lnb_ctx* c) { if (!c) return fail("null argument"); HIPCHK(hipSetDevice(c->m->device)); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
+
+// ---- one pass over this stage's layers for S rows; position comes from c->st on the device ----------
+static int enqueue_layers(lnb_ctx* c, int S, bool with_cb) {
+    lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = c->stream;
+    const float divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));   // llamatransformer.go:464
+    for (int l = m->layer_begin; l < m->layer_end; l++) {
+        LayerW& L = m->layers[l - m->layer_begin];
+        auto t0 = std::chrono::steady_clock::now();
+        GemvParams g{};
+        // attn_norm + wq|wk|wv + RoPE + KV append  (llamatransformer.go:222, :297-403)
+        g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
+        g.cis = m->cis; g.q_out = c->q; g.cache_k = c->ck[l - m->layer_begin]; g.cache_v = c->cv[l - m->layer_begin];
+        g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
+        HIPCHK(lnbk_gemv(&g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, L.wqkv.n_blocks, st));
+        // scores / softmax / PV  (:409-514)
+        AttnParams ap{}; ap.q = c->q; ap.cache_k = g.cache_k; ap.cache_v = g.cache_v; ap.out = c->att; ap.st = c->st;
+        ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len; ap.divisor = divisor;
+        HIPCHK(lnbk_attn(&ap, st));
+        // wo + residual  (:522, :232)
+        GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = c->h; o.res = c->x;
+        HIPCHK(lnbk_gemv(&o, L.wo.rw, 1, EPI_RESID, 0, L.wo.n_blocks, st));
+        // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
+        GemvParams f{}; f.w = L.w13.w; f.x = c->h; f.norm_w = L.ffn_norm; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
+        f.out = c->ffn; f.silu = m->silu;
+        HIPCHK(lnbk_gemv(&f, L.w13.rw, 2, EPI_SILU_MUL, 1, L.w13.n_blocks, st));
+        // w2 + residual  (:619, :248)
+        GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = c->h;
+        HIPCHK(lnbk_gemv(&d, L.w2.rw, 1, EPI_RESID, 0, L.w2.n_blocks, st));
+        if (with_cb && c->cb) {
+            HIPCHK(hipStreamSynchronize(st));
+            double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            c->cb(l + 1, a.n_layers, secs, c->cb_user);                       // llamatransformer.go:163
+        }
+    }
+    return 0;
+}
+// final RMSNorm + output projection of `rows` rows starting at row `first` (llamatransformer.go:166-170)
+static int enqueue_head(lnb_ctx* c, int first, int rows) {
+    lnb_model* m = c->m;
+    GemvParams g{}; g.w = m->output.w; g.x = c->x + (size_t)first * m->a.dim; g.norm_w = m->norm; g.eps = m->a.norm_eps; g.K = m->a.dim;
+    g.n_rows = m->a.vocab_size; g.S = rows; g.st = c->st; g.out = c->logits;
+    HIPCHK(lnbk_gemv(&g, m->output.rw, 1, EPI_STORE, 1, m->output.n_blocks, c->stream));
+    return 0;
+}
+
+static int check_call(lnb_ctx* c, int seq, int start_pos) {
+    if (seq == 0) return fail("empty token array");                                            // llamatransformer.go:146-148
+    if (seq < 0 || start_pos < 0) return fail("negative sequence length or start position");
+    const int T = start_pos + seq;
+    if (T > c->m->cis_rows) return fail("incompatible locStart, locEnd values and tensor (position %d beyond the %d-row RoPE table)", T, c->m->cis_rows);
+    if (T > c->seq_len) return fail("incompatible locStart, locEnd values and tensor (position %d beyond the KV cache of %d)", T, c->seq_len);
+    if (seq > 1 && T % seq != 0) return fail("two tensor shapes cannot be broadcasted: [%d %d %d] and [%d %d]", c->m->a.n_heads, seq, T, seq, seq);
+    return 0;
+}
+
+extern "C" int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, float* logits_out, int32_t* argmax_last_out) {
+    if (!c) return fail("null argument");
+    lnb_model* m = c->m; const int V = m->a.vocab_size;
+    HIPCHK(hipSetDevice(m->device));
+    if (check_call(c, seq, start_pos)) return -1;
+    if (tokens && !m->first()) return fail("tokens given to a stage that does not own tok_embeddings");
+    if (!tokens && m->first()) return fail("first stage needs tokens");
+    if ((logits_out || argmax_last_out) && !m->last()) return fail("logits requested from a stage that does not own output.weight");
+    hipStream_t st = c->stream;
+    HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
+    if (tokens) {
+        HIPCHK(hipMemcpyAsync(c->dtok, tokens, (size_t)seq * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(c->derr, 0, 4, st));
+        HIPCHK(lnbk_embed(m->tok_embd, c->dtok, c->x, seq, m->a.dim, V, c->derr, st));       // Fwd_Get_Rows :118
+    }
+    if (enqueue_layers(c, seq, true)) return -1;
+    if (m->last() && (logits_out || argmax_last_out)) {
+        const int rows = logits_out ? seq : 1;
+        if (rows > c->logits_rows) {
+            HIPCHK(hipStreamSynchronize(st));
+            hipFree(c->logits); c->logits = nullptr;
+            HIPCHK(hipMalloc((void**)&c->logits, (size_t)rows * V * 2)); c->logits_rows = rows;
+        }
+        if (enqueue_head(c, logits_out ? 0 : seq - 1, rows)) return -1;
+        HIPCHK(lnbk_argmax(c->logits + (size_t)(rows - 1) * V, V, c->dnext, c->st, c->dout, c->dout_cap, 0, st));   // inference.go:207-211
+        if (logits_out) {
+            std::vector<uint16_t> hb((size_t)rows * V);
+            HIPCHK(hipMemcpyAsync(hb.data(), c->logits, hb.size() * 2, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            for (size_t i = 0; i < hb.size(); i++) logits_out[i] = bf_wide_h(hb[i]);              // output.ToFloat32() :175
+        }
+        if (argmax_last_out) HIPCHK(hipMemcpyAsync(argmax_last_out, c->dnext, 4, hipMemcpyDeviceToHost, st));
+    }
+    HIPCHK(hipStreamSynchronize(st));
+    if (tokens) {
+        int err = 0; HIPCHK(hipMemcpy(&err, c->derr, 4, hipMemcpyDeviceToHost));
+        if (err) return fail("token id at index %d is outside the vocabulary", err - 1);
+    }
+    return 0;
+}
+
+extern "C" int lnb_forward(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, float* logits_out, int32_t* argmax_last_out) {
+    if (!c || !tokens) return fail("null argument");
+    if (!c->m->first() || !c->m->last()) return fail("lnb_forward needs a whole-model handle; use lnb_forward_stage for pipeline stages");
+    return lnb_forward_stage(c, tokens, seq, start_pos, logits_out, argmax_last_out);
+}
+
+// one decode step = embed(token on device) -> layers -> head -> argmax that feeds the next step
+static int enqueue_decode_step(lnb_ctx* c) {
+    lnb_model* m = c->m;
+    HIPCHK(lnbk_embed(m->tok_embd, c->dtok, c->x, 1, m->a.dim, m->a.vocab_size, c->derr, c->stream));
+    if (enqueue_layers(c, 1, false)) return -1;
+    if (enqueue_head(c, 0, 1)) return -1;
+    HIPCHK(lnbk_argmax(c->logits, m->a.vocab_size, c->dtok, c->st, c->dout, c->dout_cap, 1, c->stream));
+    return 0;
+}
+
+extern "C" int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int32_t* out_tokens, float* ms_out) {
+    if (!c || !out_tokens) return fail("null argument");
+    lnb_model* m = c->m;
+    if (!m->first() || !m->last()) return fail("lnb_decode_greedy needs a whole-model handle");
+    HIPCHK(hipSetDevice(m->device));
+    if (n_steps <= 0) return fail("n_steps must be positive");
+    if (n_steps > c->dout_cap) return fail("n_steps %d exceeds the context length %d", n_steps, c->dout_cap);
+    if (check_call(c, 1, start_pos) || check_call(c, 1, start_pos + n_steps - 1)) return -1;
+    if (token < 0 || token >= m->a.vocab_size) return fail("token id at index 0 is outside the vocabulary");
+    hipStream_t st = c->stream;
+    const bool use_graph = env_int("LNB_NO_GRAPH", 0) == 0;
+    if (use_graph && !c->graph) {
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_decode_step(c);
+        hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return -1; }
+        HIPCHK(e);
+        HIPCHK(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
+        HIPCHK(hipGraphDestroy(g));
+    }
+    HIPCHK(hipMemcpyAsync(c->dtok, &token, 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(c->derr, 0, 4, st));
+    HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
+    HIPCHK(hipEventRecord(c->ev0, st));
+    for (int i = 0; i < n_steps; i++) {
+        if (use_graph) HIPCHK(hipGraphLaunch(c->graph, st));
+        else if (enqueue_decode_step(c)) return -1;
+    }
+    HIPCHK(hipEventRecord(c->ev1, st));
+    HIPCHK(hipMemcpyAsync(out_tokens, c->dout, (size_t)n_steps * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
+    int err = 0; HIPCHK(hipMemcpy(&err, c->derr, 4, hipMemcpyDeviceToHost));
+    if (err) return fail("generated token id is outside the vocabulary");
+    return 0;
+}
+
+// ---- single-op entry points for the parity tests ------------------------------------------------------
+static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w, float eps, const uint16_t* w, uint16_t* y,
+                          int rows, int n_out, int k_in, int rw) {
+    if (!x || !w || !y) return fail("null argument");
+    if (rows <= 0 || n_out <= 0 || k_in <= 0) return fail("empty operand");
+    if (k_in % 8) return fail("in_features must be a multiple of 8");
+    int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev == 0) return fail("no HIP device: liblnb_hip.so has no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    HIPCHK(lnbk_init());
+    if (rw == 0) rw = auto_rw(n_out, "LNB_RW_OP");
+    if (rw != 16 && rw != 32 && rw != 64) return fail("rw must be 16, 32 or 64");
+    if ((size_t)k_in * 4 + 2 * 16384 + 64 > 160 * 1024) return fail("in_features %d does not fit the LDS staging", k_in);
+    TiledDesc t{}; int64_t bytes = 0;
+    if (alloc_tiled(t, n_out, k_in, rw, 1, bytes)) return -1;
+    uint16_t *dx = nullptr, *dw = nullptr, *dy = nullptr, *dn = nullptr; StepState* st = nullptr;
+    HIPCHK(hipMalloc((void**)&dx, (size_t)rows * k_in * 2)); HIPCHK(hipMalloc((void**)&dw, (size_t)n_out * k_in * 2));
+    HIPCHK(hipMalloc((void**)&dy, (size_t)rows * n_out * 2)); HIPCHK(hipMalloc((void**)&st, sizeof(StepState)));
+    HIPCHK(hipMemset(st, 0, sizeof(StepState)));
+    HIPCHK(hipMemcpy(dx, x, (size_t)rows * k_in * 2, hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(dw, w, (size_t)n_out * k_in * 2, hipMemcpyHostToDevice));
+    if (norm_w) { HIPCHK(hipMalloc((void**)&dn, (size_t)k_in * 2)); HIPCHK(hipMemcpy(dn, norm_w, (size_t)k_in * 2, hipMemcpyHostToDevice)); }
+    HIPCHK(lnbk_tile(dw, t.w, n_out, k_in, 0, 0, rw, 1, 0, nullptr));
+    GemvParams g{}; g.w = t.w; g.x = dx; g.norm_w = dn; g.eps = eps; g.K = k_in; g.n_rows = n_out; g.S = rows; g.st = st; g.out = dy;
+    HIPCHK(lnbk_gemv(&g, rw, 1, EPI_STORE, norm_w ? 1 : 0, t.n_blocks, nullptr));
+    HIPCHK(hipDeviceSynchronize());
+    HIPCHK(hipMemcpy(y, dy, (size_t)rows * n_out * 2, hipMemcpyDeviceToHost));
+    hipFree(dx); hipFree(dw); hipFree(dy); hipFree(st); hipFree(t.w); if (dn) hipFree(dn);
+    return 0;
+}
+extern "C" int lnb_op_linear(int device, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int n_out, int k_in, int rw) {
+    return op_linear_impl(device, x, nullptr, 0.0f, w, y, rows, n_out, k_in, rw);
+}
+extern "C" int lnb_op_rmsnorm_linear(int device, const uint16_t* x, const uint16_t* norm_w, float eps, const uint16_t* w, uint16_t* y,
+                                     int rows, int n_out, int k_in, int rw) {
+    if (!norm_w) return fail("null argument");
+    return op_linear_impl(device, x, norm_w, eps, w, y, rows, n_out, k_in, rw);
+}

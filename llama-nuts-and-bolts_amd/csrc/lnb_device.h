@@ -1,0 +1,94 @@
+// lnb_device.h -- shared host/device definitions for the MI355X (gfx950) LlamaTransformer.Forward path.
+//
+// Numerics contract (reference: adalkiran/llama-nuts-and-bolts):
+//   * every bf16 store is a TRUNCATION of the f32 bit pattern   (src/dtype/bfloat16.go:31-33)
+//   * every matmul output is ONE f32 chain, k ascending          (src/ml/operations_lineartransform.go:46-65)
+//   * softmax in f64 without max subtraction                     (src/ml/operations_impl.go:492-508)
+// The kernels keep those chains intact: one lane owns one output element and walks k in order.
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+
+#if defined(__HIPCC__)
+#define LNB_HD __host__ __device__ __forceinline__
+#else
+#define LNB_HD inline
+#endif
+
+// ---- tiled weight layout ------------------------------------------------------------------------
+// A logical [N,K] bf16 matrix in the reference's [out_features,in_features] row-major layout is stored
+// in HBM as   [N/RW][K/8][NCH][RW][8]   so that the RW output rows owned by the RW lanes of one
+// consumer wave are contiguous for every 8-wide k chunk: one 16-byte load per lane, 1 KiB (RW=64) of
+// perfectly sequential stream per wave instruction, and each lane still sees its own row in k order.
+// NCH = number of independent chains per lane (2 for the fused w1|w3 gate/up matrix).
+struct TiledDesc {
+    uint16_t* w;      // device pointer
+    int n_rows;       // logical lane-rows (outputs per chain)
+    int k;            // in_features
+    int rw;           // rows per wave block: 16 / 32 / 64
+    int nch;          // chains per lane: 1 / 2
+    int n_blocks;     // ceil(n_rows / rw)
+};
+LNB_HD size_t tiled_index(int n, int k, int c, int K, int RW, int NCH) {
+    size_t b = (size_t)(n / RW), r = (size_t)(n % RW), kc = (size_t)(k >> 3), e = (size_t)(k & 7);
+    return ((((b * (size_t)(K >> 3) + kc) * (size_t)NCH + (size_t)c) * (size_t)RW + r) << 3) + e;
+}
+LNB_HD size_t tiled_elems(int n_rows, int K, int RW, int NCH) {
+    return (size_t)((n_rows + RW - 1) / RW) * (size_t)RW * (size_t)NCH * (size_t)K;
+}
+
+// ---- synthetic weights (same integer-exact generator as oracle/lnb_oracle.c; spec in DESIGN.md) ----
+LNB_HD uint64_t lnb_splitmix64(uint64_t z) {
+    z += 0x9E3779B97F4A7C15ULL;
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+LNB_HD int32_t lnb_synth_isum(uint64_t base, uint64_t idx) {
+    uint64_t a = lnb_splitmix64(base ^ idx);
+    uint64_t b = lnb_splitmix64(a);
+    int32_t s = 0;
+    for (int i = 0; i < 4; i++) { s += (int32_t)((a >> (16 * i)) & 0xFFFF); s += (int32_t)((b >> (16 * i)) & 0xFFFF); }
+    return s - 262140;
+}
+
+// per-decode-step device state: lets one captured hipGraph be replayed for every position
+struct StepState {
+    int32_t pos;        // start position of the current call (tokens already in the KV cache)
+    int32_t n_out;      // tokens appended to out_tokens so far
+    int32_t pad[2];
+};
+
+enum { EPI_STORE = 0, EPI_QKV_ROPE = 1, EPI_RESID = 2, EPI_SILU_MUL = 3 };
+
+struct GemvParams {
+    const uint16_t* w;          // tiled weights
+    const uint16_t* x;          // [S][K] bf16 activations (pre-norm when norm_w != nullptr)
+    const uint16_t* norm_w;     // [K] bf16 RMSNorm weight, or nullptr (no fused norm)
+    float eps;
+    int K;                      // in_features
+    int n_rows;                 // logical lane-rows
+    int S;                      // rows in this call
+    const StepState* st;        // start position lives on the device
+    // EPI_STORE / EPI_RESID / EPI_SILU_MUL
+    uint16_t* out;              // [S][n_rows] bf16
+    const uint16_t* res;        // [S][n_rows] bf16 residual (EPI_RESID)
+    const float* silu;          // f32[65536] SiLU table (EPI_SILU_MUL)
+    // EPI_QKV_ROPE
+    const float* cis;           // [rows][head_dim/2][2] f32
+    uint16_t* q_out;            // [S][n_heads*head_dim]
+    uint16_t* cache_k;          // [seq_len][n_kv*head_dim]
+    uint16_t* cache_v;
+    int q_dim, kv_dim, head_dim;
+    int out_row_offset;         // first logits row to keep (EPI_STORE with S>1 and "last row only")
+};
+
+struct AttnParams {
+    const uint16_t* q;          // [S][H*hd]
+    const uint16_t* cache_k;    // [seq_len][KVH*hd]
+    const uint16_t* cache_v;
+    uint16_t* out;              // [S][H*hd]
+    const StepState* st;
+    int S, H, KVH, hd, seq_len;
+    float divisor;              // wide(trunc(f32(sqrt(hd))))  (llamatransformer.go:464)
+};

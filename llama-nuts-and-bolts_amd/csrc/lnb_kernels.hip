@@ -1,0 +1,462 @@
+// lnb_kernels.hip -- hand-written gfx950 (MI355X / CDNA4) kernels for LlamaTransformer.Forward.
+//
+// Reference behaviour restated (never copied): adalkiran/llama-nuts-and-bolts
+//   src/model/llamatransformer.go:145-180 (Forward), :215-254 (block), :289-527 (attention),
+//   :593-624 (SwiGLU), :633-660 (RMSNorm), :753-790 (RoPE); src/ml/operations_lineartransform.go:37-70.
+//
+// Design: "exact-order" kernels.  The reference defines every output as ONE sequential f32 chain
+// over k followed by a bf16 truncation, so the kernels give each output element to one lane
+// (64 chains per wave64) and never split k.  What makes that fast on MI355X:
+//   * weights are re-tiled ONCE at load time into [N/RW][K/8][NCH][RW][8] (lnb_device.h) so a wave's
+//     weight traffic is one linear byte stream -> 16 B/lane coalesced global loads, no transposes;
+//   * loader waves stream that byte range HBM -> VGPR ring (P stages in flight, non-temporal) ->
+//     LDS double buffer; one consumer wave per row block walks k out of LDS (ds_read_b128 for the
+//     weights, broadcast ds_read_b128 for x) -- the LDS ring is the prefetch depth a latency-bound
+//     chain cannot hold in registers;
+//   * thin matrices (N=4096) use RW=16 so that all 256 CUs pull bytes while each chain stays serial;
+//   * RMSNorm is fused into the consuming GEMV (every workgroup recomputes the 4096-long serial
+//     sum while its loaders already have the first stages in flight), RoPE + KV-cache append are
+//     fused into the QKV epilogue (lane pairs exchange via one cross-lane shuffle), SiLU*up and the
+//     residual adds are epilogues too: 5 launches per transformer block.
+// Compile with -ffp-contract=off: every a*b+c below is either an explicit fmaf (product exact) or
+// must stay two roundings.
+#include <hip/hip_runtime.h>
+#include "lnb_device.h"
+
+#define DEVINL __device__ __forceinline__
+
+DEVINL float bf_lo(uint32_t u) { return __uint_as_float(u << 16); }
+DEVINL float bf_hi(uint32_t u) { return __uint_as_float(u & 0xffff0000u); }
+DEVINL float bf_wide(uint16_t b) { return __uint_as_float(((uint32_t)b) << 16); }
+DEVINL uint16_t bf_trunc(float f) { return (uint16_t)(__float_as_uint(f) >> 16); }   // bfloat16.go:31-33
+
+DEVINL uint4 ld_nt_u4(const void* p) {
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    u4v v = __builtin_nontemporal_load((const u4v*)p);
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+
+// one 8-wide k chunk of one chain: acc <- acc + x_k*w_k, k ascending (operations_lineartransform.go:46-65).
+// bf16*bf16 is exact in f32, so fmaf == mul-then-add unless the product underflows 2^-126.
+DEVINL float mac8(float acc, const float4& xa, const float4& xb, const uint4& w) {
+    acc = fmaf(xa.x, bf_lo(w.x), acc); acc = fmaf(xa.y, bf_hi(w.x), acc);
+    acc = fmaf(xa.z, bf_lo(w.y), acc); acc = fmaf(xa.w, bf_hi(w.y), acc);
+    acc = fmaf(xb.x, bf_lo(w.z), acc); acc = fmaf(xb.y, bf_hi(w.z), acc);
+    acc = fmaf(xb.z, bf_lo(w.w), acc); acc = fmaf(xb.w, bf_hi(w.w), acc);
+    return acc;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact-order streaming GEMV / skinny GEMM:   y[m, n] = trunc( sum_{k ascending} x[m,k] * W[n,k] )
+// workgroup = 128 threads: wave 0 = consumer (RW lanes active, NCH chains per lane),
+//                          wave 1 = loader  (LDS-DMA: global_load_lds_dwordx4, 1 KiB per instruction).
+// The loader keeps D-1 stages of STAGE_BYTES in flight into a D-slot LDS ring with COUNTED
+// s_waitcnt vmcnt(N) (never 0 in steady state) and hands stages over with one raw s_barrier each:
+//     loader  it: wait(stage it landed) ; barrier B_it ; issue stage it+D-1 into the slot freed by it-1
+//     consumer it:                        barrier B_it ; walk stage it
+// grid.x = S * n_blocks  (m fastest so that the S workgroups sharing a weight block run together)
+// dynamic LDS: [D*STAGE_BYTES ring][K f32 x][16 B scratch]   (one array: a second __shared__ object
+// would make hipcc drain vmcnt before every ds_read)
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* glb_ptr_t;
+#define WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
+
+template <int RW, int NCH, int STAGE_BYTES, int D, int EPI, bool NORM>
+__global__ __launch_bounds__(128) void gemv_exact_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LPS = STAGE_BYTES / 1024;                // 1 KiB LDS-DMA instructions per stage
+    constexpr int KC = STAGE_BYTES / (NCH * RW * 16);      // 8-wide k chunks per stage
+    static_assert(LPS >= 1 && KC >= 1 && (D & (D - 1)) == 0 && D >= 2, "bad stage geometry");
+    static_assert((D - 1) * LPS <= 60, "vmcnt is a 6-bit counter");
+    char* ring = smem;
+    float* xs = (float*)(smem + D * STAGE_BYTES);
+    float* scratch = xs + p.K;
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = p.K, S = p.S;
+    const int m = (S == 1) ? 0 : (int)(blockIdx.x % (unsigned)S);
+    const int b = (S == 1) ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)S);
+
+    const size_t stream_bytes = (size_t)K * NCH * RW * 2;
+    const char* wstream = (const char*)p.w + (size_t)b * stream_bytes;
+    const int nstages = (int)((stream_bytes + STAGE_BYTES - 1) / STAGE_BYTES);
+
+    if (wave == 1) {
+        // ================================ loader wave =============================================
+        const size_t last16 = stream_bytes - 16;           // clamp: never read past this block's stream
+        auto issue_stage = [&](int stage) {
+            char* dst = ring + (stage & (D - 1)) * STAGE_BYTES;
+#pragma unroll
+            for (int i = 0; i < LPS; i++) {
+                size_t off = (size_t)stage * STAGE_BYTES + (size_t)i * 1024 + (size_t)lane * 16;
+                off = off < last16 ? off : last16;
+                // aux = 2: non-temporal -- every weight byte is read once per token by exactly one CU
+                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wstream + off), (lds_ptr_t)(dst + i * 1024), 16, 0, 2);
+            }
+        };
+        for (int s = 0; s < D - 1; s++) if (s < nstages) issue_stage(s);
+        for (int it = 0; it < nstages; it++) {
+            if (it + D - 1 < nstages) {
+                WAIT_VMCNT((D - 2) * LPS);                 // stage `it` (the oldest of D-1 in flight) has landed
+                __builtin_amdgcn_s_barrier();              // B_it: publishes stage it; consumer is done with it-1
+                issue_stage(it + D - 1);                   // refill the slot stage it-1 occupied
+            } else {
+                WAIT_VMCNT(0);                             // drain phase (last D-1 stages)
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        return;                                            // vmcnt == 0 here: no DMA can land after exit
+    }
+
+    // ==================================== consumer wave ===============================================
+    // ---- x row -> LDS as f32 (optionally through the fused RMSNorm); only this wave touches xs ------
+    const uint16_t* xrow = p.x + (size_t)m * K;
+    for (int k = lane * 8; k < K; k += 64 * 8) {
+        uint4 v = *(const uint4*)(xrow + k);
+        float4 a = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
+        float4 c = make_float4(bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
+        *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
+    }
+    if (NORM) {
+        // RMSNorm.doNormalization (llamatransformer.go:641-660): Pow(x,2) exact -> Mean: serial f32 sum,
+        // k ascending (operations_impl.go:236-251) -> +eps -> f32(1/sqrt(f64)).  Every lane walks the
+        // same chain (broadcast LDS reads); the loader's first D-1 stages are in flight meanwhile.
+        float sum = 0.0f;
+        for (int k = 0; k < K; k += 8) {
+            float4 a = *(const float4*)(xs + k), c = *(const float4*)(xs + k + 4);
+            float p0 = a.x * a.x, p1 = a.y * a.y, p2 = a.z * a.z, p3 = a.w * a.w;
+            float p4 = c.x * c.x, p5 = c.y * c.y, p6 = c.z * c.z, p7 = c.w * c.w;
+            sum += p0; sum += p1; sum += p2; sum += p3; sum += p4; sum += p5; sum += p6; sum += p7;
+        }
+        float mean = __fdiv_rn(sum, (float)K);
+        mean = mean + p.eps;
+        const float r = (float)(1.0 / sqrt((double)mean));
+        for (int k = lane * 8; k < K; k += 64 * 8) {
+            uint4 wv = *(const uint4*)(p.norm_w + k);
+            float4 a = *(const float4*)(xs + k), c = *(const float4*)(xs + k + 4);
+            // trunc(x*r) then trunc(.*w): two truncations (llamatransformer.go:656,638)
+            a.x = bf_wide(bf_trunc(bf_wide(bf_trunc(a.x * r)) * bf_lo(wv.x)));
+            a.y = bf_wide(bf_trunc(bf_wide(bf_trunc(a.y * r)) * bf_hi(wv.x)));
+            a.z = bf_wide(bf_trunc(bf_wide(bf_trunc(a.z * r)) * bf_lo(wv.y)));
+            a.w = bf_wide(bf_trunc(bf_wide(bf_trunc(a.w * r)) * bf_hi(wv.y)));
+            c.x = bf_wide(bf_trunc(bf_wide(bf_trunc(c.x * r)) * bf_lo(wv.z)));
+            c.y = bf_wide(bf_trunc(bf_wide(bf_trunc(c.y * r)) * bf_hi(wv.z)));
+            c.z = bf_wide(bf_trunc(bf_wide(bf_trunc(c.z * r)) * bf_lo(wv.w)));
+            c.w = bf_wide(bf_trunc(bf_wide(bf_trunc(c.w * r)) * bf_hi(wv.w)));
+            *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
+        }
+    }
+    (void)scratch;
+
+    // ---- walk the stages: one k-ordered chain per lane (per chain) ------------------------------------
+    float acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
+    const int kchunks = K >> 3;
+    for (int it = 0; it < nstages; it++) {
+        __builtin_amdgcn_s_barrier();                                  // B_it: stage it is in the ring
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const char* src = ring + (it & (D - 1)) * STAGE_BYTES;
+        const int kc0 = it * KC;
+        int kcn = kchunks - kc0; kcn = kcn < KC ? kcn : KC;
+        if (lane < RW) {
+#pragma unroll 4
+            for (int kc = 0; kc < kcn; kc++) {
+                const float4 xa = *(const float4*)(xs + (size_t)(kc0 + kc) * 8);
+                const float4 xb = *(const float4*)(xs + (size_t)(kc0 + kc) * 8 + 4);
+#pragma unroll
+                for (int c = 0; c < NCH; c++) {
+                    const uint4 wv = *(const uint4*)(src + ((kc * NCH + c) * RW + lane) * 16);
+                    acc[c] = mac8(acc[c], xa, xb, wv);
+                }
+            }
+        }
+    }
+
+    // ---- epilogues (consumer wave, lane = output row) ---------------------------------------------
+    const int n = b * RW + lane;
+    const bool valid = (lane < RW) && (n < p.n_rows);
+    if (EPI == EPI_STORE) {
+        if (valid) p.out[(size_t)m * p.n_rows + n] = bf_trunc(acc[0]);
+    } else if (EPI == EPI_RESID) {
+        // ml.Add (operations_impl.go:320-332): trunc(wide(x) + wide(y)), y = trunc(acc)
+        if (valid) {
+            size_t o = (size_t)m * p.n_rows + n;
+            p.out[o] = bf_trunc(bf_wide(p.res[o]) + bf_wide(bf_trunc(acc[0])));
+        }
+    } else if (EPI == EPI_SILU_MUL) {
+        // Silu table lookup on the raw bf16 bits (activations.go:36-39) then MultiplyElementwise (:614)
+        if (valid) {
+            uint16_t g = bf_trunc(acc[0]), u = bf_trunc(acc[NCH - 1]);
+            uint16_t gs = bf_trunc(p.silu[g]);
+            p.out[(size_t)m * p.n_rows + n] = bf_trunc(bf_wide(gs) * bf_wide(u));
+        }
+    } else if (EPI == EPI_QKV_ROPE) {
+        // rows [0,q_dim) = xq, [q_dim,q_dim+kv_dim) = xk, rest = xv (llamatransformer.go:297-384)
+        const int pos = p.st->pos + m;
+        const uint16_t mine = bf_trunc(acc[0]);
+        const uint16_t other = (uint16_t)__shfl_xor((int)mine, 1);       // RoPE partner (2i <-> 2i+1)
+        if (valid) {
+            if (n < p.q_dim + p.kv_dim) {
+                // applyRotaryEmbeddings (:753-790): complex64 product evaluated in f64, narrowed, truncated
+                const int d = n % p.head_dim, i = d >> 1;
+                const float2 cs = *(const float2*)(p.cis + ((size_t)pos * (p.head_dim >> 1) + i) * 2);
+                const double cr = (double)cs.x, ci = (double)cs.y;
+                uint16_t r16;
+                if ((n & 1) == 0) { double a = (double)bf_wide(mine), bb = (double)bf_wide(other); r16 = bf_trunc((float)(a * cr - bb * ci)); }
+                else              { double a = (double)bf_wide(other), bb = (double)bf_wide(mine); r16 = bf_trunc((float)(a * ci + bb * cr)); }
+                if (n < p.q_dim) p.q_out[(size_t)m * p.q_dim + n] = r16;
+                else p.cache_k[(size_t)pos * p.kv_dim + (n - p.q_dim)] = r16;         // :402
+            } else {
+                p.cache_v[(size_t)pos * p.kv_dim + (n - p.q_dim - p.kv_dim)] = mine;  // :403
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact attention for one (head, query row): scores -> /sqrt(hd) -> mask -> f64 softmax -> PV.
+// llamatransformer.go:409-514.  GQA head h reads KV head h/n_rep straight from the un-repeated cache
+// (attentionRepeatKV :529-559 and the four Transposes :435-449 become index arithmetic).
+// grid (H, S), block 256, dynamic LDS: [T f64 e][T f32 p][hd f32 q][8 B Z]
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_exact_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x;
+    const int h = blockIdx.x, i = blockIdx.y;
+    const int S = p.S, hd = p.hd, KVH = p.KVH;
+    const int pos0 = p.st->pos, T = pos0 + S;
+    const int kvh = h / (p.H / KVH);
+    double* e = (double*)smem;                                                      // carve == attn_lds_bytes()
+    float* pw = (float*)(smem + (size_t)p.seq_len * 8);
+    float* qf = (float*)((char*)pw + (((size_t)p.seq_len * 4 + 15) & ~(size_t)15));
+    double* zb = (double*)((char*)qf + (((size_t)hd * 4 + 15) & ~(size_t)15));
+
+    const uint16_t* q = p.q + ((size_t)i * p.H + h) * hd;
+    for (int d = tid; d < hd; d += 256) qf[d] = bf_wide(q[d]);
+    __syncthreads();
+
+    const size_t kvstride = (size_t)KVH * hd;
+    for (int j = tid; j < T; j += 256) {
+        const bool masked = (S > 1) && ((j % S) > i);        // triu(-inf,1) broadcast by modulo (tensoriterators.go:47-55)
+        double ev = 0.0;                                     // exp(-inf) == 0
+        if (!masked) {
+            const uint16_t* kr = p.cache_k + (size_t)j * kvstride + (size_t)kvh * hd;
+            float acc = 0.0f;
+            for (int d = 0; d < hd; d += 8) {                // MatMul q.k, d ascending (operations_matmul.go:37-55)
+                const uint4 kv = *(const uint4*)(kr + d);
+                const float4 xa = *(const float4*)(qf + d), xb = *(const float4*)(qf + d + 4);
+                acc = mac8(acc, xa, xb, kv);
+            }
+            uint16_t s = bf_trunc(acc);
+            s = bf_trunc(__fdiv_rn(bf_wide(s), p.divisor)); // DivToScalar :464
+            if (S > 1) s = bf_trunc(bf_wide(s) + 0.0f);      // Add(scores, mask) with mask==0 :469-473
+            ev = exp((double)bf_wide(s));                    // Softmax impl:498
+        }
+        e[j] = ev;
+    }
+    __syncthreads();
+    if (tid == 0) {                                          // rowExpSum += exp(...), j ascending, f64 (impl:492-499)
+        double z = 0.0;
+        for (int j = 0; j < T; j++) z += e[j];
+        zb[0] = z;
+    }
+    __syncthreads();
+    const double z = zb[0];
+    for (int j = tid; j < T; j += 256) pw[j] = bf_wide(bf_trunc((float)(e[j] / z)));   // impl:506 + ToBFloat16 :493
+    __syncthreads();
+
+    // PV: out[d] = trunc(sum_{j ascending} p_j * v[j,d]); each lane owns 2 adjacent d (2 chains)
+    if (tid < (hd >> 1)) {
+        const int d0 = tid * 2;
+        const uint16_t* vb = p.cache_v + (size_t)kvh * hd + d0;
+        float a0 = 0.0f, a1 = 0.0f;
+        // masked columns have p == +0: adding +-0 never changes a0/a1 (they are never -0), so with the
+        // standard causal layout (pos0 == 0) the chain can stop at the diagonal
+        const int Tend = (S > 1 && pos0 == 0) ? (i + 1) : T;
+#pragma unroll 8
+        for (int j = 0; j < Tend; j++) {
+            const uint32_t v = *(const uint32_t*)(vb + (size_t)j * kvstride);
+            const float pj = pw[j];
+            a0 = fmaf(pj, bf_lo(v), a0); a1 = fmaf(pj, bf_hi(v), a1);
+        }
+        uint32_t packed = (uint32_t)bf_trunc(a0) | ((uint32_t)bf_trunc(a1) << 16);
+        *(uint32_t*)(p.out + ((size_t)i * p.H + h) * hd + d0) = packed;   // [S, H*hd] (:508-514)
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// small kernels
+// ------------------------------------------------------------------------------------------------
+// Fwd_Get_Rows (operations_impl.go:142-173): byte copy of embedding rows
+__global__ void embed_kernel(const uint16_t* emb, const int32_t* tokens, uint16_t* x, int dim, int vocab, int* err) {
+    const int m = blockIdx.x;
+    const int t = tokens[m];
+    if (t < 0 || t >= vocab) { if (threadIdx.x == 0) atomicExch(err, 1 + m); return; }
+    const uint4* src = (const uint4*)(emb + (size_t)t * dim);
+    uint4* dst = (uint4*)(x + (size_t)m * dim);
+    for (int i = threadIdx.x; i < dim / 8; i += blockDim.x) dst[i] = src[i];
+}
+
+// ml.Argmax (operations_impl.go:513-548): strict '<' scan from -MaxFloat32 => first maximum wins, NaN and
+// -inf are never selected (index -1 if nothing qualifies).  Parallel form: max value, lowest index.
+// Also advances the device-resident greedy loop (inference.go:211-226): next token -> tokens[0], pos += 1.
+__global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, int V, int32_t* next_token, StepState* st,
+                                                      int32_t* out_tokens, int out_cap, int advance) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    const int tid = threadIdx.x;
+    float best = -3.40282346638528859811704183484516925440e+38f; int bi = -1;
+    for (int j = tid; j < V; j += 1024) { float v = bf_wide(logits[j]); if (best < v) { best = v; bi = j; } }
+    sv[tid] = best; si[tid] = bi;
+    __syncthreads();
+    for (int s = 512; s > 0; s >>= 1) {
+        if (tid < s) {
+            float v2 = sv[tid + s]; int i2 = si[tid + s];
+            float v1 = sv[tid]; int i1 = si[tid];
+            bool take = (i2 >= 0) && (i1 < 0 || v1 < v2 || (v1 == v2 && i2 < i1));
+            if (take) { sv[tid] = v2; si[tid] = i2; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        const int tok = si[0];
+        next_token[0] = tok;
+        if (advance) {
+            int n = st->n_out;
+            if (n < out_cap) out_tokens[n] = tok;
+            st->n_out = n + 1;
+            st->pos = st->pos + 1;
+        }
+    }
+}
+
+__global__ void set_state_kernel(StepState* st, int pos, int n_out) { st->pos = pos; st->n_out = n_out; }
+
+// ---- weight re-tiling (load time, once) ------------------------------------------------------------
+__global__ void tile_scatter_kernel(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;          // one thread per 8-element chunk
+    size_t total = (size_t)rows * (K >> 3);
+    if (idx >= total) return;
+    int r = (int)(idx / (K >> 3)), kc = (int)(idx % (K >> 3));
+    uint4 v = *(const uint4*)(src + (size_t)r * K + (size_t)kc * 8);
+    *(uint4*)(dst + tiled_index(row_off + r, kc * 8, chain, K, RW, NCH)) = v;
+}
+__global__ void tile_gather_kernel(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)rows * (K >> 3);
+    if (idx >= total) return;
+    int r = (int)(idx / (K >> 3)), kc = (int)(idx % (K >> 3));
+    uint4 v = *(const uint4*)(src + tiled_index(row_off + r, kc * 8, chain, K, RW, NCH));
+    *(uint4*)(dst + (size_t)r * K + (size_t)kc * 8) = v;
+}
+// synthetic weights straight into their final layout (RW == 0: linear row-major)
+__global__ void synth_fill_kernel(uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH,
+                                  uint64_t base, int kind, float sigma) {
+    size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)rows * K;
+    if (idx >= total) return;
+    int r = (int)(idx / K), k = (int)(idx % K);
+    float g = (float)lnb_synth_isum(base, idx) * (1.0f / 53510.0f);
+    float v = kind == 1 ? fmaf(0.1f, g, 1.0f) : sigma * g;
+    size_t o = RW ? tiled_index(row_off + r, k, chain, K, RW, NCH) : idx;
+    dst[o] = bf_trunc(v);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host-side launchers (called from lnb_api.cpp)
+// ------------------------------------------------------------------------------------------------
+template <int RW, int NCH, int SB, int D, int EPI, bool NORM>
+static hipError_t launch_gemv_t(const GemvParams* p, int n_blocks, hipStream_t st) {
+    auto kfn = gemv_exact_kernel<RW, NCH, SB, D, EPI, NORM>;
+    if (!p)   // prepare: raise the dynamic-LDS limit once, outside any stream capture
+        return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    size_t lds = (size_t)D * SB + (size_t)p->K * 4 + 16;
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * n_blocks)), dim3(128), lds, st, *p);
+    return hipGetLastError();
+}
+
+template <int EPI, bool NORM, int NCH>
+static hipError_t launch_gemv_rw(const GemvParams* p, int rw, int n_blocks, hipStream_t st) {
+    // ring geometry.  thin blocks (RW 16/32, chain/latency bound): 8 x 8 KiB slots = 56 KiB in flight per CU,
+    // the depth a 16-row workgroup needs to keep its share of HBM busy.  1 KiB-per-chunk blocks (RW=64, or
+    // RW=32 with two chains; HBM bound, many workgroups per CU): 4 x 16 KiB slots, 48 KiB in flight.
+    if (rw == 16) return launch_gemv_t<16, NCH, 8192, 8, EPI, NORM>(p, n_blocks, st);
+    if (rw == 32) return NCH == 2 ? launch_gemv_t<32, NCH, 16384, 4, EPI, NORM>(p, n_blocks, st)
+                                  : launch_gemv_t<32, NCH, 8192, 8, EPI, NORM>(p, n_blocks, st);
+    if (rw == 64) return launch_gemv_t<64, NCH, 16384, 4, EPI, NORM>(p, n_blocks, st);
+    return hipErrorInvalidValue;
+}
+
+extern "C" hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, int n_blocks, hipStream_t st) {
+    if (nch == 2) {
+        if (epi == EPI_SILU_MUL && norm) return launch_gemv_rw<EPI_SILU_MUL, true, 2>(p, rw, n_blocks, st);
+        return hipErrorInvalidValue;
+    }
+    switch (epi) {
+        case EPI_STORE: return norm ? launch_gemv_rw<EPI_STORE, true, 1>(p, rw, n_blocks, st) : launch_gemv_rw<EPI_STORE, false, 1>(p, rw, n_blocks, st);
+        case EPI_QKV_ROPE: return norm ? launch_gemv_rw<EPI_QKV_ROPE, true, 1>(p, rw, n_blocks, st) : hipErrorInvalidValue;
+        case EPI_RESID: return norm ? hipErrorInvalidValue : launch_gemv_rw<EPI_RESID, false, 1>(p, rw, n_blocks, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+static size_t attn_lds_bytes(int seq_len, int hd) {
+    return (size_t)seq_len * 8 + (((size_t)seq_len * 4 + 15) & ~(size_t)15) + (((size_t)hd * 4 + 15) & ~(size_t)15) + 16;
+}
+extern "C" hipError_t lnbk_init(void) {
+    static bool done = false;
+    if (done) return hipSuccess;
+    const int rws[3] = {16, 32, 64};
+    for (int i = 0; i < 3; i++) {
+        hipError_t e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_STORE, 1, 0, nullptr)) != hipSuccess) return e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_STORE, 0, 0, nullptr)) != hipSuccess) return e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_QKV_ROPE, 1, 0, nullptr)) != hipSuccess) return e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_RESID, 0, 0, nullptr)) != hipSuccess) return e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 2, EPI_SILU_MUL, 1, 0, nullptr)) != hipSuccess) return e;
+    }
+    hipError_t e = hipFuncSetAttribute((const void*)attn_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    done = true;
+    return hipSuccess;
+}
+
+extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
+    size_t lds = attn_lds_bytes(p->seq_len, p->hd);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(attn_exact_kernel, dim3(p->H, p->S), dim3(256), lds, st, *p);
+    return hipGetLastError();
+}
+
+extern "C" hipError_t lnbk_embed(const uint16_t* emb, const int32_t* tokens, uint16_t* x, int S, int dim, int vocab, int* err, hipStream_t st) {
+    hipLaunchKernelGGL(embed_kernel, dim3(S), dim3(256), 0, st, emb, tokens, x, dim, vocab, err);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_token, StepState* state, int32_t* out_tokens,
+                                  int out_cap, int advance, hipStream_t st) {
+    hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, V, next_token, state, out_tokens, out_cap, advance);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st) {
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, state, pos, n_out);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_tile(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, int gather, hipStream_t st) {
+    size_t total = (size_t)rows * (K >> 3);
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    if (gather) hipLaunchKernelGGL(tile_gather_kernel, dim3(blocks), dim3(256), 0, st, src, dst, rows, K, row_off, chain, RW, NCH);
+    else hipLaunchKernelGGL(tile_scatter_kernel, dim3(blocks), dim3(256), 0, st, src, dst, rows, K, row_off, chain, RW, NCH);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_synth_fill(uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH,
+                                      uint64_t seed, uint32_t tensor_id, int kind, float sigma, hipStream_t st) {
+    uint64_t base = lnb_splitmix64(seed + 0x9E3779B97F4A7C15ULL * (uint64_t)(tensor_id + 1u));
+    size_t total = (size_t)rows * K;
+    unsigned blocks = (unsigned)((total + 255) / 256);
+    hipLaunchKernelGGL(synth_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, rows, K, row_off, chain, RW, NCH, base, kind, sigma);
+    return hipGetLastError();
+}

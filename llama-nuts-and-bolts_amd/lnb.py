@@ -1,0 +1,248 @@
+"""ctypes plumbing over liblnb_hip.so (the C ABI of include/lnb.h) for tests and bench.py.
+
+This is NOT a compute path: every call goes straight into the HIP library.  There is no CPU
+fallback -- if the shared library is missing or no MI355X is visible, the calls raise.
+Names mirror the reference's Go API (src/model: LlamaTransformer / InferenceContext,
+src/inference: InferenceEngine) so the parity tests read like the reference's own tests.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liblnb_hip.so")
+_CSRC = os.path.join(_HERE, "csrc")
+
+
+class LnbError(RuntimeError):
+    pass
+
+
+def build(force=False):
+    """hipcc --offload-arch=gfx950 build of the library, in-tree (the .so travels with the repo snapshot)."""
+    srcs = [os.path.join(_CSRC, f) for f in ("lnb_kernels.hip", "lnb_api.cpp", "lnb_device.h", "Makefile")]
+    srcs.append(os.path.join(_HERE, "..", "include", "lnb.h"))
+    if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
+        subprocess.check_call(["make", "-C", _CSRC, "-s"])
+    return _SO
+
+
+class ModelArgs(C.Structure):
+    """model.ModelArgs (src/model/modelargs.go:12-27)"""
+    _fields_ = [("dim", C.c_int32), ("n_layers", C.c_int32), ("n_heads", C.c_int32), ("n_kv_heads", C.c_int32),
+                ("vocab_size", C.c_int32), ("multiple_of", C.c_int32), ("ffn_dim_multiplier", C.c_double),
+                ("norm_eps", C.c_float), ("use_scaled_rope", C.c_int32), ("rope_theta", C.c_double),
+                ("max_seq_len", C.c_int32)]
+
+
+LLAMA_8B = dict(dim=4096, n_layers=32, n_heads=32, n_kv_heads=8, vocab_size=128256, multiple_of=1024,
+                ffn_dim_multiplier=1.3, norm_eps=1e-5, use_scaled_rope=1, rope_theta=500000.0, max_seq_len=2048)
+
+_lib = None
+EXPORTS = [
+    "lnb_last_error", "lnb_device_count", "lnb_model_create", "lnb_model_destroy", "lnb_model_ffn_hidden_dim",
+    "lnb_model_set_tensor", "lnb_model_get_tensor", "lnb_model_fill_synthetic", "lnb_model_finalize",
+    "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
+    "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
+    "lnb_forward_stage", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear",
+]
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise LnbError("liblnb_hip.so is not built (run __graft_entry__.build()); there is no fallback path")
+    L = C.CDLL(_SO)
+    vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    L.lnb_last_error.restype = C.c_char_p
+    L.lnb_device_count.argtypes = [C.POINTER(C.c_int)]
+    L.lnb_model_create.argtypes = [C.POINTER(ModelArgs), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.lnb_model_destroy.argtypes = [vp]
+    L.lnb_model_ffn_hidden_dim.argtypes = [C.POINTER(ModelArgs)]
+    L.lnb_model_set_tensor.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int]
+    L.lnb_model_get_tensor.argtypes = [vp, C.c_char_p, vp, C.c_int64]
+    L.lnb_model_fill_synthetic.argtypes = [vp, C.c_uint64]
+    L.lnb_model_finalize.argtypes = [vp, C.c_int]
+    L.lnb_model_rope_table.argtypes = [vp, vp, C.c_int64, C.POINTER(C.c_int)]
+    L.lnb_model_weight_bytes.argtypes = [vp]
+    L.lnb_model_weight_bytes.restype = C.c_int64
+    L.lnb_ctx_create.argtypes = [vp, C.c_int, C.POINTER(vp)]
+    L.lnb_ctx_destroy.argtypes = [vp]
+    L.lnb_ctx_reset.argtypes = [vp]
+    L.lnb_ctx_read_kv.argtypes = [vp, C.c_int, C.c_int, vp]
+    L.lnb_ctx_set_layer_callback.argtypes = [vp, vp, vp]
+    L.lnb_forward.argtypes = [vp, vp, C.c_int, C.c_int, vp, i32p]
+    L.lnb_decode_greedy.argtypes = [vp, C.c_int32, C.c_int, C.c_int, vp, f32p]
+    L.lnb_ctx_hidden_ptr.argtypes = [vp, C.c_int]
+    L.lnb_ctx_hidden_ptr.restype = vp
+    L.lnb_forward_stage.argtypes = [vp, vp, C.c_int, C.c_int, vp, i32p]
+    L.lnb_ctx_synchronize.argtypes = [vp]
+    L.lnb_ctx_stream.argtypes = [vp]
+    L.lnb_ctx_stream.restype = vp
+    L.lnb_op_linear.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lnb_op_rmsnorm_linear.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    _lib = L
+    return L
+
+
+def _chk(rc):
+    if rc != 0:
+        raise LnbError(lib().lnb_last_error().decode())
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def device_count():
+    n = C.c_int(0)
+    _chk(lib().lnb_device_count(C.byref(n)))
+    return n.value
+
+
+class LlamaTransformer:
+    """Device-resident model (one pipeline stage): model.NewLlamaTransformer, llamatransformer.go:64-113."""
+
+    def __init__(self, device=0, layer_begin=0, layer_end=None, **kw):
+        d = dict(LLAMA_8B)
+        d.update(kw)
+        self.args = ModelArgs(**d)
+        self.L = lib()
+        self.h = C.c_void_p()
+        self.layer_begin = layer_begin
+        self.layer_end = self.args.n_layers if layer_end is None else layer_end
+        _chk(self.L.lnb_model_create(C.byref(self.args), device, self.layer_begin, self.layer_end, C.byref(self.h)))
+        self.ffn_hidden = self.L.lnb_model_ffn_hidden_dim(C.byref(self.args))
+        self.head_dim = self.args.dim // self.args.n_heads
+
+    def set_tensor(self, name, arr_u16, shape=None):
+        a = np.ascontiguousarray(arr_u16, dtype=np.uint16)
+        shp = tuple(shape) if shape is not None else a.shape
+        s = (C.c_int64 * len(shp))(*shp)
+        _chk(self.L.lnb_model_set_tensor(self.h, name.encode(), _p(a), s, len(shp)))
+
+    def get_tensor(self, name, nelem):
+        out = np.empty(nelem, dtype=np.uint16)
+        _chk(self.L.lnb_model_get_tensor(self.h, name.encode(), _p(out), nelem))
+        return out
+
+    def fill_synthetic(self, seed=1234):
+        _chk(self.L.lnb_model_fill_synthetic(self.h, seed))
+        return self
+
+    def finalize(self, rope_rows=0):
+        _chk(self.L.lnb_model_finalize(self.h, rope_rows))
+        return self
+
+    @property
+    def PrecomputedFreqsCis(self):
+        rows = C.c_int(0)
+        _chk(self.L.lnb_model_rope_table(self.h, None, 0, C.byref(rows)))
+        out = np.empty((rows.value, self.head_dim // 2, 2), dtype=np.float32)
+        _chk(self.L.lnb_model_rope_table(self.h, _p(out), out.size, C.byref(rows)))
+        return out
+
+    def weight_bytes(self):
+        return int(self.L.lnb_model_weight_bytes(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.lnb_model_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class InferenceContext:
+    """model.NewInferenceContext (inferencecontext.go:17-46): device KV cache for one generation."""
+
+    def __init__(self, transformer, seq_len):
+        self.t, self.L = transformer, transformer.L
+        self.SequenceLength = seq_len
+        self.h = C.c_void_p()
+        _chk(self.L.lnb_ctx_create(transformer.h, seq_len, C.byref(self.h)))
+
+    def Forward(self, tokens, start_pos, want_logits=True):
+        """(*LlamaTransformer).Forward (llamatransformer.go:145-180) -> (logits f32 [S,V] | None, argmax of last row)."""
+        tok = np.ascontiguousarray(tokens, dtype=np.int32)
+        S, V = tok.size, self.t.args.vocab_size
+        logits = np.empty((S, V), dtype=np.float32) if want_logits else None
+        am = C.c_int32(-2)
+        _chk(self.L.lnb_forward(self.h, _p(tok), S, start_pos, _p(logits) if want_logits else None, C.byref(am)))
+        return logits, am.value
+
+    def decode_greedy(self, token, start_pos, n_steps):
+        out = np.empty(n_steps, dtype=np.int32)
+        ms = C.c_float(0)
+        _chk(self.L.lnb_decode_greedy(self.h, int(token), start_pos, n_steps, _p(out), C.byref(ms)))
+        return out, ms.value
+
+    def CacheK(self, layer):
+        return self._kv(layer, 0)
+
+    def CacheV(self, layer):
+        return self._kv(layer, 1)
+
+    def _kv(self, layer, which):
+        a = self.t.args
+        out = np.empty((self.SequenceLength, a.n_kv_heads, self.t.head_dim), dtype=np.uint16)
+        _chk(self.L.lnb_ctx_read_kv(self.h, layer, which, _p(out)))
+        return out
+
+    def reset(self):
+        _chk(self.L.lnb_ctx_reset(self.h))
+
+    def close(self):
+        if self.h:
+            self.L.lnb_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class InferenceEngine:
+    """Greedy generation loop of src/inference/inference.go:173-254 over the device path:
+    prefill(prompt) through Forward, then the decode steps as hipGraph replays on the device."""
+
+    def __init__(self, transformer, seq_len, stop_token_ids=()):
+        self.t, self.seq_len, self.stop = transformer, seq_len, set(stop_token_ids)
+
+    def GenerateTokens(self, prompt_tokens, max_new=None):
+        prompt = list(prompt_tokens)
+        if len(prompt) >= self.seq_len:
+            raise LnbError("context SequenceLength %d must be higher than prompt tokens length %d" % (self.seq_len, len(prompt)))
+        ctx = InferenceContext(self.t, self.seq_len)
+        try:
+            n_new = self.seq_len - len(prompt) if max_new is None else min(max_new, self.seq_len - len(prompt))
+            _, first = ctx.Forward(prompt, 0, want_logits=False)
+            out = [first]
+            if first not in self.stop and n_new > 1:
+                more, _ = ctx.decode_greedy(first, len(prompt), n_new - 1)
+                for t in more:
+                    out.append(int(t))
+                    if int(t) in self.stop:
+                        break
+            return out
+        finally:
+            ctx.close()
+
+
+def op_linear(x_u16, w_u16, rw=0, device=0):
+    x = np.ascontiguousarray(x_u16, dtype=np.uint16)
+    w = np.ascontiguousarray(w_u16, dtype=np.uint16)
+    rows, k = x.shape
+    n = w.shape[0]
+    y = np.empty((rows, n), dtype=np.uint16)
+    _chk(lib().lnb_op_linear(device, _p(x), _p(w), _p(y), rows, n, k, rw))
+    return y
+
+
+def op_rmsnorm_linear(x_u16, norm_w_u16, eps, w_u16, rw=0, device=0):
+    x = np.ascontiguousarray(x_u16, dtype=np.uint16)
+    w = np.ascontiguousarray(w_u16, dtype=np.uint16)
+    nw = np.ascontiguousarray(norm_w_u16, dtype=np.uint16)
+    rows, k = x.shape
+    n = w.shape[0]
+    y = np.empty((rows, n), dtype=np.uint16)
+    _chk(lib().lnb_op_rmsnorm_linear(device, _p(x), _p(nw), np.float32(eps), _p(w), _p(y), rows, n, k, rw))
+    return y

@@ -1,0 +1,57 @@
+"""CPU-side checks of the drop-in boundary: liblnb_hip.so builds for gfx950, loads without a GPU, exports every
+symbol include/lnb.h declares, and fails LOUDLY (no CPU fallback) when no MI355X is present."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lnb():
+    import lnb as _lnb
+    _lnb.build()
+    return _lnb
+
+
+def declared_symbols():
+    src = open(os.path.join(ROOT, "include", "lnb.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(lnb_[a-z0-9_]+)\s*\(", src)) - {"lnb_layer_cb"})
+
+
+def test_header_symbols_are_exported(lnb):
+    L = C.CDLL(os.path.join(ROOT, "llama-nuts-and-bolts_amd", "liblnb_hip.so"))
+    names = declared_symbols()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(L, n), "missing export %s" % n
+    assert set(names) == set(lnb.EXPORTS)
+
+
+def test_no_cpu_fallback(lnb):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(lnb.LnbError):
+        lnb.LlamaTransformer(dim=256, n_layers=1, n_heads=4, n_kv_heads=2, vocab_size=64, multiple_of=64)
+    import numpy as np
+    with pytest.raises(lnb.LnbError):
+        lnb.op_linear(np.zeros((1, 8), dtype=np.uint16), np.zeros((4, 8), dtype=np.uint16))
+
+
+def test_product_never_references_the_oracle():
+    pkg = os.path.join(ROOT, "llama-nuts-and-bolts_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", ".go", "Makefile")):
+                txt = open(os.path.join(dirpath, f), errors="ignore").read()
+                assert "oracle/" not in txt.replace("oracle/lnb_oracle.c; spec", "") or f == "lnb_device.h", (dirpath, f)
+                assert "import oracle" not in txt and "from oracle" not in txt, (dirpath, f)
+
+
+def test_ffn_hidden_dim_matches_reference_formula(lnb):
+    a = lnb.ModelArgs(**lnb.LLAMA_8B)
+    assert lnb.lib().lnb_model_ffn_hidden_dim(C.byref(a)) == 14336            # llamatransformer.go:569-577
