@@ -113,6 +113,12 @@ int lnb_ctx_synchronize(lnb_ctx* c);
 /* raw HIP stream (hipStream_t) the ctx enqueues on, for event timing by the caller */
 void* lnb_ctx_stream(lnb_ctx* c);
 
+/* ---- measurement aid (bench.py roofline leg): average HIP-event time of ONE kernel class of the decode step.
+ * which: 0 attn_norm+QKV+RoPE GEMV, 1 attention, 2 wo GEMV, 3 ffn_norm+w1|w3 GEMV, 4 w2 GEMV, 5 norm+output GEMV,
+ * 6 the five kernels of a whole block.  Consecutive launches cycle through this stage's layers so every launch
+ * streams its weights from HBM instead of the 256 MiB Infinity Cache.  The KV cache content at `pos` is overwritten. */
+int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, float* avg_ms_out);
+
 /* ---- single-op entry points (the src/ml operators on the hot path), used by the parity tests --------
  * y[rows,n] = trunc(sum_k x[rows,k]*w[n,k])  == ml.LinearTransformation (operations_impl.go:427-447);
  * host buffers in the reference layout; rw in {0(auto),16,32,64} selects the tiling */

@@ -379,37 +379,44 @@ extern "C" void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which) { (void)which; return
 extern "C" void* lnb_ctx_stream(lnb_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int lnb_ctx_synchronize(lnb_ctx* c) { if (!c) return fail("null argument"); HIPCHK(hipSetDevice(c->m->device)); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
 
-// ---- one pass over this stage's layers for S rows; position comes from c->st on the device ----------
-static int enqueue_layers(lnb_ctx* c, int S, bool with_cb) {
+// ---- the five launches of one transformer block (position comes from c->st on the device) -----------
+enum { K_QKV = 0, K_ATTN = 1, K_WO = 2, K_W13 = 3, K_W2 = 4, K_HEAD = 5, K_LAYER = 6 };
+static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = c->stream;
-    const float divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));   // llamatransformer.go:464
-    for (int l = m->layer_begin; l < m->layer_end; l++) {
-        LayerW& L = m->layers[l - m->layer_begin];
-        auto t0 = std::chrono::steady_clock::now();
-        GemvParams g{};
-        // attn_norm + wq|wk|wv + RoPE + KV append  (llamatransformer.go:222, :297-403)
-        g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
-        g.cis = m->cis; g.q_out = c->q; g.cache_k = c->ck[l - m->layer_begin]; g.cache_v = c->cv[l - m->layer_begin];
-        g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
-        HIPCHK(lnbk_gemv(&g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, L.wqkv.n_blocks, st));
-        // scores / softmax / PV  (:409-514)
-        AttnParams ap{}; ap.q = c->q; ap.cache_k = g.cache_k; ap.cache_v = g.cache_v; ap.out = c->att; ap.st = c->st;
-        ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len; ap.divisor = divisor;
-        HIPCHK(lnbk_attn(&ap, st));
-        // wo + residual  (:522, :232)
+    LayerW& L = m->layers[l - m->layer_begin];
+    uint16_t* ck = c->ck[l - m->layer_begin]; uint16_t* cv = c->cv[l - m->layer_begin];
+    switch (which) {
+    case K_QKV: {   // attn_norm + wq|wk|wv + RoPE + KV append  (llamatransformer.go:222, :297-403)
+        GemvParams g{}; g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
+        g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
+        HIPCHK(lnbk_gemv(&g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, L.wqkv.n_blocks, st)); return 0; }
+    case K_ATTN: {  // scores / softmax / PV  (:409-514)
+        AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st;
+        ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len;
+        ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
+        HIPCHK(lnbk_attn(&ap, st)); return 0; }
+    case K_WO: {    // wo + residual  (:522, :232)
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = c->h; o.res = c->x;
-        HIPCHK(lnbk_gemv(&o, L.wo.rw, 1, EPI_RESID, 0, L.wo.n_blocks, st));
-        // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
+        HIPCHK(lnbk_gemv(&o, L.wo.rw, 1, EPI_RESID, 0, L.wo.n_blocks, st)); return 0; }
+    case K_W13: {   // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
         GemvParams f{}; f.w = L.w13.w; f.x = c->h; f.norm_w = L.ffn_norm; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
         f.out = c->ffn; f.silu = m->silu;
-        HIPCHK(lnbk_gemv(&f, L.w13.rw, 2, EPI_SILU_MUL, 1, L.w13.n_blocks, st));
-        // w2 + residual  (:619, :248)
+        HIPCHK(lnbk_gemv(&f, L.w13.rw, 2, EPI_SILU_MUL, 1, L.w13.n_blocks, st)); return 0; }
+    case K_W2: {    // w2 + residual  (:619, :248)
         GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = c->h;
-        HIPCHK(lnbk_gemv(&d, L.w2.rw, 1, EPI_RESID, 0, L.w2.n_blocks, st));
+        HIPCHK(lnbk_gemv(&d, L.w2.rw, 1, EPI_RESID, 0, L.w2.n_blocks, st)); return 0; }
+    }
+    return fail("bad kernel id");
+}
+static int enqueue_layers(lnb_ctx* c, int S, bool with_cb) {
+    lnb_model* m = c->m;
+    for (int l = m->layer_begin; l < m->layer_end; l++) {
+        auto t0 = std::chrono::steady_clock::now();
+        for (int k = K_QKV; k <= K_W2; k++) if (enqueue_layer_kernel(c, l, S, k)) return -1;
         if (with_cb && c->cb) {
-            HIPCHK(hipStreamSynchronize(st));
+            HIPCHK(hipStreamSynchronize(c->stream));
             double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-            c->cb(l + 1, a.n_layers, secs, c->cb_user);                       // llamatransformer.go:163
+            c->cb(l + 1, m->a.n_layers, secs, c->cb_user);                    // llamatransformer.go:163
         }
     }
     return 0;
@@ -525,6 +532,34 @@ extern "C" int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
     int err = 0; HIPCHK(hipMemcpy(&err, c->derr, 4, hipMemcpyDeviceToHost));
     if (err) return fail("generated token id is outside the vocabulary");
+    return 0;
+}
+
+extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, float* avg_ms_out) {
+    if (!c || !avg_ms_out) return fail("null argument");
+    lnb_model* m = c->m;
+    HIPCHK(hipSetDevice(m->device));
+    if (iters <= 0 || which < 0 || which > K_LAYER) return fail("bad arguments");
+    if (check_call(c, 1, pos)) return -1;
+    if (which == K_HEAD && !m->last()) return fail("this stage does not own output.weight");
+    hipStream_t st = c->stream;
+    HIPCHK(lnbk_set_state(c->st, pos, 0, st));
+    const int nl = m->layer_end - m->layer_begin;
+    // consecutive launches walk through the layers so that every launch streams its weights from HBM
+    // (one layer's 235 MB gate/up matrix would otherwise sit in the 256 MiB Infinity Cache)
+    auto run = [&](int i) -> int {
+        int l = m->layer_begin + (i % nl);
+        if (which == K_HEAD) return enqueue_head(c, 0, 1);
+        if (which == K_LAYER) { for (int k = K_QKV; k <= K_W2; k++) if (enqueue_layer_kernel(c, l, 1, k)) return -1; return 0; }
+        return enqueue_layer_kernel(c, l, 1, which);
+    };
+    for (int i = 0; i < 3; i++) if (run(i)) return -1;
+    HIPCHK(hipEventRecord(c->ev0, st));
+    for (int i = 0; i < iters; i++) if (run(i + 3)) return -1;
+    HIPCHK(hipEventRecord(c->ev1, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms_out = ms / (float)iters;
     return 0;
 }
 

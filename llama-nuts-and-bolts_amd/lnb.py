@@ -47,6 +47,7 @@ EXPORTS = [
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
     "lnb_forward_stage", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear",
+    "lnb_profile_kernel",
 ]
 
 
@@ -83,6 +84,7 @@ def lib():
     L.lnb_ctx_synchronize.argtypes = [vp]
     L.lnb_ctx_stream.argtypes = [vp]
     L.lnb_ctx_stream.restype = vp
+    L.lnb_profile_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p]
     L.lnb_op_linear.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_op_rmsnorm_linear.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     _lib = L
@@ -179,6 +181,11 @@ class InferenceContext:
         _chk(self.L.lnb_decode_greedy(self.h, int(token), start_pos, n_steps, _p(out), C.byref(ms)))
         return out, ms.value
 
+    def profile_kernel(self, which, pos, iters):
+        ms = C.c_float(0)
+        _chk(self.L.lnb_profile_kernel(self.h, which, pos, iters, C.byref(ms)))
+        return ms.value
+
     def CacheK(self, layer):
         return self._kv(layer, 0)
 
@@ -246,3 +253,18 @@ def op_rmsnorm_linear(x_u16, norm_w_u16, eps, w_u16, rw=0, device=0):
     y = np.empty((rows, n), dtype=np.uint16)
     _chk(lib().lnb_op_rmsnorm_linear(device, _p(x), _p(nw), np.float32(eps), _p(w), _p(y), rows, n, k, rw))
     return y
+
+
+_M64 = (1 << 64) - 1
+
+
+def _splitmix64(z):
+    z = (z + 0x9E3779B97F4A7C15) & _M64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & _M64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & _M64
+    return z ^ (z >> 31)
+
+
+def synth_tokens(seed, n, vocab):
+    """Synthetic prompt of DESIGN.md ("Synthetic weights"): tok[i] = splitmix64(seed ^ i*golden) mod vocab."""
+    return np.array([_splitmix64(seed ^ ((i * 0x9E3779B97F4A7C15) & _M64)) % vocab for i in range(n)], dtype=np.int32)
