@@ -83,7 +83,10 @@ static int env_int(const char* name, int dflt) { const char* s = getenv(name); r
 static int auto_rw(int lane_rows, const char* env) {
     int v = env_int(env, 0);
     if (v == 16 || v == 32 || v == 64) return v;
-    if (lane_rows <= 8192) return 16;       // thin: spread the rows over all 256 CUs
+    // thin matrices: one workgroup (16 or 32 rows) per CU, all resident at once on the 256 CUs -- a second round of
+    // workgroups would double the serial chain time
+    if (lane_rows <= 16 * 256) return 16;
+    if (lane_rows <= 32 * 256) return 32;
     if (lane_rows <= 32768) return 32;
     return 64;
 }
@@ -575,7 +578,7 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     HIPCHK(lnbk_init());
     if (rw == 0) rw = auto_rw(n_out, "LNB_RW_OP");
     if (rw != 16 && rw != 32 && rw != 64) return fail("rw must be 16, 32 or 64");
-    if ((size_t)k_in * 4 + 2 * 16384 + 64 > 160 * 1024) return fail("in_features %d does not fit the LDS staging", k_in);
+    if ((size_t)k_in * 4 > 120 * 1024) return fail("in_features %d does not fit the LDS staging", k_in);
     TiledDesc t{}; int64_t bytes = 0;
     if (alloc_tiled(t, n_out, k_in, rw, 1, bytes)) return -1;
     uint16_t *dx = nullptr, *dw = nullptr, *dy = nullptr, *dn = nullptr; StepState* st = nullptr;

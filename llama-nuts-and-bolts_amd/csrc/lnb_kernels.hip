@@ -21,6 +21,7 @@
 // Compile with -ffp-contract=off: every a*b+c below is either an explicit fmaf (product exact) or
 // must stay two roundings.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include "lnb_device.h"
 
 #define DEVINL __device__ __forceinline__
@@ -47,137 +48,120 @@ DEVINL float mac8(float acc, const float4& xa, const float4& xb, const uint4& w)
 }
 
 // ------------------------------------------------------------------------------------------------
-// Exact-order streaming GEMV / skinny GEMM:   y[m, n] = trunc( sum_{k ascending} x[m,k] * W[n,k] )
-// workgroup = 128 threads: wave 0 = consumer (RW lanes active, NCH chains per lane),
-//                          wave 1 = loader  (LDS-DMA: global_load_lds_dwordx4, 1 KiB per instruction).
-// The loader keeps D-1 stages of STAGE_BYTES in flight into a D-slot LDS ring with COUNTED
-// s_waitcnt vmcnt(N) (never 0 in steady state) and hands stages over with one raw s_barrier each:
-//     loader  it: wait(stage it landed) ; barrier B_it ; issue stage it+D-1 into the slot freed by it-1
-//     consumer it:                        barrier B_it ; walk stage it
-// grid.x = S * n_blocks  (m fastest so that the S workgroups sharing a weight block run together)
-// dynamic LDS: [D*STAGE_BYTES ring][K f32 x][16 B scratch]   (one array: a second __shared__ object
-// would make hipcc drain vmcnt before every ds_read)
+// The serial chains.  Measured on gfx950 (tools/microbench.hip, profiles/): ONE wave issues one
+// instruction per ~4.4 cycles whatever it is, and a dependent v_add_f32 / v_fmac_f32 costs 4.33
+// cycles, so a k-ordered chain runs at its latency floor only if the wave that owns it executes ~1
+// instruction per k step.  bf16*bf16 products are EXACT in f32, so the chain is split by role:
+//   helper waves (other SIMDs of the CU) unpack the bf16 weights, multiply by x and leave the exact f32
+//   products in LDS;  the chain wave only does  acc = acc + p_k  (one v_add_f32 per step, operands
+//   fetched 4 steps per ds_read_b128), with all 64 lanes active (a partially masked wave issues slower).
+// mul-then-add is also literally what the reference does (operations_lineartransform.go:60-64).
 // ------------------------------------------------------------------------------------------------
+DEVINL float add4(float acc, const float4& p) { acc += p.x; acc += p.y; acc += p.z; acc += p.w; return acc; }
+// zero-instruction "use" of 16 loaded registers: makes hipcc place ONE counted s_waitcnt lgkmcnt(N) for the whole
+// group (LDS returns in order) instead of one wait per ds_read_b128 result in front of the adds
+DEVINL void touch16(const float4& a, const float4& b, const float4& c, const float4& d) {
+    asm volatile("" ::"v"(a.x), "v"(a.y), "v"(a.z), "v"(a.w), "v"(b.x), "v"(b.y), "v"(b.z), "v"(b.w),
+                 "v"(c.x), "v"(c.y), "v"(c.z), "v"(c.w), "v"(d.x), "v"(d.y), "v"(d.z), "v"(d.w));
+}
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+DEVINL float4 mul4(const float4& x, float w0, float w1, float w2, float w3) {   // packed f32 multiplies (exact products)
+    f32x2 a = {x.x, x.y}, b = {x.z, x.w}, u = {w0, w1}, v = {w2, w3};
+    a = a * u; b = b * v;
+    return make_float4(a.x, a.y, b.x, b.y);
+}
+
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 #define WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
-template <int RW, int NCH, int STAGE_BYTES, int D, int EPI, bool NORM>
-__global__ __launch_bounds__(128) void gemv_exact_kernel(GemvParams p) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LPS = STAGE_BYTES / 1024;                // 1 KiB LDS-DMA instructions per stage
-    constexpr int KC = STAGE_BYTES / (NCH * RW * 16);      // 8-wide k chunks per stage
-    static_assert(LPS >= 1 && KC >= 1 && (D & (D - 1)) == 0 && D >= 2, "bad stage geometry");
-    static_assert((D - 1) * LPS <= 60, "vmcnt is a 6-bit counter");
-    char* ring = smem;
-    float* xs = (float*)(smem + D * STAGE_BYTES);
-    float* scratch = xs + p.K;
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-    const int K = p.K, S = p.S;
-    const int m = (S == 1) ? 0 : (int)(blockIdx.x % (unsigned)S);
-    const int b = (S == 1) ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)S);
-
-    const size_t stream_bytes = (size_t)K * NCH * RW * 2;
-    const char* wstream = (const char*)p.w + (size_t)b * stream_bytes;
-    const int nstages = (int)((stream_bytes + STAGE_BYTES - 1) / STAGE_BYTES);
-
-    if (wave == 1) {
-        // ================================ loader wave =============================================
-        const size_t last16 = stream_bytes - 16;           // clamp: never read past this block's stream
-        auto issue_stage = [&](int stage) {
-            char* dst = ring + (stage & (D - 1)) * STAGE_BYTES;
+// x row -> LDS as f32, zero padded up to kpad (a whole number of stages + 64 floats of slack, so the
+// software-pipelined readers may run one group ahead), optionally through the fused RMSNorm.
+// Executed by ONE wave (the consumer); xs is private to it.
+template <bool NORM>
+DEVINL void stage_x(const GemvParams& p, const uint16_t* xrow, float* xs, int kpad, int lane) {
+    const int K = p.K;
+    for (int k0 = lane * 8; k0 < kpad; k0 += 4 * 64 * 8) {       // 4 row chunks per iteration: loads first, then use
+        uint4 v[4];
 #pragma unroll
-            for (int i = 0; i < LPS; i++) {
-                size_t off = (size_t)stage * STAGE_BYTES + (size_t)i * 1024 + (size_t)lane * 16;
-                off = off < last16 ? off : last16;
-                // aux = 2: non-temporal -- every weight byte is read once per token by exactly one CU
-                __builtin_amdgcn_global_load_lds((glb_ptr_t)(wstream + off), (lds_ptr_t)(dst + i * 1024), 16, 0, 2);
-            }
-        };
-        for (int s = 0; s < D - 1; s++) if (s < nstages) issue_stage(s);
-        for (int it = 0; it < nstages; it++) {
-            if (it + D - 1 < nstages) {
-                WAIT_VMCNT((D - 2) * LPS);                 // stage `it` (the oldest of D-1 in flight) has landed
-                __builtin_amdgcn_s_barrier();              // B_it: publishes stage it; consumer is done with it-1
-                issue_stage(it + D - 1);                   // refill the slot stage it-1 occupied
-            } else {
-                WAIT_VMCNT(0);                             // drain phase (last D-1 stages)
-                __builtin_amdgcn_s_barrier();
-            }
-        }
-        return;                                            // vmcnt == 0 here: no DMA can land after exit
-    }
-
-    // ==================================== consumer wave ===============================================
-    // ---- x row -> LDS as f32 (optionally through the fused RMSNorm); only this wave touches xs ------
-    const uint16_t* xrow = p.x + (size_t)m * K;
-    for (int k = lane * 8; k < K; k += 64 * 8) {
-        uint4 v = *(const uint4*)(xrow + k);
-        float4 a = make_float4(bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
-        float4 c = make_float4(bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
-        *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
-    }
-    if (NORM) {
-        // RMSNorm.doNormalization (llamatransformer.go:641-660): Pow(x,2) exact -> Mean: serial f32 sum,
-        // k ascending (operations_impl.go:236-251) -> +eps -> f32(1/sqrt(f64)).  Every lane walks the
-        // same chain (broadcast LDS reads); the loader's first D-1 stages are in flight meanwhile.
-        float sum = 0.0f;
-        for (int k = 0; k < K; k += 8) {
-            float4 a = *(const float4*)(xs + k), c = *(const float4*)(xs + k + 4);
-            float p0 = a.x * a.x, p1 = a.y * a.y, p2 = a.z * a.z, p3 = a.w * a.w;
-            float p4 = c.x * c.x, p5 = c.y * c.y, p6 = c.z * c.z, p7 = c.w * c.w;
-            sum += p0; sum += p1; sum += p2; sum += p3; sum += p4; sum += p5; sum += p6; sum += p7;
-        }
-        float mean = __fdiv_rn(sum, (float)K);
-        mean = mean + p.eps;
-        const float r = (float)(1.0 / sqrt((double)mean));
-        for (int k = lane * 8; k < K; k += 64 * 8) {
-            uint4 wv = *(const uint4*)(p.norm_w + k);
-            float4 a = *(const float4*)(xs + k), c = *(const float4*)(xs + k + 4);
-            // trunc(x*r) then trunc(.*w): two truncations (llamatransformer.go:656,638)
-            a.x = bf_wide(bf_trunc(bf_wide(bf_trunc(a.x * r)) * bf_lo(wv.x)));
-            a.y = bf_wide(bf_trunc(bf_wide(bf_trunc(a.y * r)) * bf_hi(wv.x)));
-            a.z = bf_wide(bf_trunc(bf_wide(bf_trunc(a.z * r)) * bf_lo(wv.y)));
-            a.w = bf_wide(bf_trunc(bf_wide(bf_trunc(a.w * r)) * bf_hi(wv.y)));
-            c.x = bf_wide(bf_trunc(bf_wide(bf_trunc(c.x * r)) * bf_lo(wv.z)));
-            c.y = bf_wide(bf_trunc(bf_wide(bf_trunc(c.y * r)) * bf_hi(wv.z)));
-            c.z = bf_wide(bf_trunc(bf_wide(bf_trunc(c.z * r)) * bf_lo(wv.w)));
-            c.w = bf_wide(bf_trunc(bf_wide(bf_trunc(c.w * r)) * bf_hi(wv.w)));
-            *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
-        }
-    }
-    (void)scratch;
-
-    // ---- walk the stages: one k-ordered chain per lane (per chain) ------------------------------------
-    float acc[NCH];
+        for (int i = 0; i < 4; i++) { const int k = k0 + i * 512; v[i] = make_uint4(0, 0, 0, 0); if (k < K) v[i] = *(const uint4*)(xrow + k); }
 #pragma unroll
-    for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
-    const int kchunks = K >> 3;
-    for (int it = 0; it < nstages; it++) {
-        __builtin_amdgcn_s_barrier();                                  // B_it: stage it is in the ring
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const char* src = ring + (it & (D - 1)) * STAGE_BYTES;
-        const int kc0 = it * KC;
-        int kcn = kchunks - kc0; kcn = kcn < KC ? kcn : KC;
-        if (lane < RW) {
-#pragma unroll 4
-            for (int kc = 0; kc < kcn; kc++) {
-                const float4 xa = *(const float4*)(xs + (size_t)(kc0 + kc) * 8);
-                const float4 xb = *(const float4*)(xs + (size_t)(kc0 + kc) * 8 + 4);
-#pragma unroll
-                for (int c = 0; c < NCH; c++) {
-                    const uint4 wv = *(const uint4*)(src + ((kc * NCH + c) * RW + lane) * 16);
-                    acc[c] = mac8(acc[c], xa, xb, wv);
+        for (int i = 0; i < 4; i++) {
+            const int k = k0 + i * 512;
+            if (k < kpad) {
+                float4 a = make_float4(bf_lo(v[i].x), bf_hi(v[i].x), bf_lo(v[i].y), bf_hi(v[i].y));
+                float4 c = make_float4(bf_lo(v[i].z), bf_hi(v[i].z), bf_lo(v[i].w), bf_hi(v[i].w));
+                if (NORM) {   // Pow(x,2): exact in f32 (operations_impl.go:197-217)
+                    a.x = a.x * a.x; a.y = a.y * a.y; a.z = a.z * a.z; a.w = a.w * a.w;
+                    c.x = c.x * c.x; c.y = c.y * c.y; c.z = c.z * c.z; c.w = c.w * c.w;
                 }
+                *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
             }
         }
     }
+    if (!NORM) return;
+    // RMSNorm.doNormalization (llamatransformer.go:641-660): Mean = serial f32 sum, k ascending (impl:236-251),
+    // /K, +eps (f32), f32(1/sqrt(f64)).  Every lane walks the same chain (broadcast LDS reads, 16 steps per
+    // iteration with the next 16 values already in flight).
+    // (padding zeros are added too: sum >= +0 is never changed by + 0.0)
+    float sum = 0.0f;
+    float4 a0 = *(const float4*)(xs), a1 = *(const float4*)(xs + 4), a2 = *(const float4*)(xs + 8), a3 = *(const float4*)(xs + 12);
+    for (int k0 = 0; k0 < K; k0 += 16) {
+        const float4 n0 = *(const float4*)(xs + k0 + 16), n1 = *(const float4*)(xs + k0 + 20);
+        const float4 n2 = *(const float4*)(xs + k0 + 24), n3 = *(const float4*)(xs + k0 + 28);
+        __builtin_amdgcn_sched_barrier(0);
+        touch16(a0, a1, a2, a3);
+        __builtin_amdgcn_sched_barrier(0);
+        sum = add4(sum, a0); sum = add4(sum, a1); sum = add4(sum, a2); sum = add4(sum, a3);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+    }
+    float mean = __fdiv_rn(sum, (float)K);
+    mean = mean + p.eps;
+    const float r = (float)(1.0 / sqrt((double)mean));
+    for (int k0 = lane * 8; k0 < K; k0 += 4 * 64 * 8) {   // x is re-read (L2 hit) instead of keeping a second LDS copy
+        uint4 v[4], wv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = k0 + i * 512;
+            v[i] = make_uint4(0, 0, 0, 0); wv[i] = v[i];
+            if (k < K) { v[i] = *(const uint4*)(xrow + k); wv[i] = *(const uint4*)(p.norm_w + k); }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int k = k0 + i * 512;
+            if (k < K) {
+                float4 a, c;   // trunc(x*r) then trunc(.*w): two truncations (llamatransformer.go:656,638)
+                a.x = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v[i].x) * r)) * bf_lo(wv[i].x)));
+                a.y = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v[i].x) * r)) * bf_hi(wv[i].x)));
+                a.z = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v[i].y) * r)) * bf_lo(wv[i].y)));
+                a.w = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v[i].y) * r)) * bf_hi(wv[i].y)));
+                c.x = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v[i].z) * r)) * bf_lo(wv[i].z)));
+                c.y = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v[i].z) * r)) * bf_hi(wv[i].z)));
+                c.z = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v[i].w) * r)) * bf_lo(wv[i].w)));
+                c.w = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v[i].w) * r)) * bf_hi(wv[i].w)));
+                *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
+            }
+        }
+    }
+    // zero the slack the chain above may have left as squares beyond K (k in [K, kpad) was written as 0 already)
+}
 
-    // ---- epilogues (consumer wave, lane = output row) ---------------------------------------------
-    const int n = b * RW + lane;
-    const bool valid = (lane < RW) && (n < p.n_rows);
+// LDS-DMA of one stage of the block's weight stream into ring slot (stage mod D); addresses clamped into the stream
+template <int STAGE_BYTES, int D>
+DEVINL void issue_stage(const char* wstream, size_t last16, char* ring, int stage, int lane) {
+    char* dst = ring + (stage & (D - 1)) * STAGE_BYTES;
+#pragma unroll
+    for (int i = 0; i < STAGE_BYTES / 1024; i++) {
+        size_t off = (size_t)stage * STAGE_BYTES + (size_t)i * 1024 + (size_t)lane * 16;
+        off = off < last16 ? off : last16;
+        // aux = 2: non-temporal -- every weight byte is read once per token by exactly one CU
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wstream + off), (lds_ptr_t)(dst + i * 1024), 16, 0, 2);
+    }
+}
+
+template <int NCH, int EPI>
+DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, int n, bool valid) {
     if (EPI == EPI_STORE) {
         if (valid) p.out[(size_t)m * p.n_rows + n] = bf_trunc(acc[0]);
     } else if (EPI == EPI_RESID) {
@@ -214,6 +198,145 @@ __global__ __launch_bounds__(128) void gemv_exact_kernel(GemvParams p) {
             }
         }
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Exact-order streaming GEMV / skinny GEMM:   y[m, n] = trunc( sum_{k ascending} x[m,k] * W[n,k] )
+//
+// workgroup = 2 + NH waves on different SIMDs of one CU, software pipeline of depth 3 with ONE raw
+// s_barrier per stage:
+//   wave 1     loader : LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, non-temporal) keeps
+//                       DA-1 stages of the block's bf16 weight stream in flight into ring A with COUNTED
+//                       s_waitcnt vmcnt(N) -- never 0 in steady state;
+//   waves 2..  helpers: ring A (bf16 [kc][chain][row][8]) x xs -> ring B (f32 products [k4][chain][row][4]),
+//                       double buffered;
+//   wave 0     chain  : RW rows (lane & (RW-1)), NCH chains per lane: per 16 k-steps 4 ds_read_b128 + 16
+//                       v_add_f32 per chain.
+// iteration `it`: loader waits for stage it | helpers convert stage it-1 | chain walks stage it-2.
+// "thin" matrices (wq|wk|wv, wo, w2: latency bound) use RW=16 -> one workgroup per CU on all 256 CUs;
+// "fat" ones (w1|w3, output: HBM bound) use RW=32/64 and two workgroups per CU.
+// grid.x = S * n_blocks (m fastest so that the S workgroups sharing a weight block run together)
+// dynamic LDS: [DA*SA ring A][2 * 2*SA ring B][kpad f32 x]  (one array: a second __shared__ object would
+// make hipcc drain vmcnt before every ds_read)
+// ------------------------------------------------------------------------------------------------
+template <int RW, int NCH, int SA, int DA, int NH, int EPI, bool NORM>
+__global__ __launch_bounds__((2 + NH) * 64) void gemv_chain_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int LPS = SA / 1024;                        // 1 KiB LDS-DMA instructions per stage
+    constexpr int KC = SA / (NCH * RW * 16);              // 8-wide k chunks per stage
+    constexpr int GS = KC / 2;                            // 16-step groups per stage
+    constexpr int SB = 2 * SA;                            // f32 product stage
+    constexpr int UNITS = SA / 16;                        // 16-byte (8 x bf16) units per stage
+    static_assert(LPS >= 1 && KC >= 2 && (KC & 1) == 0 && (DA & (DA - 1)) == 0 && DA >= 2, "bad stage geometry");
+    static_assert((DA - 1) * LPS <= 60, "vmcnt is a 6-bit counter");
+    static_assert(UNITS % (64 * NH) == 0, "helpers split a stage evenly");
+    char* ringA = smem;
+    char* ringB = smem + DA * SA;
+    float* xs = (float*)(smem + DA * SA + 2 * SB);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = p.K, S = p.S;
+    const int m = (S == 1) ? 0 : (int)(blockIdx.x % (unsigned)S);
+    const int b = (S == 1) ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)S);
+    const size_t stream_bytes = (size_t)K * NCH * RW * 2;
+    const char* wstream = (const char*)p.w + (size_t)b * stream_bytes;
+    const int nstages = (int)((stream_bytes + SA - 1) / SA);
+    const int nit = nstages + 2;
+
+    if (wave == 1) {
+        // ================================ loader wave =============================================
+        const size_t last16 = stream_bytes - 16;
+        for (int s = 0; s < DA - 1; s++) if (s < nstages) issue_stage<SA, DA>(wstream, last16, ringA, s, lane);
+        for (int it = 0; it < nit; it++) {
+            if (it + DA - 1 < nstages) {
+                WAIT_VMCNT((DA - 2) * LPS);                // stage it landed; DA-2 younger stages stay in flight
+                __builtin_amdgcn_s_barrier();
+                issue_stage<SA, DA>(wstream, last16, ringA, it + DA - 1, lane);   // slot of stage it-1: converted before this barrier
+            } else {
+                WAIT_VMCNT(0);                             // drain phase
+                __builtin_amdgcn_s_barrier();
+            }
+        }
+        return;                                            // vmcnt == 0: no DMA can land after exit
+    }
+    if (wave >= 2) {
+        // ================================ helper waves ============================================
+        const int hw = wave - 2;
+        for (int it = 0; it < nit; it++) {
+            const int s = it - 1;
+            if (s >= 0 && s < nstages) {
+                const char* src = ringA + (s & (DA - 1)) * SA;
+                char* dst = ringB + (s & 1) * SB;
+                const float* xst = xs + (size_t)s * (KC * 8);
+                constexpr int NP = UNITS / (64 * NH);                   // passes: all reads first, then the products
+                uint4 v[NP]; float4 xa[NP], xb[NP];
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    const int q = (i * NH + hw) * 64 + lane;               // q = (kc*NCH + c)*RW + r
+                    const int kc = q / (NCH * RW);
+                    v[i] = *(const uint4*)(src + q * 16);
+                    xa[i] = *(const float4*)(xst + kc * 8); xb[i] = *(const float4*)(xst + kc * 8 + 4);
+                }
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    const int q = (i * NH + hw) * 64 + lane;
+                    const int kc = q / (NCH * RW), u = q % (NCH * RW);
+                    // exact products (8-bit x 8-bit significands): val1F32 * val2F32, operations_lineartransform.go:60
+                    *(float4*)(dst + ((2 * kc) * (NCH * RW) + u) * 16) = mul4(xa[i], bf_lo(v[i].x), bf_hi(v[i].x), bf_lo(v[i].y), bf_hi(v[i].y));
+                    *(float4*)(dst + ((2 * kc + 1) * (NCH * RW) + u) * 16) = mul4(xb[i], bf_lo(v[i].z), bf_hi(v[i].z), bf_lo(v[i].w), bf_hi(v[i].w));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // ds_writes complete before the barrier
+            __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // next stage's DMA bytes / xs are visible after it
+        }
+        return;
+    }
+    // ==================================== chain wave ==================================================
+    const int kpad = nstages * KC * 8 + 64;
+    stage_x<NORM>(p, p.x + (size_t)m * K, xs, kpad, lane);
+    float acc[NCH];
+#pragma unroll
+    for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
+    const int row = lane & (RW - 1);
+    // every stage is walked in full: beyond K the x values (hence the products) are +0, and acc + 0 == acc
+    // because acc is never -0
+    for (int it = 0; it < nit; it++) {
+        const int s = it - 2;
+        if (s >= 0) {
+            const char* src = ringB + (s & 1) * SB + row * 16;
+            // software pipeline: group g+1's 16 products per chain are in flight while group g is added
+            float4 pb[2][NCH][4];
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int j = 0; j < 4; j++) pb[0][c][j] = *(const float4*)(src + ((j * NCH + c) * RW) * 16);
+#pragma unroll
+            for (int g = 0; g < GS; g++) {
+                const int cur = g & 1, nxt = cur ^ 1;
+                if (g + 1 < GS) {
+#pragma unroll
+                    for (int c = 0; c < NCH; c++)
+#pragma unroll
+                        for (int j = 0; j < 4; j++) pb[nxt][c][j] = *(const float4*)(src + (((4 * (g + 1) + j) * NCH + c) * RW) * 16);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // keep the prefetch ABOVE the adds (hipcc otherwise sinks it next to its use)
+#pragma unroll
+                for (int c = 0; c < NCH; c++) touch16(pb[cur][c][0], pb[cur][c][1], pb[cur][c][2], pb[cur][c][3]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < 4; j++)
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) acc[c] = add4(acc[c], pb[cur][c][j]);   // valDstF32 += p, k ascending (:63)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // it == 0: publishes xs to the helpers
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    gemv_epilogue<NCH, EPI>(p, acc, m, b * RW + lane, (lane < RW) && (b * RW + lane < p.n_rows));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -368,26 +491,28 @@ __global__ void synth_fill_kernel(uint16_t* dst, int rows, int K, int row_off, i
 // ------------------------------------------------------------------------------------------------
 // host-side launchers (called from lnb_api.cpp)
 // ------------------------------------------------------------------------------------------------
-template <int RW, int NCH, int SB, int D, int EPI, bool NORM>
-static hipError_t launch_gemv_t(const GemvParams* p, int n_blocks, hipStream_t st) {
-    auto kfn = gemv_exact_kernel<RW, NCH, SB, D, EPI, NORM>;
+// x staging: a whole number of stages (steps per stage = stage_bytes / (nch*rw*2)) + 64 floats of slack
+static size_t xs_bytes(int K, int steps_per_stage) { return ((size_t)((K + steps_per_stage - 1) / steps_per_stage) * steps_per_stage + 64) * 4; }
+
+template <int RW, int NCH, int SA, int DA, int NH, int EPI, bool NORM>
+static hipError_t launch_chain_t(const GemvParams* p, int n_blocks, hipStream_t st) {
+    auto kfn = gemv_chain_kernel<RW, NCH, SA, DA, NH, EPI, NORM>;
     if (!p)   // prepare: raise the dynamic-LDS limit once, outside any stream capture
         return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    size_t lds = (size_t)D * SB + (size_t)p->K * 4 + 16;
+    size_t lds = (size_t)DA * SA + 4 * (size_t)SA + xs_bytes(p->K, SA / (NCH * RW * 2));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * n_blocks)), dim3(128), lds, st, *p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * n_blocks)), dim3((2 + NH) * 64), lds, st, *p);
     return hipGetLastError();
 }
 
 template <int EPI, bool NORM, int NCH>
 static hipError_t launch_gemv_rw(const GemvParams* p, int rw, int n_blocks, hipStream_t st) {
-    // ring geometry.  thin blocks (RW 16/32, chain/latency bound): 8 x 8 KiB slots = 56 KiB in flight per CU,
-    // the depth a 16-row workgroup needs to keep its share of HBM busy.  1 KiB-per-chunk blocks (RW=64, or
-    // RW=32 with two chains; HBM bound, many workgroups per CU): 4 x 16 KiB slots, 48 KiB in flight.
-    if (rw == 16) return launch_gemv_t<16, NCH, 8192, 8, EPI, NORM>(p, n_blocks, st);
-    if (rw == 32) return NCH == 2 ? launch_gemv_t<32, NCH, 16384, 4, EPI, NORM>(p, n_blocks, st)
-                                  : launch_gemv_t<32, NCH, 8192, 8, EPI, NORM>(p, n_blocks, st);
-    if (rw == 64) return launch_gemv_t<64, NCH, 16384, 4, EPI, NORM>(p, n_blocks, st);
+    // ring geometry.  thin (RW 16; chain bound; one workgroup per CU): 8 x 8 KiB bf16 slots = 56 KiB in flight
+    // per CU + 32 KiB of products + x.  fat (RW 32/64; HBM bound): 8 x 4 KiB slots + 16 KiB of products + x
+    // = ~64 KiB -> two workgroups per CU, 56 KiB in flight per CU, two helper waves.
+    if (rw == 16) return launch_chain_t<16, NCH, 8192, 8, 2, EPI, NORM>(p, n_blocks, st);
+    if (rw == 32) return launch_chain_t<32, NCH, (NCH == 2 ? 4096 : 8192), 8, 2, EPI, NORM>(p, n_blocks, st);
+    if (rw == 64) return launch_chain_t<64, NCH, 4096, 8, 2, EPI, NORM>(p, n_blocks, st);
     return hipErrorInvalidValue;
 }
 

@@ -66,11 +66,76 @@ __global__ void k_exact(const uint32_t* w, const uint32_t* x, int K2, uint32_t* 
     o_fma[t] = __float_as_uint(a); o_dot[t] = __float_as_uint(d);
 }
 
+
+#define DPPQ(j) " quad_perm:[" #j "," #j "," #j "," #j "] row_mask:0xf bank_mask:0xf\n\t"
+__device__ __forceinline__ void fmac16_dpp(float& acc, const float4& x4, const float4& w0, const float4& w1, const float4& w2, const float4& w3) {
+    asm volatile("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %1, %5" DPPQ(0)  "v_fmac_f32_dpp %0, %2, %6" DPPQ(0)  "v_fmac_f32_dpp %0, %3, %7" DPPQ(0)  "v_fmac_f32_dpp %0, %4, %8" DPPQ(0)
+        "v_fmac_f32_dpp %0, %1, %9" DPPQ(1)  "v_fmac_f32_dpp %0, %2, %10" DPPQ(1) "v_fmac_f32_dpp %0, %3, %11" DPPQ(1) "v_fmac_f32_dpp %0, %4, %12" DPPQ(1)
+        "v_fmac_f32_dpp %0, %1, %13" DPPQ(2) "v_fmac_f32_dpp %0, %2, %14" DPPQ(2) "v_fmac_f32_dpp %0, %3, %15" DPPQ(2) "v_fmac_f32_dpp %0, %4, %16" DPPQ(2)
+        "v_fmac_f32_dpp %0, %1, %17" DPPQ(3) "v_fmac_f32_dpp %0, %2, %18" DPPQ(3) "v_fmac_f32_dpp %0, %3, %19" DPPQ(3) "v_fmac_f32_dpp %0, %4, %20" DPPQ(3)
+        : "+v"(acc)
+        : "v"(x4.x), "v"(x4.y), "v"(x4.z), "v"(x4.w),
+          "v"(w0.x), "v"(w0.y), "v"(w0.z), "v"(w0.w), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w),
+          "v"(w2.x), "v"(w2.y), "v"(w2.z), "v"(w2.w), "v"(w3.x), "v"(w3.y), "v"(w3.z), "v"(w3.w));
+}
+__device__ __forceinline__ void fmac16_plain(float& acc, const float4& x4, const float4& w0, const float4& w1, const float4& w2, const float4& w3) {
+    asm volatile(
+        "v_fmac_f32 %0, %1, %5\n\tv_fmac_f32 %0, %2, %6\n\tv_fmac_f32 %0, %3, %7\n\tv_fmac_f32 %0, %4, %8\n\t"
+        "v_fmac_f32 %0, %1, %9\n\tv_fmac_f32 %0, %2, %10\n\tv_fmac_f32 %0, %3, %11\n\tv_fmac_f32 %0, %4, %12\n\t"
+        "v_fmac_f32 %0, %1, %13\n\tv_fmac_f32 %0, %2, %14\n\tv_fmac_f32 %0, %3, %15\n\tv_fmac_f32 %0, %4, %16\n\t"
+        "v_fmac_f32 %0, %1, %17\n\tv_fmac_f32 %0, %2, %18\n\tv_fmac_f32 %0, %3, %19\n\tv_fmac_f32 %0, %4, %20\n\t"
+        : "+v"(acc)
+        : "v"(x4.x), "v"(x4.y), "v"(x4.z), "v"(x4.w),
+          "v"(w0.x), "v"(w0.y), "v"(w0.z), "v"(w0.w), "v"(w1.x), "v"(w1.y), "v"(w1.z), "v"(w1.w),
+          "v"(w2.x), "v"(w2.y), "v"(w2.z), "v"(w2.w), "v"(w3.x), "v"(w3.y), "v"(w3.z), "v"(w3.w));
+}
+// mode 0: registers only, dpp;  1: registers only, plain fmac;  2: LDS operands, prefetch distance 1, dpp;  3: distance 2, dpp
+// 4: LDS operands distance 2, plain fmac
+template <int MODE>
+__global__ void k_block(float* out, long long* cyc, int iters, int active) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x & 63;
+    for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((float*)smem)[i] = 1.0f + i * 1e-6f;
+    __syncthreads();
+    float acc = 0.f;
+    const float* px = (const float*)smem + (lane & 3) * 4;
+    const char* src = smem + 16384 + lane * 16;
+    long long t0 = clock64();
+    if (lane < active) {
+        if (MODE <= 1) {
+            float4 x = *(const float4*)px, w0 = *(const float4*)src, w1 = *(const float4*)(src + 1024), w2 = *(const float4*)(src + 2048), w3 = *(const float4*)(src + 3072);
+            for (int i = 0; i < iters; i++) {
+#pragma unroll
+                for (int g = 0; g < 16; g++) { if (MODE == 0) fmac16_dpp(acc, x, w0, w1, w2, w3); else fmac16_plain(acc, x, w0, w1, w2, w3); }
+            }
+        } else {
+            constexpr int DIST = (MODE == 2) ? 1 : 2;
+            for (int i = 0; i < iters; i++) {
+                float4 xq[3], w[3][4];
+#pragma unroll
+                for (int d = 0; d < DIST; d++) { xq[d] = *(const float4*)(px + d * 16); for (int j = 0; j < 4; j++) w[d][j] = *(const float4*)(src + ((4 * d + j) * 16) * 16); }
+#pragma unroll
+                for (int g = 0; g < 16; g++) {
+                    const int cur = g % (DIST + 1), nxt = (g + DIST) % (DIST + 1);
+                    if (g + DIST < 16) { xq[nxt] = *(const float4*)(px + (g + DIST) * 16); for (int j = 0; j < 4; j++) w[nxt][j] = *(const float4*)(src + ((4 * (g + DIST) + j) * 16) * 16); }
+                    if (MODE == 4) fmac16_plain(acc, xq[cur], w[cur][0], w[cur][1], w[cur][2], w[cur][3]);
+                    else fmac16_dpp(acc, xq[cur], w[cur][0], w[cur][1], w[cur][2], w[cur][3]);
+                }
+            }
+        }
+    }
+    long long t1 = clock64();
+    out[blockIdx.x * blockDim.x + threadIdx.x] = acc;
+    if (threadIdx.x == 0) cyc[blockIdx.x] = t1 - t0;
+}
+
 int main() {
     float* out; long long* cyc; uint32_t* w;
     CHK(hipMalloc(&out, 1 << 20)); CHK(hipMalloc(&cyc, 4096 * 8)); CHK(hipMalloc(&w, 1 << 16));
     CHK(hipMemset(w, 0x3f, 1 << 16));
     const int iters = 2000;
+    hipFuncSetAttribute((const void*)k_block<0>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024); hipFuncSetAttribute((const void*)k_block<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024); hipFuncSetAttribute((const void*)k_block<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024); hipFuncSetAttribute((const void*)k_block<3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024); hipFuncSetAttribute((const void*)k_block<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160*1024);
     int blocks[] = {1, 256};
     int threads[] = {64, 256, 512, 1024};
     for (int kind = 0; kind < 3; kind++) for (int bi = 0; bi < 2; bi++) for (int ti = 0; ti < 4; ti++) {
@@ -86,6 +151,23 @@ int main() {
         double mx = 0; for (int i = 0; i < nb; i++) if (h[i] > mx) mx = (double)h[i];
         const char* names[] = {"dep_fmac", "unpack+fmac (per element)", "dot2c zero-partner (per element)"};
         printf("%-34s blocks=%3d threads=%4d (waves/SIMD=%.2f): %.2f clk64-ticks per chain step\n", names[kind], nb, nt, nt / 256.0, mx / (iters * 64.0));
+    }
+
+    {
+        const char* nm[] = {"fmac_dpp regs", "fmac plain regs", "fmac_dpp LDS operands dist1", "fmac_dpp LDS operands dist2", "fmac plain LDS operands dist2"};
+        for (int mode = 0; mode < 5; mode++) for (int act = 16; act <= 64; act += 48) {
+            for (int rep = 0; rep < 2; rep++) {
+                if (mode == 0) hipLaunchKernelGGL(k_block<0>, dim3(256), dim3(64), 98304, 0, out, cyc, 200, act);
+                if (mode == 1) hipLaunchKernelGGL(k_block<1>, dim3(256), dim3(64), 98304, 0, out, cyc, 200, act);
+                if (mode == 2) hipLaunchKernelGGL(k_block<2>, dim3(256), dim3(64), 98304, 0, out, cyc, 200, act);
+                if (mode == 3) hipLaunchKernelGGL(k_block<3>, dim3(256), dim3(64), 98304, 0, out, cyc, 200, act);
+                if (mode == 4) hipLaunchKernelGGL(k_block<4>, dim3(256), dim3(64), 98304, 0, out, cyc, 200, act);
+                CHK(hipDeviceSynchronize());
+            }
+            long long h[256]; CHK(hipMemcpy(h, cyc, 256 * 8, hipMemcpyDeviceToHost));
+            double mx = 0; for (int i = 0; i < 256; i++) if (h[i] > mx) mx = (double)h[i];
+            printf("%-34s active lanes=%2d: %.2f ticks per chain step\n", nm[mode], act, mx / (200.0 * 256));
+        }
     }
     // clock64 tick rate vs wall: report both
     {
