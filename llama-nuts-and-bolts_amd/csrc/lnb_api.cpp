@@ -16,7 +16,7 @@
 #include "lnb_device.h"
 
 extern "C" {
-hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, int n_blocks, hipStream_t st);
+hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st);
 hipError_t lnbk_attn(const AttnParams* p, hipStream_t st);
 hipError_t lnbk_embed(const uint16_t* emb, const int32_t* tokens, uint16_t* x, int S, int dim, int vocab, int* err, hipStream_t st);
 hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_token, StepState* state, int32_t* out_tokens, int out_cap, int advance, hipStream_t st);
@@ -87,9 +87,12 @@ static int auto_rw(int lane_rows, const char* env) {
     // workgroups would double the serial chain time
     if (lane_rows <= 16 * 256) return 16;
     if (lane_rows <= 32 * 256) return 32;
-    if (lane_rows <= 32768) return 32;
     return 64;
 }
+static int g_num_cus = 256;
+static long long* g_dbg = nullptr;   // LNB_GEMV_TIMING=1: per-wave timing dump of the profiled launch
+// one resident workgroup per CU: a matrix with more row blocks than CUs is walked persistently
+static void set_grid(GemvParams& g, const TiledDesc& t) { g.dbg = g_dbg; g.n_blocks = t.n_blocks; g.n_wg = t.n_blocks < g_num_cus ? t.n_blocks : g_num_cus; }
 static int alloc_tiled(TiledDesc& t, int n_rows, int K, int rw, int nch, int64_t& bytes) {
     t.n_rows = n_rows; t.k = K; t.rw = rw; t.nch = nch; t.n_blocks = (n_rows + rw - 1) / rw;
     size_t n = tiled_elems(n_rows, K, rw, nch) * 2;
@@ -135,6 +138,7 @@ extern "C" int lnb_model_create(const lnb_model_args* args, int device, int laye
     if (device < 0 || device >= ndev) return fail("device %d out of range (%d devices)", device, ndev);
     HIPCHK(hipSetDevice(device));
     HIPCHK(lnbk_init());
+    { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); if (prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount; }
     lnb_model* m = new lnb_model();
     m->a = a; m->device = device; m->layer_begin = layer_begin; m->layer_end = layer_end;
     m->head_dim = hd; m->n_rep = a.n_heads / a.n_kv_heads; m->ffn_hidden = lnb_model_ffn_hidden_dim(&a);
@@ -154,7 +158,7 @@ extern "C" int lnb_model_create(const lnb_model_args* args, int device, int laye
         if (alloc_linear(&L.attn_norm, dim, wb) || alloc_linear(&L.ffn_norm, dim, wb)) return -1;
         if (alloc_tiled(L.wqkv, m->q_dim + 2 * m->kv_dim, dim, auto_rw(m->q_dim + 2 * m->kv_dim, "LNB_RW_QKV"), 1, wb)) return -1;
         if (alloc_tiled(L.wo, dim, m->q_dim, auto_rw(dim, "LNB_RW_WO"), 1, wb)) return -1;
-        if (alloc_tiled(L.w13, F, dim, auto_rw(2 * F, "LNB_RW_W13") > 32 ? 32 : auto_rw(2 * F, "LNB_RW_W13"), 2, wb)) return -1;
+        if (alloc_tiled(L.w13, F, dim, auto_rw(F, "LNB_RW_W13"), 2, wb)) return -1;
         if (alloc_tiled(L.w2, dim, F, auto_rw(dim, "LNB_RW_W2"), 1, wb)) return -1;
         snprintf(nm, sizeof nm, "layers.%d.attention_norm.weight", l); reg_linear(m, nm, L.attn_norm, dim, base + 0, 1);
         snprintf(nm, sizeof nm, "layers.%d.attention.wq.weight", l); reg_tiled(m, nm, &L.wqkv, m->q_dim, dim, 0, 0, base + 1);
@@ -392,7 +396,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     case K_QKV: {   // attn_norm + wq|wk|wv + RoPE + KV append  (llamatransformer.go:222, :297-403)
         GemvParams g{}; g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
         g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
-        HIPCHK(lnbk_gemv(&g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, L.wqkv.n_blocks, st)); return 0; }
+        set_grid(g, L.wqkv); HIPCHK(lnbk_gemv(&g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, st)); return 0; }
     case K_ATTN: {  // scores / softmax / PV  (:409-514)
         AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st;
         ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len;
@@ -400,14 +404,14 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = c->h; o.res = c->x;
-        HIPCHK(lnbk_gemv(&o, L.wo.rw, 1, EPI_RESID, 0, L.wo.n_blocks, st)); return 0; }
+        set_grid(o, L.wo); HIPCHK(lnbk_gemv(&o, L.wo.rw, 1, EPI_RESID, 0, st)); return 0; }
     case K_W13: {   // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
         GemvParams f{}; f.w = L.w13.w; f.x = c->h; f.norm_w = L.ffn_norm; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
         f.out = c->ffn; f.silu = m->silu;
-        HIPCHK(lnbk_gemv(&f, L.w13.rw, 2, EPI_SILU_MUL, 1, L.w13.n_blocks, st)); return 0; }
+        set_grid(f, L.w13); HIPCHK(lnbk_gemv(&f, L.w13.rw, 2, EPI_SILU_MUL, 1, st)); return 0; }
     case K_W2: {    // w2 + residual  (:619, :248)
         GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = c->h;
-        HIPCHK(lnbk_gemv(&d, L.w2.rw, 1, EPI_RESID, 0, L.w2.n_blocks, st)); return 0; }
+        set_grid(d, L.w2); HIPCHK(lnbk_gemv(&d, L.w2.rw, 1, EPI_RESID, 0, st)); return 0; }
     }
     return fail("bad kernel id");
 }
@@ -429,7 +433,8 @@ static int enqueue_head(lnb_ctx* c, int first, int rows) {
     lnb_model* m = c->m;
     GemvParams g{}; g.w = m->output.w; g.x = c->x + (size_t)first * m->a.dim; g.norm_w = m->norm; g.eps = m->a.norm_eps; g.K = m->a.dim;
     g.n_rows = m->a.vocab_size; g.S = rows; g.st = c->st; g.out = c->logits;
-    HIPCHK(lnbk_gemv(&g, m->output.rw, 1, EPI_STORE, 1, m->output.n_blocks, c->stream));
+    set_grid(g, m->output);
+    HIPCHK(lnbk_gemv(&g, m->output.rw, 1, EPI_STORE, 1, c->stream));
     return 0;
 }
 
@@ -563,6 +568,25 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     HIPCHK(hipStreamSynchronize(st));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *avg_ms_out = ms / (float)iters;
+    if (env_int("LNB_GEMV_TIMING", 0) && which != K_ATTN && which != K_LAYER) {
+        const size_t n = (size_t)4096 * 8 * 4;
+        long long* dbuf = nullptr;
+        HIPCHK(hipMalloc((void**)&dbuf, n * 8)); HIPCHK(hipMemset(dbuf, 0, n * 8));
+        g_dbg = dbuf;
+        int rc = run(7);
+        g_dbg = nullptr;
+        if (rc) { hipFree(dbuf); return -1; }
+        HIPCHK(hipStreamSynchronize(st));
+        std::vector<long long> h(n);
+        HIPCHK(hipMemcpy(h.data(), dbuf, n * 8, hipMemcpyDeviceToHost));
+        hipFree(dbuf);
+        fprintf(stderr, "[timing] kernel class %d: per-wave s_memtime ticks (avg over workgroups)\n", which);
+        for (int w = 0; w < 8; w++) {
+            double tot = 0, wait = 0, tx = 0, mx = 0; int cnt = 0;
+            for (int g = 0; g < 4096; g++) { const long long* d = &h[((size_t)g * 8 + w) * 4]; if (d[0] > 0) { tot += d[0]; wait += d[1]; tx += d[2]; if (d[0] > mx) mx = (double)d[0]; cnt++; } }
+            if (cnt) fprintf(stderr, "[timing]   wave %d: n=%d total=%.0f (max %.0f) barrier_wait=%.0f x_or_vmwait=%.0f\n", w, cnt, tot / cnt, mx, wait / cnt, tx / cnt);
+        }
+    }
     return 0;
 }
 
@@ -590,7 +614,8 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     if (norm_w) { HIPCHK(hipMalloc((void**)&dn, (size_t)k_in * 2)); HIPCHK(hipMemcpy(dn, norm_w, (size_t)k_in * 2, hipMemcpyHostToDevice)); }
     HIPCHK(lnbk_tile(dw, t.w, n_out, k_in, 0, 0, rw, 1, 0, nullptr));
     GemvParams g{}; g.w = t.w; g.x = dx; g.norm_w = dn; g.eps = eps; g.K = k_in; g.n_rows = n_out; g.S = rows; g.st = st; g.out = dy;
-    HIPCHK(lnbk_gemv(&g, rw, 1, EPI_STORE, norm_w ? 1 : 0, t.n_blocks, nullptr));
+    set_grid(g, t);
+    HIPCHK(lnbk_gemv(&g, rw, 1, EPI_STORE, norm_w ? 1 : 0, nullptr));
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(y, dy, (size_t)rows * n_out * 2, hipMemcpyDeviceToHost));
     hipFree(dx); hipFree(dw); hipFree(dy); hipFree(st); hipFree(t.w); if (dn) hipFree(dn);

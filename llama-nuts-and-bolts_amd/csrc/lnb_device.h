@@ -69,6 +69,8 @@ struct GemvParams {
     int K;                      // in_features
     int n_rows;                 // logical lane-rows
     int S;                      // rows in this call
+    int n_blocks;               // row blocks of RW rows
+    int n_wg;                   // workgroups per x row; workgroup w owns blocks w, w+n_wg, ...
     const StepState* st;        // start position lives on the device
     // EPI_STORE / EPI_RESID / EPI_SILU_MUL
     uint16_t* out;              // [S][n_rows] bf16
@@ -80,7 +82,7 @@ struct GemvParams {
     uint16_t* cache_k;          // [seq_len][n_kv*head_dim]
     uint16_t* cache_v;
     int q_dim, kv_dim, head_dim;
-    int out_row_offset;         // first logits row to keep (EPI_STORE with S>1 and "last row only")
+    long long* dbg;             // optional per-wave timing dump (nullptr in production)
 };
 
 struct AttnParams {

@@ -75,88 +75,100 @@ typedef __attribute__((address_space(3))) void* lds_ptr_t;
 typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 #define WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
+// ---- x staging (cooperative: the chain wave and the helper waves are the NS "stagers") -----------------
 // x row -> LDS as f32, zero padded up to kpad (a whole number of stages + 64 floats of slack, so the
 // software-pipelined readers may run one group ahead), optionally through the fused RMSNorm.
-// Executed by ONE wave (the consumer); xs is private to it.
-template <bool NORM>
-DEVINL void stage_x(const GemvParams& p, const uint16_t* xrow, float* xs, int kpad, int lane) {
-    const int K = p.K;
-    for (int k0 = lane * 8; k0 < kpad; k0 += 4 * 64 * 8) {       // 4 row chunks per iteration: loads first, then use
-        uint4 v[4];
+// The global loads of x are ISSUED BEFORE the loaders start their LDS-DMA burst (barrier B0) -- otherwise the
+// 8 KB of x queue behind ~56 KiB of weight prefetch per CU (measured: +4 us per launch).
+constexpr int X_CH = 12;                                  // 512-element chunks per stager wave held in registers
+template <bool NORM, int NS>
+DEVINL void x_issue(const GemvParams& p, const uint16_t* xrow, int sidx, int lane, uint4 (&xv)[X_CH], uint4 (&nv)[X_CH]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) { const int k = k0 + i * 512; v[i] = make_uint4(0, 0, 0, 0); if (k < K) v[i] = *(const uint4*)(xrow + k); }
+    for (int i = 0; i < X_CH; i++) {
+        const int k = ((i * NS + sidx) * 64 + lane) * 8;
+        xv[i] = make_uint4(0, 0, 0, 0); nv[i] = xv[i];
+        if (k < p.K) { xv[i] = *(const uint4*)(xrow + k); if (NORM) nv[i] = *(const uint4*)(p.norm_w + k); }
+    }
+}
+// squares (NORM: Pow(x,2), exact in f32, operations_impl.go:197-217) or plain values; zeros in [K, kpad)
+template <bool NORM, int NS>
+DEVINL void x_store(const GemvParams& p, float* xs, int kpad, int sidx, int lane, const uint4 (&xv)[X_CH]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int k = k0 + i * 512;
-            if (k < kpad) {
-                float4 a = make_float4(bf_lo(v[i].x), bf_hi(v[i].x), bf_lo(v[i].y), bf_hi(v[i].y));
-                float4 c = make_float4(bf_lo(v[i].z), bf_hi(v[i].z), bf_lo(v[i].w), bf_hi(v[i].w));
-                if (NORM) {   // Pow(x,2): exact in f32 (operations_impl.go:197-217)
-                    a.x = a.x * a.x; a.y = a.y * a.y; a.z = a.z * a.z; a.w = a.w * a.w;
-                    c.x = c.x * c.x; c.y = c.y * c.y; c.z = c.z * c.z; c.w = c.w * c.w;
-                }
-                *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
+    for (int i = 0; i < X_CH; i++) {
+        const int k = ((i * NS + sidx) * 64 + lane) * 8;
+        if (k < kpad) {
+            float4 a = make_float4(bf_lo(xv[i].x), bf_hi(xv[i].x), bf_lo(xv[i].y), bf_hi(xv[i].y));
+            float4 c = make_float4(bf_lo(xv[i].z), bf_hi(xv[i].z), bf_lo(xv[i].w), bf_hi(xv[i].w));
+            if (NORM) {
+                a.x = a.x * a.x; a.y = a.y * a.y; a.z = a.z * a.z; a.w = a.w * a.w;
+                c.x = c.x * c.x; c.y = c.y * c.y; c.z = c.z * c.z; c.w = c.w * c.w;
             }
+            *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
         }
     }
-    if (!NORM) return;
-    // RMSNorm.doNormalization (llamatransformer.go:641-660): Mean = serial f32 sum, k ascending (impl:236-251),
-    // /K, +eps (f32), f32(1/sqrt(f64)).  Every lane walks the same chain (broadcast LDS reads, 16 steps per
-    // iteration with the next 16 values already in flight).
-    // (padding zeros are added too: sum >= +0 is never changed by + 0.0)
+}
+// RMSNorm.doNormalization (llamatransformer.go:641-660): Mean = serial f32 sum of the squares in xs, k ascending
+// (operations_impl.go:236-251), /K, +eps (f32), f32(1/sqrt(f64)).  Every lane of the chain wave walks the same chain
+// (broadcast LDS reads; ping-pong register sets, 16 steps added while the next 16 values are in flight; the
+// padding zeros are added too: sum >= +0 is never changed by + 0.0).
+DEVINL float rms_scale(const GemvParams& p, const float* xs) {
+    const int K = p.K;
     float sum = 0.0f;
     float4 a0 = *(const float4*)(xs), a1 = *(const float4*)(xs + 4), a2 = *(const float4*)(xs + 8), a3 = *(const float4*)(xs + 12);
-    for (int k0 = 0; k0 < K; k0 += 16) {
-        const float4 n0 = *(const float4*)(xs + k0 + 16), n1 = *(const float4*)(xs + k0 + 20);
-        const float4 n2 = *(const float4*)(xs + k0 + 24), n3 = *(const float4*)(xs + k0 + 28);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const float4 b0 = *(const float4*)(xs + k0 + 16), b1 = *(const float4*)(xs + k0 + 20);
+        const float4 b2 = *(const float4*)(xs + k0 + 24), b3 = *(const float4*)(xs + k0 + 28);
         __builtin_amdgcn_sched_barrier(0);
         touch16(a0, a1, a2, a3);
         __builtin_amdgcn_sched_barrier(0);
         sum = add4(sum, a0); sum = add4(sum, a1); sum = add4(sum, a2); sum = add4(sum, a3);
         __builtin_amdgcn_sched_barrier(0);
-        a0 = n0; a1 = n1; a2 = n2; a3 = n3;
+        a0 = *(const float4*)(xs + k0 + 32); a1 = *(const float4*)(xs + k0 + 36);
+        a2 = *(const float4*)(xs + k0 + 40); a3 = *(const float4*)(xs + k0 + 44);
+        __builtin_amdgcn_sched_barrier(0);
+        touch16(b0, b1, b2, b3);
+        __builtin_amdgcn_sched_barrier(0);
+        sum = add4(sum, b0); sum = add4(sum, b1); sum = add4(sum, b2); sum = add4(sum, b3);
+        __builtin_amdgcn_sched_barrier(0);
     }
     float mean = __fdiv_rn(sum, (float)K);
     mean = mean + p.eps;
-    const float r = (float)(1.0 / sqrt((double)mean));
-    for (int k0 = lane * 8; k0 < K; k0 += 4 * 64 * 8) {   // x is re-read (L2 hit) instead of keeping a second LDS copy
-        uint4 v[4], wv[4];
+    return (float)(1.0 / sqrt((double)mean));
+}
+// trunc(x*r) then trunc(.*w): two truncations (llamatransformer.go:656,638), from the registers loaded by x_issue
+template <int NS>
+DEVINL void x_normalize(const GemvParams& p, float* xs, float r, int sidx, int lane, const uint4 (&xv)[X_CH], const uint4 (&nv)[X_CH]) {
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int k = k0 + i * 512;
-            v[i] = make_uint4(0, 0, 0, 0); wv[i] = v[i];
-            if (k < K) { v[i] = *(const uint4*)(xrow + k); wv[i] = *(const uint4*)(p.norm_w + k); }
-        }
-#pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const int k = k0 + i * 512;
-            if (k < K) {
-                float4 a, c;   // trunc(x*r) then trunc(.*w): two truncations (llamatransformer.go:656,638)
-                a.x = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v[i].x) * r)) * bf_lo(wv[i].x)));
-                a.y = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v[i].x) * r)) * bf_hi(wv[i].x)));
-                a.z = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v[i].y) * r)) * bf_lo(wv[i].y)));
-                a.w = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v[i].y) * r)) * bf_hi(wv[i].y)));
-                c.x = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v[i].z) * r)) * bf_lo(wv[i].z)));
-                c.y = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v[i].z) * r)) * bf_hi(wv[i].z)));
-                c.z = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v[i].w) * r)) * bf_lo(wv[i].w)));
-                c.w = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v[i].w) * r)) * bf_hi(wv[i].w)));
-                *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
-            }
+    for (int i = 0; i < X_CH; i++) {
+        const int k = ((i * NS + sidx) * 64 + lane) * 8;
+        if (k < p.K) {
+            const uint4 v = xv[i], wv = nv[i];
+            float4 a, c;
+            a.x = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v.x) * r)) * bf_lo(wv.x)));
+            a.y = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v.x) * r)) * bf_hi(wv.x)));
+            a.z = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v.y) * r)) * bf_lo(wv.y)));
+            a.w = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v.y) * r)) * bf_hi(wv.y)));
+            c.x = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v.z) * r)) * bf_lo(wv.z)));
+            c.y = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v.z) * r)) * bf_hi(wv.z)));
+            c.z = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_lo(v.w) * r)) * bf_lo(wv.w)));
+            c.w = bf_wide(bf_trunc(bf_wide(bf_trunc(bf_hi(v.w) * r)) * bf_hi(wv.w)));
+            *(float4*)(xs + k) = a; *(float4*)(xs + k + 4) = c;
         }
     }
-    // zero the slack the chain above may have left as squares beyond K (k in [K, kpad) was written as 0 already)
 }
 
-// LDS-DMA of one stage of the block's weight stream into ring slot (stage mod D); addresses clamped into the stream
-template <int STAGE_BYTES, int D>
-DEVINL void issue_stage(const char* wstream, size_t last16, char* ring, int stage, int lane) {
-    char* dst = ring + (stage & (D - 1)) * STAGE_BYTES;
+// LDS-DMA of one stage of a block's weight stream into ring slot `slot`; loader `lw` of NL issues every NL-th
+// 1 KiB piece; addresses clamped into the stream
+template <int STAGE_BYTES, int NL>
+DEVINL void issue_stage(const char* wstream, size_t last16, char* ring, int slot, int stage, int lw, int lane) {
+    char* dst = ring + slot * STAGE_BYTES;
 #pragma unroll
-    for (int i = 0; i < STAGE_BYTES / 1024; i++) {
-        size_t off = (size_t)stage * STAGE_BYTES + (size_t)i * 1024 + (size_t)lane * 16;
+    for (int i = 0; i < STAGE_BYTES / 1024 / NL; i++) {
+        const int piece = i * NL + lw;
+        size_t off = (size_t)stage * STAGE_BYTES + (size_t)piece * 1024 + (size_t)lane * 16;
         off = off < last16 ? off : last16;
         // aux = 2: non-temporal -- every weight byte is read once per token by exactly one CU
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wstream + off), (lds_ptr_t)(dst + i * 1024), 16, 0, 2);
+        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wstream + off), (lds_ptr_t)(dst + piece * 1024), 16, 0, 2);
     }
 }
 
@@ -203,31 +215,38 @@ DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, i
 // ------------------------------------------------------------------------------------------------
 // Exact-order streaming GEMV / skinny GEMM:   y[m, n] = trunc( sum_{k ascending} x[m,k] * W[n,k] )
 //
-// workgroup = 2 + NH waves on different SIMDs of one CU, software pipeline of depth 3 with ONE raw
-// s_barrier per stage:
-//   wave 1     loader : LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, non-temporal) keeps
-//                       DA-1 stages of the block's bf16 weight stream in flight into ring A with COUNTED
-//                       s_waitcnt vmcnt(N) -- never 0 in steady state;
-//   waves 2..  helpers: ring A (bf16 [kc][chain][row][8]) x xs -> ring B (f32 products [k4][chain][row][4]),
-//                       double buffered;
-//   wave 0     chain  : RW rows (lane & (RW-1)), NCH chains per lane: per 16 k-steps 4 ds_read_b128 + 16
-//                       v_add_f32 per chain.
-// iteration `it`: loader waits for stage it | helpers convert stage it-1 | chain walks stage it-2.
-// "thin" matrices (wq|wk|wv, wo, w2: latency bound) use RW=16 -> one workgroup per CU on all 256 CUs;
-// "fat" ones (w1|w3, output: HBM bound) use RW=32/64 and two workgroups per CU.
-// grid.x = S * n_blocks (m fastest so that the S workgroups sharing a weight block run together)
+// workgroup = 1 + NL + NH waves, ONE workgroup per CU (every wave on its own SIMD: two issue-hungry waves
+// on one SIMD halve each other's rate), software pipeline of depth 3 with ONE raw s_barrier per stage:
+//   wave 0            chain  : RW rows (lane & (RW-1)), NCH chains per lane: per 16 k-steps 4 ds_read_b128 +
+//                              16 v_add_f32 per chain;
+//   waves 1..NL       loaders: LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, non-temporal) keep
+//                              DA-1 stages of bf16 weights in flight into ring A with COUNTED s_waitcnt
+//                              vmcnt(N) -- never 0 in steady state;
+//   waves NL+1..      helpers: ring A (bf16 [kc][chain][row][8]) x xs -> ring B (f32 products
+//                              [k4][chain][row][4]), double buffered.
+// iteration t: loaders wait for stage t | helpers convert stage t-1 | chain walks stage t-2.
+// A workgroup is PERSISTENT over its row blocks (b = wg, wg + n_wg, ...): x is staged (and RMS-normalised)
+// once, the DMA pipeline runs across block boundaries, the epilogue runs at every block end.
+// "thin" matrices (wq|wk|wv, wo, w2: latency bound) use RW=16/32 with one block per workgroup on all CUs;
+// "fat" ones (w1|w3, output: HBM bound) use RW=64.
+// grid.x = S * n_wg (m fastest so that the S workgroups sharing a weight block run together)
 // dynamic LDS: [DA*SA ring A][2 * 2*SA ring B][kpad f32 x]  (one array: a second __shared__ object would
 // make hipcc drain vmcnt before every ds_read)
 // ------------------------------------------------------------------------------------------------
-template <int RW, int NCH, int SA, int DA, int NH, int EPI, bool NORM>
-__global__ __launch_bounds__((2 + NH) * 64) void gemv_chain_kernel(GemvParams p) {
+// optional per-wave timing (GemvParams.dbg != nullptr): [wg][wave][4] = {total, barrier wait, x staging, -} in s_memtime ticks
+#define TIMED_BARRIER() do { if (p.dbg) { long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
+#define DBG_EXIT() do { if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; } } while (0)
+
+template <int RW, int NCH, int SA, int DA, int NL, int NH, int EPI, bool NORM>
+__global__ __launch_bounds__((1 + NL + NH) * 64) void gemv_chain_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int LPS = SA / 1024;                        // 1 KiB LDS-DMA instructions per stage
+    long long t_begin = p.dbg ? clock64() : 0, t_wait = 0, t_x = 0;
+    constexpr int LPS = SA / 1024 / NL;                   // 1 KiB LDS-DMA instructions per stage per loader
     constexpr int KC = SA / (NCH * RW * 16);              // 8-wide k chunks per stage
     constexpr int GS = KC / 2;                            // 16-step groups per stage
     constexpr int SB = 2 * SA;                            // f32 product stage
     constexpr int UNITS = SA / 16;                        // 16-byte (8 x bf16) units per stage
-    static_assert(LPS >= 1 && KC >= 2 && (KC & 1) == 0 && (DA & (DA - 1)) == 0 && DA >= 2, "bad stage geometry");
+    static_assert(LPS >= 1 && (SA / 1024) % NL == 0 && KC >= 2 && (KC & 1) == 0 && (DA & (DA - 1)) == 0 && DA >= 2, "bad stage geometry");
     static_assert((DA - 1) * LPS <= 60, "vmcnt is a 6-bit counter");
     static_assert(UNITS % (64 * NH) == 0, "helpers split a stage evenly");
     char* ringA = smem;
@@ -238,37 +257,70 @@ __global__ __launch_bounds__((2 + NH) * 64) void gemv_chain_kernel(GemvParams p)
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const int K = p.K, S = p.S;
     const int m = (S == 1) ? 0 : (int)(blockIdx.x % (unsigned)S);
-    const int b = (S == 1) ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)S);
+    const int wg = (S == 1) ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)S);
     const size_t stream_bytes = (size_t)K * NCH * RW * 2;
-    const char* wstream = (const char*)p.w + (size_t)b * stream_bytes;
     const int nstages = (int)((stream_bytes + SA - 1) / SA);
-    const int nit = nstages + 2;
+    const int nb_mine = (p.n_blocks - wg + p.n_wg - 1) / p.n_wg;       // row blocks wg, wg+n_wg, ...
+    const int T = nb_mine * nstages;                                   // global stage count of this workgroup
+    const int nit = T + 2;
+    constexpr int NS = 1 + NH;                                         // x stagers: chain wave + helpers
+    static_assert(NH >= 2, "x staging is sized for >= 3 stager waves");
+    const int kpad = nstages * KC * 8 + 64;                            // launcher guarantees kpad <= X_CH*NS*512
+    const uint16_t* xrow = p.x + (size_t)m * K;
 
-    if (wave == 1) {
-        // ================================ loader wave =============================================
+    if (wave >= 1 && wave <= NL) {
+        // ================================ loader waves ============================================
+        const int lw = wave - 1;
         const size_t last16 = stream_bytes - 16;
-        for (int s = 0; s < DA - 1; s++) if (s < nstages) issue_stage<SA, DA>(wstream, last16, ringA, s, lane);
+        auto issue = [&](int t) {                                      // global stage t -> (block, stage in block)
+            const int j = t / nstages, st = t - j * nstages;
+            const char* wstream = (const char*)p.w + (size_t)(wg + j * p.n_wg) * stream_bytes;
+            issue_stage<SA, NL>(wstream, last16, ringA, t & (DA - 1), st, lw, lane);
+        };
+        TIMED_BARRIER();                                               // B0: the stagers' x loads are issued
+        for (int t = 0; t < DA - 1; t++) if (t < T) issue(t);
+        TIMED_BARRIER();                                               // B1: xs (or the squares) are in LDS
+        if (NORM) { TIMED_BARRIER(); TIMED_BARRIER(); }                // B2: r published, B3: xs normalised
         for (int it = 0; it < nit; it++) {
-            if (it + DA - 1 < nstages) {
+            if (it + DA - 1 < T) {
+                if (p.dbg) { long long tb_ = clock64(); WAIT_VMCNT((DA - 2) * LPS); t_x += clock64() - tb_; } else
                 WAIT_VMCNT((DA - 2) * LPS);                // stage it landed; DA-2 younger stages stay in flight
-                __builtin_amdgcn_s_barrier();
-                issue_stage<SA, DA>(wstream, last16, ringA, it + DA - 1, lane);   // slot of stage it-1: converted before this barrier
+                TIMED_BARRIER();
+                issue(it + DA - 1);                        // slot of stage it-1: converted before this barrier
             } else {
                 WAIT_VMCNT(0);                             // drain phase
-                __builtin_amdgcn_s_barrier();
+                TIMED_BARRIER();
             }
         }
+        DBG_EXIT();
         return;                                            // vmcnt == 0: no DMA can land after exit
     }
-    if (wave >= 2) {
+    if (wave > NL) {
         // ================================ helper waves ============================================
-        const int hw = wave - 2;
+        const int hw = wave - 1 - NL;
+        {
+            uint4 xv[X_CH], nv[X_CH];
+            x_issue<NORM, NS>(p, xrow, 1 + hw, lane, xv, nv);
+            TIMED_BARRIER();                                           // B0
+            x_store<NORM, NS>(p, xs, kpad, 1 + hw, lane, xv);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            TIMED_BARRIER();                                           // B1
+            if (NORM) {
+                TIMED_BARRIER();                                       // B2
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                x_normalize<NS>(p, xs, xs[kpad], 1 + hw, lane, xv, nv);
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                TIMED_BARRIER();                                       // B3
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        int st = 0;                                        // stage-in-block of global stage it-1
         for (int it = 0; it < nit; it++) {
-            const int s = it - 1;
-            if (s >= 0 && s < nstages) {
-                const char* src = ringA + (s & (DA - 1)) * SA;
-                char* dst = ringB + (s & 1) * SB;
-                const float* xst = xs + (size_t)s * (KC * 8);
+            const int t = it - 1;
+            if (t >= 0 && t < T) {
+                const char* src = ringA + (t & (DA - 1)) * SA;
+                char* dst = ringB + (t & 1) * SB;
+                const float* xst = xs + (size_t)st * (KC * 8);
                 constexpr int NP = UNITS / (64 * NH);                   // passes: all reads first, then the products
                 uint4 v[NP]; float4 xa[NP], xb[NP];
 #pragma unroll
@@ -286,26 +338,47 @@ __global__ __launch_bounds__((2 + NH) * 64) void gemv_chain_kernel(GemvParams p)
                     *(float4*)(dst + ((2 * kc) * (NCH * RW) + u) * 16) = mul4(xa[i], bf_lo(v[i].x), bf_hi(v[i].x), bf_lo(v[i].y), bf_hi(v[i].y));
                     *(float4*)(dst + ((2 * kc + 1) * (NCH * RW) + u) * 16) = mul4(xb[i], bf_lo(v[i].z), bf_hi(v[i].z), bf_lo(v[i].w), bf_hi(v[i].w));
                 }
+                if (++st == nstages) st = 0;
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // ds_writes complete before the barrier
-            __builtin_amdgcn_s_barrier();
+            TIMED_BARRIER();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // next stage's DMA bytes / xs are visible after it
         }
+        DBG_EXIT();
         return;
     }
     // ==================================== chain wave ==================================================
-    const int kpad = nstages * KC * 8 + 64;
-    stage_x<NORM>(p, p.x + (size_t)m * K, xs, kpad, lane);
+    {
+        uint4 xv[X_CH], nv[X_CH];
+        x_issue<NORM, NS>(p, xrow, 0, lane, xv, nv);
+        TIMED_BARRIER();                                               // B0
+        x_store<NORM, NS>(p, xs, kpad, 0, lane, xv);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        TIMED_BARRIER();                                               // B1
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        if (NORM) {
+            const float r = rms_scale(p, xs);
+            if (lane == 0) xs[kpad] = r;
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            TIMED_BARRIER();                                           // B2
+            x_normalize<NS>(p, xs, r, 0, lane, xv, nv);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            TIMED_BARRIER();                                           // B3
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+    if (p.dbg) t_x = clock64() - t_begin;
     float acc[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
     const int row = lane & (RW - 1);
+    int st = 0, blk = wg;
     // every stage is walked in full: beyond K the x values (hence the products) are +0, and acc + 0 == acc
     // because acc is never -0
     for (int it = 0; it < nit; it++) {
-        const int s = it - 2;
-        if (s >= 0) {
-            const char* src = ringB + (s & 1) * SB + row * 16;
+        const int t = it - 2;
+        if (t >= 0) {
+            const char* src = ringB + (t & 1) * SB + row * 16;
             // software pipeline: group g+1's 16 products per chain are in flight while group g is added
             float4 pb[2][NCH][4];
 #pragma unroll
@@ -331,12 +404,18 @@ __global__ __launch_bounds__((2 + NH) * 64) void gemv_chain_kernel(GemvParams p)
                     for (int c = 0; c < NCH; c++) acc[c] = add4(acc[c], pb[cur][c][j]);   // valDstF32 += p, k ascending (:63)
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (++st == nstages) {                                     // end of a row block: write it out, start the next
+                gemv_epilogue<NCH, EPI>(p, acc, m, blk * RW + lane, (lane < RW) && (blk * RW + lane < p.n_rows));
+#pragma unroll
+                for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
+                st = 0; blk += p.n_wg;
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // it == 0: publishes xs to the helpers
-        __builtin_amdgcn_s_barrier();
+        TIMED_BARRIER();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    gemv_epilogue<NCH, EPI>(p, acc, m, b * RW + lane, (lane < RW) && (b * RW + lane < p.n_rows));
+    DBG_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -492,39 +571,42 @@ __global__ void synth_fill_kernel(uint16_t* dst, int rows, int K, int row_off, i
 // host-side launchers (called from lnb_api.cpp)
 // ------------------------------------------------------------------------------------------------
 // x staging: a whole number of stages (steps per stage = stage_bytes / (nch*rw*2)) + 64 floats of slack
-static size_t xs_bytes(int K, int steps_per_stage) { return ((size_t)((K + steps_per_stage - 1) / steps_per_stage) * steps_per_stage + 64) * 4; }
+static size_t xs_bytes(int K, int steps_per_stage) { return ((size_t)((K + steps_per_stage - 1) / steps_per_stage) * steps_per_stage + 64) * 4 + 16; }
 
-template <int RW, int NCH, int SA, int DA, int NH, int EPI, bool NORM>
-static hipError_t launch_chain_t(const GemvParams* p, int n_blocks, hipStream_t st) {
-    auto kfn = gemv_chain_kernel<RW, NCH, SA, DA, NH, EPI, NORM>;
+template <int RW, int NCH, int SA, int DA, int NL, int NH, int EPI, bool NORM>
+static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
+    auto kfn = gemv_chain_kernel<RW, NCH, SA, DA, NL, NH, EPI, NORM>;
     if (!p)   // prepare: raise the dynamic-LDS limit once, outside any stream capture
         return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     size_t lds = (size_t)DA * SA + 4 * (size_t)SA + xs_bytes(p->K, SA / (NCH * RW * 2));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * n_blocks)), dim3((2 + NH) * 64), lds, st, *p);
+    if (xs_bytes(p->K, SA / (NCH * RW * 2)) / 4 > (size_t)X_CH * (1 + NH) * 512) return hipErrorInvalidValue;   // x staging registers
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3((1 + NL + NH) * 64), lds, st, *p);
     return hipGetLastError();
 }
 
 template <int EPI, bool NORM, int NCH>
-static hipError_t launch_gemv_rw(const GemvParams* p, int rw, int n_blocks, hipStream_t st) {
-    // ring geometry.  thin (RW 16; chain bound; one workgroup per CU): 8 x 8 KiB bf16 slots = 56 KiB in flight
-    // per CU + 32 KiB of products + x.  fat (RW 32/64; HBM bound): 8 x 4 KiB slots + 16 KiB of products + x
-    // = ~64 KiB -> two workgroups per CU, 56 KiB in flight per CU, two helper waves.
-    if (rw == 16) return launch_chain_t<16, NCH, 8192, 8, 2, EPI, NORM>(p, n_blocks, st);
-    if (rw == 32) return launch_chain_t<32, NCH, (NCH == 2 ? 4096 : 8192), 8, 2, EPI, NORM>(p, n_blocks, st);
-    if (rw == 64) return launch_chain_t<64, NCH, 4096, 8, 2, EPI, NORM>(p, n_blocks, st);
+static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
+    // ring geometry (one workgroup per CU).
+    //  RW 16/32 (thin; chain bound): 8 x 8 KiB bf16 slots = 56 KiB in flight per CU + 32 KiB of products + x.
+    //  RW 64 (fat; HBM bound): one chain: 8 x 8 KiB slots; two chains (w1|w3): 4 x 16 KiB slots and two loader
+    //  waves (a CU then has to pull ~50 GB/s, more than one LDS-DMA wave sustains).
+    if (rw == 16) return launch_chain_t<16, NCH, 8192, 8, 1, 2, EPI, NORM>(p, st);
+    if (rw == 32) return launch_chain_t<32, NCH, 8192, 8, 1, 2, EPI, NORM>(p, st);
+    if (rw == 64) return NCH == 2 ? launch_chain_t<64, NCH, 16384, 4, 2, 4, EPI, NORM>(p, st)
+                                  : launch_chain_t<64, NCH, 8192, 8, 1, 4, EPI, NORM>(p, st);
     return hipErrorInvalidValue;
 }
 
-extern "C" hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, int n_blocks, hipStream_t st) {
+extern "C" hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st) {
     if (nch == 2) {
-        if (epi == EPI_SILU_MUL && norm) return launch_gemv_rw<EPI_SILU_MUL, true, 2>(p, rw, n_blocks, st);
+        if (epi == EPI_SILU_MUL && norm) return launch_gemv_rw<EPI_SILU_MUL, true, 2>(p, rw, st);
         return hipErrorInvalidValue;
     }
     switch (epi) {
-        case EPI_STORE: return norm ? launch_gemv_rw<EPI_STORE, true, 1>(p, rw, n_blocks, st) : launch_gemv_rw<EPI_STORE, false, 1>(p, rw, n_blocks, st);
-        case EPI_QKV_ROPE: return norm ? launch_gemv_rw<EPI_QKV_ROPE, true, 1>(p, rw, n_blocks, st) : hipErrorInvalidValue;
-        case EPI_RESID: return norm ? hipErrorInvalidValue : launch_gemv_rw<EPI_RESID, false, 1>(p, rw, n_blocks, st);
+        case EPI_STORE: return norm ? launch_gemv_rw<EPI_STORE, true, 1>(p, rw, st) : launch_gemv_rw<EPI_STORE, false, 1>(p, rw, st);
+        case EPI_QKV_ROPE: return norm ? launch_gemv_rw<EPI_QKV_ROPE, true, 1>(p, rw, st) : hipErrorInvalidValue;
+        case EPI_RESID: return norm ? hipErrorInvalidValue : launch_gemv_rw<EPI_RESID, false, 1>(p, rw, st);
         default: return hipErrorInvalidValue;
     }
 }
@@ -538,11 +620,11 @@ extern "C" hipError_t lnbk_init(void) {
     const int rws[3] = {16, 32, 64};
     for (int i = 0; i < 3; i++) {
         hipError_t e;
-        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_STORE, 1, 0, nullptr)) != hipSuccess) return e;
-        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_STORE, 0, 0, nullptr)) != hipSuccess) return e;
-        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_QKV_ROPE, 1, 0, nullptr)) != hipSuccess) return e;
-        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_RESID, 0, 0, nullptr)) != hipSuccess) return e;
-        if ((e = lnbk_gemv(nullptr, rws[i], 2, EPI_SILU_MUL, 1, 0, nullptr)) != hipSuccess) return e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_STORE, 1, nullptr)) != hipSuccess) return e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_STORE, 0, nullptr)) != hipSuccess) return e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_QKV_ROPE, 1, nullptr)) != hipSuccess) return e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_RESID, 0, nullptr)) != hipSuccess) return e;
+        if ((e = lnbk_gemv(nullptr, rws[i], 2, EPI_SILU_MUL, 1, nullptr)) != hipSuccess) return e;
     }
     hipError_t e = hipFuncSetAttribute((const void*)attn_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) return e;
