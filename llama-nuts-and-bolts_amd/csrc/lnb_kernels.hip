@@ -85,9 +85,16 @@ template <bool NORM, int NS>
 DEVINL void x_issue(const GemvParams& p, const uint16_t* xrow, int sidx, int lane, uint4 (&xv)[X_CH], uint4 (&nv)[X_CH]) {
 #pragma unroll
     for (int i = 0; i < X_CH; i++) {
+        // UNCONDITIONAL loads (address clamped, value zeroed afterwards): a predicated load would make hipcc
+        // wait for each one before issuing the next (measured: 12 serialized round trips)
         const int k = ((i * NS + sidx) * 64 + lane) * 8;
-        xv[i] = make_uint4(0, 0, 0, 0); nv[i] = xv[i];
-        if (k < p.K) { xv[i] = *(const uint4*)(xrow + k); if (NORM) nv[i] = *(const uint4*)(p.norm_w + k); }
+        const int kc = k < p.K ? k : p.K - 8;
+        uint4 a = *(const uint4*)(xrow + kc);
+        uint4 b = make_uint4(0, 0, 0, 0);
+        if (NORM) b = *(const uint4*)(p.norm_w + kc);
+        const bool in = k < p.K;
+        xv[i] = make_uint4(in ? a.x : 0u, in ? a.y : 0u, in ? a.z : 0u, in ? a.w : 0u);
+        nv[i] = b;
     }
 }
 // squares (NORM: Pow(x,2), exact in f32, operations_impl.go:197-217) or plain values; zeros in [K, kpad)
@@ -157,21 +164,6 @@ DEVINL void x_normalize(const GemvParams& p, float* xs, float r, int sidx, int l
     }
 }
 
-// LDS-DMA of one stage of a block's weight stream into ring slot `slot`; loader `lw` of NL issues every NL-th
-// 1 KiB piece; addresses clamped into the stream
-template <int STAGE_BYTES, int NL>
-DEVINL void issue_stage(const char* wstream, size_t last16, char* ring, int slot, int stage, int lw, int lane) {
-    char* dst = ring + slot * STAGE_BYTES;
-#pragma unroll
-    for (int i = 0; i < STAGE_BYTES / 1024 / NL; i++) {
-        const int piece = i * NL + lw;
-        size_t off = (size_t)stage * STAGE_BYTES + (size_t)piece * 1024 + (size_t)lane * 16;
-        off = off < last16 ? off : last16;
-        // aux = 2: non-temporal -- every weight byte is read once per token by exactly one CU
-        __builtin_amdgcn_global_load_lds((glb_ptr_t)(wstream + off), (lds_ptr_t)(dst + piece * 1024), 16, 0, 2);
-    }
-}
-
 template <int NCH, int EPI>
 DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, int n, bool valid) {
     if (EPI == EPI_STORE) {
@@ -215,43 +207,56 @@ DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, i
 // ------------------------------------------------------------------------------------------------
 // Exact-order streaming GEMV / skinny GEMM:   y[m, n] = trunc( sum_{k ascending} x[m,k] * W[n,k] )
 //
-// workgroup = 1 + NL + NH waves, ONE workgroup per CU (every wave on its own SIMD: two issue-hungry waves
-// on one SIMD halve each other's rate), software pipeline of depth 3 with ONE raw s_barrier per stage:
-//   wave 0            chain  : RW rows (lane & (RW-1)), NCH chains per lane: per 16 k-steps 4 ds_read_b128 +
-//                              16 v_add_f32 per chain;
-//   waves 1..NL       loaders: LDS-DMA (global_load_lds_dwordx4, 1 KiB per instruction, non-temporal) keep
-//                              DA-1 stages of bf16 weights in flight into ring A with COUNTED s_waitcnt
-//                              vmcnt(N) -- never 0 in steady state;
-//   waves NL+1..      helpers: ring A (bf16 [kc][chain][row][8]) x xs -> ring B (f32 products
-//                              [k4][chain][row][4]), double buffered.
-// iteration t: loaders wait for stage t | helpers convert stage t-1 | chain walks stage t-2.
+// workgroup = 1 + NH waves, ONE workgroup per CU (every wave on its own SIMD: two issue-hungry waves on
+// one SIMD halve each other's rate), ONE raw s_barrier per stage:
+//   waves 1..NH  helpers: stream the block's bf16 weights HBM -> VGPR (16 B/lane non-temporal loads, a
+//                         register ring of R stages in flight, COUNTED s_waitcnt vmcnt(N) -- never 0 in
+//                         steady state), multiply by x (exact products) and leave f32 products
+//                         [k4][chain][row][4] in a double-buffered LDS ring;
+//   wave 0       chain  : RW rows (lane & (RW-1)), NCH chains per lane: per 16 k-steps 4 ds_read_b128 +
+//                         16 v_add_f32 per chain.
+// iteration t: helpers produce stage t | chain walks stage t-1.
+// (An LDS-DMA loader wave + separate multiplier waves was measured first: the extra LDS round trip of the
+//  bf16 bytes and the DMA's arbitration against ds traffic capped a CU at ~12 GB/s; see DESIGN.md.)
 // A workgroup is PERSISTENT over its row blocks (b = wg, wg + n_wg, ...): x is staged (and RMS-normalised)
-// once, the DMA pipeline runs across block boundaries, the epilogue runs at every block end.
+// once, the load pipeline runs across block boundaries, the epilogue runs at every block end.
 // "thin" matrices (wq|wk|wv, wo, w2: latency bound) use RW=16/32 with one block per workgroup on all CUs;
 // "fat" ones (w1|w3, output: HBM bound) use RW=64.
 // grid.x = S * n_wg (m fastest so that the S workgroups sharing a weight block run together)
-// dynamic LDS: [DA*SA ring A][2 * 2*SA ring B][kpad f32 x]  (one array: a second __shared__ object would
-// make hipcc drain vmcnt before every ds_read)
+// dynamic LDS: [2 * 2*SA product ring][kpad f32 x + 16 B]
 // ------------------------------------------------------------------------------------------------
-// optional per-wave timing (GemvParams.dbg != nullptr): [wg][wave][4] = {total, barrier wait, x staging, -} in s_memtime ticks
+// optional per-wave timing (GemvParams.dbg != nullptr): [wg][wave][4] = {total, barrier wait, x staging / vm wait, -} in s_memtime ticks
 #define TIMED_BARRIER() do { if (p.dbg) { long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
 #define DBG_EXIT() do { if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; } } while (0)
 
-template <int RW, int NCH, int SA, int DA, int NL, int NH, int EPI, bool NORM>
-__global__ __launch_bounds__((1 + NL + NH) * 64) void gemv_chain_kernel(GemvParams p) {
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+// asm loads are invisible to hipcc's s_waitcnt bookkeeping: the ring below is waited for by hand (wait_ring)
+// saddr form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset -> no per-load VALU address arithmetic
+DEVINL void ld_nt_asm(u32x4& dst, unsigned voff, const char* sbase) { asm volatile("global_load_dwordx4 %0, %1, %2 nt ; RING_LOAD" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory"); }
+// the "; RING_RETIRE ..." comment names the registers this wait retires: tools/isa_audit.py checks on the compiled
+// code that hipcc touches no ring register between its asm load and the wait that retires it
+template <int N, int NP> DEVINL void wait_ring(u32x4 (&b)[NP]) {
+    static_assert(NP == 1 || NP == 2 || NP == 4 || NP == 8, "loads per stage per helper");
+    if constexpr (NP == 1) asm volatile("s_waitcnt vmcnt(%1) ; RING_RETIRE %0" : "+v"(b[0]) : "n"(N) : "memory");
+    if constexpr (NP == 2) asm volatile("s_waitcnt vmcnt(%2) ; RING_RETIRE %0 %1" : "+v"(b[0]), "+v"(b[1]) : "n"(N) : "memory");
+    if constexpr (NP == 4) asm volatile("s_waitcnt vmcnt(%4) ; RING_RETIRE %0 %1 %2 %3" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]) : "n"(N) : "memory");
+    if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(%8) ; RING_RETIRE %0 %1 %2 %3 %4 %5 %6 %7" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "n"(N) : "memory");
+}
+
+template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
+__global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long t_begin = p.dbg ? clock64() : 0, t_wait = 0, t_x = 0;
-    constexpr int LPS = SA / 1024 / NL;                   // 1 KiB LDS-DMA instructions per stage per loader
     constexpr int KC = SA / (NCH * RW * 16);              // 8-wide k chunks per stage
     constexpr int GS = KC / 2;                            // 16-step groups per stage
     constexpr int SB = 2 * SA;                            // f32 product stage
     constexpr int UNITS = SA / 16;                        // 16-byte (8 x bf16) units per stage
-    static_assert(LPS >= 1 && (SA / 1024) % NL == 0 && KC >= 2 && (KC & 1) == 0 && (DA & (DA - 1)) == 0 && DA >= 2, "bad stage geometry");
-    static_assert((DA - 1) * LPS <= 60, "vmcnt is a 6-bit counter");
-    static_assert(UNITS % (64 * NH) == 0, "helpers split a stage evenly");
-    char* ringA = smem;
-    char* ringB = smem + DA * SA;
-    float* xs = (float*)(smem + DA * SA + 2 * SB);
+    constexpr int NP = UNITS / (64 * NH);                 // 16 B loads per lane per stage per helper
+    static_assert(KC >= 2 && (KC & 1) == 0, "bad stage geometry");
+    static_assert(UNITS % (64 * NH) == 0 && R * NP <= 60, "vmcnt is a 6-bit counter");
+    static_assert(NH >= 2, "x staging is sized for >= 3 stager waves");
+    char* ringB = smem;
+    float* xs = (float*)(smem + 2 * SB);
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -262,88 +267,88 @@ __global__ __launch_bounds__((1 + NL + NH) * 64) void gemv_chain_kernel(GemvPara
     const int nstages = (int)((stream_bytes + SA - 1) / SA);
     const int nb_mine = (p.n_blocks - wg + p.n_wg - 1) / p.n_wg;       // row blocks wg, wg+n_wg, ...
     const int T = nb_mine * nstages;                                   // global stage count of this workgroup
-    const int nit = T + 2;
     constexpr int NS = 1 + NH;                                         // x stagers: chain wave + helpers
-    static_assert(NH >= 2, "x staging is sized for >= 3 stager waves");
     const int kpad = nstages * KC * 8 + 64;                            // launcher guarantees kpad <= X_CH*NS*512
     const uint16_t* xrow = p.x + (size_t)m * K;
 
-    if (wave >= 1 && wave <= NL) {
-        // ================================ loader waves ============================================
-        const int lw = wave - 1;
-        const size_t last16 = stream_bytes - 16;
-        auto issue = [&](int t) {                                      // global stage t -> (block, stage in block)
-            const int j = t / nstages, st = t - j * nstages;
-            const char* wstream = (const char*)p.w + (size_t)(wg + j * p.n_wg) * stream_bytes;
-            issue_stage<SA, NL>(wstream, last16, ringA, t & (DA - 1), st, lw, lane);
-        };
-        TIMED_BARRIER();                                               // B0: the stagers' x loads are issued
-        for (int t = 0; t < DA - 1; t++) if (t < T) issue(t);
-        TIMED_BARRIER();                                               // B1: xs (or the squares) are in LDS
-        if (NORM) { TIMED_BARRIER(); TIMED_BARRIER(); }                // B2: r published, B3: xs normalised
-        for (int it = 0; it < nit; it++) {
-            if (it + DA - 1 < T) {
-                if (p.dbg) { long long tb_ = clock64(); WAIT_VMCNT((DA - 2) * LPS); t_x += clock64() - tb_; } else
-                WAIT_VMCNT((DA - 2) * LPS);                // stage it landed; DA-2 younger stages stay in flight
-                TIMED_BARRIER();
-                issue(it + DA - 1);                        // slot of stage it-1: converted before this barrier
-            } else {
-                WAIT_VMCNT(0);                             // drain phase
-                TIMED_BARRIER();
-            }
-        }
-        DBG_EXIT();
-        return;                                            // vmcnt == 0: no DMA can land after exit
-    }
-    if (wave > NL) {
+    // wave roles: with more than 3 helpers the chain wave is wave 3 -- waves w and w+4 share a SIMD, so waves 0..2
+    // and 4..6 (six helpers) pair up on three SIMDs and the chain wave keeps the fourth one to itself
+    constexpr int CW = (NH > 3) ? 3 : 0;
+    if (wave != CW) {
         // ================================ helper waves ============================================
-        const int hw = wave - 1 - NL;
+        const int hw = wave < CW ? wave : wave - 1;
+        u32x4 buf[R][NP];
         {
             uint4 xv[X_CH], nv[X_CH];
             x_issue<NORM, NS>(p, xrow, 1 + hw, lane, xv, nv);
-            TIMED_BARRIER();                                           // B0
-            x_store<NORM, NS>(p, xs, kpad, 1 + hw, lane, xv);
+            x_store<NORM, NS>(p, xs, kpad, 1 + hw, lane, xv);          // (hipcc waits for the x loads here)
+        // the weight stream starts only now, BEHIND the x loads in this CU's memory queue
+        // issue cursor: next global stage to load = (block ib, stage is); past the end it re-reads the last stage
+        const size_t last16 = stream_bytes - 16;
+        unsigned loff[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) loff[i] = (unsigned)(((i * NH + hw) * 64 + lane) * 16);
+        int ib = wg, is = 0, issued = 0;
+        auto issue_next = [&](u32x4 (&dst)[NP]) {
+            const size_t soff = (size_t)is * SA;
+            const char* sb = (const char*)p.w + (size_t)ib * stream_bytes + soff;     // wave-uniform
+            // branch-free clamp (only the last, partial stage of a block ever clamps): one v_min_u32 per load
+            const unsigned lim = (soff + SA <= stream_bytes) ? 0xFFFFFFFFu : (unsigned)(last16 - soff);
+#pragma unroll
+            for (int i = 0; i < NP; i++) ld_nt_asm(dst[i], loff[i] < lim ? loff[i] : lim, sb);
+            if (issued + 1 < T) { issued++; if (++is == nstages) { is = 0; ib += p.n_wg; } }
+        };
+#pragma unroll
+            for (int j = 0; j < R; j++) issue_next(buf[j]);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            TIMED_BARRIER();                                           // B1
+            TIMED_BARRIER();                                           // B1: xs (or the squares) are in LDS
             if (NORM) {
-                TIMED_BARRIER();                                       // B2
+                TIMED_BARRIER();                                       // B2: r published
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 x_normalize<NS>(p, xs, xs[kpad], 1 + hw, lane, xv, nv);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-                TIMED_BARRIER();                                       // B3
+                TIMED_BARRIER();                                       // B3: xs normalised
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        }
-        int st = 0;                                        // stage-in-block of global stage it-1
-        for (int it = 0; it < nit; it++) {
-            const int t = it - 1;
-            if (t >= 0 && t < T) {
-                const char* src = ringA + (t & (DA - 1)) * SA;
-                char* dst = ringB + (t & 1) * SB;
-                const float* xst = xs + (size_t)st * (KC * 8);
-                constexpr int NP = UNITS / (64 * NH);                   // passes: all reads first, then the products
-                uint4 v[NP]; float4 xa[NP], xb[NP];
+        int st = 0;                                        // stage-in-block of the stage being converted
+        for (int it0 = 0; it0 <= T; it0 += R) {
 #pragma unroll
-                for (int i = 0; i < NP; i++) {
-                    const int q = (i * NH + hw) * 64 + lane;               // q = (kc*NCH + c)*RW + r
-                    const int kc = q / (NCH * RW);
-                    v[i] = *(const uint4*)(src + q * 16);
-                    xa[i] = *(const float4*)(xst + kc * 8); xb[i] = *(const float4*)(xst + kc * 8 + 4);
-                }
+            for (int j = 0; j < R; j++) {
+                const int t = it0 + j;
+                if (t <= T) {
+                    if (t < T) {
+                        const long long tb_ = p.dbg ? clock64() : 0;
+                        wait_ring<(R - 1) * NP, NP>(buf[j]);           // stage t landed; R-1 younger stages stay in flight
+                        if (p.dbg) t_x += clock64() - tb_;
+                        char* dst = ringB + (t & 1) * SB;
+                        const float* xst = xs + (size_t)st * (KC * 8);
+                        float4 xa[NP], xb[NP];
 #pragma unroll
-                for (int i = 0; i < NP; i++) {
-                    const int q = (i * NH + hw) * 64 + lane;
-                    const int kc = q / (NCH * RW), u = q % (NCH * RW);
-                    // exact products (8-bit x 8-bit significands): val1F32 * val2F32, operations_lineartransform.go:60
-                    *(float4*)(dst + ((2 * kc) * (NCH * RW) + u) * 16) = mul4(xa[i], bf_lo(v[i].x), bf_hi(v[i].x), bf_lo(v[i].y), bf_hi(v[i].y));
-                    *(float4*)(dst + ((2 * kc + 1) * (NCH * RW) + u) * 16) = mul4(xb[i], bf_lo(v[i].z), bf_hi(v[i].z), bf_lo(v[i].w), bf_hi(v[i].w));
+                        for (int i = 0; i < NP; i++) {
+                            const int q = (i * NH + hw) * 64 + lane;       // q = (kc*NCH + c)*RW + r
+                            const int kc = q / (NCH * RW);
+                            xa[i] = *(const float4*)(xst + kc * 8); xb[i] = *(const float4*)(xst + kc * 8 + 4);
+                        }
+#pragma unroll
+                        for (int i = 0; i < NP; i++) {
+                            const int q = (i * NH + hw) * 64 + lane;
+                            const int kc = q / (NCH * RW), u = q % (NCH * RW);
+                            const u32x4 v = buf[j][i];
+                            // exact products (8-bit x 8-bit significands): val1F32 * val2F32, operations_lineartransform.go:60
+                            *(float4*)(dst + ((2 * kc) * (NCH * RW) + u) * 16) = mul4(xa[i], bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
+                            *(float4*)(dst + ((2 * kc + 1) * (NCH * RW) + u) * 16) = mul4(xb[i], bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
+                        }
+                        if (++st == nstages) st = 0;
+                        __builtin_amdgcn_sched_barrier(0);             // refill AFTER the slot has been consumed (no register copies)
+                        issue_next(buf[j]);                            // refill this register slot with stage t+R
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // ds_writes complete before the barrier
+                    TIMED_BARRIER();
                 }
-                if (++st == nstages) st = 0;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // ds_writes complete before the barrier
-            TIMED_BARRIER();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");     // next stage's DMA bytes / xs are visible after it
         }
+        }
+        asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
         DBG_EXIT();
         return;
     }
@@ -351,7 +356,6 @@ __global__ __launch_bounds__((1 + NL + NH) * 64) void gemv_chain_kernel(GemvPara
     {
         uint4 xv[X_CH], nv[X_CH];
         x_issue<NORM, NS>(p, xrow, 0, lane, xv, nv);
-        TIMED_BARRIER();                                               // B0
         x_store<NORM, NS>(p, xs, kpad, 0, lane, xv);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         TIMED_BARRIER();                                               // B1
@@ -375,8 +379,8 @@ __global__ __launch_bounds__((1 + NL + NH) * 64) void gemv_chain_kernel(GemvPara
     int st = 0, blk = wg;
     // every stage is walked in full: beyond K the x values (hence the products) are +0, and acc + 0 == acc
     // because acc is never -0
-    for (int it = 0; it < nit; it++) {
-        const int t = it - 2;
+    for (int it = 0; it <= T; it++) {
+        const int t = it - 1;
         if (t >= 0) {
             const char* src = ringB + (t & 1) * SB + row * 16;
             // software pipeline: group g+1's 16 products per chain are in flight while group g is added
@@ -411,7 +415,6 @@ __global__ __launch_bounds__((1 + NL + NH) * 64) void gemv_chain_kernel(GemvPara
                 st = 0; blk += p.n_wg;
             }
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");         // it == 0: publishes xs to the helpers
         TIMED_BARRIER();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
@@ -573,28 +576,27 @@ __global__ void synth_fill_kernel(uint16_t* dst, int rows, int K, int row_off, i
 // x staging: a whole number of stages (steps per stage = stage_bytes / (nch*rw*2)) + 64 floats of slack
 static size_t xs_bytes(int K, int steps_per_stage) { return ((size_t)((K + steps_per_stage - 1) / steps_per_stage) * steps_per_stage + 64) * 4 + 16; }
 
-template <int RW, int NCH, int SA, int DA, int NL, int NH, int EPI, bool NORM>
+template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
 static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
-    auto kfn = gemv_chain_kernel<RW, NCH, SA, DA, NL, NH, EPI, NORM>;
+    auto kfn = gemv_chain_kernel<RW, NCH, SA, NH, R, EPI, NORM>;
     if (!p)   // prepare: raise the dynamic-LDS limit once, outside any stream capture
         return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    size_t lds = (size_t)DA * SA + 4 * (size_t)SA + xs_bytes(p->K, SA / (NCH * RW * 2));
+    size_t lds = 4 * (size_t)SA + xs_bytes(p->K, SA / (NCH * RW * 2));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (xs_bytes(p->K, SA / (NCH * RW * 2)) / 4 > (size_t)X_CH * (1 + NH) * 512) return hipErrorInvalidValue;   // x staging registers
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3((1 + NL + NH) * 64), lds, st, *p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3((1 + NH) * 64), lds, st, *p);
     return hipGetLastError();
 }
 
 template <int EPI, bool NORM, int NCH>
 static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
-    // ring geometry (one workgroup per CU).
-    //  RW 16/32 (thin; chain bound): 8 x 8 KiB bf16 slots = 56 KiB in flight per CU + 32 KiB of products + x.
-    //  RW 64 (fat; HBM bound): one chain: 8 x 8 KiB slots; two chains (w1|w3): 4 x 16 KiB slots and two loader
-    //  waves (a CU then has to pull ~50 GB/s, more than one LDS-DMA wave sustains).
-    if (rw == 16) return launch_chain_t<16, NCH, 8192, 8, 1, 2, EPI, NORM>(p, st);
-    if (rw == 32) return launch_chain_t<32, NCH, 8192, 8, 1, 2, EPI, NORM>(p, st);
-    if (rw == 64) return NCH == 2 ? launch_chain_t<64, NCH, 16384, 4, 2, 4, EPI, NORM>(p, st)
-                                  : launch_chain_t<64, NCH, 8192, 8, 1, 4, EPI, NORM>(p, st);
+    // stage geometry (one workgroup per CU).  SA = bf16 bytes per stage, R = stages in flight per helper.
+    //  RW 16/32 (thin; chain bound): 8 KiB stages, 2 helpers x 4 loads x 7 stages = 56 KiB in flight per CU.
+    //  RW 64 (fat; HBM bound): 12 KiB stages, six helpers paired on three SIMDs (the chain wave owns the fourth),
+    //  6 x 2 loads x 5 stages = 60 KiB in flight per CU.
+    if (rw == 16) return launch_chain_t<16, NCH, 8192, 2, 7, EPI, NORM>(p, st);
+    if (rw == 32) return launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
+    if (rw == 64) return launch_chain_t<64, NCH, 12288, 6, 5, EPI, NORM>(p, st);
     return hipErrorInvalidValue;
 }
 
