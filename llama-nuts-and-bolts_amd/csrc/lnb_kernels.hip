@@ -80,9 +80,12 @@ typedef const __attribute__((address_space(1))) void* glb_ptr_t;
 // software-pipelined readers may run one group ahead), optionally through the fused RMSNorm.
 // The global loads of x are ISSUED BEFORE the loaders start their LDS-DMA burst (barrier B0) -- otherwise the
 // 8 KB of x queue behind ~56 KiB of weight prefetch per CU (measured: +4 us per launch).
-constexpr int X_CH = 12;                                  // 512-element chunks per stager wave held in registers
+// 512-element chunks per stager wave held in registers: 12 for the plain kernels (K up to 18k with 3 stagers), 6 for the
+// RMSNorm kernels (K = dim <= 8192; they also hold the norm weights and must stay clear of the 256-VGPR budget)
+template <bool NORM> struct XCh { static constexpr int value = NORM ? 6 : 12; };
 template <bool NORM, int NS>
-DEVINL void x_issue(const GemvParams& p, const uint16_t* xrow, int sidx, int lane, uint4 (&xv)[X_CH], uint4 (&nv)[X_CH]) {
+DEVINL void x_issue(const GemvParams& p, const uint16_t* xrow, int sidx, int lane, uint4 (&xv)[XCh<NORM>::value], uint4 (&nv)[XCh<NORM>::value]) {
+    constexpr int X_CH = XCh<NORM>::value;
 #pragma unroll
     for (int i = 0; i < X_CH; i++) {
         // UNCONDITIONAL loads (address clamped, value zeroed afterwards): a predicated load would make hipcc
@@ -99,7 +102,8 @@ DEVINL void x_issue(const GemvParams& p, const uint16_t* xrow, int sidx, int lan
 }
 // squares (NORM: Pow(x,2), exact in f32, operations_impl.go:197-217) or plain values; zeros in [K, kpad)
 template <bool NORM, int NS>
-DEVINL void x_store(const GemvParams& p, float* xs, int kpad, int sidx, int lane, const uint4 (&xv)[X_CH]) {
+DEVINL void x_store(const GemvParams& p, float* xs, int kpad, int sidx, int lane, const uint4 (&xv)[XCh<NORM>::value]) {
+    constexpr int X_CH = XCh<NORM>::value;
 #pragma unroll
     for (int i = 0; i < X_CH; i++) {
         const int k = ((i * NS + sidx) * 64 + lane) * 8;
@@ -118,6 +122,8 @@ DEVINL void x_store(const GemvParams& p, float* xs, int kpad, int sidx, int lane
 // (operations_impl.go:236-251), /K, +eps (f32), f32(1/sqrt(f64)).  Every lane of the chain wave walks the same chain
 // (broadcast LDS reads; ping-pong register sets, 16 steps added while the next 16 values are in flight; the
 // padding zeros are added too: sum >= +0 is never changed by + 0.0).
+// An exact parity-map scan of this sum (lnb_seqsum.h, fuzzed in tests/test_seqsum.py) was measured on MI355X at the
+// same ~16 us as this plain chain in its one-wave form and is therefore not wired in; see DESIGN.md.
 DEVINL float rms_scale(const GemvParams& p, const float* xs) {
     const int K = p.K;
     float sum = 0.0f;
@@ -144,10 +150,14 @@ DEVINL float rms_scale(const GemvParams& p, const float* xs) {
 }
 // trunc(x*r) then trunc(.*w): two truncations (llamatransformer.go:656,638), from the registers loaded by x_issue
 template <int NS>
-DEVINL void x_normalize(const GemvParams& p, float* xs, float r, int sidx, int lane, const uint4 (&xv)[X_CH], const uint4 (&nv)[X_CH]) {
+DEVINL void x_normalize(const GemvParams& p, float* xs, int kpad, float r, int sidx, int lane, const uint4 (&xv)[XCh<true>::value], const uint4 (&nv)[XCh<true>::value]) {
+    constexpr int X_CH = XCh<true>::value;
 #pragma unroll
     for (int i = 0; i < X_CH; i++) {
         const int k = ((i * NS + sidx) * 64 + lane) * 8;
+        if (k >= p.K && k < kpad) {   // the (padded) squares may have spilled past K: the stage walkers need zeros there
+            *(float4*)(xs + k) = make_float4(0.f, 0.f, 0.f, 0.f); *(float4*)(xs + k + 4) = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
         if (k < p.K) {
             const uint4 v = xv[i], wv = nv[i];
             float4 a, c;
@@ -268,7 +278,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
     const int nb_mine = (p.n_blocks - wg + p.n_wg - 1) / p.n_wg;       // row blocks wg, wg+n_wg, ...
     const int T = nb_mine * nstages;                                   // global stage count of this workgroup
     constexpr int NS = 1 + NH;                                         // x stagers: chain wave + helpers
-    const int kpad = nstages * KC * 8 + 64;                            // launcher guarantees kpad <= X_CH*NS*512
+    const int kpad = nstages * KC * 8 + 320;                           // launcher guarantees kpad <= X_CH*NS*512
     const uint16_t* xrow = p.x + (size_t)m * K;
 
     // wave roles: with more than 3 helpers the chain wave is wave 3 -- waves w and w+4 share a SIMD, so waves 0..2
@@ -279,7 +289,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
         const int hw = wave < CW ? wave : wave - 1;
         u32x4 buf[R][NP];
         {
-            uint4 xv[X_CH], nv[X_CH];
+            uint4 xv[XCh<NORM>::value], nv[XCh<NORM>::value];
             x_issue<NORM, NS>(p, xrow, 1 + hw, lane, xv, nv);
             x_store<NORM, NS>(p, xs, kpad, 1 + hw, lane, xv);          // (hipcc waits for the x loads here)
         // the weight stream starts only now, BEHIND the x loads in this CU's memory queue
@@ -305,7 +315,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
             if (NORM) {
                 TIMED_BARRIER();                                       // B2: r published
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                x_normalize<NS>(p, xs, xs[kpad], 1 + hw, lane, xv, nv);
+                if constexpr (NORM) x_normalize<NS>(p, xs, kpad, xs[kpad], 1 + hw, lane, xv, nv);
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
                 TIMED_BARRIER();                                       // B3: xs normalised
             }
@@ -354,7 +364,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
     }
     // ==================================== chain wave ==================================================
     {
-        uint4 xv[X_CH], nv[X_CH];
+        uint4 xv[XCh<NORM>::value], nv[XCh<NORM>::value];
         x_issue<NORM, NS>(p, xrow, 0, lane, xv, nv);
         x_store<NORM, NS>(p, xs, kpad, 0, lane, xv);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -365,7 +375,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
             if (lane == 0) xs[kpad] = r;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             TIMED_BARRIER();                                           // B2
-            x_normalize<NS>(p, xs, r, 0, lane, xv, nv);
+            if constexpr (NORM) x_normalize<NS>(p, xs, kpad, r, 0, lane, xv, nv);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             TIMED_BARRIER();                                           // B3
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -574,7 +584,7 @@ __global__ void synth_fill_kernel(uint16_t* dst, int rows, int K, int row_off, i
 // host-side launchers (called from lnb_api.cpp)
 // ------------------------------------------------------------------------------------------------
 // x staging: a whole number of stages (steps per stage = stage_bytes / (nch*rw*2)) + 64 floats of slack
-static size_t xs_bytes(int K, int steps_per_stage) { return ((size_t)((K + steps_per_stage - 1) / steps_per_stage) * steps_per_stage + 64) * 4 + 16; }
+static size_t xs_bytes(int K, int steps_per_stage) { return ((size_t)((K + steps_per_stage - 1) / steps_per_stage) * steps_per_stage + 320) * 4 + 16; }
 
 template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
 static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
@@ -583,7 +593,7 @@ static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
         return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     size_t lds = 4 * (size_t)SA + xs_bytes(p->K, SA / (NCH * RW * 2));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (xs_bytes(p->K, SA / (NCH * RW * 2)) / 4 > (size_t)X_CH * (1 + NH) * 512) return hipErrorInvalidValue;   // x staging registers
+    if (xs_bytes(p->K, SA / (NCH * RW * 2)) / 4 > (size_t)XCh<NORM>::value * (1 + NH) * 512) return hipErrorInvalidValue;   // x staging registers
     hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3((1 + NH) * 64), lds, st, *p);
     return hipGetLastError();
 }

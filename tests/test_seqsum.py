@@ -1,0 +1,54 @@
+"""Fuzz of csrc/lnb_seqsum.h (exact parity-map evaluation of the reference's sequential f32 sum of squares,
+src/ml/operations_impl.go:236-251) against the plain sequential loop, on the CPU."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SO = os.path.join(HERE, "native", "libseqsum_host.so")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    src = os.path.join(HERE, "native", "seqsum_host.cpp")
+    hdr = os.path.join(HERE, "..", "llama-nuts-and-bolts_amd", "csrc", "lnb_seqsum.h")
+    if not os.path.exists(SO) or os.path.getmtime(SO) < max(os.path.getmtime(src), os.path.getmtime(hdr)):
+        subprocess.check_call(["g++", "-O2", "-ffp-contract=off", "-shared", "-fPIC", src, "-o", SO])
+    L = C.CDLL(SO)
+    L.seqsum_ref.restype = C.c_float; L.seqsum_scan.restype = C.c_float
+    L.seqsum_ref.argtypes = [C.c_void_p, C.c_int]; L.seqsum_scan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    return L
+
+
+def bf16(a):
+    return ((a.astype(np.float32).view(np.uint32) >> 16) << 16).view(np.float32)
+
+
+def test_scan_is_bit_identical_to_the_sequential_sum(lib):
+    rng = np.random.default_rng(1)
+    fast = []
+    for trial in range(3000):
+        kind, K = trial % 7, 4096
+        if kind == 0: x = bf16(rng.standard_normal(K))
+        elif kind == 1: x = bf16(rng.standard_normal(K) * 10 ** rng.uniform(-18, 6))
+        elif kind == 2: x = bf16(2.0 ** rng.integers(-12, 4, K))                      # powers of two: ties everywhere
+        elif kind == 3: x = bf16(rng.standard_normal(K) * (rng.random(K) < 0.05))      # mostly zeros
+        elif kind == 4: x = bf16(np.exp(rng.uniform(-40, 5, K)))                       # subnormal squares .. large
+        elif kind == 5: x = bf16(np.full(K, 2.0 ** rng.integers(-8, 8)))
+        else: x = bf16(np.abs(rng.standard_normal(K)) * np.where(rng.random(K) < 0.01, 1e4, 1.0))
+        p = np.ascontiguousarray((x.astype(np.float64) ** 2).astype(np.float32))
+        nf = C.c_int(0)
+        r = lib.seqsum_ref(p.ctypes.data, K)
+        s = lib.seqsum_scan(p.ctypes.data, K, 64, C.byref(nf))
+        assert np.float32(r).view(np.uint32) == np.float32(s).view(np.uint32), (trial, kind)
+        fast.append(nf.value)
+    assert np.mean(fast) > 40          # most blocks take the verified integer path
+    for K, nb in [(256, 64), (8192, 64), (4096, 32), (64, 64), (1024, 16)]:
+        for _ in range(200):
+            x = bf16(rng.standard_normal(K) * 10 ** rng.uniform(-3, 3))
+            p = np.ascontiguousarray((x.astype(np.float64) ** 2).astype(np.float32))
+            assert np.float32(lib.seqsum_ref(p.ctypes.data, K)).view(np.uint32) == \
+                np.float32(lib.seqsum_scan(p.ctypes.data, K, nb, None)).view(np.uint32)
