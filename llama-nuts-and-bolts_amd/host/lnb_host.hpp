@@ -1,0 +1,169 @@
+// lnb_host.hpp -- C++ host-side mirror of the reference's Go API for the LlamaTransformer.Forward path, written over
+// the C ABI of include/lnb.h (the reference is compiled Go; no Go toolchain exists on this image, so the host layer
+// the north star asks for in Go is provided in C++ with the SAME names, argument meaning and error behaviour, and the
+// cgo form of the same calls is in llama-nuts-and-bolts_amd/go/ and INTEGRATION.md).
+//
+//   reference (Go)                                              here (C++)
+//   model.ModelArgs                 src/model/modelargs.go:12    lnb::ModelArgs
+//   model.Model{Tensors,ModelArgs}  src/model/model.go           lnb::Model  (name -> host bf16 tensor, as the loader leaves it)
+//   model.NewLlamaTransformer       llamatransformer.go:64       lnb::LlamaTransformer::New(model, device)
+//   (*LlamaTransformer).Forward     llamatransformer.go:145      lnb::LlamaTransformer::Forward(ctx, tokens, startPos, &logits)
+//   model.NewInferenceContext       inferencecontext.go:17       lnb::InferenceContext(transformer, inferenceArgs, logFn)
+//   inference.NewInferenceEngine    inference.go:50              lnb::InferenceEngine(transformer, inferenceArgs, logFn)
+//   generateTokensInternal          inference.go:173             lnb::InferenceEngine::GenerateTokens(prompt, onToken)
+// Errors: the Go functions return (value, error); here a std::runtime_error carries the same message text.
+#pragma once
+#include <cstdint>
+#include <functional>
+#include <map>
+#include <memory>
+#include <cstdio>
+#include <set>
+#include <stdexcept>
+#include <string>
+#include <vector>
+#include "../../include/lnb.h"
+
+namespace lnb {
+
+using TokenId = int32_t;
+
+struct ModelArgs {                       // modelargs.go:12-27, defaults :29-44
+    int Dim = 4096, N_Layers = 32, N_Heads = 32, N_KVHeads = -1, VocabSize = -1, MultipleOf = 256;
+    double FFNDimMultiplier = -1;
+    float NormEpsilon = 1e-5f;
+    bool UseScaledRope = false;
+    double RopeTheta = 500000;
+    int MaxSequenceLength = 2048;
+    lnb_model_args c() const {
+        lnb_model_args a{};
+        a.dim = Dim; a.n_layers = N_Layers; a.n_heads = N_Heads; a.n_kv_heads = N_KVHeads; a.vocab_size = VocabSize;
+        a.multiple_of = MultipleOf; a.ffn_dim_multiplier = FFNDimMultiplier; a.norm_eps = NormEpsilon;
+        a.use_scaled_rope = UseScaledRope ? 1 : 0; a.rope_theta = RopeTheta; a.max_seq_len = MaxSequenceLength;
+        return a;
+    }
+};
+
+struct HostTensor {                      // ml.Tensor of DT_BF16 as the loader produces it (row-major, mmap-backed in the reference)
+    std::vector<int64_t> Size;
+    const uint16_t* RawData = nullptr;
+};
+
+struct Model {                           // model.Model: what LoadModel returns (src/model/loader.go:18-70)
+    ModelArgs Args;
+    std::map<std::string, HostTensor> Tensors;
+    std::set<TokenId> StopTokenIds;      // Vocabulary.StopTokenIds (src/tiktoken/tiktokenreader.go:48-82)
+    bool Synthetic = false;              // no checkpoint: random-init on the device
+    uint64_t SyntheticSeed = 1234;
+};
+
+struct InferenceArgs { int SequenceLength = 0; };   // src/common/inferenceargs.go:3-11
+
+inline void check(int rc) { if (rc != 0) throw std::runtime_error(lnb_last_error()); }
+
+class LlamaTransformer {
+public:
+    // model.NewLlamaTransformer: binds every tensor by name and shape (getTensor/getLayerTensor, loader.go:183-192),
+    // builds PrecomputedFreqsCis (llamatransformer.go:109)
+    static LlamaTransformer* New(const Model& model, int device = 0) {
+        auto* t = new LlamaTransformer();
+        t->args_ = model.Args;
+        lnb_model_args a = model.Args.c();
+        check(lnb_model_create(&a, device, 0, model.Args.N_Layers, &t->h_));
+        try {
+            if (model.Synthetic) check(lnb_model_fill_synthetic(t->h_, model.SyntheticSeed));
+            else for (const auto& kv : model.Tensors)
+                check(lnb_model_set_tensor(t->h_, kv.first.c_str(), kv.second.RawData, kv.second.Size.data(), (int)kv.second.Size.size()));
+            check(lnb_model_finalize(t->h_, 0));
+        } catch (...) { lnb_model_destroy(t->h_); delete t; throw; }
+        return t;
+    }
+    ~LlamaTransformer() { if (h_) lnb_model_destroy(h_); }
+    std::vector<float> PrecomputedFreqsCis() const {                 // exported field, llamatransformer.go:24
+        int rows = 0; check(lnb_model_rope_table(h_, nullptr, 0, &rows));
+        std::vector<float> out((size_t)rows * (args_.Dim / args_.N_Heads));
+        check(lnb_model_rope_table(h_, out.data(), (int64_t)out.size(), &rows));
+        return out;
+    }
+    const ModelArgs& Args() const { return args_; }
+    lnb_model* handle() const { return h_; }
+private:
+    LlamaTransformer() = default;
+    ModelArgs args_; lnb_model* h_ = nullptr;
+};
+
+using LogFn = std::function<void(const std::string&)>;
+
+class InferenceContext {                 // inferencecontext.go:8-52
+public:
+    InferenceContext(const LlamaTransformer& t, InferenceArgs ia, LogFn logFn = nullptr) : t_(t), logFn_(std::move(logFn)) {
+        SequenceLength = ia.SequenceLength > 0 ? ia.SequenceLength : t.Args().MaxSequenceLength;
+        check(lnb_ctx_create(t.handle(), SequenceLength, &h_));
+        if (logFn_) check(lnb_ctx_set_layer_callback(h_, &InferenceContext::layer_cb, this));
+    }
+    ~InferenceContext() { if (h_) lnb_ctx_destroy(h_); }
+    int SequenceLength = 0;
+    std::vector<uint16_t> CacheK(int layer) const { return kv(layer, 0); }   // exported fields, poked by the reference's tests
+    std::vector<uint16_t> CacheV(int layer) const { return kv(layer, 1); }
+    lnb_ctx* handle() const { return h_; }
+private:
+    static void layer_cb(int layer, int n, double secs, void* user) {      // infContext.Logf(...), llamatransformer.go:163
+        auto* self = (InferenceContext*)user;
+        char buf[160]; snprintf(buf, sizeof buf, "Transformer block layer %d / %d was run, took %.4f sec(s)", layer, n, secs);
+        self->logFn_(buf);
+    }
+    std::vector<uint16_t> kv(int layer, int which) const {
+        const ModelArgs& a = t_.Args(); const int kvh = a.N_KVHeads < 0 ? a.N_Heads : a.N_KVHeads;
+        std::vector<uint16_t> out((size_t)SequenceLength * kvh * (a.Dim / a.N_Heads));
+        check(lnb_ctx_read_kv(h_, layer, which, out.data()));
+        return out;
+    }
+    const LlamaTransformer& t_; LogFn logFn_; lnb_ctx* h_ = nullptr;
+};
+
+// (*LlamaTransformer).Forward(infContext, inputTokens, startPos) -> logits [seq, vocab] f32 (llamatransformer.go:145-180)
+inline std::vector<float> Forward(const LlamaTransformer& t, InferenceContext& ctx, const std::vector<TokenId>& inputTokens, int startPos) {
+    std::vector<float> logits(inputTokens.size() * (size_t)t.Args().VocabSize);
+    check(lnb_forward(ctx.handle(), inputTokens.data(), (int)inputTokens.size(), startPos, logits.data(), nullptr));
+    return logits;
+}
+
+enum GenerationState { GSInProgress = 1, GSFinishedByReachingEOS = 2, GSFinishedByReachingSeqLen = 3 };   // inference.go:13-17
+
+class InferenceEngine {                  // inference.go:40-56
+public:
+    InferenceEngine(const Model& model, const LlamaTransformer& t, InferenceArgs ia, LogFn logFn = nullptr)
+        : model_(model), t_(t), ia_(ia), logFn_(std::move(logFn)) {}
+    InferenceContext* CreateInferenceContext() { return new InferenceContext(t_, ia_, logFn_); }       // :256-258
+    // generateTokensInternal (:173-254): prefill through Forward, then the decode loop (Forward(1 token) + Argmax +
+    // token feedback) as hipGraph replays on the device; onToken receives (state, token) like generatedTokensCh.
+    void GenerateTokens(const std::vector<TokenId>& promptTokens, const std::function<void(GenerationState, TokenId)>& onToken) {
+        std::unique_ptr<InferenceContext> ctx(CreateInferenceContext());
+        const int promptLength = (int)promptTokens.size();
+        if (promptLength >= ctx->SequenceLength)
+            throw std::runtime_error("context SequenceLength " + std::to_string(ctx->SequenceLength) +
+                                     " must be higher than prompt tokens length " + std::to_string(promptLength));
+        TokenId next = -1;
+        check(lnb_forward(ctx->handle(), promptTokens.data(), promptLength, 0, nullptr, &next));
+        int curPos = promptLength;
+        auto emit = [&](TokenId tok) -> bool {                        // stop conditions, :233-252
+            if (model_.StopTokenIds.count(tok)) { onToken(GSFinishedByReachingEOS, tok); return false; }
+            if (curPos + 1 == ctx->SequenceLength) { onToken(GSFinishedByReachingSeqLen, tok); return false; }
+            onToken(GSInProgress, tok); return true;
+        };
+        if (!emit(next)) return;
+        const int chunk = 32;                                         // tokens generated on the device between host stop-id checks
+        while (true) {
+            const int remaining = ctx->SequenceLength - 1 - curPos;
+            const int n = remaining < chunk ? remaining : chunk;
+            if (n <= 0) return;
+            std::vector<TokenId> out(n);
+            check(lnb_decode_greedy(ctx->handle(), next, curPos, n, out.data(), nullptr));
+            for (int i = 0; i < n; i++) { curPos++; next = out[i]; if (!emit(next)) return; }
+        }
+    }
+private:
+    const Model& model_; const LlamaTransformer& t_; InferenceArgs ia_; LogFn logFn_;
+};
+
+}  // namespace lnb

@@ -1,0 +1,202 @@
+"""Layer-sharded pipeline over the GPUs of one node (BASELINE.json configs[3], [4]).
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI).  Rank r owns transformer blocks
+[r*L/N, (r+1)*L/N) and their KV caches (`lnb_model_create(..., layer_begin, layer_end)`); rank 0 also owns
+tok_embeddings, rank N-1 also norm + output.  The only exchange of the path is point to point: the bf16 hidden
+state [S, dim] from rank r to r+1 (8 KiB per decoded token for dim 4096) and the 4-byte next-token id from rank N-1
+back to rank 0.  There is no all-reduce / all-gather anywhere (that would be tensor parallelism).
+
+A single greedy sequence is serial across stages, so N independent sequences (one InferenceContext each, exactly
+what the reference creates per GenerateString call, src/inference/inference.go:174) are kept in flight:
+work item i = (phase i // N, sequence i % N), phase 0 = prefill of the prompt, phase k >= 1 = decode step k-1;
+at tick t rank r runs item t - r.  Item (k, s) reaches rank 0 one tick after rank N-1 finished (k-1, s), so the
+token ring closes without bubbles, and every tick is ONE grouped isend/irecv per rank (batch_isend_irecv:
+ncclGroupStart/End, so the send to r+1 and the receive from r-1 progress together and cannot deadlock).
+
+The compute of a tick is delegated to a `stage` object so the schedule is testable on CPU (gloo, world_size 2)
+with a pure-python stage: tests/test_pipeline_gloo.py.
+"""
+import json
+import os
+import time
+
+import numpy as np
+
+
+class Stage:
+    """Interface of one pipeline stage.  Buffers are torch tensors that live where the backend can send them."""
+
+    def hidden_buffer(self, seq, rows):      # int16 [rows, dim] view of the stage's hidden state for sequence `seq`
+        raise NotImplementedError
+
+    def run(self, seq, rows, start_pos, tokens):   # tokens: np.int32[rows] on the first stage else None
+        """consume hidden_buffer(seq) (or tokens), leave the output in hidden_buffer(seq); last stage returns the argmax token"""
+        raise NotImplementedError
+
+    def synchronize(self):
+        pass
+
+
+def schedule(rank, world, n_phases):
+    """yield (tick, item_index or None) for this rank; item i = (phase i // world, seq i % world)"""
+    n_items = n_phases * world
+    for t in range(n_items + world - 1):
+        i = t - rank
+        yield t, (i if 0 <= i < n_items else None)
+
+
+def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, hi=None, state=None):
+    """Run ticks [lo, hi) of the schedule; `state` carries the in-flight item and the token tensors between calls
+    (bench.py runs an untimed window and then a timed one).  prompts: `world` np.int32 arrays of equal length P.
+    state["produced"][s] = tokens generated for sequence s (last rank); state["received"][s] on rank 0."""
+    P = len(prompts[0])
+    n_phases = 1 + n_decode
+    first, last = rank == 0, rank == world - 1
+    nxt, prv = (rank + 1) % world, (rank - 1) % world
+    if state is None:
+        state = {}
+    if "tok_out" not in state:
+        state.update(prev=None, tok_out=torch.zeros(1, dtype=torch.int32, device=device),
+                     tok_in=torch.zeros(1, dtype=torch.int32, device=device),
+                     produced=[[] for _ in range(world)], received=[[] for _ in range(world)])
+    tok_out, tok_in = state["tok_out"], state["tok_in"]
+    if hi is None:
+        hi = n_phases * world + world - 1
+    for t, item in schedule(rank, world, n_phases):
+        if t < lo:
+            continue
+        if t >= hi:
+            break
+        ops = []
+        # --- send the previous tick's result downstream -------------------------------------------------------
+        if state["prev"] is not None and world > 1:
+            k, s = divmod(state["prev"], world)
+            rows = P if k == 0 else 1
+            if not last:
+                ops.append(dist.P2POp(dist.isend, stage.hidden_buffer(s, rows), nxt))
+            elif k + 1 < n_phases:        # the token of the final phase is not needed by rank 0
+                ops.append(dist.P2POp(dist.isend, tok_out, nxt))
+        # --- receive this tick's input --------------------------------------------------------------------------
+        if item is not None and world > 1:
+            k, s = divmod(item, world)
+            rows = P if k == 0 else 1
+            if not first:
+                ops.append(dist.P2POp(dist.irecv, stage.hidden_buffer(s, rows), prv))
+            elif k > 0:
+                ops.append(dist.P2POp(dist.irecv, tok_in, prv))
+        if ops:
+            for req in dist.batch_isend_irecv(ops):
+                req.wait()
+            if device != "cpu":
+                torch.cuda.synchronize()       # RCCL ran on torch's stream; the HIP library has its own
+        # --- compute ----------------------------------------------------------------------------------------------
+        if item is not None:
+            k, s = divmod(item, world)
+            if k == 0:
+                rows, pos, toks = P, 0, (np.ascontiguousarray(prompts[s], dtype=np.int32) if first else None)
+            else:
+                rows, pos, toks = 1, P + k - 1, None
+                if first:
+                    tok = int(tok_in.item()) if world > 1 else state["produced"][s][-1]
+                    state["received"][s].append(tok)
+                    toks = np.array([tok], dtype=np.int32)
+            out = stage.run(s, rows, pos, toks)
+            if last:
+                state["produced"][s].append(int(out))
+                tok_out.fill_(int(out))
+            stage.synchronize()
+        state["prev"] = item
+    return state
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+class LnbStage(Stage):
+    """One GPU's share of the model behind the C ABI (lnb_forward_stage)."""
+
+    def __init__(self, lnb, torch, cfg, rank, world, n_seq, seq_len, device_index):
+        import ctypes as C
+        self.lnb, self.torch, self.C = lnb, torch, C
+        L = cfg["n_layers"]
+        lb, le = rank * L // world, (rank + 1) * L // world
+        self.first, self.last = rank == 0, rank == world - 1
+        self.model = lnb.LlamaTransformer(device=device_index, layer_begin=lb, layer_end=le, **cfg).fill_synthetic(1234)
+        self.model.finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"]))
+        self.ctx = [lnb.InferenceContext(self.model, seq_len) for _ in range(n_seq)]
+        self.dim, self.device_index = cfg["dim"], device_index
+        self._views = {}
+
+    def hidden_buffer(self, seq, rows):
+        key = (seq, rows)
+        if key not in self._views:
+            ptr = self.lnb.lib().lnb_ctx_hidden_ptr(self.ctx[seq].h, 0)
+
+            class _Wrap:   # zero-copy view of the library's device buffer (CUDA array interface v2)
+                __cuda_array_interface__ = {"shape": (rows, self.dim), "typestr": "<i2", "data": (int(ptr), False), "version": 2}
+            self._views[key] = self.torch.as_tensor(_Wrap(), device="cuda:%d" % self.device_index)
+        return self._views[key]
+
+    def run(self, seq, rows, start_pos, tokens):
+        C, L = self.C, self.lnb.lib()
+        am = C.c_int32(-2)
+        tok_p = tokens.ctypes.data_as(C.c_void_p) if tokens is not None else None
+        self.lnb._chk(L.lnb_forward_stage(self.ctx[seq].h, tok_p, rows, start_pos, None, C.byref(am) if self.last else None))
+        return am.value if self.last else None
+
+    def close(self):
+        for c in self.ctx:
+            c.close()
+        self.model.close()
+
+
+def bench_main(args, cfg, name):
+    """bench.py --gpus N under torchrun: weak scaling, N sequences in flight, one rank per GPU."""
+    import torch
+    import torch.distributed as dist
+    import lnb
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if world != args.gpus:
+        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(local)
+    dist.init_process_group("nccl", rank=rank, world_size=world)
+    device = "cuda:%d" % local
+    P, W, K = args.prompt_len, args.warmup, args.steps
+    seq_len = P + W + K + 8
+    stage = LnbStage(lnb, torch, cfg, rank, world, world, seq_len, local)
+    prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(world)]
+    n_decode = W + K
+    t_split = world * (1 + W)              # prefill phase + W warm-up decode rounds
+    t_end = world * (1 + W + K)
+    state = run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, 0, t_split)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    # the timed window: every rank runs exactly K*world items (K decode steps of each of the `world` sequences)
+    run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, t_split, t_end, state)
+    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    wall = float(tmax.item())
+    if rank == 0:
+        import bench as _b
+        tokens = K * world
+        tps = tokens / wall
+        a = {k: cfg[k] for k in ("dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size")}
+        Tbar = P + W + (K - 1) / 2.0 + 1.0
+        B = _b.algorithmic_bytes_per_token(a, stage.model.ffn_hidden, Tbar)
+        res = {"metric": "decode tokens/s Llama-3.1-8B bf16 @1/2/4/8 MI355X; % HBM roofline", "value": round(tps, 2), "unit": "tokens/s",
+               "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "%s bf16, %dxMI355X layer pipeline (%d blocks/GPU), RCCL p2p hidden-state hand-off, %d sequences in flight, "
+                                      "prompt %d -> +%d tokens each" % (name, world, cfg["n_layers"] // world, world, P, K),
+                          "prompt_len": P, "sequences_in_flight": world, "parallelism": "pp%d" % world,
+                          "mode": "exact-order (token-id identical to the CPU reference path)"},
+               "roofline": {"bound": "hbm", "achieved": round(tps * B / 1e9, 1), "peak": _b.PEAK_HBM_GBS * world, "unit": "GB/s",
+                            "frac": round(tps * B / 1e9 / (_b.PEAK_HBM_GBS * world), 4), "traffic": None,
+                            "note": "whole job: tokens/s x algorithmic bytes per token over N x 8 TB/s"}}
+        print(json.dumps(res))
+    stage.close()
+    dist.destroy_process_group()
+    return 0

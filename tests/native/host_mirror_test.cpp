@@ -1,0 +1,27 @@
+// Drives the C++ host mirror (llama-nuts-and-bolts_amd/host/lnb_host.hpp) the way cmd/main.go drives the Go API:
+// build a (synthetic) model, create the engine, generate.  Prints the generated token ids (one line) so the python
+// tests can compare them with the oracle.  Without a GPU NewLlamaTransformer must fail loudly (no CPU fallback).
+#include "../../llama-nuts-and-bolts_amd/host/lnb_host.hpp"
+#include <cstdio>
+#include <cstdlib>
+int main(int argc, char** argv) {
+    lnb::Model model;
+    model.Args.Dim = 256; model.Args.N_Layers = 2; model.Args.N_Heads = 4; model.Args.N_KVHeads = 2; model.Args.VocabSize = 1024;
+    model.Args.MultipleOf = 64; model.Args.FFNDimMultiplier = 1.3; model.Args.UseScaledRope = true;
+    model.Synthetic = true; model.SyntheticSeed = 1234;
+    int seq_len = argc > 1 ? atoi(argv[1]) : 40;
+    try {
+        std::unique_ptr<lnb::LlamaTransformer> t(lnb::LlamaTransformer::New(model, 0));
+        int layers_logged = 0;
+        lnb::InferenceEngine engine(model, *t, lnb::InferenceArgs{seq_len}, [&](const std::string&) { layers_logged++; });
+        std::vector<lnb::TokenId> prompt;
+        for (int i = 2; i < argc; i++) prompt.push_back(atoi(argv[i]));
+        printf("tokens:");
+        engine.GenerateTokens(prompt, [&](lnb::GenerationState st, lnb::TokenId tok) { printf(" %d", tok); if (st != lnb::GSInProgress) printf(" state=%d", (int)st); });
+        printf("\nlayers_logged: %d\n", layers_logged);
+    } catch (const std::exception& e) {
+        printf("error: %s\n", e.what());
+        return 3;
+    }
+    return 0;
+}

@@ -55,3 +55,18 @@ def test_product_never_references_the_oracle():
 def test_ffn_hidden_dim_matches_reference_formula(lnb):
     a = lnb.ModelArgs(**lnb.LLAMA_8B)
     assert lnb.lib().lnb_model_ffn_hidden_dim(C.byref(a)) == 14336            # llamatransformer.go:569-577
+
+
+def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(lnb):
+    """llama-nuts-and-bolts_amd/host/lnb_host.hpp (C++ mirror of the Go API) links against the C ABI; on a box
+    without an MI355X NewLlamaTransformer must return the library's error, not fall back."""
+    import subprocess
+    import torch
+    exe = os.path.join(ROOT, "tests", "native", "host_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(ROOT, "tests", "native", "host_mirror_test.cpp"), "-o", exe,
+                           "-L" + os.path.join(ROOT, "llama-nuts-and-bolts_amd"), "-llnb_hip", "-Wl,-rpath," + os.path.join(ROOT, "llama-nuts-and-bolts_amd"),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    if torch.cuda.is_available():
+        pytest.skip("GPU present: covered by tests/test_gpu_parity.py")
+    r = subprocess.run([exe, "40", "1", "2", "3"], capture_output=True, text=True)
+    assert r.returncode == 3 and "error:" in r.stdout

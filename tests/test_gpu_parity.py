@@ -231,3 +231,24 @@ def test_pipeline_stages_on_one_device_equal_whole_model(lnb, tiny_pair):
     for c in (c0, c1):
         c.close()
     s0.close(); s1.close()
+
+
+def test_cpp_host_mirror_generates_the_oracle_tokens(lnb, tiny_pair):
+    """The C++ mirror of the Go API (host/lnb_host.hpp: NewLlamaTransformer, InferenceEngine.GenerateTokens with the
+    per-layer Logf hook) drives the same C ABI: its greedy continuation equals the oracle's."""
+    import subprocess
+    om, _ = tiny_pair
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "host_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(root, "tests", "native", "host_mirror_test.cpp"), "-o", exe,
+                           "-L" + os.path.join(root, "llama-nuts-and-bolts_amd"), "-llnb_hip", "-Wl,-rpath," + os.path.join(root, "llama-nuts-and-bolts_amd"),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    prompt = [7, 99, 512, 3, 64]
+    r = subprocess.run([exe, "48"] + [str(t) for t in prompt], capture_output=True, text=True, check=True)
+    line = [l for l in r.stdout.splitlines() if l.startswith("tokens:")][0]
+    got = [int(t) for t in line.split()[1:] if t.lstrip("-").isdigit()]
+    ref, _ = orc.Context(om, 48).generate(np.array(prompt, dtype=np.int32), 43)
+    assert got == [int(t) for t in ref]
+    assert "state=3" in line                                         # GSFinishedByReachingSeqLen (inference.go:240-246)
+    logged = int([l for l in r.stdout.splitlines() if l.startswith("layers_logged:")][0].split()[1])
+    assert logged == 2                                               # Logf fired once per layer of the prefill Forward

@@ -1,0 +1,118 @@
+"""world_size-2 (and 3) CPU test of the layer-pipeline schedule (llama-nuts-and-bolts_amd/pipeline.py) over gloo with a
+pure-python stage: checks the tick schedule, the grouped isend/irecv pairing (no deadlock), the token ring back to
+rank 0, KV-like per-sequence state and the split untimed/timed windows bench.py uses -- against a single-process
+evaluation of the same staged function."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "llama-nuts-and-bolts_amd"))
+import pipeline  # noqa: E402
+
+DIM, VOCAB, P = 8, 97, 5
+
+
+class FakeStage(pipeline.Stage):
+    """stage r of `world`: a deterministic integer 'layer stack' with per-sequence state (a stand-in for the KV cache)"""
+
+    def __init__(self, rank, world, n_seq):
+        self.rank, self.world = rank, world
+        self.buf = {s: torch.zeros(P, DIM, dtype=torch.int16) for s in range(n_seq)}
+        self.kv = {s: 0 for s in range(n_seq)}
+        self.log = []
+
+    def hidden_buffer(self, seq, rows):
+        return self.buf[seq][:rows]
+
+    def run(self, seq, rows, start_pos, tokens):
+        h = self.buf[seq][:rows]
+        if tokens is not None:
+            assert self.rank == 0
+            for i, t in enumerate(tokens):
+                h[i] = torch.arange(DIM, dtype=torch.int16) * 3 + int(t) % 50 + start_pos + i
+        self.kv[seq] = (self.kv[seq] * 31 + int(h.to(torch.int64).sum()) + start_pos) % 1009
+        h.copy_(((h.to(torch.int32) * (self.rank + 2) + self.kv[seq]) % 251).to(torch.int16))
+        self.log.append((seq, rows, start_pos))
+        if self.rank == self.world - 1:
+            return (int(h[rows - 1].to(torch.int64).sum()) * 7 + seq) % VOCAB
+        return None
+
+
+def reference(world, prompts, n_decode):
+    stages = [FakeStage(r, world, len(prompts)) for r in range(world)]
+    out = []
+    for s, pr in enumerate(prompts):
+        toks, cur, pos, rows = [], np.asarray(pr, dtype=np.int32), 0, len(pr)
+        for step in range(n_decode + 1):
+            h = None
+            for r, st in enumerate(stages):
+                if r > 0:
+                    st.buf[s][:rows] = h
+                t = st.run(s, rows, pos, cur if r == 0 else None)
+                h = st.buf[s][:rows].clone()
+            toks.append(t)
+            pos, rows, cur = (len(pr) if step == 0 else pos + 1), 1, np.array([t], dtype=np.int32)
+        out.append(toks)
+    return out
+
+
+def _worker(rank, world, port, n_decode, split, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    prompts = [np.arange(P, dtype=np.int32) * (s + 2) % VOCAB for s in range(world)]
+    stage = FakeStage(rank, world, world)
+    if split:
+        st = pipeline.run_ticks(rank, world, stage, dist, torch, prompts, n_decode, "cpu", 0, split)
+        dist.barrier()
+        st = pipeline.run_ticks(rank, world, stage, dist, torch, prompts, n_decode, "cpu", split, None, st)
+    else:
+        st = pipeline.run_ticks(rank, world, stage, dist, torch, prompts, n_decode, "cpu")
+    q.put((rank, st["produced"], st["received"], stage.log))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world,n_decode,split", [(2, 6, 0), (2, 6, 7), (3, 4, 5)])
+def test_pipeline_schedule_matches_single_process(world, n_decode, split):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_decode, split, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, produced, received, log = q.get(timeout=120)
+        res[rank] = (produced, received, log)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    prompts = [np.arange(P, dtype=np.int32) * (s + 2) % VOCAB for s in range(world)]
+    ref = reference(world, prompts, n_decode)
+    assert res[world - 1][0] == ref                                   # tokens produced by the last stage
+    assert res[0][1] == [r[:-1] for r in ref]                         # tokens rank 0 received back (all but the final one)
+    for r in range(world):                                            # every rank ran every item exactly once, in item order
+        log = res[r][2]
+        assert len(log) == world * (n_decode + 1)
+        assert log[:world] == [(s, P, 0) for s in range(world)]
+        assert log[world:2 * world] == [(s, 1, P) for s in range(world)]
+
+
+def test_single_rank_pipeline_is_the_plain_greedy_loop():
+    prompts = [np.arange(P, dtype=np.int32) * 2 % VOCAB]
+    st = pipeline.run_ticks(0, 1, FakeStage(0, 1, 1), dist, torch, prompts, 5, "cpu")
+    assert st["produced"] == reference(1, prompts, 5)
