@@ -54,7 +54,7 @@ def cpu_baseline(model_cfg, prompt, n_steps):
     """Reference-equivalent CPU path (oracle/ = C restatement of src/ml + src/model, same arithmetic and order,
     outputs spread over all host cores like the reference's goroutine fan-out) on a bounded sample."""
     from oracle import oracle as orc
-    ncores = os.cpu_count() or 1
+    ncores = orc.default_threads()        # threads actually used (capped at 64, see oracle/oracle.py)
     t0 = time.time()
     om = orc.Model(**model_cfg).fill_synthetic(1234, ncores).finalize()
     oc = orc.Context(om, len(prompt) + n_steps + 1, ncores)
@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--steps", type=int, default=256)
     ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--prompt-len", type=int, default=128)
-    ap.add_argument("--cpu-steps", type=int, default=6, help="decode steps of the CPU baseline sample (0 = skip)")
+    ap.add_argument("--cpu-steps", type=int, default=24, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-iters", type=int, default=64)
     ap.add_argument("--model", default="llama8b", choices=["llama8b", "tiny", "llama70b-like"])
     args = ap.parse_args()
@@ -140,9 +140,7 @@ def main():
                       "prompt_len": P, "sequences_in_flight": 1, "parallelism": "single GPU", "mode": "exact-order (token-id identical to the CPU reference path)",
                       "hip_event_ms_per_step": round(ev_ms / K, 4), "weight_bytes_resident": model.weight_bytes(), "model_build_s": round(t_load, 1)},
            "roofline": roofline, "kernels": kernels, "last_tokens": [int(t) for t in out[-4:]]}
-    if args.cpu_steps > 0 and args.model != "tiny":
-        res["cpu_baseline"] = cpu_baseline(cfg, prompt[:4], args.cpu_steps)
-    elif args.cpu_steps > 0:
+    if args.cpu_steps > 0:
         res["cpu_baseline"] = cpu_baseline(cfg, prompt[:4], args.cpu_steps)
     ctx.close(); model.close()
     print(json.dumps(res))
