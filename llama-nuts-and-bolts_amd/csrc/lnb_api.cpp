@@ -324,7 +324,8 @@ extern "C" int lnb_ctx_create(lnb_model* m, int seq_len, lnb_ctx** out) {
     HIPCHK(hipSetDevice(m->device));
     lnb_ctx* c = new lnb_ctx();
     c->m = m; c->seq_len = seq_len > 0 ? seq_len : m->a.max_seq_len;        // inferencecontext.go:22-26
-    if ((size_t)c->seq_len * 12 + 1024 > 150 * 1024) { delete c; return fail("seq_len %d exceeds the %d positions the attention kernel stages in LDS", c->seq_len, (150 * 1024 - 1024) / 12); }
+    if ((size_t)c->seq_len * 12 + 2 * 64 * (size_t)m->head_dim * 4 + 4096 > 160 * 1024 || (m->head_dim != 128 && m->head_dim != 64 && m->head_dim != 32))
+        { delete c; return fail("seq_len %d too long for the LDS staging of the attention kernel, or head_dim %d not one of 32/64/128", c->seq_len, m->head_dim); }
     HIPCHK(hipStreamCreate(&c->stream));
     HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
     const size_t kvn = (size_t)c->seq_len * m->kv_dim;
@@ -377,7 +378,15 @@ extern "C" int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which, uint16_t* host)
     if (layer < c->m->layer_begin || layer >= c->m->layer_end) return fail("layer %d is not owned by this stage", layer);
     const size_t kvn = (size_t)c->seq_len * c->m->kv_dim;
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(host, (which ? c->cv : c->ck)[layer - c->m->layer_begin], kvn * 2, hipMemcpyDeviceToHost));
+    if (which) { HIPCHK(hipMemcpy(host, c->cv[layer - c->m->layer_begin], kvn * 2, hipMemcpyDeviceToHost)); return 0; }
+    // K lives as [kv head][d/8][position][8] on the device; hand it back in the reference's [position][kv head][d] order
+    std::vector<uint16_t> raw(kvn);
+    HIPCHK(hipMemcpy(raw.data(), c->ck[layer - c->m->layer_begin], kvn * 2, hipMemcpyDeviceToHost));
+    const int hd = c->m->head_dim, nk = hd >> 3, KVH = c->m->kv_dim / hd;
+    for (int j = 0; j < c->seq_len; j++)
+        for (int kh = 0; kh < KVH; kh++)
+            for (int d = 0; d < hd; d++)
+                host[(size_t)j * c->m->kv_dim + kh * hd + d] = raw[(((size_t)kh * nk + (d >> 3)) * c->seq_len + j) * 8 + (d & 7)];
     return 0;
 }
 
@@ -395,10 +404,10 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     switch (which) {
     case K_QKV: {   // attn_norm + wq|wk|wv + RoPE + KV append  (llamatransformer.go:222, :297-403)
         GemvParams g{}; g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
-        g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
+        g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.seq_len = c->seq_len; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
         set_grid(g, L.wqkv); HIPCHK(lnbk_gemv(&g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, st)); return 0; }
     case K_ATTN: {  // scores / softmax / PV  (:409-514)
-        AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st;
+        AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st; ap.dbg = g_dbg;
         ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len;
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
@@ -568,6 +577,24 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     HIPCHK(hipStreamSynchronize(st));
     float ms = 0; HIPCHK(hipEventElapsedTime(&ms, c->ev0, c->ev1));
     *avg_ms_out = ms / (float)iters;
+    if (env_int("LNB_GEMV_TIMING", 0) && which == K_ATTN) {
+        long long* dbuf = nullptr;
+        HIPCHK(hipMalloc((void**)&dbuf, 64 * 8)); HIPCHK(hipMemset(dbuf, 0, 64 * 8));
+        g_dbg = dbuf;
+        int rc = run(7);
+        g_dbg = nullptr;
+        if (rc) { hipFree(dbuf); return -1; }
+        HIPCHK(hipStreamSynchronize(st));
+        long long h[64] = {0};
+        HIPCHK(hipMemcpy(h, dbuf, sizeof h, hipMemcpyDeviceToHost));
+        hipFree(dbuf);
+        for (int w = 0; w < 4; w++) {
+            fprintf(stderr, "[timing] attention pos %d wave %d phases (s_memtime ticks):", pos, w);
+            for (int k = 1; k < 7; k++) fprintf(stderr, " %lld", h[w * 16 + k] - h[w * 16 + k - 1]);
+            fprintf(stderr, " | first pass: chain %lld exp %lld", h[w * 16 + 7] - h[w * 16 + 1], h[w * 16 + 8] - h[w * 16 + 7]);
+            fprintf(stderr, "\n");
+        }
+    }
     if (env_int("LNB_GEMV_TIMING", 0) && which != K_ATTN && which != K_LAYER) {
         const size_t n = (size_t)4096 * 8 * 4;
         long long* dbuf = nullptr;

@@ -79,18 +79,20 @@ struct GemvParams {
     // EPI_QKV_ROPE
     const float* cis;           // [rows][head_dim/2][2] f32
     uint16_t* q_out;            // [S][n_heads*head_dim]
-    uint16_t* cache_k;          // [seq_len][n_kv*head_dim]
-    uint16_t* cache_v;
+    uint16_t* cache_k;          // [n_kv][head_dim/8][seq_len][8]  (position-contiguous per 8-dim chunk: coalesced score reads)
+    uint16_t* cache_v;          // [seq_len][n_kv*head_dim]
+    int seq_len;
     int q_dim, kv_dim, head_dim;
     long long* dbg;             // optional per-wave timing dump (nullptr in production)
 };
 
 struct AttnParams {
     const uint16_t* q;          // [S][H*hd]
-    const uint16_t* cache_k;    // [seq_len][KVH*hd]
-    const uint16_t* cache_v;
+    const uint16_t* cache_k;    // [KVH][hd/8][seq_len][8]
+    const uint16_t* cache_v;    // [seq_len][KVH*hd]
     uint16_t* out;              // [S][H*hd]
     const StepState* st;
     int S, H, KVH, hd, seq_len;
     float divisor;              // wide(trunc(f32(sqrt(hd))))  (llamatransformer.go:464)
+    long long* dbg;             // LNB_GEMV_TIMING: phase stamps of workgroup (0,0)
 };

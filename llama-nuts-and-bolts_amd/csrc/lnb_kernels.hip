@@ -206,7 +206,10 @@ DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, i
                 if ((n & 1) == 0) { double a = (double)bf_wide(mine), bb = (double)bf_wide(other); r16 = bf_trunc((float)(a * cr - bb * ci)); }
                 else              { double a = (double)bf_wide(other), bb = (double)bf_wide(mine); r16 = bf_trunc((float)(a * ci + bb * cr)); }
                 if (n < p.q_dim) p.q_out[(size_t)m * p.q_dim + n] = r16;
-                else p.cache_k[(size_t)pos * p.kv_dim + (n - p.q_dim)] = r16;         // :402
+                else {                                                                // :402, K cache layout [kv head][d/8][position][8]
+                    const int kc = n - p.q_dim, kh = kc / p.head_dim;
+                    p.cache_k[(((size_t)kh * (p.head_dim >> 3) + (d >> 3)) * p.seq_len + pos) * 8 + (d & 7)] = r16;
+                }
             } else {
                 p.cache_v[(size_t)pos * p.kv_dim + (n - p.q_dim - p.kv_dim)] = mine;  // :403
             }
@@ -435,70 +438,218 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
 // Exact attention for one (head, query row): scores -> /sqrt(hd) -> mask -> f64 softmax -> PV.
 // llamatransformer.go:409-514.  GQA head h reads KV head h/n_rep straight from the un-repeated cache
 // (attentionRepeatKV :529-559 and the four Transposes :435-449 become index arithmetic).
-// grid (H, S), block 256, dynamic LDS: [T f64 e][T f32 p][hd f32 q][8 B Z]
+// grid (H, S), block 256 = 4 waves:
+//   scores : every thread owns one cached position j: the 128-long q.k chain (d ascending), 16 B loads of its K row;
+//   Z      : wave 0 walks sum_j exp(s_j) in f64, j ascending, 8 values per iteration with the next 8 in flight;
+//   PV     : the same role split as the GEMV -- waves 2,3 produce the EXACT products p_j*v[j,d] (bf16 x bf16) into
+//            a double-buffered LDS ring laid out [j/4][d][4]; waves 0,1 own one output dim per lane and only add.
+// dynamic LDS: [T f64 e][T f32 p (+ zero pad)][hd f32 q][16 B][2 x 64 x hd f32 product ring]
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_exact_kernel(AttnParams p) {
+constexpr int ATT_JC = 64;                                  // cached positions per PV chunk
+__host__ __device__ inline size_t attn_off_pw(int seq_len) { return (((size_t)seq_len + 32) * 8 + 15) & ~(size_t)15; }
+__host__ __device__ inline size_t attn_off_q(int seq_len) { return attn_off_pw(seq_len) + ((((size_t)seq_len + ATT_JC) * 4 + 15) & ~(size_t)15); }
+__host__ __device__ inline size_t attn_off_z(int seq_len, int hd) { return attn_off_q(seq_len) + (((size_t)hd * 4 + 15) & ~(size_t)15); }
+__host__ __device__ inline size_t attn_off_ring(int seq_len, int hd) { return attn_off_z(seq_len, hd) + 16; }
+
+constexpr int ATT_NT = 512;                                 // 8 waves: two per SIMD (one wave alone issues ~1 instruction / 4.4 cycles)
+constexpr int ATT_NPROD = 4;                                // PV: waves 0,1 add; waves 2,3,6,7 produce; waves 4,5 share the adders' SIMDs and
+                                                            // stay idle there (two issue-hungry waves on one SIMD halve each other)
+constexpr int ATT_VU = ATT_JC / 4 / ATT_NPROD;              // 4-row units per producer per chunk
+
+// V rows of PV chunk c for producer pwv.  One 16 B load covers 8 dims of one position: 16 lanes per row, 4 rows per instruction,
+// units u -> positions c*64 + (ATT_NPROD*u + pwv)*4 + lane/16.  A PV step (~64 dependent adds) is several times shorter
+// than a load round trip, so three chunks are kept in flight; hipcc drains vmcnt(0) around loop-carried register prefetch,
+// hence the same hand-counted asm ring as the GEMV (RING_LOAD / RING_RETIRE, checked by tools/isa_audit.py).
+// Always issued (rows clamped to T-1, whose p is +0 beyond the row) so that the count is the same on every path.
+DEVINL void attn_load_v(u32x4 (&v)[ATT_VU], const uint16_t* vbase, uint32_t row_bytes, int c, int pwv, int lane, int T) {
+    const uint32_t dq = (uint32_t)(lane & 15) * 16u;                      // byte offset of this lane's 8 dims
+#pragma unroll
+    for (int u = 0; u < ATT_VU; u++) {
+        int j = c * ATT_JC + (ATT_NPROD * u + pwv) * 4 + (lane >> 4);
+        j = j < T ? j : T - 1;
+        const char* a = (const char*)vbase + ((size_t)(uint32_t)j * row_bytes + dq);
+        asm volatile("global_load_dwordx4 %0, %1, off ; RING_LOAD" : "=v"(v[u]) : "v"(a) : "memory");
+    }
+}
+template <int N> DEVINL void attn_retire_v(u32x4 (&v)[ATT_VU]) {      // v's loads are done once at most N younger ones are outstanding
+    static_assert(ATT_VU == 4, "operand list below");
+    asm volatile("s_waitcnt vmcnt(%4) ; RING_RETIRE %0 %1 %2 %3" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]) : "n"(N) : "memory");
+}
+
+// K rows of one scores pass: lane owns position j; chunk c of its row sits at kbase[c*seq_len + j] (position-contiguous)
+template <int NK> DEVINL void attn_load_k(uint4 (&k)[NK], const uint4* kbase, int seq_len, int j) {
+    const uint4* kr = kbase + j;
+#pragma unroll
+    for (int c = 0; c < NK; c++) { k[c] = *kr; kr += seq_len; }
+}
+
+// score + exp of one cached position (llamatransformer.go:456-473, Softmax impl:498)
+template <int NK> DEVINL void attn_score(const uint4 (&k)[NK], const float* qf, int j, int T, int S, int i, float divisor, double* e) {
+    if (j >= T) return;
+    const bool masked = (S > 1) && ((j % S) > i);            // triu(-inf,1) broadcast by modulo (tensoriterators.go:47-55)
+    double ev = 0.0;                                         // exp(-inf) == 0
+    if (!masked) {
+        float acc = 0.0f;
+#pragma unroll
+        for (int c = 0; c < NK; c++) {                       // MatMul q.k, d ascending (operations_matmul.go:37-55)
+            const float4 xa = *(const float4*)(qf + c * 8), xb = *(const float4*)(qf + c * 8 + 4);
+            acc = mac8(acc, xa, xb, k[c]);
+        }
+        uint16_t s = bf_trunc(acc);
+        s = bf_trunc(__fdiv_rn(bf_wide(s), divisor));       // DivToScalar :464
+        if (S > 1) s = bf_trunc(bf_wide(s) + 0.0f);          // Add(scores, mask) with mask==0 :469-473
+        ev = exp((double)bf_wide(s));
+    }
+    e[j] = ev;
+}
+
+// one PV pipeline step: producers turn chunk c (rows already in vc) into exact products in ring slot c&1 ([position][dim] f32)
+// after putting chunk c+3's rows in flight (vn); chain waves add chunk c-1.  Every wave ends the step at the same barrier.
+template <int HD> DEVINL void attn_pv_step(int c, int nchunks, int wave, int lane, int T, const uint16_t* vbase, uint32_t row_bytes,
+                                           const float* pw, char* ring, u32x4 (&vc)[ATT_VU], u32x4 (&vn)[ATT_VU], float& acc) {
+    constexpr int SLOT = ATT_JC * HD * 4;
+    const int pwv = (wave & 3) - 2 + ((wave >> 2) << 1);   // waves 2,3,6,7 -> producers 0..3
+    if ((wave & 3) >= 2) {
+        attn_load_v(vn, vbase, row_bytes, c + 3, pwv, lane, T);
+        attn_retire_v<3 * ATT_VU>(vc);                       // chunks c+1, c+2, c+3 stay in flight
+        if (c < nchunks && (lane & 15) * 8 < HD) {
+            const int jl0 = pwv * 4 + (lane >> 4);
+            char* dst = ring + (c & 1) * SLOT + (lane & 15) * 32 + jl0 * (HD * 4);
+            const float* pp = pw + c * ATT_JC + jl0;
+#pragma unroll
+            for (int u = 0; u < ATT_VU; u++) {               // position jl0 + 4*ATT_NPROD*u of the chunk
+                const float pj = pp[4 * ATT_NPROD * u];
+                const u32x4 v = vc[u];                       // exact products: 8-bit x 8-bit significands
+                *(float4*)(dst + u * 4 * ATT_NPROD * HD * 4) = make_float4(pj * bf_lo(v.x), pj * bf_hi(v.x), pj * bf_lo(v.y), pj * bf_hi(v.y));
+                *(float4*)(dst + u * 4 * ATT_NPROD * HD * 4 + 16) = make_float4(pj * bf_lo(v.z), pj * bf_hi(v.z), pj * bf_lo(v.w), pj * bf_hi(v.w));
+            }
+        }
+    } else if (wave < 2 && c > 0 && c <= nchunks) {
+        const int d = wave * 64 + lane;
+        if (d < HD) {
+            // positions past the end of the row carry p == +0: their products are +-0 and acc is never -0, so whole chunks are added
+            const float* src = (const float*)(ring + ((c - 1) & 1) * SLOT) + d;
+            float a[ATT_JC];
+#pragma unroll
+            for (int j = 0; j < ATT_JC; j++) a[j] = src[j * HD];          // whole chunk in flight at once
+#pragma unroll
+            for (int j = 0; j < ATT_JC; j++) acc += a[j];
+        }
+    }
+    __syncthreads();
+}
+
+template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x;
+    constexpr int NK = HD / 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x, i = blockIdx.y;
-    const int S = p.S, hd = p.hd, KVH = p.KVH;
+    const int S = p.S, KVH = p.KVH;
     const int pos0 = p.st->pos, T = pos0 + S;
     const int kvh = h / (p.H / KVH);
-    double* e = (double*)smem;                                                      // carve == attn_lds_bytes()
-    float* pw = (float*)(smem + (size_t)p.seq_len * 8);
-    float* qf = (float*)((char*)pw + (((size_t)p.seq_len * 4 + 15) & ~(size_t)15));
-    double* zb = (double*)((char*)qf + (((size_t)hd * 4 + 15) & ~(size_t)15));
+    double* e = (double*)smem;
+    float* pw = (float*)(smem + attn_off_pw(p.seq_len));
+    float* qf = (float*)(smem + attn_off_q(p.seq_len));
+    double* zb = (double*)(smem + attn_off_z(p.seq_len, HD));
+    char* ring = smem + attn_off_ring(p.seq_len, HD);
+    const uint32_t row_bytes = (uint32_t)KVH * HD * 2;
+    // K cache is stored [kv head][d/8][position][8] so that "one position per lane" reads are contiguous across the wave
+    const uint4* kbase = (const uint4*)p.cache_k + (size_t)kvh * NK * p.seq_len;
+    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD;
+    const int Tend = (S > 1 && pos0 == 0) ? (i + 1) : T;    // see PV below
+    const int nchunks = (Tend + ATT_JC - 1) / ATT_JC;
+#define ATT_STAMP(n) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) p.dbg[wave * 16 + (n)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    ATT_STAMP(0);
 
-    const uint16_t* q = p.q + ((size_t)i * p.H + h) * hd;
-    for (int d = tid; d < hd; d += 256) qf[d] = bf_wide(q[d]);
+    // q first (everything waits on it), then what does not depend on q: this thread's K row and chunk 0 of V (producers)
+    const uint16_t* q = p.q + ((size_t)i * p.H + h) * HD;
+    const uint16_t q16 = q[tid < HD ? tid : 0];             // unconditional: a predicated load would be waited on at once
+    uint4 ka[NK], kb[NK];
+    attn_load_k<NK>(ka, kbase, p.seq_len, tid < T ? tid : T - 1);
+    if (tid < HD) qf[tid] = bf_wide(q16);
     __syncthreads();
+    ATT_STAMP(1);
 
-    const size_t kvstride = (size_t)KVH * hd;
-    for (int j = tid; j < T; j += 256) {
-        const bool masked = (S > 1) && ((j % S) > i);        // triu(-inf,1) broadcast by modulo (tensoriterators.go:47-55)
-        double ev = 0.0;                                     // exp(-inf) == 0
-        if (!masked) {
-            const uint16_t* kr = p.cache_k + (size_t)j * kvstride + (size_t)kvh * hd;
-            float acc = 0.0f;
-            for (int d = 0; d < hd; d += 8) {                // MatMul q.k, d ascending (operations_matmul.go:37-55)
-                const uint4 kv = *(const uint4*)(kr + d);
-                const float4 xa = *(const float4*)(qf + d), xb = *(const float4*)(qf + d + 4);
-                acc = mac8(acc, xa, xb, kv);
-            }
-            uint16_t s = bf_trunc(acc);
-            s = bf_trunc(__fdiv_rn(bf_wide(s), p.divisor)); // DivToScalar :464
-            if (S > 1) s = bf_trunc(bf_wide(s) + 0.0f);      // Add(scores, mask) with mask==0 :469-473
-            ev = exp((double)bf_wide(s));                    // Softmax impl:498
+    // scores: ATT_NT positions per pass, the next pass's rows in flight during this pass's chains (registers ping-pong)
+    for (int j0 = 0; j0 < T; j0 += 2 * ATT_NT) {
+        const int j = j0 + tid;
+        const bool more = j0 + ATT_NT < T, more2 = j0 + 2 * ATT_NT < T;       // block-uniform
+        if (more) attn_load_k<NK>(kb, kbase, p.seq_len, j + ATT_NT < T ? j + ATT_NT : T - 1);
+        attn_score<NK>(ka, qf, j, T, S, i, p.divisor, e);
+        if (more) {
+            if (more2) attn_load_k<NK>(ka, kbase, p.seq_len, j + 2 * ATT_NT < T ? j + 2 * ATT_NT : T - 1);
+            attn_score<NK>(kb, qf, j + ATT_NT, T, S, i, p.divisor, e);
         }
-        e[j] = ev;
     }
+    // zero padding so that the Z chain can run whole groups (x + 0.0 == x for x >= +0)
+    for (int j = T + tid; j < ((T + 31) & ~31); j += ATT_NT) e[j] = 0.0;
+    // producers: the first three PV chunks of V go in flight now and land during the Z chain
+    u32x4 v0[ATT_VU], v1[ATT_VU], v2[ATT_VU], v3[ATT_VU];
+    if ((wave & 3) >= 2) {
+        const int pwv = (wave & 3) - 2 + ((wave >> 2) << 1);
+        attn_load_v(v0, vbase, row_bytes, 0, pwv, lane, T);
+        attn_load_v(v1, vbase, row_bytes, 1, pwv, lane, T);
+        attn_load_v(v2, vbase, row_bytes, 2, pwv, lane, T);
+    }
+    ATT_STAMP(2);
     __syncthreads();
-    if (tid == 0) {                                          // rowExpSum += exp(...), j ascending, f64 (impl:492-499)
+    ATT_STAMP(3);
+    if (wave == 0) {                                         // rowExpSum += exp(...), j ascending, f64 (impl:492-499)
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        const d2* e2 = (const d2*)e;
         double z = 0.0;
-        for (int j = 0; j < T; j++) z += e[j];
-        zb[0] = z;
+        d2 a[8], b[8];
+#define ATT_TOUCH8(r) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]))
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = e2[u];
+        ATT_TOUCH8(a);
+        for (int j = 0; j < T; j += 32) {                    // 16 values per half, the other half's reads in flight, one wait per half;
+                                                             // branch-free (e is zero-padded to 32): a conditional second half made
+                                                             // hipcc sink the adds below the wait and expose the LDS latency
+#pragma unroll
+            for (int u = 0; u < 8; u++) b[u] = e2[((j + 16) >> 1) + u];
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { z += a[u].x; z += a[u].y; }
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_TOUCH8(b);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = e2[((j + 32) >> 1) + u];      // may run into the p / ring region: unused then
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int u = 0; u < 8; u++) { z += b[u].x; z += b[u].y; }
+            __builtin_amdgcn_sched_barrier(0);
+            ATT_TOUCH8(a);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (lane == 0) zb[0] = z;
     }
+    ATT_STAMP(4);
     __syncthreads();
     const double z = zb[0];
-    for (int j = tid; j < T; j += 256) pw[j] = bf_wide(bf_trunc((float)(e[j] / z)));   // impl:506 + ToBFloat16 :493
+    const int Tp = (T + ATT_JC - 1) / ATT_JC * ATT_JC;
+    for (int j = tid; j < Tp; j += ATT_NT)                   // impl:506 + ToBFloat16 :493 ; +0 padding up to the chunk
+        pw[j] = j < T ? bf_wide(bf_trunc((float)(e[j] / z))) : 0.0f;
     __syncthreads();
+    ATT_STAMP(5);
 
-    // PV: out[d] = trunc(sum_{j ascending} p_j * v[j,d]); each lane owns 2 adjacent d (2 chains)
-    if (tid < (hd >> 1)) {
-        const int d0 = tid * 2;
-        const uint16_t* vb = p.cache_v + (size_t)kvh * hd + d0;
-        float a0 = 0.0f, a1 = 0.0f;
-        // masked columns have p == +0: adding +-0 never changes a0/a1 (they are never -0), so with the
-        // standard causal layout (pos0 == 0) the chain can stop at the diagonal
-        const int Tend = (S > 1 && pos0 == 0) ? (i + 1) : T;
-#pragma unroll 8
-        for (int j = 0; j < Tend; j++) {
-            const uint32_t v = *(const uint32_t*)(vb + (size_t)j * kvstride);
-            const float pj = pw[j];
-            a0 = fmaf(pj, bf_lo(v), a0); a1 = fmaf(pj, bf_hi(v), a1);
-        }
-        uint32_t packed = (uint32_t)bf_trunc(a0) | ((uint32_t)bf_trunc(a1) << 16);
-        *(uint32_t*)(p.out + ((size_t)i * p.H + h) * hd + d0) = packed;   // [S, H*hd] (:508-514)
+    // PV: out[d] = trunc(sum_{j ascending} p_j * v[j,d]).  Masked columns have p == +0 and acc is never -0, so with the
+    // standard causal layout (pos0 == 0) the chain can stop at the chunk that holds the diagonal (Tend).
+    float acc = 0.0f;
+    for (int c = 0; c <= nchunks; c += 4) {                  // four steps per trip: the V register sets rotate without copies
+        attn_pv_step<HD>(c, nchunks, wave, lane, T, vbase, row_bytes, pw, ring, v0, v3, acc);
+        attn_pv_step<HD>(c + 1, nchunks, wave, lane, T, vbase, row_bytes, pw, ring, v1, v0, acc);
+        if (c + 2 > nchunks) break;
+        attn_pv_step<HD>(c + 2, nchunks, wave, lane, T, vbase, row_bytes, pw, ring, v2, v1, acc);
+        attn_pv_step<HD>(c + 3, nchunks, wave, lane, T, vbase, row_bytes, pw, ring, v3, v2, acc);
+    }
+    asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");   // prefetches past the last chunk
+    ATT_STAMP(6);
+    if (wave < 2) {
+        const int d = wave * 64 + lane;
+        if (d < HD) p.out[((size_t)i * p.H + h) * HD + d] = bf_trunc(acc);   // [S, H*hd] (:508-514)
     }
 }
 
@@ -524,7 +675,29 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, in
     __shared__ int si[1024];
     const int tid = threadIdx.x;
     float best = -3.40282346638528859811704183484516925440e+38f; int bi = -1;
-    for (int j = tid; j < V; j += 1024) { float v = bf_wide(logits[j]); if (best < v) { best = v; bi = j; } }
+    // 16 B loads, four in flight per thread (the scalar one-load-per-iteration form was pure latency: 42 us for V=128256);
+    // each thread still visits its own elements in ascending index order, so '<' keeps the first maximum
+    const int nv = ((((uintptr_t)logits) & 15) == 0) ? V >> 3 : 0;
+    const uint4* l4 = (const uint4*)logits;
+    for (int c0 = tid; c0 < nv; c0 += 4096) {
+        uint4 w[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int c = c0 + u * 1024; w[u] = l4[c < nv ? c : c0]; }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int c = c0 + u * 1024;
+            if (c < nv) {
+                const uint32_t q[4] = {w[u].x, w[u].y, w[u].z, w[u].w};
+#pragma unroll
+                for (int t = 0; t < 4; t++) {
+                    const float a = bf_lo(q[t]), b = bf_hi(q[t]);
+                    if (best < a) { best = a; bi = c * 8 + 2 * t; }
+                    if (best < b) { best = b; bi = c * 8 + 2 * t + 1; }
+                }
+            }
+        }
+    }
+    for (int j = nv * 8 + tid; j < V; j += 1024) { float v = bf_wide(logits[j]); if (best < v) { best = v; bi = j; } }
     sv[tid] = best; si[tid] = bi;
     __syncthreads();
     for (int s = 512; s > 0; s >>= 1) {
@@ -623,9 +796,7 @@ extern "C" hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, i
     }
 }
 
-static size_t attn_lds_bytes(int seq_len, int hd) {
-    return (size_t)seq_len * 8 + (((size_t)seq_len * 4 + 15) & ~(size_t)15) + (((size_t)hd * 4 + 15) & ~(size_t)15) + 16;
-}
+static size_t attn_lds_bytes(int seq_len, int hd) { return attn_off_ring(seq_len, hd) + 2 * (size_t)ATT_JC * hd * 4; }
 extern "C" hipError_t lnbk_init(void) {
     static bool done = false;
     if (done) return hipSuccess;
@@ -638,8 +809,10 @@ extern "C" hipError_t lnbk_init(void) {
         if ((e = lnbk_gemv(nullptr, rws[i], 1, EPI_RESID, 0, nullptr)) != hipSuccess) return e;
         if ((e = lnbk_gemv(nullptr, rws[i], 2, EPI_SILU_MUL, 1, nullptr)) != hipSuccess) return e;
     }
-    hipError_t e = hipFuncSetAttribute((const void*)attn_exact_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
+    hipError_t e;
+    if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     done = true;
     return hipSuccess;
 }
@@ -647,7 +820,12 @@ extern "C" hipError_t lnbk_init(void) {
 extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     size_t lds = attn_lds_bytes(p->seq_len, p->hd);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(attn_exact_kernel, dim3(p->H, p->S), dim3(256), lds, st, *p);
+    switch (p->hd) {
+    case 128: hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
+    case 64: hipLaunchKernelGGL(attn_exact_kernel<64>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
+    case 32: hipLaunchKernelGGL(attn_exact_kernel<32>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
+    default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

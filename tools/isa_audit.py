@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Static audit of the hand-counted register ring in gemv_chain_kernel (llama-nuts-and-bolts_amd/csrc/lnb_kernels.hip).
+"""Static audit of the hand-counted register rings in gemv_chain_kernel and attn_exact_kernel (llama-nuts-and-bolts_amd/csrc/lnb_kernels.hip).
 
 The helper waves issue `global_load_dwordx4 ... nt` from inline asm (invisible to hipcc's s_waitcnt bookkeeping) and
 retire them with a hand-written counted `s_waitcnt vmcnt(N)`.  hipcc is free to copy / reuse VGPRs it believes are
@@ -145,7 +145,7 @@ def main(asm_path=None):
         txt = open(asm).read().split("\n")
     funcs, cur = {}, None
     for i, ln in enumerate(txt):
-        m = re.match(r"^(_Z17gemv_chain_kernel\S*):", ln)
+        m = re.match(r"^(_Z17(?:gemv_chain|attn_exact)_kernel\S*):", ln)
         if m:
             cur = []; funcs[m.group(1)] = cur
             continue
