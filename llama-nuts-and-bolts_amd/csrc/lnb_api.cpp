@@ -80,9 +80,11 @@ struct lnb_ctx {
 };
 
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
-static int auto_rw(int lane_rows, const char* env) {
+static int auto_rw(int lane_rows, const char* env, int K = 0, bool plain = false) {
     int v = env_int(env, 0);
-    if (v == 16 || v == 32 || v == 64) return v;
+    if (v == 16 || v == 32 || v == 64 || (v == 4 && plain && K % 128 == 0)) return v;
+    // thin matrices without a fused norm / rope epilogue: the row-broadcast kernel (products stay in registers)
+    if (plain && lane_rows <= 16 * 256 && K > 0 && K % 128 == 0 && (size_t)K * 4 <= 150 * 1024) return 4;
     // thin matrices: one workgroup (16 or 32 rows) per CU, all resident at once on the 256 CUs -- a second round of
     // workgroups would double the serial chain time
     if (lane_rows <= 16 * 256) return 16;
@@ -94,7 +96,7 @@ static long long* g_dbg = nullptr;   // LNB_GEMV_TIMING=1: per-wave timing dump 
 // one resident workgroup per CU: a matrix with more row blocks than CUs is walked persistently
 static void set_grid(GemvParams& g, const TiledDesc& t) { g.dbg = g_dbg; g.n_blocks = t.n_blocks; g.n_wg = t.n_blocks < g_num_cus ? t.n_blocks : g_num_cus; }
 static int alloc_tiled(TiledDesc& t, int n_rows, int K, int rw, int nch, int64_t& bytes) {
-    t.n_rows = n_rows; t.k = K; t.rw = rw; t.nch = nch; t.n_blocks = (n_rows + rw - 1) / rw;
+    t.n_rows = n_rows; t.k = K; t.rw = rw; t.nch = nch; t.n_blocks = rw == 4 ? (n_rows + 15) / 16 : (n_rows + rw - 1) / rw;   // rw 4: 16-row workgroups
     size_t n = tiled_elems(n_rows, K, rw, nch) * 2;
     HIPCHK(hipMalloc((void**)&t.w, n));
     HIPCHK(hipMemset(t.w, 0, n));
@@ -157,9 +159,9 @@ extern "C" int lnb_model_create(const lnb_model_args* args, int device, int laye
         char nm[128]; uint32_t base = 16u * (uint32_t)(l + 1);
         if (alloc_linear(&L.attn_norm, dim, wb) || alloc_linear(&L.ffn_norm, dim, wb)) return -1;
         if (alloc_tiled(L.wqkv, m->q_dim + 2 * m->kv_dim, dim, auto_rw(m->q_dim + 2 * m->kv_dim, "LNB_RW_QKV"), 1, wb)) return -1;
-        if (alloc_tiled(L.wo, dim, m->q_dim, auto_rw(dim, "LNB_RW_WO"), 1, wb)) return -1;
+        if (alloc_tiled(L.wo, dim, m->q_dim, auto_rw(dim, "LNB_RW_WO", m->q_dim, true), 1, wb)) return -1;
         if (alloc_tiled(L.w13, F, dim, auto_rw(F, "LNB_RW_W13"), 2, wb)) return -1;
-        if (alloc_tiled(L.w2, dim, F, auto_rw(dim, "LNB_RW_W2"), 1, wb)) return -1;
+        if (alloc_tiled(L.w2, dim, F, auto_rw(dim, "LNB_RW_W2", F, true), 1, wb)) return -1;
         snprintf(nm, sizeof nm, "layers.%d.attention_norm.weight", l); reg_linear(m, nm, L.attn_norm, dim, base + 0, 1);
         snprintf(nm, sizeof nm, "layers.%d.attention.wq.weight", l); reg_tiled(m, nm, &L.wqkv, m->q_dim, dim, 0, 0, base + 1);
         snprintf(nm, sizeof nm, "layers.%d.attention.wk.weight", l); reg_tiled(m, nm, &L.wqkv, m->kv_dim, dim, m->q_dim, 0, base + 2);
@@ -565,7 +567,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     // consecutive launches walk through the layers so that every launch streams its weights from HBM
     // (one layer's 235 MB gate/up matrix would otherwise sit in the 256 MiB Infinity Cache)
     auto run = [&](int i) -> int {
-        int l = m->layer_begin + (i % nl);
+        int l = m->layer_begin + (env_int("LNB_PROFILE_SAME_LAYER", 0) ? 0 : (i % nl));
         if (which == K_HEAD) return enqueue_head(c, 0, 1);
         if (which == K_LAYER) { for (int k = K_QKV; k <= K_W2; k++) if (enqueue_layer_kernel(c, l, 1, k)) return -1; return 0; }
         return enqueue_layer_kernel(c, l, 1, which);
@@ -609,9 +611,9 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
         hipFree(dbuf);
         fprintf(stderr, "[timing] kernel class %d: per-wave s_memtime ticks (avg over workgroups)\n", which);
         for (int w = 0; w < 8; w++) {
-            double tot = 0, wait = 0, tx = 0, mx = 0; int cnt = 0;
-            for (int g = 0; g < 4096; g++) { const long long* d = &h[((size_t)g * 8 + w) * 4]; if (d[0] > 0) { tot += d[0]; wait += d[1]; tx += d[2]; if (d[0] > mx) mx = (double)d[0]; cnt++; } }
-            if (cnt) fprintf(stderr, "[timing]   wave %d: n=%d total=%.0f (max %.0f) barrier_wait=%.0f x_or_vmwait=%.0f\n", w, cnt, tot / cnt, mx, wait / cnt, tx / cnt);
+            double tot = 0, wait = 0, tx = 0, mx = 0, aux = 0; int cnt = 0;
+            for (int g = 0; g < 4096; g++) { const long long* d = &h[((size_t)g * 8 + w) * 4]; if (d[0] > 0) { tot += d[0]; wait += d[1]; tx += d[2]; aux += d[3]; if (d[0] > mx) mx = (double)d[0]; cnt++; } }
+            if (cnt) fprintf(stderr, "[timing]   wave %d: n=%d total=%.0f (max %.0f) barrier_wait=%.0f x_or_vmwait=%.0f rms_fold_or_walk=%.0f\n", w, cnt, tot / cnt, mx, wait / cnt, tx / cnt, aux / cnt);
         }
     }
     return 0;
@@ -627,8 +629,8 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     if (ndev == 0) return fail("no HIP device: liblnb_hip.so has no CPU fallback");
     HIPCHK(hipSetDevice(device));
     HIPCHK(lnbk_init());
-    if (rw == 0) rw = auto_rw(n_out, "LNB_RW_OP");
-    if (rw != 16 && rw != 32 && rw != 64) return fail("rw must be 16, 32 or 64");
+    if (rw == 0) rw = auto_rw(n_out, "LNB_RW_OP", k_in, norm_w == nullptr);
+    if (rw != 16 && rw != 32 && rw != 64 && !(rw == 4 && !norm_w && k_in % 128 == 0)) return fail("rw must be 16, 32 or 64 (or 4: row-broadcast layout, no fused norm, in_features a multiple of 128)");
     if ((size_t)k_in * 4 > 120 * 1024) return fail("in_features %d does not fit the LDS staging", k_in);
     TiledDesc t{}; int64_t bytes = 0;
     if (alloc_tiled(t, n_out, k_in, rw, 1, bytes)) return -1;

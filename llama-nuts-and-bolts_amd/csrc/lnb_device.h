@@ -29,11 +29,17 @@ struct TiledDesc {
     int nch;          // chains per lane: 1 / 2
     int n_blocks;     // ceil(n_rows / rw)
 };
+//
+// RW == 4 selects the ROW-BROADCAST layout of rowcast_kernel (thin matrices, K % 128 == 0, NCH == 1):
+//   [N/4 wave tiles][K/128 chunks][row%4][k%16][(k%128)/16]  -- a wave streams 1 KiB per 128-step chunk, lane (q, j) of the
+// wave holds, in k order, the eight weights of row 4t+q whose k is congruent to j modulo 16.
 LNB_HD size_t tiled_index(int n, int k, int c, int K, int RW, int NCH) {
+    if (RW == 4) return ((((size_t)(n >> 2) * (size_t)(K >> 7) + (size_t)(k >> 7)) * 64 + (size_t)((n & 3) * 16 + (k & 15))) << 3) + (size_t)((k & 127) >> 4);
     size_t b = (size_t)(n / RW), r = (size_t)(n % RW), kc = (size_t)(k >> 3), e = (size_t)(k & 7);
     return ((((b * (size_t)(K >> 3) + kc) * (size_t)NCH + (size_t)c) * (size_t)RW + r) << 3) + e;
 }
 LNB_HD size_t tiled_elems(int n_rows, int K, int RW, int NCH) {
+    if (RW == 4) return (size_t)((n_rows + 15) / 16) * 16 * (size_t)K;       // whole 16-row workgroups
     return (size_t)((n_rows + RW - 1) / RW) * (size_t)RW * (size_t)NCH * (size_t)K;
 }
 

@@ -22,7 +22,9 @@
 // must stay two roundings.
 #include <hip/hip_runtime.h>
 #include <cstdlib>
+#include <type_traits>
 #include "lnb_device.h"
+#include "lnb_seqsum.h"
 
 #define DEVINL __device__ __forceinline__
 
@@ -119,32 +121,120 @@ DEVINL void x_store(const GemvParams& p, float* xs, int kpad, int sidx, int lane
     }
 }
 // RMSNorm.doNormalization (llamatransformer.go:641-660): Mean = serial f32 sum of the squares in xs, k ascending
-// (operations_impl.go:236-251), /K, +eps (f32), f32(1/sqrt(f64)).  Every lane of the chain wave walks the same chain
-// (broadcast LDS reads; ping-pong register sets, 16 steps added while the next 16 values are in flight; the
-// padding zeros are added too: sum >= +0 is never changed by + 0.0).
-// An exact parity-map scan of this sum (lnb_seqsum.h, fuzzed in tests/test_seqsum.py) was measured on MI355X at the
-// same ~16 us as this plain chain in its one-wave form and is therefore not wired in; see DESIGN.md.
-DEVINL float rms_scale(const GemvParams& p, const float* xs) {
-    const int K = p.K;
-    float sum = 0.0f;
-    float4 a0 = *(const float4*)(xs), a1 = *(const float4*)(xs + 4), a2 = *(const float4*)(xs + 8), a3 = *(const float4*)(xs + 12);
-    for (int k0 = 0; k0 < K; k0 += 32) {
-        const float4 b0 = *(const float4*)(xs + k0 + 16), b1 = *(const float4*)(xs + k0 + 20);
-        const float4 b2 = *(const float4*)(xs + k0 + 24), b3 = *(const float4*)(xs + k0 + 28);
-        __builtin_amdgcn_sched_barrier(0);
-        touch16(a0, a1, a2, a3);
-        __builtin_amdgcn_sched_barrier(0);
-        sum = add4(sum, a0); sum = add4(sum, a1); sum = add4(sum, a2); sum = add4(sum, a3);
-        __builtin_amdgcn_sched_barrier(0);
-        a0 = *(const float4*)(xs + k0 + 32); a1 = *(const float4*)(xs + k0 + 36);
-        a2 = *(const float4*)(xs + k0 + 40); a3 = *(const float4*)(xs + k0 + 44);
-        __builtin_amdgcn_sched_barrier(0);
-        touch16(b0, b1, b2, b3);
-        __builtin_amdgcn_sched_barrier(0);
-        sum = add4(sum, b0); sum = add4(sum, b1); sum = add4(sum, b2); sum = add4(sum, b3);
-        __builtin_amdgcn_sched_barrier(0);
+// (operations_impl.go:236-251), /K, +eps (f32), f32(1/sqrt(f64)).
+//
+// 4096 dependent roundings cost >= 7.4 us as a plain chain (measured ~15 us with its LDS reads) in front of EVERY
+// workgroup of the RMSNorm-fused GEMVs.  The sum is evaluated EXACTLY in parallel instead (lnb_seqsum.h): inside one
+// binade an f32 add of a non-negative term is the integer map M -> M + c_{M&1}, and such maps compose.
+//   helpers (NH waves): lane = one leaf of 8 consecutive squares; approximate prefix sums (wave scan + wave totals) guess
+//                       the leaf's binade; the leaf map is folded; a segmented inclusive wave scan composes every run of
+//                       valid equal-binade leaves; run ends and invalid leaves are flagged in a 64-bit item mask;
+//   chain wave (walker): adds the first RMS_HEAD squares one by one (the sum changes binade every few terms there) while
+//                       the helpers fold, then visits only the items: a run's composed map is applied when it starts
+//                       exactly at the walker's position, its binade matches the running sum and the sum stays inside it
+//                       (a wrong guess can never be used); anything else is replayed term by term.
+// Bit-identical to the sequential loop for every input (fuzzed on the CPU: tests/test_seqsum.py emulates this lane by
+// lane; on the GPU: tests/test_gpu_parity.py through lnb_op_rmsnorm_linear); ~17 items + ~5 replayed leaves for gaussian x.
+// A leaf is seq_leaf_size(K, NH*64) terms (one leaf per folding lane; the last one may run into the zero padding).
+constexpr int RMS_HEAD = 256;
+__host__ __device__ inline size_t rms_scratch_bytes(int NH) { return (size_t)NH * (512 + 8 + 4) + 64; }
+// LDS scratch (the idle product ring): SeqNode rec[NH][64] | uint64 items[NH] | float wtot[NH]
+
+template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, char* scratch, int hw, int lane, long long& t_dbg) {
+    const long long tf0_ = p.dbg ? clock64() : 0;
+    const int LEAF = seq_leaf_size(p.K, NH * 64), nleaf = (p.K + LEAF - 1) / LEAF;
+    SeqNode* rec = (SeqNode*)scratch;
+    unsigned long long* items = (unsigned long long*)(scratch + (size_t)NH * 512);
+    float* wtot = (float*)(scratch + (size_t)NH * 520);
+    const int headleaf = (p.K < RMS_HEAD ? p.K : RMS_HEAD) / LEAF;
+    const int b = hw * 64 + lane;
+    const float* q = xs + (size_t)(b < nleaf ? b : nleaf - 1) * LEAF;    // (xs is zero padded past K: the last leaf may over-read)
+    float bsum = 0.0f;
+    for (int i = 0; i < LEAF; i += 4) { const float4 v = *(const float4*)(q + i); bsum += (v.x + v.y) + (v.z + v.w); }   // only feeds the guess
+    bsum = b < nleaf ? bsum : 0.0f;
+    float incl = bsum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    if (lane == 63) wtot[hw] = incl;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_s_barrier();                                        // X1: wave totals published
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float base = 0.0f;
+#pragma unroll
+    for (int w = 0; w < NH; w++) { const float v = wtot[w]; base += w < hw ? v : 0.0f; }
+    SeqNode n; n.a = 0u; n.b = 0u;
+    if (b < nleaf) n = seq_leaf(q, LEAF, base + (incl - bsum), base + incl);
+    SeqNode left; left.a = (uint32_t)__shfl_up((int)n.a, 1); left.b = 0u;
+    int f = seq_is_start(lane, n, left, b == headleaf);
+    const int fnext = __shfl_down(f, 1);
+    const unsigned long long mask = __ballot((n.a >> 24) == 0u || lane == 63 || fnext);
+    if (lane == 0) items[hw] = mask;
+    int start = lane;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {                                   // segmented Hillis-Steele scan of the leaf maps
+        SeqNode o; o.a = (uint32_t)__shfl_up((int)n.a, d); o.b = (uint32_t)__shfl_up((int)n.b, d);
+        const int ofs = __shfl_up((f << 8) | start, d);
+        if (lane >= d && !f) seq_scan_step(n, f, start, o, ofs >> 8, ofs & 0xFF);
     }
-    float mean = __fdiv_rn(sum, (float)K);
+    n.b |= (uint32_t)start << 24;                                        // c1 < 2^24: the run's first leaf rides in the top byte
+    rec[hw * 64 + lane] = n;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (p.dbg) t_dbg = clock64() - tf0_;                                 // fold time incl. the X1 wait
+    __builtin_amdgcn_s_barrier();                                        // X2: records published
+}
+
+// the items of one wave's 64 leaves: rc = this lane's record, from leaf `pos` up to `nloc`; sq = the wave's first square.
+// Scalar code (SGPRs + v_readlane); the accept test is evaluated branch-free, the only branch is the rare replay.
+DEVINL uint32_t rms_walk_heap(uint32_t sb, const SeqNode& rc, unsigned long long mask, int pos, int nloc, const float* sq, int LEAF) {
+    mask &= ~0ull << pos;                                                // items in front of the head are done
+    if (nloc < 64) mask &= ~(~0ull << nloc);                             // leaves past the end of the row
+    while (mask) {
+        const int i = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)rc.a, i), nb = (uint32_t)__builtin_amdgcn_readlane((int)rc.b, i);
+        const uint32_t e = na >> 24, es = sb >> 23;
+        const uint32_t M = (sb & 0x7FFFFFu) | 0x800000u;
+        const uint32_t Mn = M + (((M & 1u) ? nb : na) & 0xFFFFFFu);
+        const uint32_t ok = (uint32_t)((nb >> 24) == (uint32_t)pos) & (uint32_t)(e == es) & (uint32_t)(e != 0u) & (uint32_t)(Mn < 0x1000000u);
+        const uint32_t snew = (es << 23) | (Mn & 0x7FFFFFu);
+        if (__builtin_expect(!ok, 0)) {                                  // replay leaves pos..i term by term
+            float f = __uint_as_float(sb);
+            const float* qe = sq + (size_t)(i + 1) * LEAF;
+            for (const float* q = sq + (size_t)pos * LEAF; q < qe; q += 4) f = add4(f, *(const float4*)q);
+            sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(f));
+        } else sb = snew;
+        pos = i + 1;
+    }
+    return sb;
+}
+
+template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* xs, const char* scratch, int lane, long long& t_dbg) {
+    const int K = p.K, LEAF = seq_leaf_size(K, NH * 64), nleaf = (K + LEAF - 1) / LEAF;
+    const SeqNode* rec = (const SeqNode*)scratch;
+    const unsigned long long* items = (const unsigned long long*)(scratch + (size_t)NH * 512);
+    __builtin_amdgcn_s_barrier();                                        // X1 (the helpers' wave totals)
+    // head of the sum, term by term, while the helpers fold
+    const int headleaf = (K < RMS_HEAD ? K : RMS_HEAD) / LEAF, head = headleaf * LEAF;
+    float sum = 0.0f;
+    for (int k0 = 0; k0 < head; k0 += 4) sum = add4(sum, *(const float4*)(xs + k0));
+    __builtin_amdgcn_s_barrier();                                        // X2 (the records)
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
+    const long long tw0_ = p.dbg ? clock64() : 0;
+    SeqNode rc[NH];
+    unsigned long long mk[NH];
+#pragma unroll
+    for (int w = 0; w < NH; w++) { rc[w] = rec[w * 64 + lane]; mk[w] = items[w]; }
+#pragma unroll
+    for (int w = 0; w < NH; w++) {
+        int nloc = nleaf - w * 64; nloc = nloc < 0 ? 0 : (nloc > 64 ? 64 : nloc);
+        int pos = headleaf - w * 64; pos = pos < 0 ? 0 : pos;
+        const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mk[w]);
+        const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mk[w] >> 32));
+        sb = rms_walk_heap(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF);
+    }
+    if (p.dbg) t_dbg = clock64() - tw0_;                                 // walk time
+    float mean = __fdiv_rn(__uint_as_float(sb), (float)K);
     mean = mean + p.eps;
     return (float)(1.0 / sqrt((double)mean));
 }
@@ -240,7 +330,7 @@ DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, i
 // ------------------------------------------------------------------------------------------------
 // optional per-wave timing (GemvParams.dbg != nullptr): [wg][wave][4] = {total, barrier wait, x staging / vm wait, -} in s_memtime ticks
 #define TIMED_BARRIER() do { if (p.dbg) { long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
-#define DBG_EXIT() do { if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; } } while (0)
+#define DBG_EXIT() do { if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; d_[3] = t_aux; } } while (0)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // asm loads are invisible to hipcc's s_waitcnt bookkeeping: the ring below is waited for by hand (wait_ring)
@@ -259,7 +349,7 @@ template <int N, int NP> DEVINL void wait_ring(u32x4 (&b)[NP]) {
 template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
 __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    long long t_begin = p.dbg ? clock64() : 0, t_wait = 0, t_x = 0;
+    long long t_begin = p.dbg ? clock64() : 0, t_wait = 0, t_x = 0, t_aux = 0;
     constexpr int KC = SA / (NCH * RW * 16);              // 8-wide k chunks per stage
     constexpr int GS = KC / 2;                            // 16-step groups per stage
     constexpr int SB = 2 * SA;                            // f32 product stage
@@ -316,6 +406,8 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             TIMED_BARRIER();                                           // B1: xs (or the squares) are in LDS
             if (NORM) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                rms_fold<NH>(p, xs, ringB, hw, lane, t_aux);                  // X1, X2 inside
                 TIMED_BARRIER();                                       // B2: r published
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if constexpr (NORM) x_normalize<NS>(p, xs, kpad, xs[kpad], 1 + hw, lane, xv, nv);
@@ -374,7 +466,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
         TIMED_BARRIER();                                               // B1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (NORM) {
-            const float r = rms_scale(p, xs);
+            const float r = rms_scale_wide<NH>(p, xs, ringB, lane, t_aux);     // X1, X2 inside
             if (lane == 0) xs[kpad] = r;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             TIMED_BARRIER();                                           // B2
@@ -432,6 +524,119 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     DBG_EXIT();
+}
+
+// ------------------------------------------------------------------------------------------------
+// Row-broadcast exact GEMV for THIN matrices (wo, w2: 16 output rows per CU are all there is to do).
+//
+// In gemv_chain_kernel a chain lane receives its products through the LDS: measured on gfx950 a ds_read_b128 occupies the
+// wave for ~12.5 cycles, i.e. ~3.1 cycles per k-step on top of the 4.33-cycle dependent add, and the thin kernels are pure
+// chain latency (K x ~7.6 cycles).  Here the products never leave the register file:
+//   a wave owns 4 output rows, one per DPP row of 16 lanes; lane (q, j) streams the weights of row q with k = j (mod 16)
+//   (16 B = eight of them, k ascending, per 128-step chunk), multiplies them by x (exact products) and every lane of the
+//   row adds the 16 lanes' products in k order with  v_add_f32_dpp row_newbcast:j  -- a DPP operand costs nothing measurable
+//   (8.75 vs 8.63 ticks per dependent add in tools/chainbench2.hip), so a k-step is ~4.33 cycles + ~0.8 of producer work.
+// All 16 lanes of a row compute the same sum (same operands, same order); lane j == 0 stores it.
+// Four waves (16 rows) per workgroup share x (f32, transposed per chunk in LDS); weights come through the same hand-counted
+// register ring as gemv_chain_kernel (RING_LOAD / RING_RETIRE, tools/isa_audit.py).
+// grid.x = S * n_wg, block = 256; dynamic LDS = K * 4 bytes.
+// ------------------------------------------------------------------------------------------------
+constexpr int RC_R = 14;                                    // 1 KiB chunks in flight per wave (56 KiB per CU)
+// 16 dependent adds in ONE asm statement: acc += pr(lane 0) ... += pr(lane 15) of this lane's DPP row.  (One statement per add
+// made hipcc's hazard recognizer put an s_nop behind every one of them -- it cannot see which operand is the DPP one -- and
+// doubled the step time.  Inside the block no further wait states are needed: acc is the plain operand.)
+DEVINL void chain16(float& acc, const float& pr) {
+    asm volatile("s_nop 1\n\t"          // VALU write of pr -> DPP read: 2 wait states, whatever hipcc scheduled in front
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf" "\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf"
+                 : "+v"(acc) : "v"(pr));
+}
+DEVINL void chain128(float& acc, const float (&pr)[8]) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) chain16(acc, pr[i]);
+}
+template <int EPI>
+__global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* xT = (float*)smem;                                // x[128c + 16i + j] at xT[(c*16 + j)*8 + i]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int K = p.K, S = p.S, nchunks = K >> 7;
+    const int m = (S == 1) ? 0 : (int)(blockIdx.x % (unsigned)S);
+    const int wg = (S == 1) ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)S);
+    const int nb_mine = (p.n_blocks - wg + p.n_wg - 1) / p.n_wg;       // 16-row blocks wg, wg+n_wg, ...
+    const int T = nb_mine * nchunks;                                   // chunks this wave walks
+    const size_t tile_bytes = (size_t)nchunks * 1024;                  // one wave tile (4 rows)
+    const unsigned voff = (unsigned)lane * 16u;
+    // weight ring first (it does not depend on x), then x
+    u32x4 buf[RC_R];
+    // issue cursor: a running wave-uniform pointer (1 KiB per chunk; at the end of a tile jump to this wave's tile of the
+    // next block); past the last chunk it stays put and re-reads
+    const char* sb = (const char*)p.w + ((size_t)wg * 4 + wave) * tile_bytes;
+    const size_t blk_jump = (size_t)p.n_wg * 4 * tile_bytes - tile_bytes;                                  // from the end of a tile
+    int ic = 0, issued = 0;
+    auto issue_next = [&](u32x4& dst) {
+        ld_nt_asm(dst, voff, sb);
+        if (issued + 1 < T) { issued++; sb += 1024; if (++ic == nchunks) { ic = 0; sb += blk_jump; } }
+    };
+#pragma unroll
+    for (int j = 0; j < RC_R; j++) issue_next(buf[j]);
+    {
+        const uint16_t* xrow = p.x + (size_t)m * K;
+        for (int u = tid; u < (K >> 3); u += 256) {
+            const uint4 v = *(const uint4*)(xrow + u * 8);
+            const int k = u * 8, c = k >> 7, i = (k & 127) >> 4, j0 = k & 15;
+            float* d = xT + ((size_t)(c * 16 + j0) * 8 + i);
+            d[0] = bf_lo(v.x); d[8] = bf_hi(v.x); d[16] = bf_lo(v.y); d[24] = bf_hi(v.y);
+            d[32] = bf_lo(v.z); d[40] = bf_hi(v.z); d[48] = bf_lo(v.w); d[56] = bf_hi(v.w);
+        }
+    }
+    __syncthreads();                                         // (hipcc waits for its own x loads; the asm ring stays in flight)
+    const float* xl = xT + (size_t)(lane & 15) * 8;
+    float acc = 0.0f;
+    float pr[8];
+    auto products = [&](float (&d)[8], const u32x4& v, int c) {        // exact: 8-bit x 8-bit significands
+        const float4 xa = *(const float4*)(xl + (size_t)c * 128), xb = *(const float4*)(xl + (size_t)c * 128 + 4);
+        d[0] = xa.x * bf_lo(v.x); d[1] = xa.y * bf_hi(v.x); d[2] = xa.z * bf_lo(v.y); d[3] = xa.w * bf_hi(v.y);
+        d[4] = xb.x * bf_lo(v.z); d[5] = xb.y * bf_hi(v.z); d[6] = xb.z * bf_lo(v.w); d[7] = xb.w * bf_hi(v.w);
+    };
+    int c = 0, blk = wg;
+    for (int t0 = 0; t0 < T; t0 += RC_R) {
+#pragma unroll
+        for (int j = 0; j < RC_R; j++) {
+            if (t0 + j < T) {
+                wait_ring<RC_R - 1, 1>(*(u32x4(*)[1])&buf[j]);            // chunk t0+j landed; RC_R-1 younger ones stay in flight
+                products(pr, buf[j], c);
+                __builtin_amdgcn_sched_barrier(0);                     // refill AFTER the slot has been consumed
+                issue_next(buf[j]);
+                chain128(acc, pr);                                     // valDstF32 += p, k ascending (operations_lineartransform.go:63)
+                if (++c == nchunks) {                                  // end of this wave's 4 rows
+                    const int n = blk * 16 + wave * 4 + (lane >> 4);
+                    if ((lane & 15) == 0 && n < p.n_rows) {
+                        const size_t o = (size_t)m * p.n_rows + n;
+                        if (EPI == EPI_RESID) p.out[o] = bf_trunc(bf_wide(p.res[o]) + bf_wide(bf_trunc(acc)));   // ml.Add, operations_impl.go:320-332
+                        else p.out[o] = bf_trunc(acc);
+                    }
+                    acc = 0.0f; c = 0; blk += p.n_wg;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -730,6 +935,11 @@ __global__ void tile_scatter_kernel(const uint16_t* src, uint16_t* dst, int rows
     if (idx >= total) return;
     int r = (int)(idx / (K >> 3)), kc = (int)(idx % (K >> 3));
     uint4 v = *(const uint4*)(src + (size_t)r * K + (size_t)kc * 8);
+    if (RW == 4) {                                           // row-broadcast layout: the 8 k's are not adjacent
+        const uint16_t* e = (const uint16_t*)&v;
+        for (int i = 0; i < 8; i++) dst[tiled_index(row_off + r, kc * 8 + i, chain, K, RW, NCH)] = e[i];
+        return;
+    }
     *(uint4*)(dst + tiled_index(row_off + r, kc * 8, chain, K, RW, NCH)) = v;
 }
 __global__ void tile_gather_kernel(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH) {
@@ -737,6 +947,10 @@ __global__ void tile_gather_kernel(const uint16_t* src, uint16_t* dst, int rows,
     size_t total = (size_t)rows * (K >> 3);
     if (idx >= total) return;
     int r = (int)(idx / (K >> 3)), kc = (int)(idx % (K >> 3));
+    if (RW == 4) {
+        for (int i = 0; i < 8; i++) dst[(size_t)r * K + (size_t)kc * 8 + i] = src[tiled_index(row_off + r, kc * 8 + i, chain, K, RW, NCH)];
+        return;
+    }
     uint4 v = *(const uint4*)(src + tiled_index(row_off + r, kc * 8, chain, K, RW, NCH));
     *(uint4*)(dst + (size_t)r * K + (size_t)kc * 8) = v;
 }
@@ -767,6 +981,7 @@ static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
     size_t lds = 4 * (size_t)SA + xs_bytes(p->K, SA / (NCH * RW * 2));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (xs_bytes(p->K, SA / (NCH * RW * 2)) / 4 > (size_t)XCh<NORM>::value * (1 + NH) * 512) return hipErrorInvalidValue;   // x staging registers
+    if (NORM && (rms_scratch_bytes(NH) > 4 * (size_t)SA || seq_leaf_size(p->K, NH * 64) > 256)) return hipErrorInvalidValue;   // records live in the idle ring; leaf over-read stays inside the x padding
     hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3((1 + NH) * 64), lds, st, *p);
     return hipGetLastError();
 }
@@ -778,12 +993,26 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     //  RW 64 (fat; HBM bound): 12 KiB stages, six helpers paired on three SIMDs (the chain wave owns the fourth),
     //  6 x 2 loads x 5 stages = 60 KiB in flight per CU.
     if (rw == 16) return launch_chain_t<16, NCH, 8192, 2, 7, EPI, NORM>(p, st);
-    if (rw == 32) return launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
-    if (rw == 64) return launch_chain_t<64, NCH, 12288, 6, 5, EPI, NORM>(p, st);
+    if (rw == 32) return NORM ? launch_chain_t<32, NCH, 6144, 6, 10, EPI, NORM>(p, st) : launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
+    if (rw == 64) return launch_chain_t<64, NCH, 12288, 6, 8, EPI, NORM>(p, st);
     return hipErrorInvalidValue;
 }
 
+template <int EPI> static hipError_t launch_rowcast(const GemvParams* p, hipStream_t st) {
+    auto kfn = rowcast_kernel<EPI>;
+    if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if ((p->K & 127) || (size_t)p->K * 4 > 150 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3(256), (size_t)p->K * 4, st, *p);
+    return hipGetLastError();
+}
+
 extern "C" hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st) {
+    if (rw == 4) {                                           // row-broadcast layout (thin matrices)
+        if (nch != 1 || norm) return hipErrorInvalidValue;
+        if (epi == EPI_STORE) return launch_rowcast<EPI_STORE>(p, st);
+        if (epi == EPI_RESID) return launch_rowcast<EPI_RESID>(p, st);
+        return hipErrorInvalidValue;
+    }
     if (nch == 2) {
         if (epi == EPI_SILU_MUL && norm) return launch_gemv_rw<EPI_SILU_MUL, true, 2>(p, rw, st);
         return hipErrorInvalidValue;
@@ -800,6 +1029,7 @@ static size_t attn_lds_bytes(int seq_len, int hd) { return attn_off_ring(seq_len
 extern "C" hipError_t lnbk_init(void) {
     static bool done = false;
     if (done) return hipSuccess;
+    { hipError_t e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_STORE, 0, nullptr)) != hipSuccess) return e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_RESID, 0, nullptr)) != hipSuccess) return e4; }
     const int rws[3] = {16, 32, 64};
     for (int i = 0; i < 3; i++) {
         hipError_t e;

@@ -70,3 +70,59 @@ SEQ_HD int32_t seq_guess(float lo, float hi) {
     if (el != eh || el == 0 || el == 0xFF) return 0;
     return el;
 }
+
+// ---- packed nodes and their composition (the multi-wave tree form used by the RMSNorm prologue) --------------------
+// A node is the parity map of a run of consecutive terms evaluated for ONE binade e:  M -> M + c_{M&1}.
+// Packed in two words: a = (e << 24) | c0, b = c1, with c0, c1 < 2^24; e == 0 means "invalid, replay the terms".
+// Such maps compose:  (f then g)(par) = f.c[par] + g.c[par ^ (f.c[par] & 1)]  when both were evaluated for the same e.
+struct SeqNode { uint32_t a, b; };
+
+SEQ_HD SeqNode seq_pack(const SeqBlock& blk) {
+    SeqNode n; n.a = 0; n.b = 0;
+    if (blk.ok && blk.e > 0 && blk.e < 0xFF && (uint32_t)blk.c0 < 0x1000000u && (uint32_t)blk.c1 < 0x1000000u) {
+        n.a = ((uint32_t)blk.e << 24) | (uint32_t)blk.c0; n.b = (uint32_t)blk.c1;
+    }
+    return n;
+}
+SEQ_HD SeqNode seq_compose(const SeqNode& f, const SeqNode& g) {
+    const uint32_t ef = f.a >> 24, eg = g.a >> 24;
+    const uint32_t fc0 = f.a & 0xFFFFFFu, fc1 = f.b, gc0 = g.a & 0xFFFFFFu, gc1 = g.b;
+    const uint32_t o0 = 0u - (fc0 & 1u), o1 = 0u - (fc1 & 1u);           // mask selects (no ?: -> no scratch lookup tables)
+    const uint32_t c0 = fc0 + ((gc1 & o0) | (gc0 & ~o0));                // entry parity 0 -> parity fc0&1 in front of g
+    const uint32_t c1 = fc1 + ((gc0 & o1) | (gc1 & ~o1));                // entry parity 1 -> parity 1^(fc1&1)
+    const uint32_t ok = (ef != 0u && ef == eg && c0 < 0x1000000u && c1 < 0x1000000u) ? 0xFFFFFFFFu : 0u;
+    SeqNode h; h.a = ((ef << 24) | c0) & ok; h.b = c1 & ok;
+    return h;
+}
+// apply a node to the running sum given as f32 bits (sign 0); returns 0 if the terms must be replayed
+SEQ_HD int seq_apply_node(uint32_t& sb, const SeqNode& n) {
+    const uint32_t e = n.a >> 24, es = sb >> 23;
+    if (e == 0u || e != es) return 0;
+    const uint32_t M = (sb & 0x7FFFFFu) | 0x800000u;
+    const uint32_t Mn = M + ((M & 1u) ? n.b : (n.a & 0xFFFFFFu));
+    if (Mn >= 0x1000000u) return 0;                                       // left the binade somewhere inside the run
+    sb = (es << 23) | (Mn & 0x7FFFFFu);
+    return 1;
+}
+// leaf size of the multi-wave form: the K terms are split over at most `lanes` leaves (one per folding lane); a multiple of
+// 4 (float4 reads), at least 8.  The last leaf may run past K: the terms there are +0 and change nothing.
+SEQ_HD int seq_leaf_size(int K, int lanes) { int l = (K + lanes - 1) / lanes; l = (l + 3) & ~3; return l < 8 ? 8 : l; }
+// fold `n` consecutive terms into a leaf node for the binade guessed from the approximate sums around them
+SEQ_HD SeqNode seq_leaf(const float* p, int n, float lo, float hi) {
+    SeqBlock b; b.c0 = 0; b.c1 = 0; b.e = seq_guess(lo, hi); b.ok = b.e != 0;
+    for (int i = 0; i < n; i++) seq_step(b, p[i]);
+    return seq_pack(b);
+}
+
+// ---- segmented inclusive scan of leaf maps (one wave = 64 leaves) -------------------------------------------------
+// a leaf starts a new run when it or its left neighbour is invalid, when the binade changes, or when forced
+SEQ_HD int seq_is_start(int lane, const SeqNode& me, const SeqNode& left, int forced) {
+    const uint32_t e = me.a >> 24, el = left.a >> 24;
+    return (lane == 0 || e == 0u || el == 0u || e != el || forced) ? 1 : 0;
+}
+// one Hillis-Steele step for a lane that is not cut yet (f == 0): absorb the run that ends right in front of this one
+SEQ_HD void seq_scan_step(SeqNode& n, int& f, int& start, const SeqNode& o, int of, int ostart) {
+    const SeqNode h = seq_compose(o, n);
+    if (h.a >> 24) { n = h; f = of; start = ostart; }
+    else f = 1;                                   // (cannot happen inside a verified binade; the walker checks `start` anyway)
+}

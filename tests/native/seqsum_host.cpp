@@ -31,3 +31,83 @@ extern "C" float seqsum_scan(const float* p, int K, int nb, int* n_fast_out) {
     if (n_fast_out) *n_fast_out = fast;
     return s;
 }
+
+
+// ---- the multi-wave form (rms_fold / rms_scale_wide in lnb_kernels.hip), emulated lane by lane -------------------------
+// NH folding waves of 64 lanes; lane = one leaf of LEAF = seq_leaf_size(K, NH*64) terms (zero padded past K).  Per wave
+// ("heap" of 64 leaves) a segmented inclusive scan composes the leaf maps of every run of equal-binade valid leaves; the
+// walker adds the first `head` terms one by one, then visits only the run ends and the invalid leaves (item mask),
+// applying the run's composed map when it starts exactly at the walker's position and verifies, else replaying the
+// leaves' terms.  Returns the sum; *visits = items visited, *raw = leaves replayed.
+extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, int* visits, int* raw) {
+    const int LEAF = seq_leaf_size(K, NH * 64), nleaf = (K + LEAF - 1) / LEAF, TB = NH * 64;
+    std::vector<float> pv((size_t)TB * LEAF + 64, 0.0f);
+    for (int k = 0; k < K; k++) pv[k] = pin[k];
+    const float* p = pv.data();
+    std::vector<float> bs(TB, 0.0f), lo(TB), hi(TB);
+    for (int b = 0; b < nleaf; b++) {
+        const float* q = p + (size_t)b * LEAF;
+        float v = 0.0f;
+        for (int i = 0; i < LEAF; i += 4) v += (q[i] + q[i + 1]) + (q[i + 2] + q[i + 3]);       // (only a guess: any order)
+        bs[b] = v;
+    }
+    float run = 0.0f;                                                      // approximate prefix: wave scans + wave totals
+    for (int g = 0; g < NH; g++) {
+        float incl = 0.0f;
+        for (int l = 0; l < 64; l++) { const int b = g * 64 + l; lo[b] = run + incl; incl += bs[b]; hi[b] = run + incl; }
+        run += incl;
+    }
+    int head = head_terms < K ? head_terms : K;
+    const int headleaf = head / LEAF;
+    head = headleaf * LEAF;
+    std::vector<SeqNode> rec((size_t)TB);
+    std::vector<uint64_t> items(NH);
+    for (int g = 0; g < NH; g++) {
+        SeqNode n[64]; int f[64], st[64];
+        for (int l = 0; l < 64; l++) {
+            const int b = g * 64 + l;
+            n[l].a = 0; n[l].b = 0;
+            if (b < nleaf) n[l] = seq_leaf(p + (size_t)b * LEAF, LEAF, lo[b], hi[b]);
+        }
+        for (int l = 0; l < 64; l++) f[l] = seq_is_start(l, n[l], l ? n[l - 1] : n[l], g * 64 + l == headleaf);
+        uint64_t mask = 0;
+        for (int l = 0; l < 64; l++) if (!(n[l].a >> 24) || l == 63 || f[l + 1]) mask |= 1ull << l;
+        for (int l = 0; l < 64; l++) st[l] = l;
+        for (int d = 1; d < 64; d <<= 1) {                                 // Hillis-Steele, all lanes in lock step
+            SeqNode nn[64]; int ff[64], ss[64];
+            for (int l = 0; l < 64; l++) {
+                nn[l] = n[l]; ff[l] = f[l]; ss[l] = st[l];
+                if (l >= d && !f[l]) seq_scan_step(nn[l], ff[l], ss[l], n[l - d], f[l - d], st[l - d]);
+            }
+            for (int l = 0; l < 64; l++) { n[l] = nn[l]; f[l] = ff[l]; st[l] = ss[l]; }
+        }
+        for (int l = 0; l < 64; l++) { rec[(size_t)g * 64 + l].a = n[l].a; rec[(size_t)g * 64 + l].b = n[l].b | ((uint32_t)st[l] << 24); }
+        items[g] = mask;
+    }
+    int nv = 0, nr = 0;
+    float s = 0.0f;
+    for (int k = 0; k < head; k++) s += p[k];
+    uint32_t sb = seq_f2u(s);
+    for (int g = 0; g < NH; g++) {
+        int nloc = nleaf - g * 64; nloc = nloc < 0 ? 0 : (nloc > 64 ? 64 : nloc);
+        int pos = headleaf - g * 64; pos = pos < 0 ? 0 : pos;
+        uint64_t mask = items[g];
+        while (mask) {
+            const int i = __builtin_ctzll(mask); mask &= mask - 1;
+            if (i < pos) continue;
+            if (i >= nloc) break;
+            nv++;
+            SeqNode n = rec[(size_t)g * 64 + i];
+            const int st = (int)(n.b >> 24); n.b &= 0xFFFFFFu;
+            if (!(st == pos && seq_apply_node(sb, n))) {
+                float f = seq_u2f(sb);
+                for (int l = pos; l <= i; l++) { const float* q = p + ((size_t)g * 64 + l) * LEAF; for (int t = 0; t < LEAF; t++) f += q[t]; nr++; }
+                sb = seq_f2u(f);
+            }
+            pos = i + 1;
+        }
+    }
+    if (visits) *visits = nv;
+    if (raw) *raw = nr;
+    return seq_u2f(sb);
+}

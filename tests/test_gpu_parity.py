@@ -54,6 +54,8 @@ def test_linear_reference_kat_on_gpu(lnb):
     (3, 100, 896, 16), (3, 100, 896, 32), (3, 100, 896, 64),      # ragged N, K not a multiple of the stage
     (1, 64, 8, 16), (5, 17, 40, 64),                               # tiny / single chunk
     (1, 4096, 4096, 16), (1, 4096, 14336, 16), (1, 6144, 4096, 16), (2, 4096, 4096, 64),
+    # rw 4 = the row-broadcast kernel (wo / w2): one chunk, ragged N (not a multiple of 4 / 16), more blocks than CUs, model shapes
+    (1, 16, 128, 4), (3, 100, 896, 4), (2, 5000, 256, 4), (1, 4096, 4096, 4), (1, 4096, 14336, 4), (4, 50, 1536, 4),
 ])
 def test_linear_bit_exact(lnb, rows, n, k, rw):
     rng = np.random.default_rng(rows * 1000003 + n * 101 + k + rw)
@@ -90,6 +92,35 @@ def test_rmsnorm_linear_bit_exact(lnb, rows, n, k, rw):
     y = lnb.op_rmsnorm_linear(x, nw, 1e-5, w, rw=rw)
     xn = np.zeros_like(x)
     orc.lib().orc_rmsnorm_bf16(orc._p(x), orc._p(nw), orc._p(xn), rows, k, np.float32(1e-5), None)
+    assert (y == orc_linear(xn, w)).all()
+
+
+@pytest.mark.parametrize("k,rw", [(4096, 16), (4096, 64), (8192, 32), (512, 16), (3072, 64), (64, 16)])
+def test_rmsnorm_exact_parallel_sum_adversarial(lnb, k, rw):
+    """The RMSNorm sum of squares is evaluated by the exact parity-map tree (rms_scale_wide); inputs chosen to stress it:
+    huge dynamic range, ties everywhere (powers of two), sparse rows, subnormal squares, outliers, leading zeros."""
+    rng = np.random.default_rng(k + rw)
+    rows = []
+    for kind in range(12):
+        if kind == 0: x = rng.standard_normal(k)
+        elif kind == 1: x = rng.standard_normal(k) * 1e-15
+        elif kind == 2: x = 2.0 ** rng.integers(-12, 4, k)
+        elif kind == 3: x = rng.standard_normal(k) * (rng.random(k) < 0.05)
+        elif kind == 4: x = np.exp(rng.uniform(-40, 5, k))
+        elif kind == 5: x = np.full(k, 2.0 ** rng.integers(-8, 8))
+        elif kind == 6: x = np.abs(rng.standard_normal(k)) * np.where(rng.random(k) < 0.01, 1e4, 1.0)
+        elif kind == 7: x = np.where(np.arange(k) < k // 3, 0.0, rng.standard_normal(k))
+        elif kind == 8: x = np.zeros(k)
+        elif kind == 9: x = rng.standard_normal(k) * 1e12
+        elif kind == 10: x = np.where(np.arange(k) == k - 1, 3e4, 1e-3 * rng.standard_normal(k))
+        else: x = rng.standard_normal(k) * np.exp(rng.uniform(-20, 8, k))
+        rows.append(x)
+    x = bf(np.stack(rows))
+    nw = bf(1 + 0.1 * rng.standard_normal(k))
+    w = bf(rng.standard_normal((64, k)) * 0.05)
+    y = lnb.op_rmsnorm_linear(x, nw, 1e-5, w, rw=rw)
+    xn = np.zeros_like(x)
+    orc.lib().orc_rmsnorm_bf16(orc._p(x), orc._p(nw), orc._p(xn), x.shape[0], k, np.float32(1e-5), None)
     assert (y == orc_linear(xn, w)).all()
 
 

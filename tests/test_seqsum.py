@@ -20,6 +20,8 @@ def lib():
     L = C.CDLL(SO)
     L.seqsum_ref.restype = C.c_float; L.seqsum_scan.restype = C.c_float
     L.seqsum_ref.argtypes = [C.c_void_p, C.c_int]; L.seqsum_scan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.seqsum_tree.restype = C.c_float
+    L.seqsum_tree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return L
 
 
@@ -52,3 +54,35 @@ def test_scan_is_bit_identical_to_the_sequential_sum(lib):
             p = np.ascontiguousarray((x.astype(np.float64) ** 2).astype(np.float32))
             assert np.float32(lib.seqsum_ref(p.ctypes.data, K)).view(np.uint32) == \
                 np.float32(lib.seqsum_scan(p.ctypes.data, K, nb, None)).view(np.uint32)
+
+
+def _cases(rng, K, trial):
+    kind = trial % 8
+    if kind == 0: x = bf16(rng.standard_normal(K))
+    elif kind == 1: x = bf16(rng.standard_normal(K) * 10 ** rng.uniform(-18, 6))
+    elif kind == 2: x = bf16(2.0 ** rng.integers(-12, 4, K))                      # powers of two: ties everywhere
+    elif kind == 3: x = bf16(rng.standard_normal(K) * (rng.random(K) < 0.05))      # mostly zeros
+    elif kind == 4: x = bf16(np.exp(rng.uniform(-40, 5, K)))                       # subnormal squares .. large
+    elif kind == 5: x = bf16(np.full(K, 2.0 ** rng.integers(-8, 8)))
+    elif kind == 6: x = bf16(np.abs(rng.standard_normal(K)) * np.where(rng.random(K) < 0.01, 1e4, 1.0))
+    else: x = bf16(np.where(np.arange(K) < rng.integers(0, K), 0.0, rng.standard_normal(K)))   # leading zeros
+    return np.ascontiguousarray((x.astype(np.float64) ** 2).astype(np.float32))
+
+
+def test_tree_walk_is_bit_identical_to_the_sequential_sum(lib):
+    """The multi-wave form used by the RMSNorm prologue (rms_fold / rms_scale_wide): one leaf per folding lane,
+    segmented scan per wave, walker over the item mask."""
+    rng = np.random.default_rng(7)
+    visits, raws = [], []
+    for trial in range(2400):
+        K = [4096, 4096, 8192, 256, 512, 1024, 64, 3072, 5120, 8][trial % 10] if trial >= 800 else 4096
+        NH = [7, 6, 2][trial % 3]
+        p = _cases(rng, K, trial)
+        nv, nr = C.c_int(0), C.c_int(0)
+        r = lib.seqsum_ref(p.ctypes.data, K)
+        s = lib.seqsum_tree(p.ctypes.data, K, NH, 256, C.byref(nv), C.byref(nr))
+        assert np.float32(r).view(np.uint32) == np.float32(s).view(np.uint32), (trial, K, NH)
+        if K == 4096 and trial % 8 == 0:
+            visits.append(nv.value); raws.append(nr.value)
+    # gaussian activations: the serial part is a few dozen node visits instead of 4096 dependent adds
+    assert np.mean(visits) < 40 and np.mean(raws) < 12, (np.mean(visits), np.mean(raws))

@@ -145,7 +145,7 @@ def main(asm_path=None):
         txt = open(asm).read().split("\n")
     funcs, cur = {}, None
     for i, ln in enumerate(txt):
-        m = re.match(r"^(_Z17(?:gemv_chain|attn_exact)_kernel\S*):", ln)
+        m = re.match(r"^(_Z1[47](?:gemv_chain|attn_exact|rowcast)_kernel\S*):", ln)
         if m:
             cur = []; funcs[m.group(1)] = cur
             continue
