@@ -388,9 +388,16 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
         // the weight stream starts only now, BEHIND the x loads in this CU's memory queue
         // issue cursor: next global stage to load = (block ib, stage is); past the end it re-reads the last stage
         const size_t last16 = stream_bytes - 16;
+        // unit of load i:  q = (kc*NCH + c)*RW + r.  One chain: q = (i*NH + hw)*64 + lane.  Two chains (w1|w3): the lane takes BOTH
+        // chains of (kc, r) = ((hw*64 + lane) / RW, (hw*64 + lane) % RW) -- load i is chain i -- so that it can leave the
+        // products pair-interleaved (gate_k, up_k) for the chain wave's v_pk_add_f32
+        static_assert(NCH == 1 || (NCH == 2 && NP % 2 == 0), "two chains: an even number of loads per lane (pairs)");
         unsigned loff[NP];
 #pragma unroll
-        for (int i = 0; i < NP; i++) loff[i] = (unsigned)(((i * NH + hw) * 64 + lane) * 16);
+        for (int i = 0; i < NP; i++) {
+            const int pq = ((i >> 1) * NH + hw) * 64 + lane;               // pair index of load i (two chains)
+            loff[i] = NCH == 2 ? (unsigned)((((pq / RW) * 2 + (i & 1)) * RW + (pq % RW)) * 16) : (unsigned)(((i * NH + hw) * 64 + lane) * 16);
+        }
         int ib = wg, is = 0, issued = 0;
         auto issue_next = [&](u32x4 (&dst)[NP]) {
             const size_t soff = (size_t)is * SA;
@@ -427,6 +434,22 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
                         if (p.dbg) t_x += clock64() - tb_;
                         char* dst = ringB + (t & 1) * SB;
                         const float* xst = xs + (size_t)st * (KC * 8);
+                        if constexpr (NCH == 2) {
+                            // both chains of (kc, r): products written pair-interleaved, [k4][half][r] x (gate_s, up_s, gate_s+1, up_s+1)
+#pragma unroll
+                            for (int pi = 0; pi < NP / 2; pi++) {
+                                const int pq = (pi * NH + hw) * 64 + lane, kc = pq / RW, r = pq % RW;
+                                const float4 xa = *(const float4*)(xst + kc * 8), xb = *(const float4*)(xst + kc * 8 + 4);
+                                const u32x4 vg = buf[j][2 * pi], vu = buf[j][(2 * pi + 1) % NP];
+                                const float4 ga = mul4(xa, bf_lo(vg.x), bf_hi(vg.x), bf_lo(vg.y), bf_hi(vg.y)), gb = mul4(xb, bf_lo(vg.z), bf_hi(vg.z), bf_lo(vg.w), bf_hi(vg.w));
+                                const float4 ua = mul4(xa, bf_lo(vu.x), bf_hi(vu.x), bf_lo(vu.y), bf_hi(vu.y)), ub = mul4(xb, bf_lo(vu.z), bf_hi(vu.z), bf_lo(vu.w), bf_hi(vu.w));
+                                char* d = dst + r * 16;
+                                *(float4*)(d + ((4 * kc + 0) * RW) * 16) = make_float4(ga.x, ua.x, ga.y, ua.y);
+                                *(float4*)(d + ((4 * kc + 1) * RW) * 16) = make_float4(ga.z, ua.z, ga.w, ua.w);
+                                *(float4*)(d + ((4 * kc + 2) * RW) * 16) = make_float4(gb.x, ub.x, gb.y, ub.y);
+                                *(float4*)(d + ((4 * kc + 3) * RW) * 16) = make_float4(gb.z, ub.z, gb.w, ub.w);
+                            }
+                        } else {
                         float4 xa[NP], xb[NP];
 #pragma unroll
                         for (int i = 0; i < NP; i++) {
@@ -442,6 +465,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
                             // exact products (8-bit x 8-bit significands): val1F32 * val2F32, operations_lineartransform.go:60
                             *(float4*)(dst + ((2 * kc) * (NCH * RW) + u) * 16) = mul4(xa[i], bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
                             *(float4*)(dst + ((2 * kc + 1) * (NCH * RW) + u) * 16) = mul4(xb[i], bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
+                        }
                         }
                         if (++st == nstages) st = 0;
                         __builtin_amdgcn_sched_barrier(0);             // refill AFTER the slot has been consumed (no register copies)
@@ -507,10 +531,26 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
 #pragma unroll
                 for (int c = 0; c < NCH; c++) touch16(pb[cur][c][0], pb[cur][c][1], pb[cur][c][2], pb[cur][c][3]);
                 __builtin_amdgcn_sched_barrier(0);
+                if constexpr (NCH == 2) {
+                    // pb[cur][half][j] = (gate_s, up_s, gate_s+1, up_s+1): both chains advance with one v_pk_add_f32 per k-step
+                    // (6.0 cycles per dependent op against 2 x 4.33; written as separate adds hipcc paired them anyway, behind two
+                    // v_mov per step to build the register pairs)
+                    f32x2 a2 = {acc[0], acc[1]};
+#pragma unroll
+                    for (int j = 0; j < 4; j++)
+#pragma unroll
+                        for (int h = 0; h < 2; h++) {
+                            const float4 q4 = pb[cur][h][j];
+                            a2 = a2 + f32x2{q4.x, q4.y};
+                            a2 = a2 + f32x2{q4.z, q4.w};
+                        }
+                    acc[0] = a2.x; acc[1] = a2.y;
+                } else {
 #pragma unroll
                 for (int j = 0; j < 4; j++)
 #pragma unroll
                     for (int c = 0; c < NCH; c++) acc[c] = add4(acc[c], pb[cur][c][j]);   // valDstF32 += p, k ascending (:63)
+                }
                 __builtin_amdgcn_sched_barrier(0);
             }
             if (++st == nstages) {                                     // end of a row block: write it out, start the next
@@ -643,12 +683,16 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
 // Exact attention for one (head, query row): scores -> /sqrt(hd) -> mask -> f64 softmax -> PV.
 // llamatransformer.go:409-514.  GQA head h reads KV head h/n_rep straight from the un-repeated cache
 // (attentionRepeatKV :529-559 and the four Transposes :435-449 become index arithmetic).
-// grid (H, S), block 256 = 4 waves:
-//   scores : every thread owns one cached position j: the 128-long q.k chain (d ascending), 16 B loads of its K row;
-//   Z      : wave 0 walks sum_j exp(s_j) in f64, j ascending, 8 values per iteration with the next 8 in flight;
-//   PV     : the same role split as the GEMV -- waves 2,3 produce the EXACT products p_j*v[j,d] (bf16 x bf16) into
-//            a double-buffered LDS ring laid out [j/4][d][4]; waves 0,1 own one output dim per lane and only add.
-// dynamic LDS: [T f64 e][T f32 p (+ zero pad)][hd f32 q][16 B][2 x 64 x hd f32 product ring]
+// grid (H, S), block 512 = 8 waves (two per SIMD: a single wave issues at most one instruction per ~4.4 cycles):
+//   scores : every thread owns one cached position j (512 per pass): the 128-long q.k chain (d ascending) over its K row, read
+//            with 16 B loads that are contiguous across the wave (K cache layout [kv head][d/8][position][8]); the next pass's
+//            rows are in flight during this pass's chains (register ping-pong); then exp in f64;
+//   Z      : wave 0 walks sum_j exp(s_j) in f64, j ascending, 16 values per half-iteration with the other half's LDS reads in
+//            flight and one counted wait per half (~9 cycles per dependent v_add_f64);
+//   PV     : the role split of the GEMV -- waves 2,3,6,7 produce the EXACT products p_j*v[j,d] (bf16 x bf16) into a double-
+//            buffered LDS ring [position][dim] (V rows come through a hand-counted asm prefetch ring three chunks deep);
+//            waves 0,1 own one output dim per lane and only add, a whole 64-position chunk in flight per step.
+// dynamic LDS: [T f64 e (+ zero pad)][T f32 p (+ zero pad)][hd f32 q][16 B][2 x 64 x hd f32 product ring]
 // ------------------------------------------------------------------------------------------------
 constexpr int ATT_JC = 64;                                  // cached positions per PV chunk
 __host__ __device__ inline size_t attn_off_pw(int seq_len) { return (((size_t)seq_len + 32) * 8 + 15) & ~(size_t)15; }
@@ -993,7 +1037,7 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     //  RW 64 (fat; HBM bound): 12 KiB stages, six helpers paired on three SIMDs (the chain wave owns the fourth),
     //  6 x 2 loads x 5 stages = 60 KiB in flight per CU.
     if (rw == 16) return launch_chain_t<16, NCH, 8192, 2, 7, EPI, NORM>(p, st);
-    if (rw == 32) return NORM ? launch_chain_t<32, NCH, 6144, 6, 10, EPI, NORM>(p, st) : launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
+    if (rw == 32) return (NORM && NCH == 1) ? launch_chain_t<32, 1, 6144, 6, 10, EPI, NORM>(p, st) : launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
     if (rw == 64) return launch_chain_t<64, NCH, 12288, 6, 8, EPI, NORM>(p, st);
     return hipErrorInvalidValue;
 }
