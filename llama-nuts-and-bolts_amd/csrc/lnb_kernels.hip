@@ -659,9 +659,13 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
 #pragma unroll
         for (int j = 0; j < RC_R; j++) {
             if (t0 + j < T) {
-                wait_ring<RC_R - 1, 1>(*(u32x4(*)[1])&buf[j]);            // chunk t0+j landed; RC_R-1 younger ones stay in flight
+                // chunk t0+j landed; RC_R-1 younger ones stay in flight.  (The wait names buf[j] itself: handing wait_ring a cast
+                // reference made hipcc copy the register BEFORE the wait -- caught by tools/isa_audit.py.)
+                asm volatile("s_waitcnt vmcnt(%1) ; RING_RETIRE %0" : "+v"(buf[j]) : "n"(RC_R - 1) : "memory");
                 products(pr, buf[j], c);
-                __builtin_amdgcn_sched_barrier(0);                     // refill AFTER the slot has been consumed
+                // pin the products in front of the refill: otherwise hipcc sinks the unpack/multiply into the chain below, behind
+                // the asm that reloads buf[j], and keeps the old value alive through a register copy made BEFORE the wait
+                asm volatile("" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]), "+v"(pr[4]), "+v"(pr[5]), "+v"(pr[6]), "+v"(pr[7]));
                 issue_next(buf[j]);
                 chain128(acc, pr);                                     // valDstF32 += p, k ascending (operations_lineartransform.go:63)
                 if (++c == nchunks) {                                  // end of this wave's 4 rows
@@ -752,38 +756,39 @@ template <int NK> DEVINL void attn_score(const uint4 (&k)[NK], const float* qf, 
     e[j] = ev;
 }
 
-// one PV pipeline step: producers turn chunk c (rows already in vc) into exact products in ring slot c&1 ([position][dim] f32)
-// after putting chunk c+3's rows in flight (vn); chain waves add chunk c-1.  Every wave ends the step at the same barrier.
-template <int HD> DEVINL void attn_pv_step(int c, int nchunks, int wave, int lane, int T, const uint16_t* vbase, uint32_t row_bytes,
-                                           const float* pw, char* ring, u32x4 (&vc)[ATT_VU], u32x4 (&vn)[ATT_VU], float& acc) {
+// PV pipeline, one barrier per step on every wave: at step c the producers turn chunk c (rows already in vc) into exact products
+// in ring slot c&1 ([position][dim] f32) after putting chunk c+3's rows in flight (vn); the adders add chunk c-1.
+// The roles are split ONCE (three loops with the same barrier count) so that the ring's load/retire pairing is a property of
+// straight-line code that tools/isa_audit.py can check.
+template <int HD> DEVINL void attn_pv_produce(int c, int nchunks, int pwv, int lane, int T, const uint16_t* vbase, uint32_t row_bytes,
+                                              const float* pw, char* ring, u32x4 (&vc)[ATT_VU], u32x4 (&vn)[ATT_VU]) {
     constexpr int SLOT = ATT_JC * HD * 4;
-    const int pwv = (wave & 3) - 2 + ((wave >> 2) << 1);   // waves 2,3,6,7 -> producers 0..3
-    if ((wave & 3) >= 2) {
-        attn_load_v(vn, vbase, row_bytes, c + 3, pwv, lane, T);
-        attn_retire_v<3 * ATT_VU>(vc);                       // chunks c+1, c+2, c+3 stay in flight
-        if (c < nchunks && (lane & 15) * 8 < HD) {
-            const int jl0 = pwv * 4 + (lane >> 4);
-            char* dst = ring + (c & 1) * SLOT + (lane & 15) * 32 + jl0 * (HD * 4);
-            const float* pp = pw + c * ATT_JC + jl0;
+    attn_load_v(vn, vbase, row_bytes, c + 3, pwv, lane, T);
+    attn_retire_v<3 * ATT_VU>(vc);                           // chunks c+1, c+2, c+3 stay in flight
+    if (c < nchunks && (lane & 15) * 8 < HD) {
+        const int jl0 = pwv * 4 + (lane >> 4);
+        char* dst = ring + (c & 1) * SLOT + (lane & 15) * 32 + jl0 * (HD * 4);
+        const float* pp = pw + c * ATT_JC + jl0;
 #pragma unroll
-            for (int u = 0; u < ATT_VU; u++) {               // position jl0 + 4*ATT_NPROD*u of the chunk
-                const float pj = pp[4 * ATT_NPROD * u];
-                const u32x4 v = vc[u];                       // exact products: 8-bit x 8-bit significands
-                *(float4*)(dst + u * 4 * ATT_NPROD * HD * 4) = make_float4(pj * bf_lo(v.x), pj * bf_hi(v.x), pj * bf_lo(v.y), pj * bf_hi(v.y));
-                *(float4*)(dst + u * 4 * ATT_NPROD * HD * 4 + 16) = make_float4(pj * bf_lo(v.z), pj * bf_hi(v.z), pj * bf_lo(v.w), pj * bf_hi(v.w));
-            }
+        for (int u = 0; u < ATT_VU; u++) {                   // position jl0 + 4*ATT_NPROD*u of the chunk
+            const float pj = pp[4 * ATT_NPROD * u];
+            const u32x4 v = vc[u];                           // exact products: 8-bit x 8-bit significands
+            *(float4*)(dst + u * 4 * ATT_NPROD * HD * 4) = make_float4(pj * bf_lo(v.x), pj * bf_hi(v.x), pj * bf_lo(v.y), pj * bf_hi(v.y));
+            *(float4*)(dst + u * 4 * ATT_NPROD * HD * 4 + 16) = make_float4(pj * bf_lo(v.z), pj * bf_hi(v.z), pj * bf_lo(v.w), pj * bf_hi(v.w));
         }
-    } else if (wave < 2 && c > 0 && c <= nchunks) {
-        const int d = wave * 64 + lane;
-        if (d < HD) {
-            // positions past the end of the row carry p == +0: their products are +-0 and acc is never -0, so whole chunks are added
-            const float* src = (const float*)(ring + ((c - 1) & 1) * SLOT) + d;
-            float a[ATT_JC];
+    }
+    __syncthreads();
+}
+template <int HD> DEVINL void attn_pv_add(int c, int nchunks, int d, const char* ring, float& acc) {
+    constexpr int SLOT = ATT_JC * HD * 4;
+    if (c > 0 && c <= nchunks && d < HD) {
+        // positions past the end of the row carry p == +0: their products are +-0 and acc is never -0, so whole chunks are added
+        const float* src = (const float*)(ring + ((c - 1) & 1) * SLOT) + d;
+        float a[ATT_JC];
 #pragma unroll
-            for (int j = 0; j < ATT_JC; j++) a[j] = src[j * HD];          // whole chunk in flight at once
+        for (int j = 0; j < ATT_JC; j++) a[j] = src[j * HD];              // whole chunk in flight at once
 #pragma unroll
-            for (int j = 0; j < ATT_JC; j++) acc += a[j];
-        }
+        for (int j = 0; j < ATT_JC; j++) acc += a[j];
     }
     __syncthreads();
 }
@@ -833,10 +838,15 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     }
     // zero padding so that the Z chain can run whole groups (x + 0.0 == x for x >= +0)
     for (int j = T + tid; j < ((T + 31) & ~31); j += ATT_NT) e[j] = 0.0;
+    // hipcc's waitcnt pass is path-insensitive: on a (statically possible, dynamically impossible) path a K prefetch of the scores
+    // loop is still pending, and it then drains vmcnt(0) in front of every PV step when a V register is reused.  An explicit
+    // vmcnt(0) here (all K loads are consumed anyway) clears its scoreboard.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     // producers: the first three PV chunks of V go in flight now and land during the Z chain
+    const bool producer = (wave & 3) >= 2;
+    const int pwv = (wave & 3) - 2 + ((wave >> 2) << 1);                   // waves 2,3,6,7 -> producers 0..3
     u32x4 v0[ATT_VU], v1[ATT_VU], v2[ATT_VU], v3[ATT_VU];
-    if ((wave & 3) >= 2) {
-        const int pwv = (wave & 3) - 2 + ((wave >> 2) << 1);
+    if (producer) {
         attn_load_v(v0, vbase, row_bytes, 0, pwv, lane, T);
         attn_load_v(v1, vbase, row_bytes, 1, pwv, lane, T);
         attn_load_v(v2, vbase, row_bytes, 2, pwv, lane, T);
@@ -887,12 +897,21 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     // PV: out[d] = trunc(sum_{j ascending} p_j * v[j,d]).  Masked columns have p == +0 and acc is never -0, so with the
     // standard causal layout (pos0 == 0) the chain can stop at the chunk that holds the diagonal (Tend).
     float acc = 0.0f;
-    for (int c = 0; c <= nchunks; c += 4) {                  // four steps per trip: the V register sets rotate without copies
-        attn_pv_step<HD>(c, nchunks, wave, lane, T, vbase, row_bytes, pw, ring, v0, v3, acc);
-        attn_pv_step<HD>(c + 1, nchunks, wave, lane, T, vbase, row_bytes, pw, ring, v1, v0, acc);
-        if (c + 2 > nchunks) break;
-        attn_pv_step<HD>(c + 2, nchunks, wave, lane, T, vbase, row_bytes, pw, ring, v2, v1, acc);
-        attn_pv_step<HD>(c + 3, nchunks, wave, lane, T, vbase, row_bytes, pw, ring, v3, v2, acc);
+    if (producer) {
+        for (int c = 0; c <= nchunks; c += 4) {              // four steps per trip: the V register sets rotate without copies
+            attn_pv_produce<HD>(c, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v0, v3);
+            attn_pv_produce<HD>(c + 1, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v1, v0);
+            attn_pv_produce<HD>(c + 2, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v2, v1);
+            attn_pv_produce<HD>(c + 3, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v3, v2);
+        }
+    } else if (wave < 2) {
+        const int d = wave * 64 + lane;
+        for (int c = 0; c <= nchunks; c += 4) {
+            attn_pv_add<HD>(c, nchunks, d, ring, acc); attn_pv_add<HD>(c + 1, nchunks, d, ring, acc);
+            attn_pv_add<HD>(c + 2, nchunks, d, ring, acc); attn_pv_add<HD>(c + 3, nchunks, d, ring, acc);
+        }
+    } else {
+        for (int c = 0; c <= nchunks; c += 4) { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
     }
     asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");   // prefetches past the last chunk
     ATT_STAMP(6);
