@@ -1052,11 +1052,14 @@ static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
 template <int EPI, bool NORM, int NCH>
 static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     // stage geometry (one workgroup per CU).  SA = bf16 bytes per stage, R = stages in flight per helper.
-    //  RW 16/32 (thin; chain bound): 8 KiB stages, 2 helpers x 4 loads x 7 stages = 56 KiB in flight per CU.
+    //  RW 16/32 plain (thin; chain bound): 8 KiB stages, 2 helpers x 4 loads x 7 stages = 56 KiB in flight per CU.
+    //  RW 32 with the fused RMSNorm (wq|wk|wv): six helpers so that the exact parallel norm sum has 384 folding lanes, and
+    //  12 KiB = 192-step stages (a stage boundary costs one barrier + one exposed LDS round trip: 96-step stages ran the
+    //  chain at 10.2 cycles per step, 192-step ones at 8.7); 6 x 2 loads x 5 stages = 60 KiB in flight per CU.
     //  RW 64 (fat; HBM bound): 12 KiB stages, six helpers paired on three SIMDs (the chain wave owns the fourth),
-    //  6 x 2 loads x 5 stages = 60 KiB in flight per CU.
+    //  6 x 2 loads x 8 stages = 96 KiB in flight per CU (5 stages: 5.8 TB/s on the LM head, 8: 6.2, 14: worse again).
     if (rw == 16) return launch_chain_t<16, NCH, 8192, 2, 7, EPI, NORM>(p, st);
-    if (rw == 32) return (NORM && NCH == 1) ? launch_chain_t<32, 1, 6144, 6, 10, EPI, NORM>(p, st) : launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
+    if (rw == 32) return (NORM && NCH == 1) ? launch_chain_t<32, 1, 12288, 6, 5, EPI, NORM>(p, st) : launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
     if (rw == 64) return launch_chain_t<64, NCH, 12288, 6, 8, EPI, NORM>(p, st);
     return hipErrorInvalidValue;
 }
