@@ -585,29 +585,140 @@ constexpr int RC_R = 14;                                    // 1 KiB chunks in f
 // 16 dependent adds in ONE asm statement: acc += pr(lane 0) ... += pr(lane 15) of this lane's DPP row.  (One statement per add
 // made hipcc's hazard recognizer put an s_nop behind every one of them -- it cannot see which operand is the DPP one -- and
 // doubled the step time.  Inside the block no further wait states are needed: acc is the plain operand.)
-DEVINL void chain16(float& acc, const float& pr) {
-    asm volatile("s_nop 1\n\t"          // VALU write of pr -> DPP read: 2 wait states, whatever hipcc scheduled in front
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf" "\n\t"
-                 "v_add_f32_dpp %0, %1, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf"
-                 : "+v"(acc) : "v"(pr));
-}
+// the 128 dependent adds of one chunk in ONE asm statement: acc += pr[i](lane 0) ... += pr[i](lane 15), i = 0..7.  (Separate
+// statements make hipcc's hazard recognizer put an s_nop behind each -- it cannot see which operand is the DPP one.)
+// VALU write of pr -> DPP read needs 2 wait states: the leading s_nop covers whatever hipcc scheduled last.
 DEVINL void chain128(float& acc, const float (&pr)[8]) {
-#pragma unroll
-    for (int i = 0; i < 8; i++) chain16(acc, pr[i]);
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %1, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %2, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %3, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %4, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %5, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %6, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %7, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:0 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:1 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:2 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:3 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:5 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:6 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:7 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:9 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:10 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:11 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:12 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:13 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:14 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %0, %8, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
+                 : "+v"(acc) : "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(pr[4]), "v"(pr[5]), "v"(pr[6]), "v"(pr[7]));
 }
 template <int EPI>
 __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
@@ -651,8 +762,8 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     float pr[8];
     auto products = [&](float (&d)[8], const u32x4& v, int c) {        // exact: 8-bit x 8-bit significands
         const float4 xa = *(const float4*)(xl + (size_t)c * 128), xb = *(const float4*)(xl + (size_t)c * 128 + 4);
-        d[0] = xa.x * bf_lo(v.x); d[1] = xa.y * bf_hi(v.x); d[2] = xa.z * bf_lo(v.y); d[3] = xa.w * bf_hi(v.y);
-        d[4] = xb.x * bf_lo(v.z); d[5] = xb.y * bf_hi(v.z); d[6] = xb.z * bf_lo(v.w); d[7] = xb.w * bf_hi(v.w);
+        const float4 pa = mul4(xa, bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y)), pb = mul4(xb, bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
+        d[0] = pa.x; d[1] = pa.y; d[2] = pa.z; d[3] = pa.w; d[4] = pb.x; d[5] = pb.y; d[6] = pb.z; d[7] = pb.w;
     };
     int c = 0, blk = wg;
     for (int t0 = 0; t0 < T; t0 += RC_R) {
