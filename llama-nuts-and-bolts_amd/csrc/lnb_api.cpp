@@ -82,9 +82,9 @@ struct lnb_ctx {
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
 static int auto_rw(int lane_rows, const char* env, int K = 0, bool plain = false) {
     int v = env_int(env, 0);
-    if (v == 16 || v == 32 || v == 64 || (v == 4 && plain && K % 128 == 0)) return v;
+    if (v == 16 || v == 32 || v == 64 || (v == 4 && plain && K % 128 == 0 && K <= 16384)) return v;
     // thin matrices without a fused norm / rope epilogue: the row-broadcast kernel (products stay in registers)
-    if (plain && lane_rows <= 16 * 256 && K > 0 && K % 128 == 0 && (size_t)K * 4 <= 150 * 1024) return 4;
+    if (plain && lane_rows <= 16 * 256 && K > 0 && K % 128 == 0 && K <= 16384) return 4;
     // thin matrices: one workgroup (16 or 32 rows) per CU, all resident at once on the 256 CUs -- a second round of
     // workgroups would double the serial chain time
     if (lane_rows <= 16 * 256) return 16;
@@ -630,7 +630,7 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     HIPCHK(hipSetDevice(device));
     HIPCHK(lnbk_init());
     if (rw == 0) rw = auto_rw(n_out, "LNB_RW_OP", k_in, norm_w == nullptr);
-    if (rw != 16 && rw != 32 && rw != 64 && !(rw == 4 && !norm_w && k_in % 128 == 0)) return fail("rw must be 16, 32 or 64 (or 4: row-broadcast layout, no fused norm, in_features a multiple of 128)");
+    if (rw != 16 && rw != 32 && rw != 64 && !(rw == 4 && !norm_w && k_in % 128 == 0 && k_in <= 16384)) return fail("rw must be 16, 32 or 64 (or 4: row-broadcast layout, no fused norm, in_features a multiple of 128)");
     if ((size_t)k_in * 4 > 120 * 1024) return fail("in_features %d does not fit the LDS staging", k_in);
     TiledDesc t{}; int64_t bytes = 0;
     if (alloc_tiled(t, n_out, k_in, rw, 1, bytes)) return -1;

@@ -724,6 +724,8 @@ template <int EPI>
 __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xT = (float*)smem;                                // x[128c + 16i + j] at xT[(c*16 + j)*8 + i]
+    const long long t_begin = p.dbg ? clock64() : 0;         // LNB_GEMV_TIMING: [wg][wave] = {total, -, prologue, -}
+    long long t_x = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int K = p.K, S = p.S, nchunks = K >> 7;
@@ -733,7 +735,27 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     const int T = nb_mine * nchunks;                                   // chunks this wave walks
     const size_t tile_bytes = (size_t)nchunks * 1024;                  // one wave tile (4 rows)
     const unsigned voff = (unsigned)lane * 16u;
-    // weight ring first (it does not depend on x), then x
+    // x first, all of its loads in flight at once, and the weight stream only once x has landed: queued in front of x -- or
+    // even right behind it -- the 14 MB burst of first weight loads delays the x rows that every CU reads (measured both ways)
+    constexpr int RC_XU = 8;                                 // 16 B units of x per thread: K <= 16384
+    const uint16_t* xrow = p.x + (size_t)m * K;
+    uint4 xv[RC_XU];
+#pragma unroll
+    for (int i = 0; i < RC_XU; i++) {
+        const int u = tid + i * 256;
+        xv[i] = *(const uint4*)(xrow + (size_t)(u < (K >> 3) ? u : 0) * 8);      // unconditional (clamped) loads
+    }
+#pragma unroll
+    for (int i = 0; i < RC_XU; i++) {
+        const int u = tid + i * 256;
+        if (u < (K >> 3)) {
+            const uint4 v = xv[i];
+            const int k = u * 8, c = k >> 7, ii = (k & 127) >> 4, j0 = k & 15;
+            float* d = xT + ((size_t)(c * 16 + j0) * 8 + ii);
+            d[0] = bf_lo(v.x); d[8] = bf_hi(v.x); d[16] = bf_lo(v.y); d[24] = bf_hi(v.y);
+            d[32] = bf_lo(v.z); d[40] = bf_hi(v.z); d[48] = bf_lo(v.w); d[56] = bf_hi(v.w);
+        }
+    }
     u32x4 buf[RC_R];
     // issue cursor: a running wave-uniform pointer (1 KiB per chunk; at the end of a tile jump to this wave's tile of the
     // next block); past the last chunk it stays put and re-reads
@@ -746,26 +768,18 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     };
 #pragma unroll
     for (int j = 0; j < RC_R; j++) issue_next(buf[j]);
-    {
-        const uint16_t* xrow = p.x + (size_t)m * K;
-        for (int u = tid; u < (K >> 3); u += 256) {
-            const uint4 v = *(const uint4*)(xrow + u * 8);
-            const int k = u * 8, c = k >> 7, i = (k & 127) >> 4, j0 = k & 15;
-            float* d = xT + ((size_t)(c * 16 + j0) * 8 + i);
-            d[0] = bf_lo(v.x); d[8] = bf_hi(v.x); d[16] = bf_lo(v.y); d[24] = bf_hi(v.y);
-            d[32] = bf_lo(v.z); d[40] = bf_hi(v.z); d[48] = bf_lo(v.w); d[56] = bf_hi(v.w);
-        }
-    }
-    __syncthreads();                                         // (hipcc waits for its own x loads; the asm ring stays in flight)
+    __syncthreads();
+    if (p.dbg) t_x = clock64() - t_begin;
     const float* xl = xT + (size_t)(lane & 15) * 8;
     float acc = 0.0f;
     float pr[8];
-    auto products = [&](float (&d)[8], const u32x4& v, int c) {        // exact: 8-bit x 8-bit significands
-        const float4 xa = *(const float4*)(xl + (size_t)c * 128), xb = *(const float4*)(xl + (size_t)c * 128 + 4);
+    auto products = [&](float (&d)[8], const u32x4& v, const float4& xa, const float4& xb) {   // exact: 8-bit x 8-bit significands
         const float4 pa = mul4(xa, bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y)), pb = mul4(xb, bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
         d[0] = pa.x; d[1] = pa.y; d[2] = pa.z; d[3] = pa.w; d[4] = pb.x; d[5] = pb.y; d[6] = pb.z; d[7] = pb.w;
     };
     int c = 0, blk = wg;
+    // the x values of a chunk are read from the LDS one chunk ahead, in the shadow of the previous chunk's 128 adds
+    float4 xa = *(const float4*)(xl), xb = *(const float4*)(xl + 4);
     for (int t0 = 0; t0 < T; t0 += RC_R) {
 #pragma unroll
         for (int j = 0; j < RC_R; j++) {
@@ -773,11 +787,16 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
                 // chunk t0+j landed; RC_R-1 younger ones stay in flight.  (The wait names buf[j] itself: handing wait_ring a cast
                 // reference made hipcc copy the register BEFORE the wait -- caught by tools/isa_audit.py.)
                 asm volatile("s_waitcnt vmcnt(%1) ; RING_RETIRE %0" : "+v"(buf[j]) : "n"(RC_R - 1) : "memory");
-                products(pr, buf[j], c);
+                products(pr, buf[j], xa, xb);
                 // pin the products in front of the refill: otherwise hipcc sinks the unpack/multiply into the chain below, behind
                 // the asm that reloads buf[j], and keeps the old value alive through a register copy made BEFORE the wait
                 asm volatile("" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]), "+v"(pr[4]), "+v"(pr[5]), "+v"(pr[6]), "+v"(pr[7]));
                 issue_next(buf[j]);
+                {
+                    const int cn = (c + 1 == nchunks) ? 0 : c + 1;     // next chunk of this row (or chunk 0 of the next block's)
+                    xa = *(const float4*)(xl + (size_t)cn * 128); xb = *(const float4*)(xl + (size_t)cn * 128 + 4);
+                }
+                __builtin_amdgcn_sched_barrier(0);                     // the reads are issued HERE, waited for after the chain
                 chain128(acc, pr);                                     // valDstF32 += p, k ascending (operations_lineartransform.go:63)
                 if (++c == nchunks) {                                  // end of this wave's 4 rows
                     const int n = blk * 16 + wave * 4 + (lane >> 4);
@@ -792,6 +811,7 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
+    if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = 0; d_[2] = t_x; d_[3] = 0; }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1178,7 +1198,7 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
 template <int EPI> static hipError_t launch_rowcast(const GemvParams* p, hipStream_t st) {
     auto kfn = rowcast_kernel<EPI>;
     if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if ((p->K & 127) || (size_t)p->K * 4 > 150 * 1024) return hipErrorInvalidValue;
+    if ((p->K & 127) || p->K > 16384) return hipErrorInvalidValue;              // x staging: 8 x 16 B per thread, K*4 bytes of LDS
     hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3(256), (size_t)p->K * 4, st, *p);
     return hipGetLastError();
 }
