@@ -93,7 +93,7 @@ def main():
         name = "random-init Llama-shape dim=8192 n_layers=80"
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 or world > 1:
+    if args.gpus > 1 or world > 1 or os.environ.get("LNB_FORCE_PIPELINE") == "1":     # (the env switch runs the N-GPU code path on one GPU)
         import pipeline
         return pipeline.bench_main(args, cfg, name)
 

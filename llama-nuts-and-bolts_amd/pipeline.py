@@ -160,8 +160,8 @@ def bench_main(args, cfg, name):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
-    dist.init_process_group("nccl", rank=rank, world_size=world)
     device = "cuda:%d" % local
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))   # rank -> GPU mapping is explicit
     P, W, K = args.prompt_len, args.warmup, args.steps
     seq_len = P + W + K + 8
     stage = LnbStage(lnb, torch, cfg, rank, world, world, seq_len, local)

@@ -264,6 +264,33 @@ def test_pipeline_stages_on_one_device_equal_whole_model(lnb, tiny_pair):
     s0.close(); s1.close()
 
 
+def test_pipeline_stage_hidden_views_are_zero_copy_torch_tensors(lnb, tiny_pair):
+    """pipeline.LnbStage (what `bench.py --gpus N` runs on every rank): the hidden state that RCCL sends/receives is a torch
+    view of the library's own device buffer (CUDA array interface).  Two logical stages on this GPU, the hand-off done
+    through those views (torch copy_ standing in for isend/irecv); tokens must equal the oracle's greedy continuation."""
+    import torch
+    import pipeline
+    om, _ = tiny_pair
+    P, steps = 6, 5
+    st0 = pipeline.LnbStage(lnb, torch, TINY, 0, 2, 1, 32, 0)
+    st1 = pipeline.LnbStage(lnb, torch, TINY, 1, 2, 1, 32, 0)
+    prompt = orc.synth_tokens(11, P, TINY["vocab_size"])
+    exp, _ = orc.Context(om, 32).generate(prompt, steps)
+    got = []
+    toks, rows, pos = np.ascontiguousarray(prompt, dtype=np.int32), P, 0
+    for _ in range(steps):
+        st0.run(0, rows, pos, toks); st0.synchronize()
+        a, b = st0.hidden_buffer(0, rows), st1.hidden_buffer(0, rows)
+        assert a.is_cuda and a.dtype == torch.int16 and tuple(a.shape) == (rows, TINY["dim"])
+        assert a.data_ptr() == lnb.lib().lnb_ctx_hidden_ptr(st0.ctx[0].h, 0)            # a view, not a copy
+        b.copy_(a); torch.cuda.synchronize()
+        tok = st1.run(0, rows, pos, None); st1.synchronize()
+        got.append(int(tok))
+        pos += rows; rows = 1; toks = np.array([tok], dtype=np.int32)
+    assert got == [int(t) for t in exp[:steps]]
+    st0.close(); st1.close()
+
+
 def test_cpp_host_mirror_generates_the_oracle_tokens(lnb, tiny_pair):
     """The C++ mirror of the Go API (host/lnb_host.hpp: NewLlamaTransformer, InferenceEngine.GenerateTokens with the
     per-layer Logf hook) drives the same C ABI: its greedy continuation equals the oracle's."""
