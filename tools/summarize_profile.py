@@ -14,8 +14,12 @@ DST = "profiles"
 os.makedirs(DST, exist_ok=True)
 shutil.copy(os.path.join(SRC, "trace", "trace_kernel_stats.csv"), os.path.join(DST, R + "_rocprofv3_kernel_stats.csv"))
 
-NAMES = {"<32, 1, 8192, 2, 7, 1, true>": "attn_norm+wq|wk|wv+RoPE+KV (thin, RW=32)", "<16, 1, 8192, 2, 7, 2, false>": "wo / w2 + residual (thin, RW=16)",
-         "<64, 2, 12288, 6, 5, 3, true>": "ffn_norm+w1|w3+SiLU*up (fat, RW=64, 2 chains)", "<64, 1, 12288, 6, 5, 0, true>": "norm+output (fat, RW=64)"}
+NAMES = {"gemv_chain_kernel<32, 1, 12288, 6, 5, 1, true>": "attn_norm+wq|wk|wv+RoPE+KV (thin, RW=32, exact parallel norm sum)",
+         "rowcast_kernel<2>": "wo / w2 + residual (row-broadcast DPP chain, 4 rows per wave)",
+         "rowcast_kernel<0>": "plain linear (row-broadcast DPP chain)",
+         "gemv_chain_kernel<64, 2, 12288, 6, 8, 3, true>": "ffn_norm+w1|w3+SiLU*up (fat, RW=64, 2 chains, v_pk_add_f32)",
+         "gemv_chain_kernel<64, 1, 12288, 6, 8, 0, true>": "norm+output (fat, RW=64)",
+         "attn_exact_kernel<128>": "attention (scores, f64 softmax, PV)"}
 trace = list(csv.DictReader(open(os.path.join(SRC, "trace", "trace_kernel_trace.csv"))))
 per = collections.defaultdict(list)
 for r in trace:
@@ -35,12 +39,12 @@ lines = ["# %s: rocprofv3 summary of `python bench.py --steps 32 --warmup 4` (Ll
          "| kernel | grid (threads) | LDS B | launches | avg us | HBM read MB (PMC, corrected) | GB/s | WAVE_CYCLES busy/wait (quad-cycles per launch) |", "|---|---|---|---|---|---|---|---|"]
 for key in sorted(per, key=lambda k: -sum(per[k])):
     kn, grid, lds = key
-    if "gemv" not in kn and "attn" not in kn and "argmax" not in kn:
+    if "gemv" not in kn and "attn" not in kn and "argmax" not in kn and "rowcast" not in kn:
         continue
     label = kn
     for pat, nm in NAMES.items():
         if pat in kn:
-            label = "gemv_chain_kernel%s — %s" % (pat, nm)
+            label = "%s — %s" % (pat, nm)
     d = per[key]
     avg = sum(d) / len(d)
     f = fetch.get(key)
