@@ -59,6 +59,9 @@ int lnb_model_ffn_hidden_dim(const lnb_model_args* args);
 int lnb_model_set_tensor(lnb_model* m, const char* name, const uint16_t* host_bf16, const int64_t* shape, int rank);
 /* read a tensor back in the reference layout (tests / debugging) */
 int lnb_model_get_tensor(lnb_model* m, const char* name, uint16_t* host_bf16, int64_t nelem);
+/* the tensors this model stage binds: index 0..n-1 -> checkpoint name, expected shape (rank 1: [n]; rank 2: [out,in]) */
+int lnb_model_num_tensors(const lnb_model* m);
+int lnb_model_tensor_info(const lnb_model* m, int index, const char** name, int64_t* shape2, int* rank);
 /* random-init every tensor of this stage on the device with the counter-based generator of DESIGN.md
  * ("Synthetic weights"): no checkpoint is needed for benchmarking */
 int lnb_model_fill_synthetic(lnb_model* m, uint64_t seed);
@@ -126,6 +129,30 @@ int lnb_op_linear(int device, const uint16_t* x, const uint16_t* w, uint16_t* y,
 /* RMSNorm.Forward (llamatransformer.go:633-639) followed by a linear layer, as the fused kernel computes it */
 int lnb_op_rmsnorm_linear(int device, const uint16_t* x, const uint16_t* norm_w, float eps, const uint16_t* w,
                           uint16_t* y, int rows, int n_out, int k_in, int rw);
+
+/* ---- weight ingestion: replaces torch.TorchModelReader + model.loadModelArgsFromFile (SURVEY.md 8f "next" #2) -------
+ * src/torch/torchmodelreader.go:39-145, src/torch/types.go:9-56, src/pickle/pickledispatch.go:13-78,
+ * src/common/memorymapper_unix.go:18-41, src/model/loader.go:183-192, src/model/modelargs.go:12-65.
+ * A checkpoint handle is a read-only mmap of a PyTorch zip file (Meta's consolidated.00.pth): entries must be STORED,
+ * exactly one *.pkl, tensors rebuilt by torch._utils._rebuild_tensor_v2 over torch.BFloat16Storage (Half/Float storages
+ * are listed but not loadable into a model).  Tensor data pointers point INTO the mmap and stay valid until
+ * lnb_checkpoint_close; lnb_model_set_tensor / lnb_model_load_checkpoint copy from there straight to the device. */
+typedef struct lnb_checkpoint lnb_checkpoint;
+enum { LNB_DTYPE_BF16 = 0, LNB_DTYPE_F16 = 1, LNB_DTYPE_F32 = 2 };
+int lnb_checkpoint_open(const char* path, lnb_checkpoint** out);
+void lnb_checkpoint_close(lnb_checkpoint* c);
+int lnb_checkpoint_num_tensors(const lnb_checkpoint* c);
+/* index of a tensor by its key, -1 if absent */
+int lnb_checkpoint_find(const lnb_checkpoint* c, const char* name);
+/* any out pointer may be NULL; shape has room for 4 dims; fails for non-contiguous tensors */
+int lnb_checkpoint_tensor(const lnb_checkpoint* c, int index, const char** name, int* dtype, int64_t* shape4, int* rank,
+                          const void** data, int64_t* nbytes);
+/* bind every tensor the model stage owns (getTensor semantics: "tensor \"x\" not found", "... has incorrect shape;
+ * expected [a b], got [c d]"); the model still needs lnb_model_finalize afterwards */
+int lnb_model_load_checkpoint(lnb_model* m, const lnb_checkpoint* c);
+/* params.json -> lnb_model_args with NewModelArgs' defaults for absent keys (n_kv_heads -1, vocab_size -1, multiple_of 256,
+ * ffn_dim_multiplier -1, norm_eps 1e-5, rope_theta 500000, use_scaled_rope false, max_seq_len 2048) */
+int lnb_model_args_from_json(const char* params_json_path, lnb_model_args* out);
 
 #ifdef __cplusplus
 }

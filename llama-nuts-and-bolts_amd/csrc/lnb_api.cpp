@@ -32,6 +32,8 @@ static int fail(const char* fmt, ...) {
     return -1;
 }
 extern "C" const char* lnb_last_error(void) { return g_err; }
+// shared with lnb_checkpoint.cpp (same library, not part of the ABI)
+extern "C" __attribute__((visibility("hidden"))) void lnb_set_error(const char* msg) { snprintf(g_err, sizeof g_err, "%s", msg); }
 #define HIPCHK(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) return fail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); } while (0)
 
 static inline float bf_wide_h(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
@@ -218,6 +220,18 @@ extern "C" int lnb_model_set_tensor(lnb_model* m, const char* name, const uint16
     if (e == hipSuccess) e = hipStreamSynchronize(m->stream);
     hipFree(stage);
     HIPCHK(e);
+    return 0;
+}
+
+// enumerate the tensors this model stage binds (names as in the checkpoint, shapes as getTensor expects them)
+extern "C" int lnb_model_num_tensors(const lnb_model* m) { return m ? (int)m->tensors.size() : 0; }
+extern "C" int lnb_model_tensor_info(const lnb_model* m, int k, const char** name, int64_t* shape, int* rank) {
+    if (!m || k < 0 || k >= (int)m->tensors.size()) return fail("tensor index %d out of range", k);
+    auto it = m->tensors.begin();
+    std::advance(it, k);
+    if (name) *name = it->first.c_str();
+    if (rank) *rank = it->second.rank;
+    if (shape) { if (it->second.rank == 1) shape[0] = it->second.cols; else { shape[0] = it->second.rows; shape[1] = it->second.cols; } }
     return 0;
 }
 

@@ -4,20 +4,19 @@
 //   src/model/llamatransformer.go:145-180 (Forward), :215-254 (block), :289-527 (attention),
 //   :593-624 (SwiGLU), :633-660 (RMSNorm), :753-790 (RoPE); src/ml/operations_lineartransform.go:37-70.
 //
-// Design: "exact-order" kernels.  The reference defines every output as ONE sequential f32 chain
-// over k followed by a bf16 truncation, so the kernels give each output element to one lane
-// (64 chains per wave64) and never split k.  What makes that fast on MI355X:
-//   * weights are re-tiled ONCE at load time into [N/RW][K/8][NCH][RW][8] (lnb_device.h) so a wave's
-//     weight traffic is one linear byte stream -> 16 B/lane coalesced global loads, no transposes;
-//   * loader waves stream that byte range HBM -> VGPR ring (P stages in flight, non-temporal) ->
-//     LDS double buffer; one consumer wave per row block walks k out of LDS (ds_read_b128 for the
-//     weights, broadcast ds_read_b128 for x) -- the LDS ring is the prefetch depth a latency-bound
-//     chain cannot hold in registers;
-//   * thin matrices (N=4096) use RW=16 so that all 256 CUs pull bytes while each chain stays serial;
-//   * RMSNorm is fused into the consuming GEMV (every workgroup recomputes the 4096-long serial
-//     sum while its loaders already have the first stages in flight), RoPE + KV-cache append are
-//     fused into the QKV epilogue (lane pairs exchange via one cross-lane shuffle), SiLU*up and the
-//     residual adds are epilogues too: 5 launches per transformer block.
+// Design: "exact-order" kernels.  The reference defines every output as ONE sequential f32 chain over k followed by a
+// bf16 truncation, so a kernel never splits k; it only decides which lane walks a chain and how that lane is fed.
+// bf16 x bf16 products are exact in f32, so everything except the dependent add can be done by other lanes / waves:
+//   * gemv_chain_kernel (norm-fused and fat matrices): weights re-tiled ONCE at load time into [N/RW][K/8][NCH][RW][8]
+//     (one linear byte stream per row block); helper waves stream them HBM -> VGPR ring (hand-counted vmcnt), multiply by x
+//     and leave f32 products in an LDS ring; ONE chain wave per CU only adds (v_pk_add_f32 for the two-chain w1|w3);
+//   * rowcast_kernel (thin wo / w2): products stay in registers; 16 lanes of a DPP row hold the products of 16 consecutive
+//     k and every lane adds them in order with v_add_f32_dpp row_newbcast -- no LDS round trip in the chain;
+//   * RMSNorm is fused into the consuming GEMV; its sequential f32 sum of squares is evaluated EXACTLY in parallel with
+//     composable parity maps (lnb_seqsum.h); RoPE + KV-cache append are fused into the QKV epilogue, SiLU*up and the
+//     residual adds are epilogues too: 5 launches per transformer block;
+//   * attn_exact_kernel: one position per lane for the scores, f64 softmax in the reference's order, exact-product PV.
+// Every register prefetch ring is inline asm with hand-counted waits; tools/isa_audit.py checks the compiled code.
 // Compile with -ffp-contract=off: every a*b+c below is either an explicit fmaf (product exact) or
 // must stay two roundings.
 #include <hip/hip_runtime.h>
@@ -73,9 +72,6 @@ DEVINL float4 mul4(const float4& x, float w0, float w1, float w2, float w3) {   
     return make_float4(a.x, a.y, b.x, b.y);
 }
 
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
-typedef const __attribute__((address_space(1))) void* glb_ptr_t;
-#define WAIT_VMCNT(N) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory")
 
 // ---- x staging (cooperative: the chain wave and the helper waves are the NS "stagers") -----------------
 // x row -> LDS as f32, zero padded up to kpad (a whole number of stages + 64 floats of slack, so the

@@ -6,6 +6,7 @@
 //   reference (Go)                                              here (C++)
 //   model.ModelArgs                 src/model/modelargs.go:12    lnb::ModelArgs
 //   model.Model{Tensors,ModelArgs}  src/model/model.go           lnb::Model  (name -> host bf16 tensor, as the loader leaves it)
+//   model.LoadModel                 src/model/loader.go:18-70    lnb::LoadModel(modelDir)  (pth zip + pickle + params.json; no tokenizer)
 //   model.NewLlamaTransformer       llamatransformer.go:64       lnb::LlamaTransformer::New(model, device)
 //   (*LlamaTransformer).Forward     llamatransformer.go:145      lnb::LlamaTransformer::Forward(ctx, tokens, startPos, &logits)
 //   model.NewInferenceContext       inferencecontext.go:17       lnb::InferenceContext(transformer, inferenceArgs, logFn)
@@ -60,6 +61,36 @@ struct Model {                           // model.Model: what LoadModel returns 
 struct InferenceArgs { int SequenceLength = 0; };   // src/common/inferenceargs.go:3-11
 
 inline void check(int rc) { if (rc != 0) throw std::runtime_error(lnb_last_error()); }
+
+// model.LoadModel (src/model/loader.go:18-70): <dir>/consolidated.00.pth (mmap'ed, tensors are views into it for the lifetime
+// of the returned Model, like the reference's never-unmapped mmap, src/torch/types.go:51-55) + <dir>/params.json.
+// The tokenizer is out of scope here: VocabSize, which the reference takes from it (loader.go:101-108),
+// is taken from the first dimension of tok_embeddings.weight when params.json does not give it.
+inline std::shared_ptr<Model> LoadModel(const std::string& modelDir) {
+    lnb_checkpoint* ck = nullptr;
+    check(lnb_checkpoint_open((modelDir + "/consolidated.00.pth").c_str(), &ck));
+    std::shared_ptr<lnb_checkpoint> keep(ck, lnb_checkpoint_close);
+    std::shared_ptr<Model> m(new Model(), [keep](Model* p) { delete p; });       // the mmap lives as long as the Model
+    lnb_model_args a{};
+    check(lnb_model_args_from_json((modelDir + "/params.json").c_str(), &a));
+    m->Args.Dim = a.dim; m->Args.N_Layers = a.n_layers; m->Args.N_Heads = a.n_heads; m->Args.N_KVHeads = a.n_kv_heads;
+    m->Args.VocabSize = a.vocab_size; m->Args.MultipleOf = a.multiple_of; m->Args.FFNDimMultiplier = a.ffn_dim_multiplier;
+    m->Args.NormEpsilon = a.norm_eps; m->Args.UseScaledRope = a.use_scaled_rope != 0; m->Args.RopeTheta = a.rope_theta;
+    m->Args.MaxSequenceLength = a.max_seq_len;
+    for (int i = 0; i < lnb_checkpoint_num_tensors(ck); i++) {
+        const char* name = nullptr; int dtype = 0, rank = 0; int64_t shape[4] = {0, 0, 0, 0}, nbytes = 0; const void* data = nullptr;
+        check(lnb_checkpoint_tensor(ck, i, &name, &dtype, shape, &rank, &data, &nbytes));
+        if (dtype != LNB_DTYPE_BF16) continue;                               // only torch.BFloat16Storage (src/torch/types.go:15)
+        HostTensor t; t.Size.assign(shape, shape + rank); t.RawData = (const uint16_t*)data;
+        m->Tensors[name] = t;
+    }
+    if (m->Args.VocabSize < 1) {
+        auto it = m->Tensors.find("tok_embeddings.weight");
+        if (it == m->Tensors.end()) throw std::runtime_error("tensor \"tok_embeddings.weight\" not found");
+        m->Args.VocabSize = (int)it->second.Size[0];
+    }
+    return m;
+}
 
 class LlamaTransformer {
 public:

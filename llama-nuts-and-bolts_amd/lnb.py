@@ -47,7 +47,9 @@ EXPORTS = [
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
     "lnb_forward_stage", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear",
-    "lnb_profile_kernel",
+    "lnb_profile_kernel", "lnb_model_num_tensors", "lnb_model_tensor_info",
+    "lnb_checkpoint_open", "lnb_checkpoint_close", "lnb_checkpoint_num_tensors", "lnb_checkpoint_find", "lnb_checkpoint_tensor",
+    "lnb_model_load_checkpoint", "lnb_model_args_from_json",
 ]
 
 
@@ -87,6 +89,17 @@ def lib():
     L.lnb_profile_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p]
     L.lnb_op_linear.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_op_rmsnorm_linear.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lnb_model_num_tensors.argtypes = [vp]
+    L.lnb_model_tensor_info.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
+    L.lnb_checkpoint_open.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.lnb_checkpoint_close.argtypes = [vp]
+    L.lnb_checkpoint_close.restype = None
+    L.lnb_checkpoint_num_tensors.argtypes = [vp]
+    L.lnb_checkpoint_find.argtypes = [vp, C.c_char_p]
+    L.lnb_checkpoint_tensor.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int), C.POINTER(C.c_int64), C.POINTER(C.c_int),
+                                        C.POINTER(vp), C.POINTER(C.c_int64)]
+    L.lnb_model_load_checkpoint.argtypes = [vp, vp]
+    L.lnb_model_args_from_json.argtypes = [C.c_char_p, C.POINTER(ModelArgs)]
     _lib = L
     return L
 
@@ -104,6 +117,46 @@ def device_count():
     n = C.c_int(0)
     _chk(lib().lnb_device_count(C.byref(n)))
     return n.value
+
+
+DTYPES = {0: ("bf16", np.uint16), 1: ("f16", np.uint16), 2: ("f32", np.float32)}
+
+
+class Checkpoint:
+    """Read-only mmap of a PyTorch zip checkpoint (torch.TorchModelReader, src/torch/torchmodelreader.go:39-145)."""
+
+    def __init__(self, path):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _chk(self.L.lnb_checkpoint_open(os.fsencode(path), C.byref(self.h)))
+
+    def __len__(self):
+        return self.L.lnb_checkpoint_num_tensors(self.h)
+
+    def tensor(self, i):
+        """(name, dtype string, shape, numpy view of the mmap'ed bytes -- valid until close())"""
+        name, dt, shape, rank, data, nb = C.c_char_p(), C.c_int(), (C.c_int64 * 4)(), C.c_int(), C.c_void_p(), C.c_int64()
+        _chk(self.L.lnb_checkpoint_tensor(self.h, i, C.byref(name), C.byref(dt), shape, C.byref(rank), C.byref(data), C.byref(nb)))
+        dname, npdt = DTYPES[dt.value]
+        shp = tuple(shape[:rank.value])
+        n = nb.value // np.dtype(npdt).itemsize
+        arr = np.ctypeslib.as_array(C.cast(data.value, C.POINTER(C.c_uint16 if npdt is np.uint16 else C.c_float)), shape=(n,)) if n else np.empty(0, npdt)
+        return name.value.decode(), dname, shp, arr.reshape(shp) if n else arr.reshape(shp)
+
+    def find(self, name):
+        return self.L.lnb_checkpoint_find(self.h, name.encode())
+
+    def close(self):
+        if self.h:
+            self.L.lnb_checkpoint_close(self.h)
+            self.h = C.c_void_p()
+
+
+def model_args_from_json(path):
+    """params.json -> dict of ModelArgs fields with the reference's defaults (src/model/modelargs.go:29-65)"""
+    a = ModelArgs()
+    _chk(lib().lnb_model_args_from_json(os.fsencode(path), C.byref(a)))
+    return {f: getattr(a, f) for f, _ in ModelArgs._fields_}
 
 
 class LlamaTransformer:
@@ -135,6 +188,19 @@ class LlamaTransformer:
     def fill_synthetic(self, seed=1234):
         _chk(self.L.lnb_model_fill_synthetic(self.h, seed))
         return self
+
+    def load_checkpoint(self, ckpt):
+        """bind every tensor of this stage from an open Checkpoint (torch.TorchModelReader + getTensor, loader.go:183-192)"""
+        _chk(self.L.lnb_model_load_checkpoint(self.h, ckpt.h))
+        return self
+
+    def tensor_infos(self):
+        out = []
+        for k in range(self.L.lnb_model_num_tensors(self.h)):
+            name, shape, rank = C.c_char_p(), (C.c_int64 * 2)(), C.c_int()
+            _chk(self.L.lnb_model_tensor_info(self.h, k, C.byref(name), shape, C.byref(rank)))
+            out.append((name.value.decode(), tuple(shape[:rank.value])))
+        return out
 
     def finalize(self, rope_rows=0):
         _chk(self.L.lnb_model_finalize(self.h, rope_rows))

@@ -5,10 +5,18 @@
 #include <cstdio>
 #include <cstdlib>
 int main(int argc, char** argv) {
-    lnb::Model model;
+    // LNB_MODEL_DIR=<dir with consolidated.00.pth + params.json>: the reference's LoadModel path instead of synthetic weights
+    std::shared_ptr<lnb::Model> loaded;
+    lnb::Model synthetic;
+    if (const char* dir = getenv("LNB_MODEL_DIR")) {
+        try { loaded = lnb::LoadModel(dir); } catch (const std::exception& e) { printf("error: %s\n", e.what()); return 3; }
+    }
+    lnb::Model& model = loaded ? *loaded : synthetic;
+    if (!loaded) {
     model.Args.Dim = 256; model.Args.N_Layers = 2; model.Args.N_Heads = 4; model.Args.N_KVHeads = 2; model.Args.VocabSize = 1024;
     model.Args.MultipleOf = 64; model.Args.FFNDimMultiplier = 1.3; model.Args.UseScaledRope = true;
     model.Synthetic = true; model.SyntheticSeed = 1234;
+    }
     int seq_len = argc > 1 ? atoi(argv[1]) : 40;
     try {
         std::unique_ptr<lnb::LlamaTransformer> t(lnb::LlamaTransformer::New(model, 0));

@@ -291,6 +291,51 @@ def test_pipeline_stage_hidden_views_are_zero_copy_torch_tensors(lnb, tiny_pair)
     st0.close(); st1.close()
 
 
+def test_model_loaded_from_a_torch_checkpoint_matches_the_oracle(lnb, tmp_path):
+    """Weight ingestion end to end (SURVEY.md 8f "next" #2): torch.save writes a real zip checkpoint with Meta's key names,
+    the library mmaps it, unpickles it and binds the tensors (host -> HBM, re-tiled); logits must be bit-identical to the
+    oracle fed the same tensors.  Also the reference's getTensor errors (loader.go:183-192)."""
+    torch = pytest.importorskip("torch")
+    cfg = dict(TINY)
+    gm = lnb.LlamaTransformer(**cfg)
+    infos = gm.tensor_infos()
+    assert len(infos) == 3 + 9 * cfg["n_layers"]
+    g = torch.Generator().manual_seed(5)
+    sd = {}
+    for name, shape in infos:
+        t = torch.randn(*shape, generator=g) * 0.05
+        if "norm" in name:
+            t = t + 1
+        sd[name] = t.to(torch.bfloat16)
+    path = str(tmp_path / "consolidated.00.pth")
+    torch.save(sd, path)
+    ck = lnb.Checkpoint(path)
+    gm.load_checkpoint(ck).finalize()
+    om = orc.Model(**cfg)
+    for name, _ in infos:
+        om.set_tensor(name, sd[name].contiguous().view(torch.int16).numpy().view(np.uint16).ravel())
+    om.finalize()
+    toks = orc.synth_tokens(21, 9, cfg["vocab_size"])
+    lo, ao = orc.Context(om, 32).forward(toks, 0)
+    gc = lnb.InferenceContext(gm, 32)
+    lg, ag = gc.Forward(toks, 0)
+    assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag
+    gc.close(); om.close()
+    # getTensor errors
+    del sd["layers.1.ffn_norm.weight"]
+    torch.save(sd, path)
+    ck2 = lnb.Checkpoint(path)
+    with pytest.raises(lnb.LnbError, match=r'tensor "layers\.1\.ffn_norm\.weight" not found'):
+        gm.load_checkpoint(ck2)
+    ck2.close()
+    sd["layers.1.ffn_norm.weight"] = torch.ones(cfg["dim"] + 1).to(torch.bfloat16)
+    torch.save(sd, path)
+    ck3 = lnb.Checkpoint(path)
+    with pytest.raises(lnb.LnbError, match=r"has incorrect shape; expected \[256\], got \[257\]"):
+        gm.load_checkpoint(ck3)
+    ck3.close(); ck.close(); gm.close()
+
+
 def test_cpp_host_mirror_generates_the_oracle_tokens(lnb, tiny_pair):
     """The C++ mirror of the Go API (host/lnb_host.hpp: NewLlamaTransformer, InferenceEngine.GenerateTokens with the
     per-layer Logf hook) drives the same C ABI: its greedy continuation equals the oracle's."""
@@ -310,3 +355,39 @@ def test_cpp_host_mirror_generates_the_oracle_tokens(lnb, tiny_pair):
     assert "state=3" in line                                         # GSFinishedByReachingSeqLen (inference.go:240-246)
     logged = int([l for l in r.stdout.splitlines() if l.startswith("layers_logged:")][0].split()[1])
     assert logged == 2                                               # Logf fired once per layer of the prefill Forward
+
+
+def test_cpp_host_mirror_loadmodel_from_a_model_directory(lnb, tmp_path):
+    """lnb::LoadModel(dir) = model.LoadModel (src/model/loader.go:18-70) without the tokenizer: consolidated.00.pth written by
+    torch.save + params.json -> NewLlamaTransformer -> GenerateTokens; tokens must equal the oracle's with the same tensors."""
+    import json
+    import subprocess
+    torch = pytest.importorskip("torch")
+    cfg = dict(TINY)
+    gm = lnb.LlamaTransformer(**cfg)
+    infos = gm.tensor_infos()
+    gm.close()
+    g = torch.Generator().manual_seed(9)
+    sd = {name: ((torch.randn(*shape, generator=g) * 0.05) + (1 if "norm" in name else 0)).to(torch.bfloat16) for name, shape in infos}
+    torch.save(sd, str(tmp_path / "consolidated.00.pth"))
+    (tmp_path / "params.json").write_text(json.dumps({"dim": cfg["dim"], "n_layers": cfg["n_layers"], "n_heads": cfg["n_heads"],
+                                                       "n_kv_heads": cfg["n_kv_heads"], "multiple_of": cfg["multiple_of"],
+                                                       "ffn_dim_multiplier": cfg["ffn_dim_multiplier"], "norm_eps": 1e-05,
+                                                       "rope_theta": 500000.0, "use_scaled_rope": True}))   # no vocab_size: from tok_embeddings
+    om = orc.Model(**cfg)
+    for name, _ in infos:
+        om.set_tensor(name, sd[name].contiguous().view(torch.int16).numpy().view(np.uint16).ravel())
+    om.finalize()
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "host_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(root, "tests", "native", "host_mirror_test.cpp"), "-o", exe,
+                           "-L" + os.path.join(root, "llama-nuts-and-bolts_amd"), "-llnb_hip", "-Wl,-rpath," + os.path.join(root, "llama-nuts-and-bolts_amd"),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    prompt = [5, 17, 300, 2]
+    r = subprocess.run([exe, "24"] + [str(t) for t in prompt], capture_output=True, text=True, check=True,
+                       env=dict(os.environ, LNB_MODEL_DIR=str(tmp_path)))
+    line = [l for l in r.stdout.splitlines() if l.startswith("tokens:")][0]
+    got = [int(t) for t in line.split()[1:] if t.lstrip("-").isdigit()]
+    ref, _ = orc.Context(om, 24).generate(np.array(prompt, dtype=np.int32), 20)
+    assert got == [int(t) for t in ref]
+    om.close()
