@@ -18,6 +18,8 @@
 extern "C" {
 hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st);
 hipError_t lnbk_attn(const AttnParams* p, hipStream_t st);
+hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st);
+hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps, hipStream_t st);
 hipError_t lnbk_embed(const uint16_t* emb, const int32_t* tokens, uint16_t* x, int S, int dim, int vocab, int* err, hipStream_t st);
 hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_token, StepState* state, int32_t* out_tokens, int out_cap, int advance, hipStream_t st);
 hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st);
@@ -75,6 +77,7 @@ struct lnb_ctx {
     StepState* st = nullptr; int32_t* dtok = nullptr; int32_t* dnext = nullptr; int* derr = nullptr;
     int32_t* dout = nullptr; int dout_cap = 0;
     uint16_t *x = nullptr, *h = nullptr, *q = nullptr, *att = nullptr, *ffn = nullptr, *logits = nullptr;
+    uint16_t* xn = nullptr;                // [seq_len][dim] normalised rows for the matrix-core prefill path
     int logits_rows = 0;
     hipGraphExec_t graph = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -357,6 +360,7 @@ extern "C" int lnb_ctx_create(lnb_model* m, int seq_len, lnb_ctx** out) {
     c->dout_cap = c->seq_len; HIPCHK(hipMalloc((void**)&c->dout, (size_t)c->dout_cap * 4));
     const size_t S = c->seq_len;
     HIPCHK(hipMalloc((void**)&c->x, S * m->a.dim * 2)); HIPCHK(hipMalloc((void**)&c->h, S * m->a.dim * 2));
+    HIPCHK(hipMalloc((void**)&c->xn, S * m->a.dim * 2));
     HIPCHK(hipMalloc((void**)&c->q, S * m->q_dim * 2)); HIPCHK(hipMalloc((void**)&c->att, S * m->q_dim * 2));
     HIPCHK(hipMalloc((void**)&c->ffn, S * m->ffn_hidden * 2));
     if (m->last()) { HIPCHK(hipMalloc((void**)&c->logits, (size_t)m->a.vocab_size * 2)); c->logits_rows = 1; }
@@ -372,7 +376,7 @@ extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     for (auto p : c->ck) hipFree(p);
     for (auto p : c->cv) hipFree(p);
     hipFree(c->st); hipFree(c->dtok); hipFree(c->dnext); hipFree(c->derr); hipFree(c->dout);
-    hipFree(c->x); hipFree(c->h); hipFree(c->q); hipFree(c->att); hipFree(c->ffn); if (c->logits) hipFree(c->logits);
+    hipFree(c->x); hipFree(c->h); hipFree(c->xn); hipFree(c->q); hipFree(c->att); hipFree(c->ffn); if (c->logits) hipFree(c->logits);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
     delete c;
@@ -413,10 +417,31 @@ extern "C" int lnb_ctx_synchronize(lnb_ctx* c) { if (!c) return fail("null argum
 
 // ---- the five launches of one transformer block (position comes from c->st on the device) -----------
 enum { K_QKV = 0, K_ATTN = 1, K_WO = 2, K_W13 = 3, K_W2 = 4, K_HEAD = 5, K_LAYER = 6 };
+// Calls of 16 or more rows (prefill) run the same exact chains on the f32 matrix cores (gemm_mfma_kernel); LNB_PREFILL_MFMA=0
+// keeps them on the S = 1 kernels (one launch row per token row), which is what the parity tests compare the two with.
+static bool use_mfma(int S) { static const int on = env_int("LNB_PREFILL_MFMA", 1); return on && S >= 16; }
+static GemmParams gemm_of(const TiledDesc& t, const uint16_t* x, int K, int n_rows, int S, const StepState* st) {
+    GemmParams g{}; g.w = t.w; g.rw = t.rw; g.nch = t.nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = S; g.st = st; return g;
+}
 static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = c->stream;
     LayerW& L = m->layers[l - m->layer_begin];
     uint16_t* ck = c->ck[l - m->layer_begin]; uint16_t* cv = c->cv[l - m->layer_begin];
+    if (use_mfma(S) && which != K_ATTN) {
+        switch (which) {
+        case K_QKV: {
+            HIPCHK(lnbk_rmsnorm_rows(c->x, L.attn_norm, c->xn, S, a.dim, a.norm_eps, st));
+            GemmParams g = gemm_of(L.wqkv, c->xn, a.dim, L.wqkv.n_rows, S, c->st);
+            g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.seq_len = c->seq_len; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
+            HIPCHK(lnbk_gemm(&g, EPI_QKV_ROPE, st)); return 0; }
+        case K_WO: { GemmParams g = gemm_of(L.wo, c->att, m->q_dim, a.dim, S, c->st); g.out = c->h; g.res = c->x; HIPCHK(lnbk_gemm(&g, EPI_RESID, st)); return 0; }
+        case K_W13: {
+            HIPCHK(lnbk_rmsnorm_rows(c->h, L.ffn_norm, c->xn, S, a.dim, a.norm_eps, st));
+            GemmParams g = gemm_of(L.w13, c->xn, a.dim, m->ffn_hidden, S, c->st); g.out = c->ffn; g.silu = m->silu;
+            HIPCHK(lnbk_gemm(&g, EPI_SILU_MUL, st)); return 0; }
+        case K_W2: { GemmParams g = gemm_of(L.w2, c->ffn, m->ffn_hidden, a.dim, S, c->st); g.out = c->x; g.res = c->h; HIPCHK(lnbk_gemm(&g, EPI_RESID, st)); return 0; }
+        }
+    }
     switch (which) {
     case K_QKV: {   // attn_norm + wq|wk|wv + RoPE + KV append  (llamatransformer.go:222, :297-403)
         GemvParams g{}; g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
@@ -456,6 +481,12 @@ static int enqueue_layers(lnb_ctx* c, int S, bool with_cb) {
 // final RMSNorm + output projection of `rows` rows starting at row `first` (llamatransformer.go:166-170)
 static int enqueue_head(lnb_ctx* c, int first, int rows) {
     lnb_model* m = c->m;
+    if (use_mfma(rows)) {
+        HIPCHK(lnbk_rmsnorm_rows(c->x + (size_t)first * m->a.dim, m->norm, c->xn, rows, m->a.dim, m->a.norm_eps, c->stream));
+        GemmParams gm = gemm_of(m->output, c->xn, m->a.dim, m->a.vocab_size, rows, c->st); gm.out = c->logits;
+        HIPCHK(lnbk_gemm(&gm, EPI_STORE, c->stream));
+        return 0;
+    }
     GemvParams g{}; g.w = m->output.w; g.x = c->x + (size_t)first * m->a.dim; g.norm_w = m->norm; g.eps = m->a.norm_eps; g.K = m->a.dim;
     g.n_rows = m->a.vocab_size; g.S = rows; g.st = c->st; g.out = c->logits;
     set_grid(g, m->output);
@@ -656,9 +687,18 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     HIPCHK(hipMemcpy(dw, w, (size_t)n_out * k_in * 2, hipMemcpyHostToDevice));
     if (norm_w) { HIPCHK(hipMalloc((void**)&dn, (size_t)k_in * 2)); HIPCHK(hipMemcpy(dn, norm_w, (size_t)k_in * 2, hipMemcpyHostToDevice)); }
     HIPCHK(lnbk_tile(dw, t.w, n_out, k_in, 0, 0, rw, 1, 0, nullptr));
+    if (use_mfma(rows)) {                                   // 16 or more rows: the matrix-core path of the prefill
+        uint16_t* dxn = nullptr;
+        if (norm_w) { HIPCHK(hipMalloc((void**)&dxn, (size_t)rows * k_in * 2)); HIPCHK(lnbk_rmsnorm_rows(dx, dn, dxn, rows, k_in, eps, nullptr)); }
+        GemmParams gm = gemm_of(t, norm_w ? dxn : dx, k_in, n_out, rows, st); gm.out = dy;
+        HIPCHK(lnbk_gemm(&gm, EPI_STORE, nullptr));
+        HIPCHK(hipDeviceSynchronize());
+        if (dxn) hipFree(dxn);
+    } else {
     GemvParams g{}; g.w = t.w; g.x = dx; g.norm_w = dn; g.eps = eps; g.K = k_in; g.n_rows = n_out; g.S = rows; g.st = st; g.out = dy;
     set_grid(g, t);
     HIPCHK(lnbk_gemv(&g, rw, 1, EPI_STORE, norm_w ? 1 : 0, nullptr));
+    }
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(y, dy, (size_t)rows * n_out * 2, hipMemcpyDeviceToHost));
     hipFree(dx); hipFree(dw); hipFree(dy); hipFree(st); hipFree(t.w); if (dn) hipFree(dn);

@@ -92,6 +92,17 @@ struct GemvParams {
     long long* dbg;             // optional per-wave timing dump (nullptr in production)
 };
 
+// exact-order prefill GEMM on the f32 matrix cores (gemm_mfma_kernel): Y[m][n] for S >= 16 rows per call
+struct GemmParams {
+    const uint16_t* w;          // tiled weights (any layout of tiled_index)
+    int rw, nch;                // layout tag of w
+    const uint16_t* x;          // [S][K] bf16 (already normalised when the GEMV would fuse the norm)
+    int K, n_rows, S;
+    const StepState* st;
+    uint16_t* out; const uint16_t* res; const float* silu;            // EPI_STORE / EPI_RESID / EPI_SILU_MUL
+    const float* cis; uint16_t* q_out; uint16_t* cache_k; uint16_t* cache_v; int seq_len, q_dim, kv_dim, head_dim;   // EPI_QKV_ROPE
+};
+
 struct AttnParams {
     const uint16_t* q;          // [S][H*hd]
     const uint16_t* cache_k;    // [KVH][hd/8][seq_len][8]

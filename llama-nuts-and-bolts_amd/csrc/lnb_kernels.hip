@@ -811,6 +811,151 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Prefill (S >= 16 rows per call): the same exact chains on the f32 MATRIX cores.
+//
+// v_mfma_f32_16x16x4_f32 is, bit for bit, the k-ordered chain  D = fma(a_k3,b_k3, fma(a_k2,b_k2, fma(a_k1,b_k1, fma(a_k0,b_k0, C))))
+// (one rounding per product, no wider internal accumulation; verified against the reference's loop on MI355X by
+// tools/mfma_exact.hip), and bf16 x bf16 products are exact, so fma == the reference's multiply-then-add.  One instruction
+// advances 16 output rows x 16 batch rows by four k-steps in 32 cycles: ~20x the chain throughput of the S = 1 kernels,
+// with identical bits.  (It does not help decode: one batch column uses 1/16 of the instruction, 10 cycles per k-step.)
+//
+// rmsnorm_rows_kernel: RMSNorm of S rows, one lane per row (each lane walks its own sequential sum of squares: the rows are
+// the parallelism here), output bf16 [S][K] with the reference's two truncations.
+// gemm_mfma_kernel: workgroup = 4 waves = 64 output rows x 128 batch rows; K is walked in 128-step slabs staged through the
+// LDS as f32, k-major and padded so that both operand fragments are bank-conflict free:
+//   A (weights): lane (i = l&15, kk = l>>4) reads As[4g+kk][16w+i];  B (x): Bs[4g+kk][16t+j]   (row strides 80 / 144 floats)
+// wave w owns n-tile w and all 8 m-tiles: 8 (16 for the two-chain w1|w3) MFMAs per 1-2 A reads + 8 B reads.
+// Weights are gathered 16 B at a time from whichever tiled layout the matrix was stored in (tiled_index).
+// grid = (ceil(n_rows/64), ceil(S/128)); dynamic LDS = (NCH*128*80 + 128*144) * 4 bytes.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void rmsnorm_rows_kernel(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
+    if (m >= S) return;
+    const uint16_t* xr = x + (size_t)m * K;
+    float sum = 0.0f;
+    for (int k = 0; k < K; k += 8) {                         // Pow(x,2) exact, Mean's serial f32 sum, k ascending (impl:197-251)
+        const uint4 v = *(const uint4*)(xr + k);
+        const float a0 = bf_lo(v.x), a1 = bf_hi(v.x), a2 = bf_lo(v.y), a3 = bf_hi(v.y), a4 = bf_lo(v.z), a5 = bf_hi(v.z), a6 = bf_lo(v.w), a7 = bf_hi(v.w);
+        sum += a0 * a0; sum += a1 * a1; sum += a2 * a2; sum += a3 * a3; sum += a4 * a4; sum += a5 * a5; sum += a6 * a6; sum += a7 * a7;
+    }
+    float mean = __fdiv_rn(sum, (float)K);
+    mean = mean + eps;
+    const float r = (float)(1.0 / sqrt((double)mean));
+    uint16_t* o = out + (size_t)m * K;
+    for (int k = 0; k < K; k += 8) {                         // trunc(trunc(x*r)*w) (llamatransformer.go:656,638)
+        const uint4 v = *(const uint4*)(xr + k), g = *(const uint4*)(w + k);
+        const uint32_t xs_[4] = {v.x, v.y, v.z, v.w}, ws_[4] = {g.x, g.y, g.z, g.w};
+        uint32_t r4[4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) {
+            const uint16_t lo = bf_trunc(bf_wide(bf_trunc(bf_lo(xs_[e]) * r)) * bf_lo(ws_[e]));
+            const uint16_t hi = bf_trunc(bf_wide(bf_trunc(bf_hi(xs_[e]) * r)) * bf_hi(ws_[e]));
+            r4[e] = (uint32_t)lo | ((uint32_t)hi << 16);
+        }
+        *(uint4*)(o + k) = make_uint4(r4[0], r4[1], r4[2], r4[3]);
+    }
+}
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int GM_NB = 64, GM_MB = 128, GM_KS = 128, GM_AS = 80, GM_BS = 144;
+template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& g, const f32x4& u, int m, int n0) {
+    // one lane: batch row m, four consecutive output rows n0..n0+3 (n0 % 4 == 0)
+    if (m >= p.S) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int n = n0 + r;
+        if (n >= p.n_rows) continue;
+        const size_t o = (size_t)m * p.n_rows + n;
+        if (EPI == EPI_STORE) p.out[o] = bf_trunc(g[r]);
+        else if (EPI == EPI_RESID) p.out[o] = bf_trunc(bf_wide(p.res[o]) + bf_wide(bf_trunc(g[r])));            // ml.Add, impl:320-332
+        else if (EPI == EPI_SILU_MUL) {                                                                           // activations.go:36-39, :614
+            const uint16_t gs = bf_trunc(p.silu[bf_trunc(g[r])]);
+            p.out[o] = bf_trunc(bf_wide(gs) * bf_wide(bf_trunc(u[r])));
+        } else if (EPI == EPI_QKV_ROPE) {                                                                         // llamatransformer.go:297-403
+            const int pos = p.st->pos + m;
+            const uint16_t mine = bf_trunc(g[r]), other = bf_trunc(g[r ^ 1]);                                      // RoPE partner 2i <-> 2i+1: same lane
+            if (n < p.q_dim + p.kv_dim) {
+                const int d = n % p.head_dim, i = d >> 1;
+                const float2 cs = *(const float2*)(p.cis + ((size_t)pos * (p.head_dim >> 1) + i) * 2);
+                const double cr = (double)cs.x, ci = (double)cs.y;
+                uint16_t r16;
+                if ((n & 1) == 0) { const double a = (double)bf_wide(mine), bb = (double)bf_wide(other); r16 = bf_trunc((float)(a * cr - bb * ci)); }
+                else              { const double a = (double)bf_wide(other), bb = (double)bf_wide(mine); r16 = bf_trunc((float)(a * ci + bb * cr)); }
+                if (n < p.q_dim) p.q_out[(size_t)m * p.q_dim + n] = r16;
+                else {
+                    const int kc = n - p.q_dim, kh = kc / p.head_dim;
+                    p.cache_k[(((size_t)kh * (p.head_dim >> 3) + (d >> 3)) * p.seq_len + pos) * 8 + (d & 7)] = r16;
+                }
+            } else p.cache_v[(size_t)pos * p.kv_dim + (n - p.q_dim - p.kv_dim)] = mine;
+        }
+    }
+}
+
+template <int EPI, int NCH>
+__global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* As = (float*)smem;                                // [NCH][GM_KS][GM_AS]
+    float* Bs = As + NCH * GM_KS * GM_AS;                    // [GM_KS][GM_BS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int n0 = blockIdx.x * GM_NB, m0 = blockIdx.y * GM_MB;
+    const int K = p.K;
+    f32x4 acc[NCH][8];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int t = 0; t < 8; t++) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int fi = lane & 15, fk = lane >> 4;
+    for (int k0 = 0; k0 < K; k0 += GM_KS) {
+        // ---- stage the slab: weights (64 lane-rows x 128 k per chain) and x (128 rows x 128 k), bf16 -> f32, k-major
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+            for (int u = tid; u < GM_NB * (GM_KS / 8); u += 256) {
+                const int row = u & (GM_NB - 1), kc = u >> 6;                           // row fastest: LDS banks = row, global units adjacent
+                int n = n0 + row; n = n < p.n_rows ? n : p.n_rows - 1;                  // clamped rows are computed and dropped
+                // 16 B unit of row n: chain layouts hold k0+8kc .. +7; the row-broadcast layout (rw 4) holds k0 + 16e + kc, e = 0..7
+                const int kf = p.rw == 4 ? k0 + kc : k0 + 8 * kc, kst = p.rw == 4 ? 16 : 1;
+                uint4 v = make_uint4(0, 0, 0, 0);
+                if (kf + 7 * kst < K) v = *(const uint4*)(p.w + tiled_index(n, kf, c, K, p.rw, p.nch));
+                float* d = As + ((size_t)c * GM_KS + (kf - k0)) * GM_AS + row;
+                d[0] = bf_lo(v.x); d[kst * GM_AS] = bf_hi(v.x); d[2 * kst * GM_AS] = bf_lo(v.y); d[3 * kst * GM_AS] = bf_hi(v.y);
+                d[4 * kst * GM_AS] = bf_lo(v.z); d[5 * kst * GM_AS] = bf_hi(v.z); d[6 * kst * GM_AS] = bf_lo(v.w); d[7 * kst * GM_AS] = bf_hi(v.w);
+            }
+        for (int u = tid; u < GM_MB * (GM_KS / 8); u += 256) {
+            const int row = u & (GM_MB - 1), kc = u >> 7;                               // row fastest (conflict-free LDS writes)
+            int m = m0 + row; m = m < p.S ? m : p.S - 1;
+            const int kf = k0 + 8 * kc;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (kf < K) v = *(const uint4*)(p.x + (size_t)m * K + kf);
+            float* d = Bs + (size_t)(8 * kc) * GM_BS + row;
+            d[0] = bf_lo(v.x); d[GM_BS] = bf_hi(v.x); d[2 * GM_BS] = bf_lo(v.y); d[3 * GM_BS] = bf_hi(v.y);
+            d[4 * GM_BS] = bf_lo(v.z); d[5 * GM_BS] = bf_hi(v.z); d[6 * GM_BS] = bf_lo(v.w); d[7 * GM_BS] = bf_hi(v.w);
+        }
+        __syncthreads();
+        // ---- 32 k-groups of 4: acc[n-tile w][m-tile t] = mfma(A, B, acc), k ascending (beyond K both operands are 0)
+        const float* ap = As + (size_t)fk * GM_AS + wave * 16 + fi;
+        const float* bp = Bs + (size_t)fk * GM_BS + fi;
+#pragma unroll 4
+        for (int g = 0; g < GM_KS / 4; g++) {
+            float a[NCH];
+#pragma unroll
+            for (int c = 0; c < NCH; c++) a[c] = ap[(size_t)c * GM_KS * GM_AS + g * 4 * GM_AS];
+#pragma unroll
+            for (int t = 0; t < 8; t++) {
+                const float b = bp[g * 4 * GM_BS + t * 16];
+#pragma unroll
+                for (int c = 0; c < NCH; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b, acc[c][t], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+    // D layout: lane holds rows (lane>>4)*4 + r of the n-tile, column lane&15 of the m-tile
+#pragma unroll
+    for (int t = 0; t < 8; t++)
+        gemm_epilogue4<EPI>(p, acc[0][t], acc[NCH - 1][t], m0 + t * 16 + (lane & 15), n0 + wave * 16 + (lane >> 4) * 4);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exact attention for one (head, query row): scores -> /sqrt(hd) -> mask -> f64 softmax -> PV.
 // llamatransformer.go:409-514.  GQA head h reads KV head h/n_rep straight from the un-repeated cache
 // (attentionRepeatKV :529-559 and the four Transposes :435-449 become index arithmetic).
@@ -1218,10 +1363,34 @@ extern "C" hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, i
     }
 }
 
+template <int EPI, int NCH> static hipError_t launch_gemm(const GemmParams* p, hipStream_t st) {
+    auto kfn = gemm_mfma_kernel<EPI, NCH>;
+    const size_t lds = ((size_t)NCH * GM_KS * GM_AS + (size_t)GM_KS * GM_BS) * 4;
+    if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)((p->n_rows + GM_NB - 1) / GM_NB), (unsigned)((p->S + GM_MB - 1) / GM_MB)), dim3(256), lds, st, *p);
+    return hipGetLastError();
+}
+// exact-order prefill GEMM (f32 MFMA); p == nullptr prepares the kernel (dynamic LDS limit) outside any stream capture
+extern "C" hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st) {
+    const int nch = p ? p->nch : 0;
+    switch (epi) {
+        case EPI_STORE: return launch_gemm<EPI_STORE, 1>(p, st);
+        case EPI_RESID: return launch_gemm<EPI_RESID, 1>(p, st);
+        case EPI_QKV_ROPE: return launch_gemm<EPI_QKV_ROPE, 1>(p, st);
+        case EPI_SILU_MUL: return (p && nch != 2) ? hipErrorInvalidValue : launch_gemm<EPI_SILU_MUL, 2>(p, st);
+        default: return hipErrorInvalidValue;
+    }
+}
+extern "C" hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps, hipStream_t st) {
+    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, x, w, out, S, K, eps);
+    return hipGetLastError();
+}
+
 static size_t attn_lds_bytes(int seq_len, int hd) { return attn_off_ring(seq_len, hd) + 2 * (size_t)ATT_JC * hd * 4; }
 extern "C" hipError_t lnbk_init(void) {
     static bool done = false;
     if (done) return hipSuccess;
+    { hipError_t eg; for (int ep = EPI_STORE; ep <= EPI_SILU_MUL; ep++) if ((eg = lnbk_gemm(nullptr, ep, nullptr)) != hipSuccess) return eg; }
     { hipError_t e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_STORE, 0, nullptr)) != hipSuccess) return e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_RESID, 0, nullptr)) != hipSuccess) return e4; }
     const int rws[3] = {16, 32, 64};
     for (int i = 0; i < 3; i++) {

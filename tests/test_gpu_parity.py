@@ -65,6 +65,33 @@ def test_linear_bit_exact(lnb, rows, n, k, rw):
     assert (y == orc_linear(x, w)).all()
 
 
+@pytest.mark.parametrize("rows,n,k,rw", [
+    (16, 64, 128, 16), (17, 100, 896, 32), (128, 256, 256, 64), (130, 4096, 4096, 16), (33, 50, 1536, 4), (128, 4096, 4096, 4),
+    (64, 300, 8, 64), (200, 96, 14336, 4),
+])
+def test_prefill_gemm_on_the_matrix_cores_is_bit_exact(lnb, rows, n, k, rw):
+    """16 or more rows go through gemm_mfma_kernel: v_mfma_f32_16x16x4_f32 is the same k-ordered f32 chain (tools/mfma_exact.hip),
+    so the outputs must still be bit-identical to the oracle -- for every weight layout, ragged M / N, K not a multiple of the
+    128-step slab."""
+    rng = np.random.default_rng(rows * 7 + n + k + rw)
+    x = bf(rng.standard_normal((rows, k)) * 10 ** rng.uniform(-2, 2))
+    w = bf(rng.standard_normal((n, k)) * 0.05)
+    y = lnb.op_linear(x, w, rw=rw)
+    assert (y == orc_linear(x, w)).all()
+
+
+def test_prefill_rmsnorm_rows_then_gemm_is_bit_exact(lnb):
+    rng = np.random.default_rng(3)
+    rows, n, k = 40, 192, 4096
+    x = bf(rng.standard_normal((rows, k)) * np.exp(rng.uniform(-6, 6, (rows, 1))))
+    nw = bf(1 + 0.1 * rng.standard_normal(k))
+    w = bf(rng.standard_normal((n, k)) * 0.05)
+    y = lnb.op_rmsnorm_linear(x, nw, 1e-5, w, rw=32)
+    xn = np.zeros_like(x)
+    orc.lib().orc_rmsnorm_bf16(orc._p(x), orc._p(nw), orc._p(xn), rows, k, np.float32(1e-5), None)
+    assert (y == orc_linear(xn, w)).all()
+
+
 def test_linear_lm_head_shape(lnb):
     rng = np.random.default_rng(7)
     x = bf(rng.standard_normal((1, 4096)))
@@ -208,6 +235,28 @@ def test_tiny_device_greedy_loop_matches_oracle(lnb, tiny_pair):
     lg, a2 = gc.Forward(prompt, 0, want_logits=True)
     assert a1 == a2 == int(orc.lib().orc_argmax_f32(orc._p(lg[-1]), lg.shape[1]))
     gc.close()
+
+
+def test_tiny_long_prefill_through_the_matrix_cores_bit_exact(lnb, tiny_pair):
+    """A 48-token prompt (>= 16 rows: rmsnorm_rows + gemm_mfma with the RoPE/KV, residual and SiLU*up epilogues, the K cache in
+    its position-contiguous layout) and a chunked continuation of 48 more rows at start_pos 48: logits, KV caches and the
+    following greedy steps must equal the oracle's bit for bit."""
+    om, gm = tiny_pair
+    oc, gc = orc.Context(om, 128), lnb.InferenceContext(gm, 128)
+    toks = orc.synth_tokens(77, 96, TINY["vocab_size"])
+    for lo_, hi_ in ((0, 48), (48, 96)):                      # second call: T = 96, S = 48 (T % S == 0, modulo-broadcast mask)
+        lo, ao = oc.forward(toks[lo_:hi_], lo_)
+        lg, ag = gc.Forward(toks[lo_:hi_], lo_)
+        assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag
+    for layer in range(TINY["n_layers"]):
+        assert (oc.cache(layer, 0)[:96] == gc.CacheK(layer)[:96]).all() and (oc.cache(layer, 1)[:96] == gc.CacheV(layer)[:96]).all()
+    tok = ag
+    for i in range(6):
+        _, to = oc.forward([tok], 96 + i, want_logits=False)
+        _, tg = gc.Forward(np.array([tok], dtype=np.int32), 96 + i, want_logits=False)
+        assert to == tg
+        tok = to
+    gc.close(); oc.close()
 
 
 def test_error_behaviour_matches_reference(lnb, tiny_pair):
