@@ -104,7 +104,9 @@ def main():
     ctx = lnb.InferenceContext(model, seq_len)
     t_load = time.time() - t_load
     prompt = lnb.synth_tokens(99, P, cfg["vocab_size"])
-    _, tok = ctx.Forward(prompt, 0, want_logits=False)            # prefill (not timed)
+    t_pf = time.perf_counter()
+    _, tok = ctx.Forward(prompt, 0, want_logits=False)            # prefill (outside the timed region; reported separately)
+    t_pf = time.perf_counter() - t_pf
     pos = P
     if W > 0:
         out, _ = ctx.decode_greedy(tok, pos, W)                   # untimed warm-up steps (captures the graph)
@@ -139,7 +141,11 @@ def main():
            "config": {"workload": "%s bf16, 1xMI355X, single-prompt greedy decode, seq_len=%d -> +%d tokens (configs[1])" % (name, P, K),
                       "prompt_len": P, "sequences_in_flight": 1, "parallelism": "single GPU", "mode": "exact-order (token-id identical to the CPU reference path)",
                       "hip_event_ms_per_step": round(ev_ms / K, 4), "weight_bytes_resident": model.weight_bytes(), "model_build_s": round(t_load, 1)},
-           "roofline": roofline, "kernels": kernels, "last_tokens": [int(t) for t in out[-4:]]}
+           "roofline": roofline, "kernels": kernels, "last_tokens": [int(t) for t in out[-4:]],
+           # prefill of the prompt: the same exact f32 chains on the matrix cores (v_mfma_f32_16x16x4_f32, bit-identical to the
+           # k-ordered loop); FLOPs = 2 x rows x layer-matmul elements; peak = f32 MFMA (MI355X_MICROARCH.md: 157.3 TFLOP/s)
+           "prefill": {"rows": P, "ms": round(1e3 * t_pf, 2), "TFLOP/s": round(2.0 * P * 6979321856 / t_pf / 1e12, 2) if name == "Llama-3.1-8B" else None,
+                       "peak_TFLOP/s": 157.3, "bound": "mfma (f32, exact order)"}}
     if args.cpu_steps > 0:
         res["cpu_baseline"] = cpu_baseline(cfg, prompt[:4], args.cpu_steps)
     ctx.close(); model.close()

@@ -819,8 +819,8 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
 // advances 16 output rows x 16 batch rows by four k-steps in 32 cycles: ~20x the chain throughput of the S = 1 kernels,
 // with identical bits.  (It does not help decode: one batch column uses 1/16 of the instruction, 10 cycles per k-step.)
 //
-// rmsnorm_rows_kernel: RMSNorm of S rows, one lane per row (each lane walks its own sequential sum of squares: the rows are
-// the parallelism here), output bf16 [S][K] with the reference's two truncations.
+// rmsnorm_rows_kernel: RMSNorm of S rows, one wave per row (the rows are the parallelism here; each wave walks its row's
+// sequential sum of squares out of the LDS), output bf16 [S][K] with the reference's two truncations.
 // gemm_mfma_kernel: workgroup = 4 waves = 64 output rows x 128 batch rows; K is walked in 128-step slabs staged through the
 // LDS as f32, k-major and padded so that both operand fragments are bank-conflict free:
 //   A (weights): lane (i = l&15, kk = l>>4) reads As[4g+kk][16w+i];  B (x): Bs[4g+kk][16t+j]   (row strides 80 / 144 floats)
@@ -829,20 +829,40 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
 // grid = (ceil(n_rows/64), ceil(S/128)); dynamic LDS = (NCH*128*80 + 128*144) * 4 bytes.
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(64) void rmsnorm_rows_kernel(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps) {
-    const int m = blockIdx.x * 64 + threadIdx.x;
-    if (m >= S) return;
+    // one wave per row: the row's squares go to the LDS with coalesced loads, every lane then walks the SAME sequential sum
+    // (broadcast float4 reads, the next 16 values in flight behind 16 adds), and the lanes share the normalisation
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float* sq = (float*)smem;                                // K (+32 zero pad) f32
+    const int m = blockIdx.x, lane = threadIdx.x;
     const uint16_t* xr = x + (size_t)m * K;
-    float sum = 0.0f;
-    for (int k = 0; k < K; k += 8) {                         // Pow(x,2) exact, Mean's serial f32 sum, k ascending (impl:197-251)
-        const uint4 v = *(const uint4*)(xr + k);
+    for (int k = lane * 8; k < K + 32; k += 512) {           // Pow(x,2): exact in f32 (impl:197-217)
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (k < K) v = *(const uint4*)(xr + k);
         const float a0 = bf_lo(v.x), a1 = bf_hi(v.x), a2 = bf_lo(v.y), a3 = bf_hi(v.y), a4 = bf_lo(v.z), a5 = bf_hi(v.z), a6 = bf_lo(v.w), a7 = bf_hi(v.w);
-        sum += a0 * a0; sum += a1 * a1; sum += a2 * a2; sum += a3 * a3; sum += a4 * a4; sum += a5 * a5; sum += a6 * a6; sum += a7 * a7;
+        if (k < K + 32) { *(float4*)(sq + k) = make_float4(a0 * a0, a1 * a1, a2 * a2, a3 * a3); *(float4*)(sq + k + 4) = make_float4(a4 * a4, a5 * a5, a6 * a6, a7 * a7); }
+    }
+    __syncthreads();
+    float sum = 0.0f;                                        // Mean's serial f32 sum, k ascending (impl:236-251); + 0.0 past K changes nothing
+    float4 a0 = *(const float4*)(sq), a1 = *(const float4*)(sq + 4), a2 = *(const float4*)(sq + 8), a3 = *(const float4*)(sq + 12);
+    for (int k0 = 0; k0 < K; k0 += 32) {
+        const float4 b0 = *(const float4*)(sq + k0 + 16), b1 = *(const float4*)(sq + k0 + 20), b2 = *(const float4*)(sq + k0 + 24), b3 = *(const float4*)(sq + k0 + 28);
+        __builtin_amdgcn_sched_barrier(0);
+        touch16(a0, a1, a2, a3);
+        __builtin_amdgcn_sched_barrier(0);
+        sum = add4(sum, a0); sum = add4(sum, a1); sum = add4(sum, a2); sum = add4(sum, a3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 32 < K) { a0 = *(const float4*)(sq + k0 + 32); a1 = *(const float4*)(sq + k0 + 36); a2 = *(const float4*)(sq + k0 + 40); a3 = *(const float4*)(sq + k0 + 44); }
+        __builtin_amdgcn_sched_barrier(0);
+        touch16(b0, b1, b2, b3);
+        __builtin_amdgcn_sched_barrier(0);
+        if (k0 + 16 < K) { sum = add4(sum, b0); sum = add4(sum, b1); sum = add4(sum, b2); sum = add4(sum, b3); }
+        __builtin_amdgcn_sched_barrier(0);
     }
     float mean = __fdiv_rn(sum, (float)K);
     mean = mean + eps;
     const float r = (float)(1.0 / sqrt((double)mean));
     uint16_t* o = out + (size_t)m * K;
-    for (int k = 0; k < K; k += 8) {                         // trunc(trunc(x*r)*w) (llamatransformer.go:656,638)
+    for (int k = lane * 8; k < K; k += 512) {                // trunc(trunc(x*r)*w) (llamatransformer.go:656,638)
         const uint4 v = *(const uint4*)(xr + k), g = *(const uint4*)(w + k);
         const uint32_t xs_[4] = {v.x, v.y, v.z, v.w}, ws_[4] = {g.x, g.y, g.z, g.w};
         uint32_t r4[4];
@@ -906,45 +926,77 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
 #pragma unroll
         for (int t = 0; t < 8; t++) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fi = lane & 15, fk = lane >> 4;
-    for (int k0 = 0; k0 < K; k0 += GM_KS) {
-        // ---- stage the slab: weights (64 lane-rows x 128 k per chain) and x (128 rows x 128 k), bf16 -> f32, k-major
+    // staging registers: the NEXT slab's 16 B units are loaded (unconditionally, addresses clamped) before the current slab's
+    // MFMAs and written to the LDS after them -- a load-use loop paid one memory round trip per unit (17 k of 25 k cycles per slab)
+    constexpr int WU = GM_NB * (GM_KS / 8) / 256, XU = GM_MB * (GM_KS / 8) / 256;        // 4 and 8 units per thread
+    uint4 wreg[NCH][WU], xreg[XU];
+    const int kst = p.rw == 4 ? 16 : 1;                      // k stride inside a 16 B weight unit (row-broadcast layout: 16)
+    auto issue = [&](int k0) {
 #pragma unroll
         for (int c = 0; c < NCH; c++)
-            for (int u = tid; u < GM_NB * (GM_KS / 8); u += 256) {
-                const int row = u & (GM_NB - 1), kc = u >> 6;                           // row fastest: LDS banks = row, global units adjacent
-                int n = n0 + row; n = n < p.n_rows ? n : p.n_rows - 1;                  // clamped rows are computed and dropped
+#pragma unroll
+            for (int q = 0; q < WU; q++) {
+                const int u = tid + q * 256, row = u & (GM_NB - 1), kc = u >> 6;           // row fastest: LDS banks = row, global units adjacent
+                int n = n0 + row; n = n < p.n_rows ? n : p.n_rows - 1;                     // clamped rows are computed and dropped
                 // 16 B unit of row n: chain layouts hold k0+8kc .. +7; the row-broadcast layout (rw 4) holds k0 + 16e + kc, e = 0..7
-                const int kf = p.rw == 4 ? k0 + kc : k0 + 8 * kc, kst = p.rw == 4 ? 16 : 1;
-                uint4 v = make_uint4(0, 0, 0, 0);
-                if (kf + 7 * kst < K) v = *(const uint4*)(p.w + tiled_index(n, kf, c, K, p.rw, p.nch));
-                float* d = As + ((size_t)c * GM_KS + (kf - k0)) * GM_AS + row;
+                int kf = p.rw == 4 ? k0 + kc : k0 + 8 * kc;
+                const bool in = kf + 7 * kst < K;
+                kf = in ? kf : 0;
+                wreg[c][q] = *(const uint4*)(p.w + tiled_index(n, kf, c, K, p.rw, p.nch));      // (zeroed past K in commit: no use here,
+                                                                                                 //  or the load would be waited for at once)
+            }
+#pragma unroll
+        for (int q = 0; q < XU; q++) {
+            const int u = tid + q * 256, row = u & (GM_MB - 1), kc = u >> 7;
+            int m = m0 + row; m = m < p.S ? m : p.S - 1;
+            int kf = k0 + 8 * kc;
+            const bool in = kf < K;
+            kf = in ? kf : 0;
+            xreg[q] = *(const uint4*)(p.x + (size_t)m * K + kf);
+        }
+    };
+    auto commit = [&](int k0) {                              // bf16 -> f32, k-major (beyond K: zeros)
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int q = 0; q < WU; q++) {
+                const int u = tid + q * 256, row = u & (GM_NB - 1), kc = u >> 6;
+                const bool in = (p.rw == 4 ? k0 + kc : k0 + 8 * kc) + 7 * kst < K;
+                const uint4 v = in ? wreg[c][q] : make_uint4(0, 0, 0, 0);
+                float* d = As + ((size_t)c * GM_KS + (p.rw == 4 ? kc : 8 * kc)) * GM_AS + row;
                 d[0] = bf_lo(v.x); d[kst * GM_AS] = bf_hi(v.x); d[2 * kst * GM_AS] = bf_lo(v.y); d[3 * kst * GM_AS] = bf_hi(v.y);
                 d[4 * kst * GM_AS] = bf_lo(v.z); d[5 * kst * GM_AS] = bf_hi(v.z); d[6 * kst * GM_AS] = bf_lo(v.w); d[7 * kst * GM_AS] = bf_hi(v.w);
             }
-        for (int u = tid; u < GM_MB * (GM_KS / 8); u += 256) {
-            const int row = u & (GM_MB - 1), kc = u >> 7;                               // row fastest (conflict-free LDS writes)
-            int m = m0 + row; m = m < p.S ? m : p.S - 1;
-            const int kf = k0 + 8 * kc;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            if (kf < K) v = *(const uint4*)(p.x + (size_t)m * K + kf);
+#pragma unroll
+        for (int q = 0; q < XU; q++) {
+            const int u = tid + q * 256, row = u & (GM_MB - 1), kc = u >> 7;
+            const uint4 v = (k0 + 8 * kc < K) ? xreg[q] : make_uint4(0, 0, 0, 0);
             float* d = Bs + (size_t)(8 * kc) * GM_BS + row;
             d[0] = bf_lo(v.x); d[GM_BS] = bf_hi(v.x); d[2 * GM_BS] = bf_lo(v.y); d[3 * GM_BS] = bf_hi(v.y);
             d[4 * GM_BS] = bf_lo(v.z); d[5 * GM_BS] = bf_hi(v.z); d[6 * GM_BS] = bf_lo(v.w); d[7 * GM_BS] = bf_hi(v.w);
         }
+    };
+    issue(0);
+    for (int k0 = 0; k0 < K; k0 += GM_KS) {
+        commit(k0);
         __syncthreads();
+        if (k0 + GM_KS < K) issue(k0 + GM_KS);               // in flight during this slab's MFMAs
         // ---- 32 k-groups of 4: acc[n-tile w][m-tile t] = mfma(A, B, acc), k ascending (beyond K both operands are 0)
         const float* ap = As + (size_t)fk * GM_AS + wave * 16 + fi;
         const float* bp = Bs + (size_t)fk * GM_BS + fi;
-#pragma unroll 4
+        // fully unrolled: 32 k-groups x (1-2 A + 8 B fragment reads, 8-16 MFMAs); hipcc's scheduler hoists the LDS reads ahead of the
+        // matrix pipe on its own when it sees the whole slab (an explicit register double buffer made it shuffle accumulators
+        // between VGPRs and AGPRs around every MFMA)
+#pragma unroll
         for (int g = 0; g < GM_KS / 4; g++) {
             float a[NCH];
 #pragma unroll
             for (int c = 0; c < NCH; c++) a[c] = ap[(size_t)c * GM_KS * GM_AS + g * 4 * GM_AS];
 #pragma unroll
             for (int t = 0; t < 8; t++) {
-                const float b = bp[g * 4 * GM_BS + t * 16];
+                const float bv = bp[g * 4 * GM_BS + t * 16];
 #pragma unroll
-                for (int c = 0; c < NCH; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], b, acc[c][t], 0, 0, 0);
+                for (int c = 0; c < NCH; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bv, acc[c][t], 0, 0, 0);
             }
         }
         __syncthreads();
@@ -1382,7 +1434,8 @@ extern "C" hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st) {
     }
 }
 extern "C" hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps, hipStream_t st) {
-    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3((unsigned)((S + 63) / 64)), dim3(64), 0, st, x, w, out, S, K, eps);
+    if (((size_t)K + 64) * 4 > 150 * 1024) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3((unsigned)S), dim3(64), ((size_t)K + 64) * 4, st, x, w, out, S, K, eps);
     return hipGetLastError();
 }
 
@@ -1390,7 +1443,8 @@ static size_t attn_lds_bytes(int seq_len, int hd) { return attn_off_ring(seq_len
 extern "C" hipError_t lnbk_init(void) {
     static bool done = false;
     if (done) return hipSuccess;
-    { hipError_t eg; for (int ep = EPI_STORE; ep <= EPI_SILU_MUL; ep++) if ((eg = lnbk_gemm(nullptr, ep, nullptr)) != hipSuccess) return eg; }
+    { hipError_t eg; for (int ep = EPI_STORE; ep <= EPI_SILU_MUL; ep++) if ((eg = lnbk_gemm(nullptr, ep, nullptr)) != hipSuccess) return eg;
+      if ((eg = hipFuncSetAttribute((const void*)rmsnorm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return eg; }
     { hipError_t e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_STORE, 0, nullptr)) != hipSuccess) return e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_RESID, 0, nullptr)) != hipSuccess) return e4; }
     const int rws[3] = {16, 32, 64};
     for (int i = 0; i < 3; i++) {
