@@ -87,7 +87,7 @@ struct lnb_ctx {
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
 static int auto_rw(int lane_rows, const char* env, int K = 0, bool plain = false) {
     int v = env_int(env, 0);
-    if (v == 16 || v == 32 || v == 64 || (v == 4 && plain && K % 128 == 0 && K <= 16384)) return v;
+    if (v == 16 || v == 32 || v == 64 || (v == 4 && plain && K % 128 == 0 && K <= 16384) || (v == 56 && lane_rows % 56 == 0)) return v;
     // thin matrices without a fused norm / rope epilogue: the row-broadcast kernel (products stay in registers)
     if (plain && lane_rows <= 16 * 256 && K > 0 && K % 128 == 0 && K <= 16384) return 4;
     // thin matrices: one workgroup (16 or 32 rows) per CU, all resident at once on the 256 CUs -- a second round of
@@ -165,7 +165,11 @@ extern "C" int lnb_model_create(const lnb_model_args* args, int device, int laye
         if (alloc_linear(&L.attn_norm, dim, wb) || alloc_linear(&L.ffn_norm, dim, wb)) return -1;
         if (alloc_tiled(L.wqkv, m->q_dim + 2 * m->kv_dim, dim, auto_rw(m->q_dim + 2 * m->kv_dim, "LNB_RW_QKV"), 1, wb)) return -1;
         if (alloc_tiled(L.wo, dim, m->q_dim, auto_rw(dim, "LNB_RW_WO", m->q_dim, true), 1, wb)) return -1;
-        if (alloc_tiled(L.w13, F, dim, auto_rw(F, "LNB_RW_W13"), 2, wb)) return -1;
+        {   // two-chain gate|up matrix: when the rows split into exactly one 56-row block per CU, take it (all CUs stream)
+            int rw13 = auto_rw(F, "LNB_RW_W13");
+            if (env_int("LNB_RW_W13", 0) == 0 && F == 56 * g_num_cus) rw13 = 56;
+            if (alloc_tiled(L.w13, F, dim, rw13, 2, wb)) return -1;
+        }
         if (alloc_tiled(L.w2, dim, F, auto_rw(dim, "LNB_RW_W2", F, true), 1, wb)) return -1;
         snprintf(nm, sizeof nm, "layers.%d.attention_norm.weight", l); reg_linear(m, nm, L.attn_norm, dim, base + 0, 1);
         snprintf(nm, sizeof nm, "layers.%d.attention.wq.weight", l); reg_tiled(m, nm, &L.wqkv, m->q_dim, dim, 0, 0, base + 1);

@@ -500,7 +500,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
     float acc[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
-    const int row = lane & (RW - 1);
+    const int row = (RW & (RW - 1)) == 0 ? (lane & (RW - 1)) : (lane < RW ? lane : lane - RW);   // RW 56: lanes 56..63 shadow rows 0..7
     int st = 0, blk = wg;
     // every stage is walked in full: beyond K the x values (hence the products) are +0, and acc + 0 == acc
     // because acc is never -0
@@ -1385,6 +1385,9 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     if (rw == 16) return launch_chain_t<16, NCH, 8192, 2, 7, EPI, NORM>(p, st);
     if (rw == 32) return (NORM && NCH == 1) ? launch_chain_t<32, 1, 12288, 6, 5, EPI, NORM>(p, st) : launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
     if (rw == 64) return launch_chain_t<64, NCH, 12288, 6, 8, EPI, NORM>(p, st);
+    // RW 56 (two chains only): 28672 gate/up rows = 256 blocks of 56 x 2 -- one block per CU on ALL 256 CUs instead of 224 of them;
+    // seven helpers (448 lanes = one (k-chunk, row) pair each), 64-step stages
+    if constexpr (NCH == 2) if (rw == 56) return launch_chain_t<56, 2, 14336, 7, 8, EPI, NORM>(p, st);
     return hipErrorInvalidValue;
 }
 
@@ -1446,6 +1449,7 @@ extern "C" hipError_t lnbk_init(void) {
     { hipError_t eg; for (int ep = EPI_STORE; ep <= EPI_SILU_MUL; ep++) if ((eg = lnbk_gemm(nullptr, ep, nullptr)) != hipSuccess) return eg;
       if ((eg = hipFuncSetAttribute((const void*)rmsnorm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return eg; }
     { hipError_t e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_STORE, 0, nullptr)) != hipSuccess) return e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_RESID, 0, nullptr)) != hipSuccess) return e4; }
+    { hipError_t e56; if ((e56 = lnbk_gemv(nullptr, 56, 2, EPI_SILU_MUL, 1, nullptr)) != hipSuccess) return e56; }
     const int rws[3] = {16, 32, 64};
     for (int i = 0; i < 3; i++) {
         hipError_t e;

@@ -259,6 +259,28 @@ def test_tiny_long_prefill_through_the_matrix_cores_bit_exact(lnb, tiny_pair):
     gc.close(); oc.close()
 
 
+def test_rw56_two_chain_blocks_bit_exact(lnb, tiny_pair, monkeypatch):
+    """The 8B gate|up matrix is stored as 256 blocks of 56 rows x 2 chains (one per CU).  Force the same kernel on the tiny
+    model (ffn hidden 896 = 16 x 56) and compare prefill + decode with the oracle."""
+    om, _ = tiny_pair
+    monkeypatch.setenv("LNB_RW_W13", "56")
+    gm = lnb.LlamaTransformer(**TINY).fill_synthetic(1234).finalize()
+    monkeypatch.delenv("LNB_RW_W13")
+    assert gm.ffn_hidden % 56 == 0
+    oc, gc = orc.Context(om, 48), lnb.InferenceContext(gm, 48)
+    toks = orc.synth_tokens(5, 7, TINY["vocab_size"])
+    lo, ao = oc.forward(toks, 0)
+    lg, ag = gc.Forward(toks, 0)
+    assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag
+    tok = ag
+    for i in range(8):
+        lo, to = oc.forward([tok], 7 + i)
+        lg, tg = gc.Forward(np.array([tok], dtype=np.int32), 7 + i)
+        assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and to == tg
+        tok = to
+    gc.close(); oc.close(); gm.close()
+
+
 def test_error_behaviour_matches_reference(lnb, tiny_pair):
     _, gm = tiny_pair
     gc = lnb.InferenceContext(gm, 16)
