@@ -17,7 +17,8 @@ shutil.copy(os.path.join(SRC, "trace", "trace_kernel_stats.csv"), os.path.join(D
 NAMES = {"gemv_chain_kernel<32, 1, 12288, 6, 5, 1, true>": "attn_norm+wq|wk|wv+RoPE+KV (thin, RW=32, exact parallel norm sum)",
          "rowcast_kernel<2>": "wo / w2 + residual (row-broadcast DPP chain, 4 rows per wave)",
          "rowcast_kernel<0>": "plain linear (row-broadcast DPP chain)",
-         "gemv_chain_kernel<64, 2, 12288, 6, 8, 3, true>": "ffn_norm+w1|w3+SiLU*up (fat, RW=64, 2 chains, v_pk_add_f32)",
+         "gemv_chain_kernel<56, 2, 14336, 7, 8, 3, true>": "ffn_norm+w1|w3+SiLU*up (fat, 256 blocks of 56 rows x 2 chains, v_pk_add_f32)",
+         "gemm_mfma_kernel": "prefill GEMM on the f32 matrix cores (exact order)", "rmsnorm_rows_kernel": "prefill RMSNorm (one wave per row)",
          "gemv_chain_kernel<64, 1, 12288, 6, 8, 0, true>": "norm+output (fat, RW=64)",
          "attn_exact_kernel<128>": "attention (scores, f64 softmax, PV)"}
 trace = list(csv.DictReader(open(os.path.join(SRC, "trace", "trace_kernel_trace.csv"))))
@@ -39,7 +40,7 @@ lines = ["# %s: rocprofv3 summary of `python bench.py --steps 32 --warmup 4` (Ll
          "| kernel | grid (threads) | LDS B | launches | avg us | HBM read MB (PMC, corrected) | GB/s | WAVE_CYCLES busy/wait (quad-cycles per launch) |", "|---|---|---|---|---|---|---|---|"]
 for key in sorted(per, key=lambda k: -sum(per[k])):
     kn, grid, lds = key
-    if "gemv" not in kn and "attn" not in kn and "argmax" not in kn and "rowcast" not in kn:
+    if "gemv" not in kn and "attn" not in kn and "argmax" not in kn and "rowcast" not in kn and "gemm_mfma" not in kn and "rmsnorm_rows" not in kn:
         continue
     label = kn
     for pat, nm in NAMES.items():
