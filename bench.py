@@ -138,7 +138,8 @@ def main():
     res = {"metric": "decode tokens/s Llama-3.1-8B bf16 @1/2/4/8 MI355X; % HBM roofline", "value": round(tps, 2), "unit": "tokens/s",
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-           "config": {"workload": "%s bf16, 1xMI355X, single-prompt greedy decode, seq_len=%d -> +%d tokens (configs[1])" % (name, P, K),
+           "config": {"workload": "%s bf16, 1xMI355X, single-prompt greedy decode, seq_len=%d -> +%d tokens (%s)"
+                                  % (name, P, K, "configs[1]" if args.model == "llama8b" else "shape of configs[4] on one GPU" if args.model == "llama70b-like" else "test shape"),
                       "prompt_len": P, "sequences_in_flight": 1, "parallelism": "single GPU", "mode": "exact-order (token-id identical to the CPU reference path)",
                       "hip_event_ms_per_step": round(ev_ms / K, 4), "weight_bytes_resident": model.weight_bytes(), "model_build_s": round(t_load, 1)},
            "roofline": roofline, "kernels": kernels, "last_tokens": [int(t) for t in out[-4:]],

@@ -1382,6 +1382,9 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     //  chain at 10.2 cycles per step, 192-step ones at 8.7); 6 x 2 loads x 5 stages = 60 KiB in flight per CU.
     //  RW 64 (fat; HBM bound): 12 KiB stages, six helpers paired on three SIMDs (the chain wave owns the fourth),
     //  6 x 2 loads x 8 stages = 96 KiB in flight per CU (5 stages: 5.8 TB/s on the LM head, 8: 6.2, 14: worse again).
+    // very long rows (70B-like w2: K = 28672): x needs more staging registers than three stager waves hold -> four helpers
+    if (p && !NORM && NCH == 1 && (rw == 16 || rw == 32) && xs_bytes(p->K, 8192 / (rw * 2)) / 4 > (size_t)XCh<false>::value * 3 * 512)
+        return rw == 16 ? launch_chain_t<16, 1, 8192, 4, 7, EPI, false>(p, st) : launch_chain_t<32, 1, 8192, 4, 7, EPI, false>(p, st);
     if (rw == 16) return launch_chain_t<16, NCH, 8192, 2, 7, EPI, NORM>(p, st);
     if (rw == 32) return (NORM && NCH == 1) ? launch_chain_t<32, 1, 12288, 6, 5, EPI, NORM>(p, st) : launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
     if (rw == 64) return launch_chain_t<64, NCH, 12288, 6, 8, EPI, NORM>(p, st);
@@ -1450,6 +1453,11 @@ extern "C" hipError_t lnbk_init(void) {
       if ((eg = hipFuncSetAttribute((const void*)rmsnorm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return eg; }
     { hipError_t e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_STORE, 0, nullptr)) != hipSuccess) return e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_RESID, 0, nullptr)) != hipSuccess) return e4; }
     { hipError_t e56; if ((e56 = lnbk_gemv(nullptr, 56, 2, EPI_SILU_MUL, 1, nullptr)) != hipSuccess) return e56; }
+    { hipError_t el;
+      if ((el = launch_chain_t<16, 1, 8192, 4, 7, EPI_STORE, false>(nullptr, nullptr)) != hipSuccess) return el;
+      if ((el = launch_chain_t<32, 1, 8192, 4, 7, EPI_STORE, false>(nullptr, nullptr)) != hipSuccess) return el;
+      if ((el = launch_chain_t<16, 1, 8192, 4, 7, EPI_RESID, false>(nullptr, nullptr)) != hipSuccess) return el;
+      if ((el = launch_chain_t<32, 1, 8192, 4, 7, EPI_RESID, false>(nullptr, nullptr)) != hipSuccess) return el; }
     const int rws[3] = {16, 32, 64};
     for (int i = 0; i < 3; i++) {
         hipError_t e;

@@ -56,6 +56,7 @@ def test_linear_reference_kat_on_gpu(lnb):
     (1, 4096, 4096, 16), (1, 4096, 14336, 16), (1, 6144, 4096, 16), (2, 4096, 4096, 64),
     # rw 4 = the row-broadcast kernel (wo / w2): one chunk, ragged N (not a multiple of 4 / 16), more blocks than CUs, model shapes
     (1, 16, 128, 4), (3, 100, 896, 4), (2, 5000, 256, 4), (1, 4096, 4096, 4), (1, 4096, 14336, 4), (4, 50, 1536, 4),
+    (1, 96, 28672, 32), (2, 40, 28672, 16),                       # 70B-like w2 rows: the four-helper configuration for very long K
 ])
 def test_linear_bit_exact(lnb, rows, n, k, rw):
     rng = np.random.default_rng(rows * 1000003 + n * 101 + k + rw)
