@@ -84,14 +84,16 @@ static int parse_zip(lnb_checkpoint* c) {
     uint64_t cd_count = rd16(b + eocd + 10), cd_size = rd32(b + eocd + 12), cd_off = rd32(b + eocd + 16);
     if (eocd >= 20 && rd32(b + eocd - 20) == 0x07064b50u) {                      // ZIP64 locator -> ZIP64 EOCD
         const uint64_t e64 = rd64(b + eocd - 20 + 8);
-        if (e64 + 56 > n || rd32(b + e64) != 0x06064b50u) return cfail("corrupt zip64 end-of-central-directory record");
+        if (e64 > n || n - e64 < 56 || rd32(b + e64) != 0x06064b50u) return cfail("corrupt zip64 end-of-central-directory record");
         cd_count = rd64(b + e64 + 32); cd_size = rd64(b + e64 + 40); cd_off = rd64(b + e64 + 48);
     }
-    if (cd_off + cd_size > n) return cfail("corrupt zip central directory");
+    if (cd_off > n || cd_size > n - cd_off) return cfail("corrupt zip central directory");   // (every bound is checked without overflow:
+                                                                                             //  the file is untrusted and read through an mmap)
     uint64_t p = cd_off;
     for (uint64_t k = 0; k < cd_count; k++) {
-        if (p + 46 > n || rd32(b + p) != 0x02014b50u) return cfail("corrupt zip central directory entry %llu", (unsigned long long)k);
+        if (p > n || n - p < 46 || rd32(b + p) != 0x02014b50u) return cfail("corrupt zip central directory entry %llu", (unsigned long long)k);
         const uint16_t method = rd16(b + p + 10), nlen = rd16(b + p + 28), xlen = rd16(b + p + 30), clen = rd16(b + p + 32);
+        if (n - p - 46 < (uint64_t)nlen + xlen + clen) return cfail("corrupt zip central directory entry %llu", (unsigned long long)k);
         uint64_t csize = rd32(b + p + 20), usize = rd32(b + p + 24), lho = rd32(b + p + 42);
         ZipEntry e; e.name.assign((const char*)b + p + 46, nlen);
         // zip64 extended information: only the fields that were 0xFFFFFFFF, in this order
@@ -106,10 +108,10 @@ static int parse_zip(lnb_checkpoint* c) {
             x += 4 + sz;
         }
         if (method != 0) return cfail("zip entry \"%s\" is compressed (method %d): torch checkpoints store their entries", e.name.c_str(), method);
-        if (lho + 30 > n || rd32(b + lho) != 0x04034b50u) return cfail("corrupt zip local header of \"%s\"", e.name.c_str());
+        if (lho > n || n - lho < 30 || rd32(b + lho) != 0x04034b50u) return cfail("corrupt zip local header of \"%s\"", e.name.c_str());
         e.data_off = lho + 30 + rd16(b + lho + 26) + rd16(b + lho + 28);       // the LOCAL name/extra lengths (torch pads here)
         e.size = usize;
-        if (e.data_off + e.size > n) return cfail("zip entry \"%s\" runs past the end of the file", e.name.c_str());
+        if (e.data_off > n || e.size > n - e.data_off) return cfail("zip entry \"%s\" runs past the end of the file", e.name.c_str());
         c->entries.push_back(e);
         p += 46 + nlen + xlen + clen;
     }
@@ -162,7 +164,7 @@ struct Unpickler {
         out->dtype = kind->i == C_STORAGE_BF16 ? LNB_DTYPE_BF16 : (kind->i == C_STORAGE_F16 ? LNB_DTYPE_F16 : LNB_DTYPE_F32);
         out->numel = pid->items[4]->i; out->data = c->base + e->data_off; out->s = fn;
         const int64_t isz = out->dtype == LNB_DTYPE_F32 ? 4 : 2;
-        if ((uint64_t)(out->numel * isz) > e->size) return cfail("storage \"%s\": %lld elements do not fit the %llu-byte zip entry", fn.c_str(), (long long)out->numel, (unsigned long long)e->size);
+        if (out->numel < 0 || (uint64_t)out->numel > e->size / (uint64_t)isz) return cfail("storage \"%s\": %lld elements do not fit the %llu-byte zip entry", fn.c_str(), (long long)out->numel, (unsigned long long)e->size);
         return 0;
     }
     int reduce(const VP& fn, const VP& args, VP& out) {
@@ -176,17 +178,28 @@ struct Unpickler {
             out = mk(V_TENSOR);
             out->dtype = a[0]->dtype; out->s = a[0]->s;
             const int64_t isz = out->dtype == LNB_DTYPE_F32 ? 4 : 2, off = a[1]->i;
+            // every product / sum below is checked against the storage size before it can overflow
+            const int64_t cap = a[0]->numel;
             int64_t numel = 1, maxoff = 0;
-            for (auto& d : a[2]->items) { if (d->kind != V_INT) return cfail("tensor size must be integers"); out->shape.push_back(d->i); numel *= d->i; }
-            for (auto& d : a[3]->items) { if (d->kind != V_INT) return cfail("tensor stride must be integers"); out->stride.push_back(d->i); }
+            for (auto& d : a[2]->items) {
+                if (d->kind != V_INT || d->i < 0) return cfail("tensor size must be non-negative integers");
+                out->shape.push_back(d->i);
+                if (d->i != 0 && numel > cap / d->i) return cfail("tensor view runs past its storage \"%s\"", a[0]->s.c_str());
+                numel *= d->i;
+            }
+            for (auto& d : a[3]->items) { if (d->kind != V_INT || d->i < 0) return cfail("tensor stride must be non-negative integers"); out->stride.push_back(d->i); }
             if (out->stride.size() != out->shape.size()) return cfail("tensor size and stride ranks differ");
             int64_t expect = 1;
             for (int k = (int)out->shape.size() - 1; k >= 0; k--) {
                 if (out->shape[k] > 1 && out->stride[k] != expect) out->contiguous = false;
-                if (out->shape[k] > 0) maxoff += (out->shape[k] - 1) * out->stride[k];
-                expect *= out->shape[k];
+                if (out->shape[k] > 1) {
+                    if (out->stride[k] > cap / (out->shape[k] - 1)) return cfail("tensor view runs past its storage \"%s\"", a[0]->s.c_str());
+                    maxoff += (out->shape[k] - 1) * out->stride[k];
+                    if (maxoff > cap) return cfail("tensor view runs past its storage \"%s\"", a[0]->s.c_str());
+                }
+                expect *= out->shape[k] > 0 ? out->shape[k] : 1;
             }
-            if (off < 0 || (numel > 0 && off + maxoff + 1 > a[0]->numel)) return cfail("tensor view runs past its storage \"%s\"", a[0]->s.c_str());
+            if (off < 0 || off > cap || (numel > 0 && maxoff >= cap - off)) return cfail("tensor view runs past its storage \"%s\"", a[0]->s.c_str());
             out->numel = numel; out->data = a[0]->data + off * isz;
             return 0;
         }

@@ -106,7 +106,7 @@ def lib():
 
 def _chk(rc):
     if rc != 0:
-        raise LnbError(lib().lnb_last_error().decode())
+        raise LnbError(lib().lnb_last_error().decode("utf-8", "replace"))
 
 
 def _p(a):
@@ -141,7 +141,7 @@ class Checkpoint:
         shp = tuple(shape[:rank.value])
         n = nb.value // np.dtype(npdt).itemsize
         arr = np.ctypeslib.as_array(C.cast(data.value, C.POINTER(C.c_uint16 if npdt is np.uint16 else C.c_float)), shape=(n,)) if n else np.empty(0, npdt)
-        return name.value.decode(), dname, shp, arr.reshape(shp) if n else arr.reshape(shp)
+        return name.value.decode("utf-8", "replace"), dname, shp, arr.reshape(shp)
 
     def find(self, name):
         return self.L.lnb_checkpoint_find(self.h, name.encode())

@@ -152,3 +152,39 @@ def test_params_json_defaults_and_values(tmp_path):
     a = lnb.model_args_from_json(str(p))
     assert (a["dim"], a["n_layers"], a["n_heads"], a["n_kv_heads"], a["vocab_size"], a["multiple_of"]) == (4096, 32, 32, -1, -1, 256)
     assert a["ffn_dim_multiplier"] == -1 and a["use_scaled_rope"] == 0 and a["rope_theta"] == 500000.0
+
+
+def test_truncated_and_corrupted_files_fail_cleanly(tmp_path):
+    """The reader parses an untrusted file straight out of an mmap: every prefix of a valid checkpoint and a few hundred random
+    byte flips must end in an error message or a successful open -- never in a crash or an out-of-bounds read."""
+    sd = {"a.weight": (torch.randn(6, 8) * 0.1).to(torch.bfloat16), "b.weight": (torch.randn(5) * 0.1).to(torch.bfloat16)}
+    ref = str(tmp_path / "ref.pth")
+    torch.save(sd, ref)
+    blob = open(ref, "rb").read()
+    rng = np.random.default_rng(0)
+    victim = str(tmp_path / "victim.pth")
+    outcomes = {"ok": 0, "error": 0}
+    cuts = sorted(set([0, 1, 21, 22, 23, len(blob) - 1] + list(rng.integers(0, len(blob), 60))))
+    for cut in cuts:
+        open(victim, "wb").write(blob[:cut])
+        try:
+            ck = lnb.Checkpoint(victim)
+            for i in range(len(ck)):
+                ck.tensor(i)
+            ck.close(); outcomes["ok"] += 1
+        except lnb.LnbError:
+            outcomes["error"] += 1
+    for trial in range(300):
+        b = bytearray(blob)
+        for _ in range(int(rng.integers(1, 4))):
+            b[int(rng.integers(0, len(b)))] = int(rng.integers(0, 256))
+        open(victim, "wb").write(bytes(b))
+        try:
+            ck = lnb.Checkpoint(victim)
+            for i in range(len(ck)):
+                name, dt, shape, arr = ck.tensor(i)
+                _ = arr.sum()                                   # touch every byte the reader says belongs to the tensor
+            ck.close(); outcomes["ok"] += 1
+        except lnb.LnbError:
+            outcomes["error"] += 1
+    assert outcomes["error"] > 30 and outcomes["ok"] > 30, outcomes
