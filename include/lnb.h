@@ -154,6 +154,24 @@ int lnb_model_load_checkpoint(lnb_model* m, const lnb_checkpoint* c);
  * ffn_dim_multiplier -1, norm_eps 1e-5, rope_theta 500000, use_scaled_rope false, max_seq_len 2048) */
 int lnb_model_args_from_json(const char* params_json_path, lnb_model_args* out);
 
+/* ---- prompt tokenisation (SURVEY.md 8f "next" #3): tiktoken reader + split pattern + byte-pair merge + chat template --------
+ * src/tiktoken/tiktokenreader.go:12-85, src/model/vocabulary.go:22-50, src/inference/tokenize.go:27-197.  Host code only.
+ * tokenizer.model = lines "<base64 token> <rank>"; 256 special tokens follow the mergeable ranks.  Pieces are BYTES. */
+typedef struct lnb_tokenizer lnb_tokenizer;
+int lnb_tokenizer_load(const char* tokenizer_model_path, lnb_tokenizer** out);
+void lnb_tokenizer_free(lnb_tokenizer* t);
+int lnb_tokenizer_vocab_size(const lnb_tokenizer* t);
+/* ids of <|begin_of_text|>, <|end_of_text|>, <|eot_id|>, <|eom_id|> (the last two are the stop ids); any pointer may be NULL */
+int lnb_tokenizer_special(const lnb_tokenizer* t, int32_t* bos, int32_t* eos, int32_t* eot, int32_t* eom);
+int lnb_tokenizer_token_id(const lnb_tokenizer* t, const char* bytes, int len);            /* -1 if absent */
+int lnb_tokenizer_piece(const lnb_tokenizer* t, int32_t id, const char** bytes, int* len);  /* Vocabulary.IdToToken */
+/* InferenceEngine.TokenizeString: returns the number of tokens written to out (capacity cap), < 0 on error */
+int lnb_tokenizer_encode(const lnb_tokenizer* t, const char* text, int len, int32_t* out, int cap);
+/* InferenceEngine.Tokenize(promptParts): <|begin_of_text|>, then per non-empty part <|start_header_id|> header <|end_header_id|>
+ * "\n\n" content <|eot_id|>, then the open assistant header */
+int lnb_tokenizer_encode_chat(const lnb_tokenizer* t, const char* const* headers, const char* const* contents, int n_parts,
+                              int32_t* out, int cap);
+
 #ifdef __cplusplus
 }
 #endif

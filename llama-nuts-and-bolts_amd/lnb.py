@@ -50,6 +50,8 @@ EXPORTS = [
     "lnb_profile_kernel", "lnb_model_num_tensors", "lnb_model_tensor_info",
     "lnb_checkpoint_open", "lnb_checkpoint_close", "lnb_checkpoint_num_tensors", "lnb_checkpoint_find", "lnb_checkpoint_tensor",
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
+    "lnb_tokenizer_load", "lnb_tokenizer_free", "lnb_tokenizer_vocab_size", "lnb_tokenizer_special", "lnb_tokenizer_token_id",
+    "lnb_tokenizer_piece", "lnb_tokenizer_encode", "lnb_tokenizer_encode_chat",
 ]
 
 
@@ -100,6 +102,15 @@ def lib():
                                         C.POINTER(vp), C.POINTER(C.c_int64)]
     L.lnb_model_load_checkpoint.argtypes = [vp, vp]
     L.lnb_model_args_from_json.argtypes = [C.c_char_p, C.POINTER(ModelArgs)]
+    L.lnb_tokenizer_load.argtypes = [C.c_char_p, C.POINTER(vp)]
+    L.lnb_tokenizer_free.argtypes = [vp]
+    L.lnb_tokenizer_free.restype = None
+    L.lnb_tokenizer_vocab_size.argtypes = [vp]
+    L.lnb_tokenizer_special.argtypes = [vp, i32p, i32p, i32p, i32p]
+    L.lnb_tokenizer_token_id.argtypes = [vp, C.c_char_p, C.c_int]
+    L.lnb_tokenizer_piece.argtypes = [vp, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
+    L.lnb_tokenizer_encode.argtypes = [vp, C.c_char_p, C.c_int, i32p, C.c_int]
+    L.lnb_tokenizer_encode_chat.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, i32p, C.c_int]
     _lib = L
     return L
 
@@ -149,6 +160,52 @@ class Checkpoint:
     def close(self):
         if self.h:
             self.L.lnb_checkpoint_close(self.h)
+            self.h = C.c_void_p()
+
+
+class Tokenizer:
+    """tiktoken vocabulary + the reference's TokenizeString / Tokenize (src/inference/tokenize.go)."""
+
+    def __init__(self, path):
+        self.L = lib()
+        self.h = C.c_void_p()
+        _chk(self.L.lnb_tokenizer_load(os.fsencode(path), C.byref(self.h)))
+        self.vocab_size = self.L.lnb_tokenizer_vocab_size(self.h)
+        b, e, t, m = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int32()
+        _chk(self.L.lnb_tokenizer_special(self.h, C.byref(b), C.byref(e), C.byref(t), C.byref(m)))
+        self.bos, self.eos, self.eot, self.eom = b.value, e.value, t.value, m.value
+
+    def encode(self, text):
+        raw = text if isinstance(text, bytes) else text.encode("utf-8")
+        cap = 4 * len(raw) + 16
+        out = (C.c_int32 * cap)()
+        n = self.L.lnb_tokenizer_encode(self.h, raw, len(raw), out, cap)
+        if n < 0:
+            raise LnbError(self.L.lnb_last_error().decode("utf-8", "replace"))
+        return list(out[:n])
+
+    def encode_chat(self, parts):
+        """parts: [(header, content), ...] -> ids with the chat template of Tokenize(promptParts)"""
+        hs = (C.c_char_p * len(parts))(*[h.encode("utf-8") for h, _ in parts])
+        cs = (C.c_char_p * len(parts))(*[c.encode("utf-8") for _, c in parts])
+        cap = 4 * sum(len(h) + len(c) for h, c in parts) + 64 * (len(parts) + 2)
+        out = (C.c_int32 * cap)()
+        n = self.L.lnb_tokenizer_encode_chat(self.h, hs, cs, len(parts), out, cap)
+        if n < 0:
+            raise LnbError(self.L.lnb_last_error().decode("utf-8", "replace"))
+        return list(out[:n])
+
+    def piece(self, tid):
+        p, n = C.c_void_p(), C.c_int()
+        _chk(self.L.lnb_tokenizer_piece(self.h, tid, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value) if n.value else b""
+
+    def token_id(self, piece_bytes):
+        return self.L.lnb_tokenizer_token_id(self.h, piece_bytes, len(piece_bytes))
+
+    def close(self):
+        if self.h:
+            self.L.lnb_tokenizer_free(self.h)
             self.h = C.c_void_p()
 
 
