@@ -7,6 +7,7 @@
 //   model.ModelArgs                 src/model/modelargs.go:12    lnb::ModelArgs
 //   model.Model{Tensors,ModelArgs}  src/model/model.go           lnb::Model  (name -> host bf16 tensor, as the loader leaves it)
 //   model.LoadModel                 src/model/loader.go:18-70    lnb::LoadModel(modelDir)  (pth zip + pickle + params.json; no tokenizer)
+//   tiktoken.Load + Vocabulary      tiktokenreader.go:39         lnb::Vocabulary (TokenizeString / Tokenize over lnb_tokenizer_*)
 //   model.NewLlamaTransformer       llamatransformer.go:64       lnb::LlamaTransformer::New(model, device)
 //   (*LlamaTransformer).Forward     llamatransformer.go:145      lnb::LlamaTransformer::Forward(ctx, tokens, startPos, &logits)
 //   model.NewInferenceContext       inferencecontext.go:17       lnb::InferenceContext(transformer, inferenceArgs, logFn)
@@ -50,8 +51,46 @@ struct HostTensor {                      // ml.Tensor of DT_BF16 as the loader p
     const uint16_t* RawData = nullptr;
 };
 
+struct PromptPart { std::string Header, Content; };     // src/inference/tokenize.go:21-25
+
+class Vocabulary {                       // model.Vocabulary + the tokenizer half of InferenceEngine (tokenize.go:27-197)
+public:
+    explicit Vocabulary(const std::string& tokenizerModelPath) {
+        if (lnb_tokenizer_load(tokenizerModelPath.c_str(), &h_) != 0) throw std::runtime_error(lnb_last_error());
+        lnb_tokenizer_special(h_, &BeginOfSentenceId, &EndOfSentenceId, &eot_, &eom_);
+    }
+    ~Vocabulary() { if (h_) lnb_tokenizer_free(h_); }
+    Vocabulary(const Vocabulary&) = delete;
+    Vocabulary& operator=(const Vocabulary&) = delete;
+    int Size() const { return lnb_tokenizer_vocab_size(h_); }
+    std::set<int32_t> StopTokenIds() const { return {eom_, eot_}; }                      // tiktokenreader.go:80
+    std::vector<int32_t> TokenizeString(const std::string& text) const {                 // tokenize.go:181-197
+        std::vector<int32_t> out(4 * text.size() + 16);
+        const int n = lnb_tokenizer_encode(h_, text.data(), (int)text.size(), out.data(), (int)out.size());
+        if (n < 0) throw std::runtime_error(lnb_last_error());
+        out.resize(n); return out;
+    }
+    std::vector<int32_t> Tokenize(const std::vector<PromptPart>& parts) const {          // tokenize.go:27-94
+        std::vector<const char*> hs, cs; size_t bytes = 0;
+        for (auto& p : parts) { hs.push_back(p.Header.c_str()); cs.push_back(p.Content.c_str()); bytes += p.Header.size() + p.Content.size(); }
+        std::vector<int32_t> out(4 * bytes + 64 * (parts.size() + 2));
+        const int n = lnb_tokenizer_encode_chat(h_, hs.data(), cs.data(), (int)parts.size(), out.data(), (int)out.size());
+        if (n < 0) throw std::runtime_error(lnb_last_error());
+        out.resize(n); return out;
+    }
+    std::string IdToToken(int32_t id) const {
+        const char* b = nullptr; int n = 0;
+        if (lnb_tokenizer_piece(h_, id, &b, &n) != 0) throw std::runtime_error(lnb_last_error());
+        return std::string(b, (size_t)n);
+    }
+    int32_t BeginOfSentenceId = -1, EndOfSentenceId = -1;
+private:
+    lnb_tokenizer* h_ = nullptr; int32_t eot_ = -1, eom_ = -1;
+};
+
 struct Model {                           // model.Model: what LoadModel returns (src/model/loader.go:18-70)
     ModelArgs Args;
+    std::shared_ptr<Vocabulary> Vocab;   // present when <dir>/tokenizer.model exists
     std::map<std::string, HostTensor> Tensors;
     std::set<TokenId> StopTokenIds;      // Vocabulary.StopTokenIds (src/tiktoken/tiktokenreader.go:48-82)
     bool Synthetic = false;              // no checkpoint: random-init on the device
@@ -83,6 +122,17 @@ inline std::shared_ptr<Model> LoadModel(const std::string& modelDir) {
         if (dtype != LNB_DTYPE_BF16) continue;                               // only torch.BFloat16Storage (src/torch/types.go:15)
         HostTensor t; t.Size.assign(shape, shape + rank); t.RawData = (const uint16_t*)data;
         m->Tensors[name] = t;
+    }
+    {   // tokenizer.model is optional here; with it, VocabSize follows loader.go:101-108
+        FILE* tf = fopen((modelDir + "/tokenizer.model").c_str(), "rb");
+        if (tf) {
+            fclose(tf);
+            m->Vocab = std::make_shared<Vocabulary>(modelDir + "/tokenizer.model");
+            m->StopTokenIds = m->Vocab->StopTokenIds();
+            if (m->Args.VocabSize < 1) m->Args.VocabSize = m->Vocab->Size();
+            else if (m->Args.VocabSize != m->Vocab->Size())
+                throw std::runtime_error("VocabSize=" + std::to_string(m->Args.VocabSize) + " and vocabulary model length=" + std::to_string(m->Vocab->Size()) + " aren't equal");
+        }
     }
     if (m->Args.VocabSize < 1) {
         auto it = m->Tensors.find("tok_embeddings.weight");
