@@ -50,3 +50,36 @@ def test_llama8b_128_token_continuation_is_token_identical():
         assert (oc.cache(layer, 1)[:seq_len - 1] == gc.CacheV(layer)[:seq_len - 1]).all()
     print("decode %d steps: %.3f ms/token on device" % (N_NEW - 1, ms / (N_NEW - 1)))
     gc.close(); gm.close(); oc.close(); om.close()
+
+
+def test_llama8b_long_prefill_on_the_matrix_cores_equals_the_row_by_row_path():
+    """configs[2]-style size-independent property at the full 8B shape: a 512-token prefill through the f32-MFMA GEMMs must be
+    bit-identical (last-row logits, next token, K/V of the first and last layer) to the same prefill done one row launch per
+    token row by the S = 1 kernels (which the test above pins to the oracle).  The oracle itself would need ~5 minutes per
+    512 tokens, so the two device paths are compared through their digests in separate processes (the switch is an env)."""
+    import hashlib
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    prog = r'''
+import hashlib, sys, numpy as np
+sys.path.insert(0, %r); sys.path.insert(0, %r)
+import lnb
+S = 512
+m = lnb.LlamaTransformer(**lnb.LLAMA_8B).fill_synthetic(1234).finalize()
+c = lnb.InferenceContext(m, S + 8)
+toks = lnb.synth_tokens(7, S, 128256)
+lg, tok = c.Forward(toks, 0, want_logits=True)
+h = hashlib.sha256()
+h.update(np.ascontiguousarray(lg[-1]).tobytes())
+for layer in (0, 31):
+    h.update(c.CacheK(layer)[:S].tobytes()); h.update(c.CacheV(layer)[:S].tobytes())
+nxt, _ = c.decode_greedy(tok, S, 4)
+print("DIGEST", h.hexdigest(), tok, [int(t) for t in nxt])
+''' % (root, os.path.join(root, "llama-nuts-and-bolts_amd"))
+    outs = []
+    for mfma in ("1", "0"):
+        r = subprocess.run([sys.executable, "-c", prog], capture_output=True, text=True, env=dict(os.environ, LNB_PREFILL_MFMA=mfma), timeout=1200)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if l.startswith("DIGEST")][0])
+    assert outs[0] == outs[1], outs
