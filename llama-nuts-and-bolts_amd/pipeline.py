@@ -1,7 +1,8 @@
 """Layer-sharded pipeline over the GPUs of one node (BASELINE.json configs[3], [4]).
 
-One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI).  Rank r owns transformer blocks
-[r*L/N, (r+1)*L/N) and their KV caches (`lnb_model_create(..., layer_begin, layer_end)`); rank 0 also owns
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI).  Rank r owns a contiguous run of
+transformer blocks (`stage_layers`: split by cost, 4,4,4,5,4,4,4,3 for 32 blocks on 8 GPUs, because the last stage also runs the
+head) and their KV caches (`lnb_model_create(..., layer_begin, layer_end)`); rank 0 also owns
 tok_embeddings, rank N-1 also norm + output.  The only exchange of the path is point to point: the bf16 hidden
 state [S, dim] from rank r to r+1 (8 KiB per decoded token for dim 4096) and the 4-byte next-token id from rank N-1
 back to rank 0.  There is no all-reduce / all-gather anywhere (that would be tensor parallelism).
@@ -110,6 +111,22 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
 
 
 # ---------------------------------------------------------------------------------------------------------------------
+def stage_layers(rank, world, n_layers, head_cost=1.2):
+    """[layer_begin, layer_end) of pipeline stage `rank`.  The last stage also runs the final norm + LM head, which costs about
+    1.2 transformer blocks of HBM time for the 8B shape (1.05 GB against 0.44 GB per block, but at the fat kernels' bandwidth), so
+    the blocks are split by cost rather than evenly: 8 stages of 32 blocks -> 4,4,4,5,4,4,4,3 instead of 8 x 4 (the tick time is
+    the slowest stage: 5 blocks instead of 4 blocks + head)."""
+    total = n_layers + head_cost
+    cuts = [0] * (world + 1)
+    cuts[world] = n_layers
+    for r in range(1, world):
+        c = int(round(r * total / world))
+        if n_layers >= world:                             # every stage keeps at least one block
+            c = max(cuts[r - 1] + 1, min(c, n_layers - (world - r)))
+        cuts[r] = max(cuts[r - 1], min(c, n_layers))
+    return cuts[rank], cuts[rank + 1]
+
+
 class LnbStage(Stage):
     """One GPU's share of the model behind the C ABI (lnb_forward_stage)."""
 
@@ -117,7 +134,7 @@ class LnbStage(Stage):
         import ctypes as C
         self.lnb, self.torch, self.C = lnb, torch, C
         L = cfg["n_layers"]
-        lb, le = rank * L // world, (rank + 1) * L // world
+        lb, le = stage_layers(rank, world, L)
         self.first, self.last = rank == 0, rank == world - 1
         self.model = lnb.LlamaTransformer(device=device_index, layer_begin=lb, layer_end=le, **cfg).fill_synthetic(1234)
         self.model.finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"]))
@@ -189,8 +206,9 @@ def bench_main(args, cfg, name):
         res = {"metric": "decode tokens/s Llama-3.1-8B bf16 @1/2/4/8 MI355X; % HBM roofline", "value": round(tps, 2), "unit": "tokens/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "%s bf16, %dxMI355X layer pipeline (%d blocks/GPU), RCCL p2p hidden-state hand-off, %d sequences in flight, "
-                                      "prompt %d -> +%d tokens each" % (name, world, cfg["n_layers"] // world, world, P, K),
+               "config": {"workload": "%s bf16, %dxMI355X layer pipeline (blocks per GPU %s), RCCL p2p hidden-state hand-off, %d sequences in flight, "
+                                      "prompt %d -> +%d tokens each" % (name, world, ",".join(str(stage_layers(r, world, cfg["n_layers"])[1] - stage_layers(r, world, cfg["n_layers"])[0])
+                                                                                                 for r in range(world)), world, P, K),
                           "prompt_len": P, "sequences_in_flight": world, "parallelism": "pp%d" % world,
                           "mode": "exact-order (token-id identical to the CPU reference path)"},
                "roofline": {"bound": "hbm", "achieved": round(tps * B / 1e9, 1), "peak": _b.PEAK_HBM_GBS * world, "unit": "GB/s",

@@ -116,3 +116,14 @@ def test_single_rank_pipeline_is_the_plain_greedy_loop():
     prompts = [np.arange(P, dtype=np.int32) * 2 % VOCAB]
     st = pipeline.run_ticks(0, 1, FakeStage(0, 1, 1), dist, torch, prompts, 5, "cpu")
     assert st["produced"] == reference(1, prompts, 5)
+
+
+def test_stage_layers_cover_every_block_once_and_lighten_the_last_stage():
+    import pipeline
+    for world, L in [(1, 32), (2, 32), (4, 32), (8, 32), (8, 80), (3, 2), (5, 7), (8, 8), (2, 1)]:
+        cuts = [pipeline.stage_layers(r, world, L) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == L
+        assert all(a[1] == b[0] for a, b in zip(cuts, cuts[1:])) and all(lo <= hi for lo, hi in cuts)
+    assert [hi - lo for lo, hi in (pipeline.stage_layers(r, 8, 32) for r in range(8))] == [4, 4, 4, 5, 4, 4, 4, 3]
+    assert [hi - lo for lo, hi in (pipeline.stage_layers(r, 4, 32) for r in range(4))] == [8, 9, 8, 7]
+    assert pipeline.stage_layers(0, 1, 32) == (0, 32)
