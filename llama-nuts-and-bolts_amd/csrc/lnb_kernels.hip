@@ -136,6 +136,24 @@ constexpr int RMS_HEAD = 256;
 __host__ __device__ inline size_t rms_scratch_bytes(int NH) { return (size_t)NH * (512 + 8 + 4) + 64; }
 // LDS scratch (the idle product ring): SeqNode rec[NH][64] | uint64 items[NH] | float wtot[NH]
 
+// wave scans on DPP data movement (VALU, no LDS round trip like ds_bpermute): in-row shifts by 1, 2, 4, 8, then lane 15 of a row
+// into the next row (rows 1, 3) and lane 31 into rows 2, 3 -- the classic gfx9 inclusive-scan order.  `old` is what lanes
+// without a source keep.
+template <int CTRL, int ROWMASK> DEVINL int dpp_mov(int v, int old) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROWMASK, 0xf, false); }
+template <int D> DEVINL int dpp_row_shr(int v, int old) { return dpp_mov<0x110 + D, 0xf>(v, old); }       // lane i <- lane i-D inside its row of 16
+DEVINL int dpp_bcast15(int v, int old) { return dpp_mov<0x142, 0xa>(v, old); }                             // rows 1,3 <- lane 15 of the row before
+DEVINL int dpp_bcast31(int v, int old) { return dpp_mov<0x143, 0xc>(v, old); }                             // rows 2,3 <- lane 31
+DEVINL int dpp_wave_shr1(int v, int old) { return dpp_mov<0x138, 0xf>(v, old); }                           // lane i <- lane i-1 (whole wave)
+DEVINL int dpp_wave_shl1(int v, int old) { return dpp_mov<0x130, 0xf>(v, old); }                           // lane i <- lane i+1
+DEVINL float wave_inclusive_sum(float v) {
+#define LNB_SUM_STEP(EXPR) { const float o_ = __int_as_float(EXPR); v += o_; }
+    LNB_SUM_STEP(dpp_row_shr<1>(__float_as_int(v), 0)) LNB_SUM_STEP(dpp_row_shr<2>(__float_as_int(v), 0))
+    LNB_SUM_STEP(dpp_row_shr<4>(__float_as_int(v), 0)) LNB_SUM_STEP(dpp_row_shr<8>(__float_as_int(v), 0))
+    LNB_SUM_STEP(dpp_bcast15(__float_as_int(v), 0)) LNB_SUM_STEP(dpp_bcast31(__float_as_int(v), 0))
+#undef LNB_SUM_STEP
+    return v;
+}
+
 template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, char* scratch, int hw, int lane, long long& t_dbg) {
     const long long tf0_ = p.dbg ? clock64() : 0;
     const int LEAF = seq_leaf_size(p.K, NH * 64), nleaf = (p.K + LEAF - 1) / LEAF;
@@ -148,9 +166,7 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
     float bsum = 0.0f;
     for (int i = 0; i < LEAF; i += 4) { const float4 v = *(const float4*)(q + i); bsum += (v.x + v.y) + (v.z + v.w); }   // only feeds the guess
     bsum = b < nleaf ? bsum : 0.0f;
-    float incl = bsum;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const float o = __shfl_up(incl, d); if (lane >= d) incl += o; }
+    const float incl = wave_inclusive_sum(bsum);             // (x + 0.0f for lanes without a source: only feeds the guess)
     if (lane == 63) wtot[hw] = incl;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_s_barrier();                                        // X1: wave totals published
@@ -160,18 +176,19 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
     for (int w = 0; w < NH; w++) { const float v = wtot[w]; base += w < hw ? v : 0.0f; }
     SeqNode n; n.a = 0u; n.b = 0u;
     if (b < nleaf) n = seq_leaf(q, LEAF, base + (incl - bsum), base + incl);
-    SeqNode left; left.a = (uint32_t)__shfl_up((int)n.a, 1); left.b = 0u;
+    SeqNode left; left.a = (uint32_t)dpp_wave_shr1((int)n.a, 0); left.b = 0u;
     int f = seq_is_start(lane, n, left, b == headleaf);
-    const int fnext = __shfl_down(f, 1);
+    const int fnext = dpp_wave_shl1(f, 1);
     const unsigned long long mask = __ballot((n.a >> 24) == 0u || lane == 63 || fnext);
     if (lane == 0) items[hw] = mask;
     int start = lane;
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {                                   // segmented Hillis-Steele scan of the leaf maps
-        SeqNode o; o.a = (uint32_t)__shfl_up((int)n.a, d); o.b = (uint32_t)__shfl_up((int)n.b, d);
-        const int ofs = __shfl_up((f << 8) | start, d);
-        if (lane >= d && !f) seq_scan_step(n, f, start, o, ofs >> 8, ofs & 0xFF);
-    }
+    // segmented inclusive scan of the leaf maps (associative: a run absorbs the run that ends right in front of it), six DPP steps
+#define LNB_SEG_STEP(MOV, VALID) { SeqNode o_; o_.a = (uint32_t)MOV((int)n.a, 0); o_.b = (uint32_t)MOV((int)n.b, 0); const int ofs_ = MOV((f << 8) | start, 0); \
+                                   if ((VALID) && !f) seq_scan_step(n, f, start, o_, ofs_ >> 8, ofs_ & 0xFF); }
+    LNB_SEG_STEP(dpp_row_shr<1>, (lane & 15) >= 1) LNB_SEG_STEP(dpp_row_shr<2>, (lane & 15) >= 2)
+    LNB_SEG_STEP(dpp_row_shr<4>, (lane & 15) >= 4) LNB_SEG_STEP(dpp_row_shr<8>, (lane & 15) >= 8)
+    LNB_SEG_STEP(dpp_bcast15, (lane & 16) != 0) LNB_SEG_STEP(dpp_bcast31, lane >= 32)
+#undef LNB_SEG_STEP
     n.b |= (uint32_t)start << 24;                                        // c1 < 2^24: the run's first leaf rides in the top byte
     rec[hw * 64 + lane] = n;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
