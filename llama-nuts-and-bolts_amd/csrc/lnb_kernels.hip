@@ -397,8 +397,10 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
         {
             uint4 xv[XCh<NORM>::value], nv[XCh<NORM>::value];
             x_issue<NORM, NS>(p, xrow, 1 + hw, lane, xv, nv);
-            x_store<NORM, NS>(p, xs, kpad, 1 + hw, lane, xv);          // (hipcc waits for the x loads here)
-        // the weight stream starts only now, BEHIND the x loads in this CU's memory queue
+            __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): x (and the norm weights) have landed; hipcc needs no
+                                                                       // wait of its own in x_store, which would drain the ring below too
+        // the weight stream starts only now, BEHIND the x loads in this CU's memory queue (in front of them, or right behind them
+        // with a counted wait, it delays x: measured), and the LDS writes of x_store run in its shadow
         // issue cursor: next global stage to load = (block ib, stage is); past the end it re-reads the last stage
         const size_t last16 = stream_bytes - 16;
         // unit of load i:  q = (kc*NCH + c)*RW + r.  One chain: q = (i*NH + hw)*64 + lane.  Two chains (w1|w3): the lane takes BOTH
@@ -423,6 +425,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
         };
 #pragma unroll
             for (int j = 0; j < R; j++) issue_next(buf[j]);
+            x_store<NORM, NS>(p, xs, kpad, 1 + hw, lane, xv);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             TIMED_BARRIER();                                           // B1: xs (or the squares) are in LDS
             if (NORM) {
@@ -758,17 +761,8 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
         const int u = tid + i * 256;
         xv[i] = *(const uint4*)(xrow + (size_t)(u < (K >> 3) ? u : 0) * 8);      // unconditional (clamped) loads
     }
-#pragma unroll
-    for (int i = 0; i < RC_XU; i++) {
-        const int u = tid + i * 256;
-        if (u < (K >> 3)) {
-            const uint4 v = xv[i];
-            const int k = u * 8, c = k >> 7, ii = (k & 127) >> 4, j0 = k & 15;
-            float* d = xT + ((size_t)(c * 16 + j0) * 8 + ii);
-            d[0] = bf_lo(v.x); d[8] = bf_hi(v.x); d[16] = bf_lo(v.y); d[24] = bf_hi(v.y);
-            d[32] = bf_lo(v.z); d[40] = bf_hi(v.z); d[48] = bf_lo(v.w); d[56] = bf_hi(v.w);
-        }
-    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): x has landed (hipcc then needs no wait of its own below, which
+                                                             // would also drain the weight loads that are issued next)
     u32x4 buf[RC_R];
     // issue cursor: a running wave-uniform pointer (1 KiB per chunk; at the end of a tile jump to this wave's tile of the
     // next block); past the last chunk it stays put and re-reads
@@ -781,6 +775,17 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     };
 #pragma unroll
     for (int j = 0; j < RC_R; j++) issue_next(buf[j]);
+#pragma unroll
+    for (int i = 0; i < RC_XU; i++) {
+        const int u = tid + i * 256;
+        if (u < (K >> 3)) {
+            const uint4 v = xv[i];
+            const int k = u * 8, c = k >> 7, ii = (k & 127) >> 4, j0 = k & 15;
+            float* d = xT + ((size_t)(c * 16 + j0) * 8 + ii);
+            d[0] = bf_lo(v.x); d[8] = bf_hi(v.x); d[16] = bf_lo(v.y); d[24] = bf_hi(v.y);
+            d[32] = bf_lo(v.z); d[40] = bf_hi(v.z); d[48] = bf_lo(v.w); d[56] = bf_hi(v.w);
+        }
+    }
     __syncthreads();
     if (p.dbg) t_x = clock64() - t_begin;
     const float* xl = xT + (size_t)(lane & 15) * 8;
