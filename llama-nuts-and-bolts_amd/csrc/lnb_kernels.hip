@@ -933,24 +933,28 @@ template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& 
     }
 }
 
-template <int EPI, int NCH>
+// WN = waves along n: 4 -> the workgroup owns 64 output rows, every wave all 8 m-tiles; 1 -> the workgroup owns 16 output rows and
+// its four waves split the 8 m-tiles (4x the workgroups for thin matrices at small S, where 64-row tiles fill a quarter of the CUs)
+template <int EPI, int NCH, int WN>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = (float*)smem;                                // [NCH][GM_KS][GM_AS]
     float* Bs = As + NCH * GM_KS * GM_AS;                    // [GM_KS][GM_BS]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int n0 = blockIdx.x * GM_NB, m0 = blockIdx.y * GM_MB;
+    constexpr int NB = 16 * WN, MT = WN == 4 ? 8 : 2;       // output rows per workgroup, m-tiles per wave
+    const int n0 = blockIdx.x * NB, m0 = blockIdx.y * GM_MB;
+    const int nt_off = WN == 4 ? wave * 16 : 0, mt0 = WN == 4 ? 0 : wave * 2;
     const int K = p.K;
-    f32x4 acc[NCH][8];
+    f32x4 acc[NCH][MT];
 #pragma unroll
     for (int c = 0; c < NCH; c++)
 #pragma unroll
-        for (int t = 0; t < 8; t++) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int t = 0; t < MT; t++) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fi = lane & 15, fk = lane >> 4;
     // staging registers: the NEXT slab's 16 B units are loaded (unconditionally, addresses clamped) before the current slab's
     // MFMAs and written to the LDS after them -- a load-use loop paid one memory round trip per unit (17 k of 25 k cycles per slab)
-    constexpr int WU = GM_NB * (GM_KS / 8) / 256, XU = GM_MB * (GM_KS / 8) / 256;        // 4 and 8 units per thread
+    constexpr int WU = NB * (GM_KS / 8) / 256, XU = GM_MB * (GM_KS / 8) / 256;           // 4 (or 1) and 8 units per thread
     uint4 wreg[NCH][WU], xreg[XU];
     const int kst = p.rw == 4 ? 16 : 1;                      // k stride inside a 16 B weight unit (row-broadcast layout: 16)
     auto issue = [&](int k0) {
@@ -958,7 +962,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
         for (int c = 0; c < NCH; c++)
 #pragma unroll
             for (int q = 0; q < WU; q++) {
-                const int u = tid + q * 256, row = u & (GM_NB - 1), kc = u >> 6;           // row fastest: LDS banks = row, global units adjacent
+                const int u = tid + q * 256, row = u & (NB - 1), kc = u / NB;               // row fastest: LDS banks = row, global units adjacent
                 int n = n0 + row; n = n < p.n_rows ? n : p.n_rows - 1;                     // clamped rows are computed and dropped
                 // 16 B unit of row n: chain layouts hold k0+8kc .. +7; the row-broadcast layout (rw 4) holds k0 + 16e + kc, e = 0..7
                 int kf = p.rw == 4 ? k0 + kc : k0 + 8 * kc;
@@ -982,7 +986,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
         for (int c = 0; c < NCH; c++)
 #pragma unroll
             for (int q = 0; q < WU; q++) {
-                const int u = tid + q * 256, row = u & (GM_NB - 1), kc = u >> 6;
+                const int u = tid + q * 256, row = u & (NB - 1), kc = u / NB;
                 const bool in = (p.rw == 4 ? k0 + kc : k0 + 8 * kc) + 7 * kst < K;
                 const uint4 v = in ? wreg[c][q] : make_uint4(0, 0, 0, 0);
                 float* d = As + ((size_t)c * GM_KS + (p.rw == 4 ? kc : 8 * kc)) * GM_AS + row;
@@ -1004,8 +1008,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
         __syncthreads();
         if (k0 + GM_KS < K) issue(k0 + GM_KS);               // in flight during this slab's MFMAs
         // ---- 32 k-groups of 4: acc[n-tile w][m-tile t] = mfma(A, B, acc), k ascending (beyond K both operands are 0)
-        const float* ap = As + (size_t)fk * GM_AS + wave * 16 + fi;
-        const float* bp = Bs + (size_t)fk * GM_BS + fi;
+        const float* ap = As + (size_t)fk * GM_AS + nt_off + fi;
+        const float* bp = Bs + (size_t)fk * GM_BS + mt0 * 16 + fi;
         // fully unrolled: 32 k-groups x (1-2 A + 8 B fragment reads, 8-16 MFMAs); hipcc's scheduler hoists the LDS reads ahead of the
         // matrix pipe on its own when it sees the whole slab (an explicit register double buffer made it shuffle accumulators
         // between VGPRs and AGPRs around every MFMA)
@@ -1015,7 +1019,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
 #pragma unroll
             for (int c = 0; c < NCH; c++) a[c] = ap[(size_t)c * GM_KS * GM_AS + g * 4 * GM_AS];
 #pragma unroll
-            for (int t = 0; t < 8; t++) {
+            for (int t = 0; t < MT; t++) {
                 const float bv = bp[g * 4 * GM_BS + t * 16];
 #pragma unroll
                 for (int c = 0; c < NCH; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bv, acc[c][t], 0, 0, 0);
@@ -1025,8 +1029,8 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
     }
     // D layout: lane holds rows (lane>>4)*4 + r of the n-tile, column lane&15 of the m-tile
 #pragma unroll
-    for (int t = 0; t < 8; t++)
-        gemm_epilogue4<EPI>(p, acc[0][t], acc[NCH - 1][t], m0 + t * 16 + (lane & 15), n0 + wave * 16 + (lane >> 4) * 4);
+    for (int t = 0; t < MT; t++)
+        gemm_epilogue4<EPI>(p, acc[0][t], acc[NCH - 1][t], m0 + (mt0 + t) * 16 + (lane & 15), n0 + nt_off + (lane >> 4) * 4);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1444,10 +1448,18 @@ extern "C" hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, i
 }
 
 template <int EPI, int NCH> static hipError_t launch_gemm(const GemmParams* p, hipStream_t st) {
-    auto kfn = gemm_mfma_kernel<EPI, NCH>;
+    auto k4 = gemm_mfma_kernel<EPI, NCH, 4>;
+    auto k1 = gemm_mfma_kernel<EPI, NCH, 1>;
     const size_t lds = ((size_t)NCH * GM_KS * GM_AS + (size_t)GM_KS * GM_BS) * 4;
-    if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    hipLaunchKernelGGL(kfn, dim3((unsigned)((p->n_rows + GM_NB - 1) / GM_NB), (unsigned)((p->S + GM_MB - 1) / GM_MB)), dim3(256), lds, st, *p);
+    if (!p) {
+        hipError_t e = hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    }
+    const unsigned mb = (unsigned)((p->S + GM_MB - 1) / GM_MB), nb4 = (unsigned)((p->n_rows + GM_NB - 1) / GM_NB);
+    if (nb4 * mb < 128)        // 64-row tiles would leave most CUs idle: 16-row tiles, the four waves split the batch rows
+        hipLaunchKernelGGL(k1, dim3((unsigned)((p->n_rows + 15) / 16), mb), dim3(256), lds, st, *p);
+    else
+        hipLaunchKernelGGL(k4, dim3(nb4, mb), dim3(256), lds, st, *p);
     return hipGetLastError();
 }
 // exact-order prefill GEMM (f32 MFMA); p == nullptr prepares the kernel (dynamic LDS limit) outside any stream capture
