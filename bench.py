@@ -70,6 +70,25 @@ def cpu_baseline(model_cfg, prompt, n_steps):
                       % (len(prompt), t1 - t0, n_steps, (t2 - t1) / n_steps)}
 
 
+# kernel symbol (prefix) of each decode kernel class of the 8B shape, for the PMC traffic lookup
+KERNEL_SYMBOLS = {"attn_norm+wqkv+rope GEMV": "gemv_chain_kernel<32, 1,", "attention": "attn_exact_kernel<128>",
+                  "ffn_norm+w1|w3+silu GEMV": "gemv_chain_kernel<56, 2,"}
+
+
+def pmc_traffic(kernel_name, model_name):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc FETCH_SIZE pass (profiles/rNN_traffic.json,
+    written by tools/summarize_profile.py; counters cannot be read from inside the process).  None if no profile covers it."""
+    sym = KERNEL_SYMBOLS.get(kernel_name)
+    d = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    if sym is None or model_name != "Llama-3.1-8B" or not os.path.isdir(d):
+        return None, None
+    for fn in sorted((f for f in os.listdir(d) if f.endswith("_traffic.json")), reverse=True):
+        for k, v in json.load(open(os.path.join(d, fn))).get("kernels", {}).items():
+            if k.startswith(sym):
+                return v["hbm_read_bytes_per_launch"], "profiles/" + fn
+    return None, None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -129,8 +148,9 @@ def main():
         kernels[KERNEL_NAMES[which]] = {"ms": round(ms, 5), "GB/s": (round(kb[which] / ms / 1e6, 1) if kb[which] else None)}
     dom = max(range(6), key=lambda i: (1 if i == 5 else cfg["n_layers"]) * kernels[KERNEL_NAMES[i]]["ms"])
     dom_ms = kernels[KERNEL_NAMES[dom]]["ms"]
+    traffic, traffic_src = pmc_traffic(KERNEL_NAMES[dom], name)
     roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(kb[dom] / dom_ms / 1e6, 1), "peak": PEAK_HBM_GBS,
-                "unit": "GB/s", "frac": round(kb[dom] / dom_ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": None,
+                "unit": "GB/s", "frac": round(kb[dom] / dom_ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": dom_ms,
                 "whole_step": {"achieved": round(tps * B / 1e9, 1), "frac": round(tps * B / 1e9 / PEAK_HBM_GBS, 4),
                                "algorithmic_bytes_per_token": int(B), "mean_context": Tbar,

@@ -899,7 +899,7 @@ __global__ __launch_bounds__(64) void rmsnorm_rows_kernel(const uint16_t* x, con
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int GM_NB = 64, GM_MB = 128, GM_KS = 128, GM_AS = 80, GM_BS = 144;
+constexpr int GM_NB = 64, GM_MB = 128, GM_KS = 128;
 template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& g, const f32x4& u, int m, int n0) {
     // one lane: batch row m, four consecutive output rows n0..n0+3 (n0 % 4 == 0)
     if (m >= p.S) return;
@@ -935,11 +935,24 @@ template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& 
 
 // WN = waves along n: 4 -> the workgroup owns 64 output rows, every wave all 8 m-tiles; 1 -> the workgroup owns 16 output rows and
 // its four waves split the 8 m-tiles (4x the workgroups for thin matrices at small S, where 64-row tiles fill a quarter of the CUs)
+// LDS operand tiles of gemm_mfma_kernel, as raw bf16 in per-lane STREAMS: the MFMA lane (i = l&15, kk = l>>4) of k-group g consumes
+// k = 4g + kk, so everything that lane will read during a 128-step slab is laid out contiguously for it:
+//   A (weights): stream (chain c, n-tile w, kk, i) = its 32 values, g ascending (64 B + 16 B pad): 4 ds_read_b128 per slab;
+//   B (x):       stream (kk, i) = [g/2][m-tile t][g&1] (512 B + 16 B pad): one ds_read_b128 = four m-tiles of two k-groups.
+// (An f32 k-major tile cost nine ds_reads per eight MFMAs and an LDS round trip in front of every pair; raw bf16 halves the LDS,
+// two workgroups fit a CU, and a staged 16 B unit -- 8 consecutive k = two k-groups -- lands as four packed words.)
+constexpr int GM_APAD = 80, GM_BPAD = 528;                  // stream strides in bytes: conflict-free 16 B reads across 16 lanes
+__host__ __device__ constexpr size_t gemm_lds_a(int NCH, int WN) { return (size_t)NCH * WN * 64 * GM_APAD; }
+__host__ __device__ constexpr size_t gemm_lds_bytes(int NCH, int WN) { return gemm_lds_a(NCH, WN) + (size_t)64 * GM_BPAD; }
+
+#ifndef GM_DBG
+#define GM_DBG 0                                            // tools/gemmbench.hip: 1 = stage only the first slab, 2 = no barriers, 4 = no LDS reads
+#endif
 template <int EPI, int NCH, int WN>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = (float*)smem;                                // [NCH][GM_KS][GM_AS]
-    float* Bs = As + NCH * GM_KS * GM_AS;                    // [GM_KS][GM_BS]
+    char* As = smem;                                         // streams [(c*WN + w)*4 + kk][i] of GM_APAD bytes
+    char* Bs = smem + gemm_lds_a(NCH, WN);                   // streams [kk][i] of GM_BPAD bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     constexpr int NB = 16 * WN, MT = WN == 4 ? 8 : 2;       // output rows per workgroup, m-tiles per wave
@@ -952,80 +965,150 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
 #pragma unroll
         for (int t = 0; t < MT; t++) acc[c][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int fi = lane & 15, fk = lane >> 4;
-    // staging registers: the NEXT slab's 16 B units are loaded (unconditionally, addresses clamped) before the current slab's
-    // MFMAs and written to the LDS after them -- a load-use loop paid one memory round trip per unit (17 k of 25 k cycles per slab)
-    constexpr int WU = NB * (GM_KS / 8) / 256, XU = GM_MB * (GM_KS / 8) / 256;           // 4 (or 1) and 8 units per thread
+    // staging registers: the NEXT slab's 16 B units are loaded before the current slab's MFMAs and written to the LDS after them
+    // (a load-use loop paid one memory round trip per unit).  Unit q of a thread: weights = row tid % NB, unit kc = tid / NB + q*256/NB
+    // of the slab; x = batch row tid % 128, unit tid / 128 + 2q.  Their addresses are a per-thread base + uniform strides (both tiled
+    // layouts are affine in the slab, unit and chain index), so a full slab is staged without a compare, a select or a divergent
+    // branch; only the last slab of a K that is not a multiple of 128 takes the checked path.
+    constexpr int WU = NB * (GM_KS / 8) / 256, XU = GM_MB * (GM_KS / 8) / 256, WQ = 256 / NB;   // 4 (or 1) and 8 units per thread
     uint4 wreg[NCH][WU], xreg[XU];
-    const int kst = p.rw == 4 ? 16 : 1;                      // k stride inside a 16 B weight unit (row-broadcast layout: 16)
+    const bool rw4 = p.rw == 4;                              // row-broadcast layout: a 16 B unit holds k0 + 16e + kc, e = 0..7
+    const int kst = rw4 ? 16 : 1;                            // k stride inside a 16 B weight unit
+    const int wrow = tid & (NB - 1), wkc = tid / NB, xrow = tid & (GM_MB - 1), xkc = tid >> 7;
+    int wn = n0 + wrow; wn = wn < p.n_rows ? wn : p.n_rows - 1;                             // clamped rows are computed and dropped
+    int xm = m0 + xrow; xm = xm < p.S ? xm : p.S - 1;
+    const uint16_t* wp = p.w + tiled_index(wn, rw4 ? wkc : 8 * wkc, 0, K, p.rw, p.nch);     // slab 0, unit q = 0, chain 0
+    const uint16_t* xp = p.x + (size_t)xm * K + 8 * xkc;
+    const size_t w_slab = rw4 ? (size_t)512 : (size_t)16 * p.nch * p.rw * 8;                // elements per 128 k
+    const size_t w_unit = rw4 ? (size_t)WQ * 8 : (size_t)WQ * p.nch * p.rw * 8;             // ... per unit step q
+    const size_t w_chain = (size_t)p.rw * 8;                                                // ... per chain (chain layouts only)
     auto issue = [&](int k0) {
+        if (k0 + GM_KS <= K) {                               // full slab (uniform branch)
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int q = 0; q < WU; q++) wreg[c][q] = *(const uint4*)(wp + c * w_chain + q * w_unit);
+#pragma unroll
+            for (int q = 0; q < XU; q++) xreg[q] = *(const uint4*)(xp + 16 * q);
+            wp += w_slab; xp += GM_KS;
+            return;
+        }
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
             for (int q = 0; q < WU; q++) {
-                const int u = tid + q * 256, row = u & (NB - 1), kc = u / NB;               // row fastest: LDS banks = row, global units adjacent
-                int n = n0 + row; n = n < p.n_rows ? n : p.n_rows - 1;                     // clamped rows are computed and dropped
-                // 16 B unit of row n: chain layouts hold k0+8kc .. +7; the row-broadcast layout (rw 4) holds k0 + 16e + kc, e = 0..7
-                int kf = p.rw == 4 ? k0 + kc : k0 + 8 * kc;
-                const bool in = kf + 7 * kst < K;
-                kf = in ? kf : 0;
-                wreg[c][q] = *(const uint4*)(p.w + tiled_index(n, kf, c, K, p.rw, p.nch));      // (zeroed past K in commit: no use here,
-                                                                                                 //  or the load would be waited for at once)
+                const int kc = wkc + q * WQ;
+                int kf = rw4 ? k0 + kc : k0 + 8 * kc;
+                kf = kf + 7 * kst < K ? kf : 0;              // (zeroed past K in commit: no use here, or the load would be waited for at once)
+                wreg[c][q] = *(const uint4*)(p.w + tiled_index(wn, kf, c, K, p.rw, p.nch));
             }
 #pragma unroll
         for (int q = 0; q < XU; q++) {
-            const int u = tid + q * 256, row = u & (GM_MB - 1), kc = u >> 7;
-            int m = m0 + row; m = m < p.S ? m : p.S - 1;
-            int kf = k0 + 8 * kc;
-            const bool in = kf < K;
-            kf = in ? kf : 0;
-            xreg[q] = *(const uint4*)(p.x + (size_t)m * K + kf);
+            int kf = k0 + 8 * (xkc + 2 * q);
+            kf = kf < K ? kf : 0;
+            xreg[q] = *(const uint4*)(p.x + (size_t)xm * K + kf);
         }
     };
-    auto commit = [&](int k0) {                              // bf16 -> f32, k-major (beyond K: zeros)
+    // a unit of 8 consecutive k = k-groups 2kc (elements 0..3) and 2kc+1 (4..7): lane-stream kk gets the word (e[kk] | e[4+kk] << 16)
+    auto pack4 = [](const uint4& v, uint32_t (&w)[4]) {
+        w[0] = (v.x & 0xFFFFu) | (v.z << 16); w[1] = (v.x >> 16) | (v.z & 0xFFFF0000u);
+        w[2] = (v.y & 0xFFFFu) | (v.w << 16); w[3] = (v.y >> 16) | (v.w & 0xFFFF0000u);
+    };
+    char* const wblk = As + (size_t)((wrow >> 4) * 4) * 16 * GM_APAD + (size_t)(wrow & 15) * GM_APAD;   // (+ c*WN*64*GM_APAD per chain)
+    char* const xblk = Bs + (size_t)(xrow & 15) * GM_BPAD + (xkc * 8 + (xrow >> 4)) * 4;
+    auto commit = [&](int k0) {                              // raw bf16, no conversion (beyond K: zeros)
+        const bool full = k0 + GM_KS <= K;
 #pragma unroll
         for (int c = 0; c < NCH; c++)
 #pragma unroll
             for (int q = 0; q < WU; q++) {
-                const int u = tid + q * 256, row = u & (NB - 1), kc = u / NB;
-                const bool in = (p.rw == 4 ? k0 + kc : k0 + 8 * kc) + 7 * kst < K;
-                const uint4 v = in ? wreg[c][q] : make_uint4(0, 0, 0, 0);
-                float* d = As + ((size_t)c * GM_KS + (p.rw == 4 ? kc : 8 * kc)) * GM_AS + row;
-                d[0] = bf_lo(v.x); d[kst * GM_AS] = bf_hi(v.x); d[2 * kst * GM_AS] = bf_lo(v.y); d[3 * kst * GM_AS] = bf_hi(v.y);
-                d[4 * kst * GM_AS] = bf_lo(v.z); d[5 * kst * GM_AS] = bf_hi(v.z); d[6 * kst * GM_AS] = bf_lo(v.w); d[7 * kst * GM_AS] = bf_hi(v.w);
+                const int kc = wkc + q * WQ;
+                uint4 v = wreg[c][q];
+                if (!full && !((rw4 ? k0 + kc : k0 + 8 * kc) + 7 * kst < K)) v = make_uint4(0, 0, 0, 0);
+                char* blk = wblk + (size_t)c * WN * 64 * GM_APAD;
+                if (rw4) {                                   // element e -> k = 16e + kc: k-group 4e + kc/4, stream kc&3
+                    char* d = blk + (size_t)(kc & 3) * 16 * GM_APAD + (kc >> 2) * 2;
+                    const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+                    for (int e = 0; e < 8; e++) *(uint16_t*)(d + e * 8) = (uint16_t)(wd[e >> 1] >> ((e & 1) * 16));
+                } else {
+                    uint32_t w4[4]; pack4(v, w4);
+#pragma unroll
+                    for (int kk = 0; kk < 4; kk++) *(uint32_t*)(blk + (size_t)kk * 16 * GM_APAD + kc * 4) = w4[kk];
+                }
             }
 #pragma unroll
         for (int q = 0; q < XU; q++) {
-            const int u = tid + q * 256, row = u & (GM_MB - 1), kc = u >> 7;
-            const uint4 v = (k0 + 8 * kc < K) ? xreg[q] : make_uint4(0, 0, 0, 0);
-            float* d = Bs + (size_t)(8 * kc) * GM_BS + row;
-            d[0] = bf_lo(v.x); d[GM_BS] = bf_hi(v.x); d[2 * GM_BS] = bf_lo(v.y); d[3 * GM_BS] = bf_hi(v.y);
-            d[4 * GM_BS] = bf_lo(v.z); d[5 * GM_BS] = bf_hi(v.z); d[6 * GM_BS] = bf_lo(v.w); d[7 * GM_BS] = bf_hi(v.w);
+            uint4 v = xreg[q];
+            if (!full && !(k0 + 8 * (xkc + 2 * q) < K)) v = make_uint4(0, 0, 0, 0);
+            uint32_t w4[4]; pack4(v, w4);
+#pragma unroll
+            for (int kk = 0; kk < 4; kk++) *(uint32_t*)(xblk + (size_t)kk * 16 * GM_BPAD + q * 64) = w4[kk];
         }
     };
+    const char* ap = As + (size_t)(((WN == 4 ? wave : 0) * 4 + fk) * 16 + fi) * GM_APAD;       // (+ c*WN*64*GM_APAD for chain c)
+    const char* bp = Bs + (size_t)(fk * 16 + fi) * GM_BPAD + mt0 * 4;
     issue(0);
     for (int k0 = 0; k0 < K; k0 += GM_KS) {
-        commit(k0);
-        __syncthreads();
-        if (k0 + GM_KS < K) issue(k0 + GM_KS);               // in flight during this slab's MFMAs
-        // ---- 32 k-groups of 4: acc[n-tile w][m-tile t] = mfma(A, B, acc), k ascending (beyond K both operands are 0)
-        const float* ap = As + (size_t)fk * GM_AS + nt_off + fi;
-        const float* bp = Bs + (size_t)fk * GM_BS + mt0 * 16 + fi;
-        // fully unrolled: 32 k-groups x (1-2 A + 8 B fragment reads, 8-16 MFMAs); hipcc's scheduler hoists the LDS reads ahead of the
-        // matrix pipe on its own when it sees the whole slab (an explicit register double buffer made it shuffle accumulators
-        // between VGPRs and AGPRs around every MFMA)
-#pragma unroll
-        for (int g = 0; g < GM_KS / 4; g++) {
-            float a[NCH];
-#pragma unroll
-            for (int c = 0; c < NCH; c++) a[c] = ap[(size_t)c * GM_KS * GM_AS + g * 4 * GM_AS];
-#pragma unroll
-            for (int t = 0; t < MT; t++) {
-                const float bv = bp[g * 4 * GM_BS + t * 16];
-#pragma unroll
-                for (int c = 0; c < NCH; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c], bv, acc[c][t], 0, 0, 0);
+        if (!(GM_DBG & 1) || k0 == 0) commit(k0);
+        if (!(GM_DBG & 2)) __syncthreads();
+        if (!(GM_DBG & 1) && k0 + GM_KS < K) issue(k0 + GM_KS);   // in flight during this slab's MFMAs
+        // ---- 32 k-groups of 4 as 16 pairs: acc[n-tile][m-tile t] = mfma(A, B, acc), k ascending (beyond K both operands are 0).
+        // Fully unrolled and software-pipelined by hand, three stages (the sched_barriers pin them):
+        //   read    pair j+2's B words (and every fourth pair the next eight groups' A words): ds_read_b128, raw bf16 pairs;
+        //   widen   pair j+1's operands into their own registers (lo half: shift, hi half: mask -- 2*(MT+NCH) VALU ops);
+        //   MFMA    pair j: 2 k-groups x MT x NCH matrix instructions back to back, nothing in between.
+        // Measured (tools/gemmbench.hip, tools/mfma_lds_bench.hip): a widening op right in front of its MFMA -- hipcc's choice, into
+        // ONE reused register -- serialises on that register (write-after-read against the MFMA in flight + the VALU->MFMA hazard
+        // nops): 52 instead of 32 cycles per MFMA; ds_reads among MFMAs are free; an LDS round trip in front of each MFMA pair
+        // (hipcc's other choice) costs 40 %.
+        constexpr int NP = GM_KS / 8, PD = 2;
+        uint32_t fb[PD + 1][MT], fa[2][NCH][4];
+        float wa[2][2][NCH], wb[2][2][MT];                  // [pair parity][k-group parity]
+        auto read_b = [&](int j) {
+            const int sl = j % (PD + 1);
+            if (GM_DBG & 4) { for (int t = 0; t < MT; t++) fb[sl][t] = (uint32_t)(k0 + j + t) * 0x10001u; return; }
+            if (MT == 8) {
+                const uint4 lo = *(const uint4*)(bp + j * 32), hi = *(const uint4*)(bp + j * 32 + 16);
+                fb[sl][0] = lo.x; fb[sl][1] = lo.y; fb[sl][2] = lo.z; fb[sl][3] = lo.w;
+                fb[sl][4 % MT] = hi.x; fb[sl][5 % MT] = hi.y; fb[sl][6 % MT] = hi.z; fb[sl][7 % MT] = hi.w;
+            } else {
+                const uint2 v = *(const uint2*)(bp + j * 32);
+                fb[sl][0] = v.x; fb[sl][1] = v.y;
             }
+        };
+        auto read_a = [&](int o) {                           // octet o: k-groups 8o .. 8o+7
+#pragma unroll
+            for (int c = 0; c < NCH; c++) {
+                if (GM_DBG & 4) { for (int e = 0; e < 4; e++) fa[o & 1][c][e] = (uint32_t)(k0 + o + e) * 0x10001u; continue; }
+                const uint4 v = *(const uint4*)(ap + (size_t)c * WN * 64 * GM_APAD + o * 16);
+                fa[o & 1][c][0] = v.x; fa[o & 1][c][1] = v.y; fa[o & 1][c][2] = v.z; fa[o & 1][c][3] = v.w;
+            }
+        };
+        auto widen = [&](int j) {
+            const int sl = j % (PD + 1), q = j & 1;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) { const uint32_t w = fa[(j >> 2) & 1][c][j & 3]; wa[q][0][c] = bf_lo(w); wa[q][1][c] = bf_hi(w); }
+#pragma unroll
+            for (int t = 0; t < MT; t++) { wb[q][0][t] = bf_lo(fb[sl][t]); wb[q][1][t] = bf_hi(fb[sl][t]); }
+        };
+        read_a(0); read_b(0); read_b(1);
+        widen(0);
+#pragma unroll
+        for (int j = 0; j < NP; j++) {
+            if (j + 2 < NP) read_b(j + 2);
+            if ((j & 3) == 1 && j + 3 < NP) read_a(j / 4 + 1);   // octet o+1 is first widened at pair 4o+3, last use of octet o-1 was pair 4o-1
+            if (j + 1 < NP) widen(j + 1);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int par = 0; par < 2; par++)
+#pragma unroll
+                for (int t = 0; t < MT; t++)
+#pragma unroll
+                    for (int c = 0; c < NCH; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j & 1][par][c], wb[j & 1][par][t], acc[c][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();
+        if (!(GM_DBG & 2)) __syncthreads();
     }
     // D layout: lane holds rows (lane>>4)*4 + r of the n-tile, column lane&15 of the m-tile
 #pragma unroll
@@ -1450,16 +1533,16 @@ extern "C" hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, i
 template <int EPI, int NCH> static hipError_t launch_gemm(const GemmParams* p, hipStream_t st) {
     auto k4 = gemm_mfma_kernel<EPI, NCH, 4>;
     auto k1 = gemm_mfma_kernel<EPI, NCH, 1>;
-    const size_t lds = ((size_t)NCH * GM_KS * GM_AS + (size_t)GM_KS * GM_BS) * 4;
+    const size_t lds4 = gemm_lds_bytes(NCH, 4), lds1 = gemm_lds_bytes(NCH, 1);                   // 53 / 73 KB (39 / 44 KB): two or more workgroups per CU
     if (!p) {
-        hipError_t e = hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        return e != hipSuccess ? e : hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        hipError_t e = hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     }
     const unsigned mb = (unsigned)((p->S + GM_MB - 1) / GM_MB), nb4 = (unsigned)((p->n_rows + GM_NB - 1) / GM_NB);
     if (nb4 * mb < 128)        // 64-row tiles would leave most CUs idle: 16-row tiles, the four waves split the batch rows
-        hipLaunchKernelGGL(k1, dim3((unsigned)((p->n_rows + 15) / 16), mb), dim3(256), lds, st, *p);
+        hipLaunchKernelGGL(k1, dim3((unsigned)((p->n_rows + 15) / 16), mb), dim3(256), lds1, st, *p);
     else
-        hipLaunchKernelGGL(k4, dim3(nb4, mb), dim3(256), lds, st, *p);
+        hipLaunchKernelGGL(k4, dim3(nb4, mb), dim3(256), lds4, st, *p);
     return hipGetLastError();
 }
 // exact-order prefill GEMM (f32 MFMA); p == nullptr prepares the kernel (dynamic LDS limit) outside any stream capture

@@ -38,6 +38,7 @@ lines = ["# %s: rocprofv3 summary of `python bench.py --steps 32 --warmup 4` (Ll
          "separately by their larger grid).  `HBM read` = FETCH_SIZE (KB) x 2 / 1024 -- the gfx950 correction of",
          "/opt/skills/guides/MI355X_MICROARCH.md section HBM (wide coalesced reads are tallied at half their bytes).", "",
          "| kernel | grid (threads) | LDS B | launches | avg us | HBM read MB (PMC, corrected) | GB/s | WAVE_CYCLES busy/wait (quad-cycles per launch) |", "|---|---|---|---|---|---|---|---|"]
+traffic = {}
 for key in sorted(per, key=lambda k: -sum(per[k])):
     kn, grid, lds = key
     if "gemv" not in kn and "attn" not in kn and "argmax" not in kn and "rowcast" not in kn and "gemm_mfma" not in kn and "rmsnorm_rows" not in kn:
@@ -50,6 +51,8 @@ for key in sorted(per, key=lambda k: -sum(per[k])):
     avg = sum(d) / len(d)
     f = fetch.get(key)
     mb = (2 * sum(f) / len(f) / 1024.0) if f else None
+    if mb and len(d) > 200:                       # decode-sized launches only (one per layer per token)
+        traffic[label.split(" — ")[0]] = {"hbm_read_bytes_per_launch": int(mb * 1024 * 1024), "avg_us_under_rocprof": round(avg, 2), "launches": len(d)}
     s = sq.get(key)
     sqtxt = ""
     if s:
@@ -61,5 +64,7 @@ for fn in ("trace_bench.json", "bench_default.json"):
     p = os.path.join(SRC, fn)
     if os.path.exists(p) and os.path.getsize(p):
         lines += ["", "## %s" % fn, "```json", open(p).read().strip(), "```"]
+json.dump({"source": "rocprofv3 --pmc FETCH_SIZE pass of bench.py (tools/gpu_profile.sh), KB x 2 x 1024: gfx950 correction of MI355X_MICROARCH.md",
+           "kernels": traffic}, open(os.path.join(DST, R + "_traffic.json"), "w"), indent=1)
 open(os.path.join(DST, R + "_summary.md"), "w").write("\n".join(lines) + "\n")
 print("\n".join(lines[:40]))
