@@ -1062,11 +1062,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
         // ONE reused register -- serialises on that register (write-after-read against the MFMA in flight + the VALU->MFMA hazard
         // nops): 52 instead of 32 cycles per MFMA; ds_reads among MFMAs are free; an LDS round trip in front of each MFMA pair
         // (hipcc's other choice) costs 40 %.
-        constexpr int NP = GM_KS / 8, PD = 2;
-        uint32_t fb[PD + 1][MT], fa[2][NCH][4];
+        constexpr int NP = GM_KS / 8;
+        uint32_t fb[2][MT], fa[2][NCH][4];                    // raw ring: pair j+1 being widened, pair j+2 being read
         float wa[2][2][NCH], wb[2][2][MT];                  // [pair parity][k-group parity]
         auto read_b = [&](int j) {
-            const int sl = j % (PD + 1);
+            const int sl = j & 1;
             if (GM_DBG & 4) { for (int t = 0; t < MT; t++) fb[sl][t] = (uint32_t)(k0 + j + t) * 0x10001u; return; }
             if (MT == 8) {
                 const uint4 lo = *(const uint4*)(bp + j * 32), hi = *(const uint4*)(bp + j * 32 + 16);
@@ -1086,19 +1086,20 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
             }
         };
         auto widen = [&](int j) {
-            const int sl = j % (PD + 1), q = j & 1;
+            const int sl = j & 1, q = j & 1;
 #pragma unroll
             for (int c = 0; c < NCH; c++) { const uint32_t w = fa[(j >> 2) & 1][c][j & 3]; wa[q][0][c] = bf_lo(w); wa[q][1][c] = bf_hi(w); }
 #pragma unroll
             for (int t = 0; t < MT; t++) { wb[q][0][t] = bf_lo(fb[sl][t]); wb[q][1][t] = bf_hi(fb[sl][t]); }
         };
-        read_a(0); read_b(0); read_b(1);
+        read_a(0); read_b(0);
         widen(0);
+        read_b(1);
 #pragma unroll
         for (int j = 0; j < NP; j++) {
+            if (j + 1 < NP) widen(j + 1);                    // (frees raw slot j+1 & 1 ... which pair j+2 then refills)
             if (j + 2 < NP) read_b(j + 2);
             if ((j & 3) == 1 && j + 3 < NP) read_a(j / 4 + 1);   // octet o+1 is first widened at pair 4o+3, last use of octet o-1 was pair 4o-1
-            if (j + 1 < NP) widen(j + 1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int par = 0; par < 2; par++)
