@@ -455,6 +455,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
         AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st; ap.dbg = g_dbg;
         ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len;
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
+        ap.mfma = use_mfma(S) ? 1 : 0;
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = c->h; o.res = c->x;

@@ -112,4 +112,5 @@ struct AttnParams {
     int S, H, KVH, hd, seq_len;
     float divisor;              // wide(trunc(f32(sqrt(hd))))  (llamatransformer.go:464)
     long long* dbg;             // LNB_GEMV_TIMING: phase stamps of workgroup (0,0)
+    int mfma;                   // S >= 16: 16-row tiles on the f32 matrix cores (attn_mfma_kernel), same bits
 };

@@ -1118,6 +1118,166 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_mfma_kernel: the prefill form of the attention (S >= 16 query rows), the same arithmetic as attn_exact_kernel below with
+// both matrix products on the exact f32 matrix cores (v_mfma_f32_16x16x4_f32 == the reference's k-ordered chain, see gemm_mfma_kernel).
+// One WAVE owns 16 query rows of one head and walks the cached positions in tiles of 16, twice:
+//   pass 1  S^T tile [16 j][16 i] = sum_d K[j][d] Q[i][d] (d ascending: 32 dependent MFMAs), then per element trunc, /sqrt(hd), mask,
+//           exp in f64; the row sums Z_i must be added in j order in f64: the tile goes through a 2.3 KB LDS patch and lane i < 16
+//           walks row i's sixteen values (the reference's serial sum, impl:492-499);
+//   pass 2  the scores again (cheaper than keeping S x T doubles), p = trunc(f32(e / Z_i)), transposed through the LDS into the A
+//           operand layout, and out[i][d] += p[i][j] v[j][d] with j ascending inside and across the MFMAs (lane n owns the HD/16
+//           consecutive output dims n*HD/16.., so one 16 B load of a V row feeds its eight MFMAs).
+// Masked positions (j % S > i, the modulo-broadcast [S,S] mask) contribute e = 0 -> p = +0; acc + (+-0) == acc and acc is never -0,
+// so with the standard causal layout (pos0 == 0) the tiles above the diagonal are skipped like attn_exact_kernel does.
+// K cache layout [kv head][d/8][position][8]: a lane (j, kk) loads its position's 16 B units and picks elements kk and 4+kk
+// (k-groups 2c, 2c+1) with one v_perm_b32 each; the four kk-lanes of a position load the same unit (L1 traffic, not HBM).
+// grid (H, ceil(S/64)), block 256 = 4 independent waves (no workgroup barrier anywhere).
+// ------------------------------------------------------------------------------------------------
+constexpr int ATM_ET = 144, ATM_PT = 80, ATM_WLDS = 16 * ATM_ET + 16 * ATM_PT + 128;     // per-wave LDS patch: e tile | p tile | Z row
+template <int HD> __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sm[4 * ATM_WLDS];
+    constexpr int NK = HD / 8, DPL = HD / 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x, i0 = (blockIdx.y * 4 + wave) * 16;
+    const int S = p.S, H = p.H, KVH = p.KVH;
+    if (i0 >= S) return;                                     // (waves are independent)
+    const int pos0 = p.st->pos, T = pos0 + S;
+    const int kvh = h / (H / KVH);
+    const int fi = lane & 15, fk = lane >> 4;
+    char* et = sm + wave * ATM_WLDS;
+    char* pt = et + 16 * ATM_ET;
+    double* zrow = (double*)(pt + 16 * ATM_PT);
+    const uint4* kbase = (const uint4*)p.cache_k + (size_t)kvh * NK * p.seq_len;
+    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD + fi * DPL;
+    const size_t vrow = (size_t)KVH * HD;
+    const uint32_t sel = 0x0c0cu | ((uint32_t)(2 * fk) << 16) | ((uint32_t)(2 * fk + 1) << 24);   // element kk of a 4-element word pair
+    const int Tmax = (S > 1 && pos0 == 0) ? (i0 + 16 < T ? i0 + 16 : T) : T;
+    const int NJ = (Tmax + 15) >> 4;
+    const int irow = i0 + fi;                                // this lane's query row in the S^T tile (column i)
+
+    float qf[2 * NK];                                        // Q[irow][4g + kk], g = 0 .. HD/4-1
+    {
+        const uint4* q = (const uint4*)(p.q + ((size_t)(irow < S ? irow : S - 1) * H + h) * HD);
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+            const uint4 u = q[c];
+            qf[2 * c] = __uint_as_float(__builtin_amdgcn_perm(u.y, u.x, sel));
+            qf[2 * c + 1] = __uint_as_float(__builtin_amdgcn_perm(u.w, u.z, sel));
+        }
+    }
+    auto load_k = [&](uint4 (&k)[NK], int j0) {
+        int j = j0 + fi; j = j < T ? j : T - 1;
+#pragma unroll
+        for (int c = 0; c < NK; c++) k[c] = kbase[(size_t)c * p.seq_len + j];
+    };
+    // raw scores of the tile: lane holds positions j0 + 4*kk + r (r = 0..3) against query row irow
+    auto qk = [&](const uint4 (&k)[NK]) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NK; c++) {                       // MatMul q.k, d ascending (operations_matmul.go:37-55)
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(__builtin_amdgcn_perm(k[c].y, k[c].x, sel)), qf[2 * c], acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(__uint_as_float(__builtin_amdgcn_perm(k[c].w, k[c].z, sel)), qf[2 * c + 1], acc, 0, 0, 0);
+        }
+        return acc;
+    };
+    // e[r] = exp(score) (0 where masked or past T)
+    auto expo = [&](const f32x4& acc, int j0, double (&e)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = j0 + 4 * fk + r;
+            const bool dead = j >= T || ((S > 1) && ((j % S) > irow));           // triu(-inf,1) broadcast by modulo (tensoriterators.go:47-55)
+            uint16_t s16 = bf_trunc(acc[r]);
+            s16 = bf_trunc(__fdiv_rn(bf_wide(s16), p.divisor));                  // DivToScalar :464
+            if (S > 1) s16 = bf_trunc(bf_wide(s16) + 0.0f);                      // Add(scores, mask) with mask == 0 :469-473
+            const double ev = exp((double)bf_wide(s16));                         // Softmax impl:498
+            e[r] = dead ? 0.0 : ev;                                              // exp(-inf) == 0
+        }
+    };
+#define ATM_LDS_TURN() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+
+    // ---- pass 1: Z_i = sum_j exp(s_ij), f64, j ascending (lane i < 16 carries row i)
+    double z = 0.0;
+    uint4 kt[NK];                                            // the tile's K rows; the next tile's are loaded into the same registers as
+                                                             // soon as the 32 MFMAs have read them, and land during the exps
+    auto zsum = [&](int j0, bool more) {
+        const f32x4 sc = qk(kt);
+        if (more) load_k(kt, j0 + 16);
+        double e[4];
+        expo(sc, j0, e);
+        typedef double d2 __attribute__((ext_vector_type(2)));
+        d2* w = (d2*)(et + fi * ATM_ET + fk * 32);
+        w[0] = d2{e[0], e[1]}; w[1] = d2{e[2], e[3]};
+        ATM_LDS_TURN();
+        if (lane < 16) {
+            const d2* row = (const d2*)(et + lane * ATM_ET);
+            d2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = row[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { z += v[u].x; z += v[u].y; }
+        }
+        ATM_LDS_TURN();
+    };
+    load_k(kt, 0);
+    for (int jt = 0; jt < NJ; jt++) zsum(jt * 16, jt + 1 < NJ);      // (wave-uniform trip count)
+    if (lane < 16) zrow[lane] = z;
+    ATM_LDS_TURN();
+    const double zi = zrow[fi];
+
+    // ---- pass 2: p = trunc(f32(e / Z_i)), out = sum_j p_j v_j (j ascending)
+    f32x4 o[DPL];
+#pragma unroll
+    for (int t = 0; t < DPL; t++) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    auto pv = [&](int j0, bool more) {
+        const f32x4 sc = qk(kt);
+        if (more) load_k(kt, j0 + 16);
+        uint4 vv[4];                                         // V[j0 + 4g + kk][dims fi*DPL ..]: in flight during the exps
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            int j = j0 + 4 * g + fk; j = j < T ? j : T - 1;
+            const uint16_t* a = vbase + (size_t)j * vrow;
+            if (DPL == 8) vv[g] = *(const uint4*)a;
+            else { const uint2 t2 = *(const uint2*)a; vv[g] = make_uint4(t2.x, t2.y, 0, 0); }
+        }
+        double e[4];
+        expo(sc, j0, e);
+        float4 pf;                                           // impl:506 + ToBFloat16 :493
+        pf.x = bf_wide(bf_trunc((float)(e[0] / zi))); pf.y = bf_wide(bf_trunc((float)(e[1] / zi)));
+        pf.z = bf_wide(bf_trunc((float)(e[2] / zi))); pf.w = bf_wide(bf_trunc((float)(e[3] / zi)));
+        *(float4*)(pt + fi * ATM_PT + fk * 16) = pf;         // p[i = fi][j = 4kk .. 4kk+3]
+        ATM_LDS_TURN();
+        float pa[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) pa[g] = *(const float*)(pt + fi * ATM_PT + (4 * g + fk) * 4);     // A operand: p[i = fi][j = 4g + kk]
+        ATM_LDS_TURN();
+#pragma unroll
+        for (int g = 0; g < 4; g++) {                        // MatMul p.v, j ascending (llamatransformer.go:504-514)
+            const uint32_t wd[4] = {vv[g].x, vv[g].y, vv[g].z, vv[g].w};
+#pragma unroll
+            for (int t = 0; t < DPL; t++)
+                o[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[g], (t & 1) ? bf_hi(wd[t >> 1]) : bf_lo(wd[t >> 1]), o[t], 0, 0, 0);
+        }
+    };
+    load_k(kt, 0);
+    for (int jt = 0; jt < NJ; jt++) pv(jt * 16, jt + 1 < NJ);
+#undef ATM_LDS_TURN
+    // D layout: lane holds query rows 4*kk + r, output dims fi*DPL + t
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = i0 + 4 * fk + r;
+        if (row >= S) continue;
+        uint32_t w[DPL / 2];
+#pragma unroll
+        for (int t = 0; t < DPL; t += 2) w[t / 2] = (uint32_t)bf_trunc(o[t][r]) | ((uint32_t)bf_trunc(o[t + 1][r]) << 16);
+        uint16_t* dst = p.out + ((size_t)row * H + h) * HD + fi * DPL;
+        if (DPL == 8) *(uint4*)dst = make_uint4(w[0], w[1], w[2 % (DPL / 2)], w[3 % (DPL / 2)]);
+        else *(uint2*)dst = make_uint2(w[0], w[1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exact attention for one (head, query row): scores -> /sqrt(hd) -> mask -> f64 softmax -> PV.
 // llamatransformer.go:409-514.  GQA head h reads KV head h/n_rep straight from the un-repeated cache
 // (attentionRepeatKV :529-559 and the four Transposes :435-449 become index arithmetic).
@@ -1594,6 +1754,11 @@ extern "C" hipError_t lnbk_init(void) {
 }
 
 extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
+    if (p->mfma && p->S >= 16 && (p->hd == 128 || p->hd == 64)) {       // prefill: 16 query rows per wave on the matrix cores
+        if (p->hd == 128) hipLaunchKernelGGL(attn_mfma_kernel<128>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
+        else hipLaunchKernelGGL(attn_mfma_kernel<64>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
+        return hipGetLastError();
+    }
     size_t lds = attn_lds_bytes(p->seq_len, p->hd);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     switch (p->hd) {
