@@ -260,6 +260,29 @@ def test_tiny_long_prefill_through_the_matrix_cores_bit_exact(lnb, tiny_pair):
     gc.close(); oc.close()
 
 
+@pytest.mark.parametrize("heads,kv_heads,dim,rows", [(4, 2, 512, 37), (4, 4, 256, 83), (2, 1, 256, 16)])
+def test_prefill_attention_tiles_ragged_rows_and_head_dims(lnb, heads, kv_heads, dim, rows):
+    """attn_mfma_kernel (16 query rows per wave): row counts that are not a multiple of 16 (clamped lanes, a partial diagonal tile),
+    head_dim 128 and 64, GQA and MHA, then a ragged chunk at start_pos > 0 (modulo-broadcast mask over T > S) and decode steps that
+    read the cache it wrote: bit-exact logits against the oracle."""
+    cfg = dict(TINY, n_heads=heads, n_kv_heads=kv_heads, dim=dim, n_layers=2, vocab_size=512)
+    om = orc.Model(**cfg).fill_synthetic(31).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(31).finalize()
+    toks = orc.synth_tokens(8, 2 * rows, cfg["vocab_size"])
+    oc, gc = orc.Context(om, 2 * rows + 8), lnb.InferenceContext(gm, 2 * rows + 8)
+    for lo_, hi_ in ((0, rows), (rows, 2 * rows)):
+        lo, ao = oc.forward(toks[lo_:hi_], lo_)
+        lg, ag = gc.Forward(toks[lo_:hi_], lo_)
+        assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag
+    tok = ag
+    for i in range(3):
+        lo, to = oc.forward([tok], 2 * rows + i)
+        lg, tg = gc.Forward(np.array([tok], dtype=np.int32), 2 * rows + i)
+        assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and to == tg
+        tok = to
+    gc.close(); oc.close(); gm.close(); om.close()
+
+
 def test_rw56_two_chain_blocks_bit_exact(lnb, tiny_pair, monkeypatch):
     """The 8B gate|up matrix is stored as 256 blocks of 56 rows x 2 chains (one per CU).  Force the same kernel on the tiny
     model (ffn hidden 896 = 16 x 56) and compare prefill + decode with the oracle."""
