@@ -20,7 +20,8 @@ NAMES = {"gemv_chain_kernel<32, 1, 12288, 6, 5, 1, true>": "attn_norm+wq|wk|wv+R
          "gemv_chain_kernel<56, 2, 14336, 7, 8, 3, true>": "ffn_norm+w1|w3+SiLU*up (fat, 256 blocks of 56 rows x 2 chains, v_pk_add_f32)",
          "gemm_mfma_kernel": "prefill GEMM on the f32 matrix cores (exact order)", "rmsnorm_rows_kernel": "prefill RMSNorm (one wave per row)",
          "gemv_chain_kernel<64, 1, 12288, 6, 8, 0, true>": "norm+output (fat, RW=64)",
-         "attn_exact_kernel<128>": "attention (scores, f64 softmax, PV)"}
+         "attn_exact_kernel<128>": "attention (scores, f64 softmax, PV)",
+         "attn_mfma_kernel<128>": "prefill attention on the f32 matrix cores (16 query rows per wave, exact order)"}
 trace = list(csv.DictReader(open(os.path.join(SRC, "trace", "trace_kernel_trace.csv"))))
 per = collections.defaultdict(list)
 for r in trace:
