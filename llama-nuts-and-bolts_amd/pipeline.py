@@ -56,9 +56,11 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
     nxt, prv = (rank + 1) % world, (rank - 1) % world
     if state is None:
         state = {}
+    # what the backend can move: device tensors for RCCL; host tensors for gloo (the CPU tests, and two ranks sharing one GPU)
+    comm = "cpu" if (world > 1 and dist.get_backend() == "gloo") else device
     if "tok_out" not in state:
-        state.update(prev=None, tok_out=torch.zeros(1, dtype=torch.int32, device=device),
-                     tok_in=torch.zeros(1, dtype=torch.int32, device=device),
+        state.update(prev=None, tok_out=torch.zeros(1, dtype=torch.int32, device=comm),
+                     tok_in=torch.zeros(1, dtype=torch.int32, device=comm),
                      produced=[[] for _ in range(world)], received=[[] for _ in range(world)])
     tok_out, tok_in = state["tok_out"], state["tok_in"]
     if hi is None:
@@ -68,13 +70,20 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
             continue
         if t >= hi:
             break
-        ops = []
+        ops, landed = [], None
+        # Only tensors from torch's own allocator are handed to the backend: the stage's hidden state lives in memory the HIP library
+        # allocated, so it is copied (8 KiB per decoded token) into / out of a torch staging tensor around the exchange.
         # --- send the previous tick's result downstream -------------------------------------------------------
         if state["prev"] is not None and world > 1:
             k, s = divmod(state["prev"], world)
             rows = P if k == 0 else 1
             if not last:
-                ops.append(dist.P2POp(dist.isend, stage.hidden_buffer(s, rows), nxt))
+                src = stage.hidden_buffer(s, rows)
+                out = state.setdefault("stage_out", {}).get(rows)
+                if out is None:
+                    out = state["stage_out"][rows] = torch.empty_like(src, device=comm)
+                out.copy_(src)
+                ops.append(dist.P2POp(dist.isend, out, nxt))
             elif k + 1 < n_phases:        # the token of the final phase is not needed by rank 0
                 ops.append(dist.P2POp(dist.isend, tok_out, nxt))
         # --- receive this tick's input --------------------------------------------------------------------------
@@ -82,14 +91,21 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
             k, s = divmod(item, world)
             rows = P if k == 0 else 1
             if not first:
-                ops.append(dist.P2POp(dist.irecv, stage.hidden_buffer(s, rows), prv))
+                dst = stage.hidden_buffer(s, rows)
+                inn = state.setdefault("stage_in", {}).get(rows)
+                if inn is None:
+                    inn = state["stage_in"][rows] = torch.empty_like(dst, device=comm)
+                ops.append(dist.P2POp(dist.irecv, inn, prv))
+                landed = (dst, inn)
             elif k > 0:
                 ops.append(dist.P2POp(dist.irecv, tok_in, prv))
         if ops:
             for req in dist.batch_isend_irecv(ops):
                 req.wait()
+            if landed is not None:
+                landed[0].copy_(landed[1])
             if device != "cpu":
-                torch.cuda.synchronize()       # RCCL ran on torch's stream; the HIP library has its own
+                torch.cuda.synchronize()       # RCCL and the copies ran on torch's streams; the HIP library has its own
         # --- compute ----------------------------------------------------------------------------------------------
         if item is not None:
             k, s = divmod(item, world)

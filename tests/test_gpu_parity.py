@@ -359,6 +359,20 @@ def test_pipeline_stages_on_one_device_equal_whole_model(lnb, tiny_pair):
     s0.close(); s1.close()
 
 
+def test_pipeline_two_processes_share_one_gpu(lnb):
+    """bench.py --gpus 2 in miniature: two torch.distributed ranks (gloo), each with half of the blocks on cuda:0, exchanging the
+    hidden state and the token ring through pipeline.run_ticks; every generated token is checked against the oracle."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    script = os.path.join(os.path.dirname(__file__), "native", "pipeline_two_rank.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "PIPELINE_TWO_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 def test_pipeline_stage_hidden_views_are_zero_copy_torch_tensors(lnb, tiny_pair):
     """pipeline.LnbStage (what `bench.py --gpus N` runs on every rank): the hidden state that RCCL sends/receives is a torch
     view of the library's own device buffer (CUDA array interface).  Two logical stages on this GPU, the hand-off done
