@@ -7,12 +7,14 @@ tok_embeddings, rank N-1 also norm + output.  The only exchange of the path is p
 state [S, dim] from rank r to r+1 (8 KiB per decoded token for dim 4096) and the 4-byte next-token id from rank N-1
 back to rank 0.  There is no all-reduce / all-gather anywhere (that would be tensor parallelism).
 
-A single greedy sequence is serial across stages, so N independent sequences (one InferenceContext each, exactly
+A single greedy sequence is serial across stages, so independent sequences (one InferenceContext each, exactly
 what the reference creates per GenerateString call, src/inference/inference.go:174) are kept in flight:
-work item i = (phase i // N, sequence i % N), phase 0 = prefill of the prompt, phase k >= 1 = decode step k-1;
-at tick t rank r runs item t - r.  Item (k, s) reaches rank 0 one tick after rank N-1 finished (k-1, s), so the
-token ring closes without bubbles, and every tick is ONE grouped isend/irecv per rank (batch_isend_irecv:
-ncclGroupStart/End, so the send to r+1 and the receive from r-1 progress together and cannot deadlock).
+work item i = (phase i // M, sequence i % M), phase 0 = prefill of the prompt, phase k >= 1 = decode step k-1.
+Lock step (M = N sequences): at tick t rank r runs item t - r; item (k, s) reaches rank 0 one tick after rank N-1 finished
+(k-1, s), so the token ring closes without bubbles.  Overlapped (M = 2N, what bench.py runs): rank r runs item t - 2r, and the
+exchange of a tick is in flight while the stage computes another sequence's item (run_ticks).  Either way every tick is ONE
+grouped isend/irecv per rank (batch_isend_irecv: ncclGroupStart/End, so the send to r+1 and the receive from r-1 progress
+together and cannot deadlock).
 
 The compute of a tick is delegated to a `stage` object so the schedule is testable on CPU (gloo, world_size 2)
 with a pure-python stage: tests/test_pipeline_gloo.py.
@@ -38,20 +40,32 @@ class Stage:
         pass
 
 
-def schedule(rank, world, n_phases):
-    """yield (tick, item_index or None) for this rank; item i = (phase i // world, seq i % world)"""
-    n_items = n_phases * world
-    for t in range(n_items + world - 1):
-        i = t - rank
+def schedule(rank, world, n_phases, n_seq=None, gap=1):
+    """yield (tick, item_index or None) for this rank; item i = (phase i // n_seq, seq i % n_seq); rank r runs item t - gap*r at tick t"""
+    n_seq = n_seq or world
+    n_items = n_phases * n_seq
+    for t in range(n_items + gap * (world - 1)):
+        i = t - gap * rank
         yield t, (i if 0 <= i < n_items else None)
 
 
 def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, hi=None, state=None):
-    """Run ticks [lo, hi) of the schedule; `state` carries the in-flight item and the token tensors between calls
-    (bench.py runs an untimed window and then a timed one).  prompts: `world` np.int32 arrays of equal length P.
-    state["produced"][s] = tokens generated for sequence s (last rank); state["received"][s] on rank 0."""
+    """Run ticks [lo, hi) of the schedule; `state` carries the in-flight items and the token tensors between calls
+    (bench.py runs an untimed window and then a timed one).  prompts: n_seq np.int32 arrays of equal length P.
+    state["produced"][s] = tokens generated for sequence s (last rank); state["received"][s] on rank 0.
+
+    n_seq == world: the lock-step schedule of the module docstring (exchange, then compute, every tick).
+    n_seq == 2*world (world > 1): adjacent stages run TWO ticks apart, so the exchange of tick t -- the result of tick t-1 going
+    downstream, the input of tick t+1 arriving -- is posted first and runs on the backend's stream WHILE the stage computes tick t's
+    item of another sequence; the tick costs max(compute, exchange) instead of their sum.  Item (k, s) leaves the last rank after
+    tick i + 2(N-1) and its token reaches rank 0 during the next one: 2N sequences close the ring without a bubble."""
     P = len(prompts[0])
+    n_seq = len(prompts)
     n_phases = 1 + n_decode
+    n_items = n_phases * n_seq
+    overlap = world > 1 and n_seq == 2 * world
+    assert overlap or n_seq == world, "run_ticks wants `world` sequences (lock step) or 2*world (overlapped exchange)"
+    gap = 2 if overlap else 1
     first, last = rank == 0, rank == world - 1
     nxt, prv = (rank + 1) % world, (rank - 1) % world
     if state is None:
@@ -60,68 +74,93 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
     comm = "cpu" if (world > 1 and dist.get_backend() == "gloo") else device
     if "tok_out" not in state:
         state.update(prev=None, tok_out=torch.zeros(1, dtype=torch.int32, device=comm),
-                     tok_in=torch.zeros(1, dtype=torch.int32, device=comm),
-                     produced=[[] for _ in range(world)], received=[[] for _ in range(world)])
+                     tok_in=torch.zeros(1, dtype=torch.int32, device=comm), tok_next=None, stage_out={}, stage_in={},
+                     produced=[[] for _ in range(n_seq)], received=[[] for _ in range(n_seq)])
     tok_out, tok_in = state["tok_out"], state["tok_in"]
     if hi is None:
-        hi = n_phases * world + world - 1
-    for t, item in schedule(rank, world, n_phases):
-        if t < lo:
-            continue
-        if t >= hi:
-            break
-        ops, landed = [], None
-        # Only tensors from torch's own allocator are handed to the backend: the stage's hidden state lives in memory the HIP library
-        # allocated, so it is copied (8 KiB per decoded token) into / out of a torch staging tensor around the exchange.
-        # --- send the previous tick's result downstream -------------------------------------------------------
-        if state["prev"] is not None and world > 1:
-            k, s = divmod(state["prev"], world)
-            rows = P if k == 0 else 1
+        hi = n_items + gap * (world - 1)
+
+    def rows_of(item):
+        return P if item // n_seq == 0 else 1
+
+    def staging(kind, like):                                  # one torch-allocated tensor per (direction, row count)
+        t_ = state[kind].get(like.shape[0])
+        if t_ is None:
+            t_ = state[kind][like.shape[0]] = torch.empty_like(like, device=comm)
+        return t_
+
+    def post(send_item, recv_item):
+        """the exchange of one tick: result of `send_item` downstream (hidden state, or the token back to rank 0), input of `recv_item`
+        from upstream.  Only tensors from torch's own allocator are handed to the backend: the stage's hidden state lives in memory
+        the HIP library allocated, so it is copied (8 KiB per decoded token) into / out of a torch staging tensor."""
+        ops, landed, got_tok = [], None, False
+        if send_item is not None and world > 1:
+            k, s = divmod(send_item, n_seq)
             if not last:
-                src = stage.hidden_buffer(s, rows)
-                out = state.setdefault("stage_out", {}).get(rows)
-                if out is None:
-                    out = state["stage_out"][rows] = torch.empty_like(src, device=comm)
+                src = stage.hidden_buffer(s, rows_of(send_item))
+                out = staging("stage_out", src)
                 out.copy_(src)
                 ops.append(dist.P2POp(dist.isend, out, nxt))
             elif k + 1 < n_phases:        # the token of the final phase is not needed by rank 0
                 ops.append(dist.P2POp(dist.isend, tok_out, nxt))
-        # --- receive this tick's input --------------------------------------------------------------------------
-        if item is not None and world > 1:
-            k, s = divmod(item, world)
-            rows = P if k == 0 else 1
+        if recv_item is not None and world > 1:
+            k, s = divmod(recv_item, n_seq)
             if not first:
-                dst = stage.hidden_buffer(s, rows)
-                inn = state.setdefault("stage_in", {}).get(rows)
-                if inn is None:
-                    inn = state["stage_in"][rows] = torch.empty_like(dst, device=comm)
+                dst = stage.hidden_buffer(s, rows_of(recv_item))
+                inn = staging("stage_in", dst)
                 ops.append(dist.P2POp(dist.irecv, inn, prv))
                 landed = (dst, inn)
             elif k > 0:
                 ops.append(dist.P2POp(dist.irecv, tok_in, prv))
-        if ops:
-            for req in dist.batch_isend_irecv(ops):
-                req.wait()
-            if landed is not None:
-                landed[0].copy_(landed[1])
-            if device != "cpu":
-                torch.cuda.synchronize()       # RCCL and the copies ran on torch's streams; the HIP library has its own
-        # --- compute ----------------------------------------------------------------------------------------------
-        if item is not None:
-            k, s = divmod(item, world)
-            if k == 0:
-                rows, pos, toks = P, 0, (np.ascontiguousarray(prompts[s], dtype=np.int32) if first else None)
-            else:
-                rows, pos, toks = 1, P + k - 1, None
-                if first:
-                    tok = int(tok_in.item()) if world > 1 else state["produced"][s][-1]
-                    state["received"][s].append(tok)
-                    toks = np.array([tok], dtype=np.int32)
-            out = stage.run(s, rows, pos, toks)
-            if last:
-                state["produced"][s].append(int(out))
-                tok_out.fill_(int(out))
-            stage.synchronize()
+                got_tok = True
+        works = dist.batch_isend_irecv(ops) if ops else []
+        return works, landed, got_tok
+
+    def finish(works, landed, got_tok):
+        for req in works:
+            req.wait()
+        if landed is not None:
+            landed[0].copy_(landed[1])
+        if got_tok:
+            state["tok_next"] = int(tok_in.item())
+        if works and device != "cpu":
+            torch.cuda.synchronize()       # RCCL and the copies ran on torch's streams; the HIP library has its own
+
+    def compute(item):
+        k, s = divmod(item, n_seq)
+        if k == 0:
+            rows, pos, toks = P, 0, (np.ascontiguousarray(prompts[s], dtype=np.int32) if first else None)
+        else:
+            rows, pos, toks = 1, P + k - 1, None
+            if first:
+                tok = state["tok_next"] if world > 1 else state["produced"][s][-1]
+                state["received"][s].append(tok)
+                toks = np.array([tok], dtype=np.int32)
+        out = stage.run(s, rows, pos, toks)
+        if last:
+            state["produced"][s].append(int(out))
+        stage.synchronize()
+        return int(out) if last else None
+
+    for t, item in schedule(rank, world, n_phases, n_seq, gap):
+        if t < lo:
+            continue
+        if t >= hi:
+            break
+        if overlap:
+            nxt_item = t + 1 - gap * rank
+            nxt_item = nxt_item if 0 <= nxt_item < n_items else None
+            pending = post(state["prev"], nxt_item)           # in flight during this tick's compute
+            tok = compute(item) if item is not None else None
+            finish(*pending)
+            if tok is not None:
+                tok_out.fill_(tok)                            # (after the send of the previous token has completed)
+        else:
+            finish(*post(state["prev"], item))
+            if item is not None:
+                tok = compute(item)
+                if tok is not None:
+                    tok_out.fill_(tok)
         state["prev"] = item
     return state
 
@@ -191,21 +230,25 @@ def bench_main(args, cfg, name):
     if world != args.gpus:
         raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29531")           # (only used by the single-process LNB_FORCE_PIPELINE=1 run)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))   # rank -> GPU mapping is explicit
     P, W, K = args.prompt_len, args.warmup, args.steps
     seq_len = P + W + K + 8
-    stage = LnbStage(lnb, torch, cfg, rank, world, world, seq_len, local)
-    prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(world)]
+    # 2*world sequences: the exchange of a tick overlaps the compute of another sequence's item (run_ticks); LNB_PIPELINE_OVERLAP=0
+    # falls back to the lock-step schedule with `world` sequences
+    n_seq = world * (2 if world > 1 and os.environ.get("LNB_PIPELINE_OVERLAP", "1") != "0" else 1)
+    stage = LnbStage(lnb, torch, cfg, rank, world, n_seq, seq_len, local)
+    prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
     n_decode = W + K
-    t_split = world * (1 + W)              # prefill phase + W warm-up decode rounds
-    t_end = world * (1 + W + K)
+    t_split = n_seq * (1 + W)              # prefill phase + W warm-up decode rounds
+    t_end = n_seq * (1 + W + K)
     state = run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, 0, t_split)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     t0 = time.perf_counter()
-    # the timed window: every rank runs exactly K*world items (K decode steps of each of the `world` sequences)
+    # the timed window: every rank runs exactly K*n_seq items (K decode steps of each sequence in flight)
     run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, t_split, t_end, state)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     wall = time.perf_counter() - t0
@@ -214,7 +257,7 @@ def bench_main(args, cfg, name):
     wall = float(tmax.item())
     if rank == 0:
         import bench as _b
-        tokens = K * world
+        tokens = K * n_seq
         tps = tokens / wall
         a = {k: cfg[k] for k in ("dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size")}
         Tbar = P + W + (K - 1) / 2.0 + 1.0
@@ -224,8 +267,8 @@ def bench_main(args, cfg, name):
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "%s bf16, %dxMI355X layer pipeline (blocks per GPU %s), RCCL p2p hidden-state hand-off, %d sequences in flight, "
                                       "prompt %d -> +%d tokens each" % (name, world, ",".join(str(stage_layers(r, world, cfg["n_layers"])[1] - stage_layers(r, world, cfg["n_layers"])[0])
-                                                                                                 for r in range(world)), world, P, K),
-                          "prompt_len": P, "sequences_in_flight": world, "parallelism": "pp%d" % world,
+                                                                                                 for r in range(world)), n_seq, P, K),
+                          "prompt_len": P, "sequences_in_flight": n_seq, "parallelism": "pp%d" % world,
                           "mode": "exact-order (token-id identical to the CPU reference path)"},
                "roofline": {"bound": "hbm", "achieved": round(tps * B / 1e9, 1), "peak": _b.PEAK_HBM_GBS * world, "unit": "GB/s",
                             "frac": round(tps * B / 1e9 / (_b.PEAK_HBM_GBS * world), 4), "traffic": None,

@@ -18,12 +18,13 @@ rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = dict(orc.TINY)
 P, n_decode = 24, 9                                           # 24-row prefill: the matrix-core path on every stage
-stage = pipeline.LnbStage(lnb, torch, cfg, rank, world, world, P + n_decode + 8, 0)
-prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(world)]
+n_seq = world * int(os.environ.get("LNB_TEST_MULT", "2"))     # 2: the overlapped schedule of bench.py --gpus N; 1: lock step
+stage = pipeline.LnbStage(lnb, torch, cfg, rank, world, n_seq, P + n_decode + 8, 0)
+prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
 st = pipeline.run_ticks(rank, world, stage, dist, torch, prompts, n_decode, "cuda:0")
 if rank == world - 1:
     om = orc.Model(**cfg).fill_synthetic(1234).finalize()
-    for s in range(world):
+    for s in range(n_seq):
         ref, _ = orc.Context(om, P + n_decode + 8).generate(prompts[s], 1 + n_decode)
         assert list(ref) == st["produced"][s], (s, list(ref), st["produced"][s])
     print("PIPELINE_TWO_RANK_OK", st["produced"][0][:4])

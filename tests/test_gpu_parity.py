@@ -359,7 +359,8 @@ def test_pipeline_stages_on_one_device_equal_whole_model(lnb, tiny_pair):
     s0.close(); s1.close()
 
 
-def test_pipeline_two_processes_share_one_gpu(lnb):
+@pytest.mark.parametrize("mult", [2, 1])
+def test_pipeline_two_processes_share_one_gpu(lnb, mult):
     """bench.py --gpus 2 in miniature: two torch.distributed ranks (gloo), each with half of the blocks on cuda:0, exchanging the
     hidden state and the token ring through pipeline.run_ticks; every generated token is checked against the oracle."""
     import socket
@@ -369,7 +370,8 @@ def test_pipeline_two_processes_share_one_gpu(lnb):
         so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
     script = os.path.join(os.path.dirname(__file__), "native", "pipeline_two_rank.py")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-                        "--master-port", str(port), script], capture_output=True, text=True, timeout=600)
+                        "--master-port", str(port), script], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, LNB_TEST_MULT=str(mult)))
     assert r.returncode == 0 and "PIPELINE_TWO_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 

@@ -63,12 +63,12 @@ def reference(world, prompts, n_decode):
     return out
 
 
-def _worker(rank, world, port, n_decode, split, q):
+def _worker(rank, world, port, n_decode, split, q, mult=1):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    prompts = [np.arange(P, dtype=np.int32) * (s + 2) % VOCAB for s in range(world)]
-    stage = FakeStage(rank, world, world)
+    prompts = [np.arange(P, dtype=np.int32) * (s + 2) % VOCAB for s in range(world * mult)]
+    stage = FakeStage(rank, world, world * mult)
     if split:
         st = pipeline.run_ticks(rank, world, stage, dist, torch, prompts, n_decode, "cpu", 0, split)
         dist.barrier()
@@ -86,12 +86,15 @@ def _free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,n_decode,split", [(2, 6, 0), (2, 6, 7), (3, 4, 5)])
-def test_pipeline_schedule_matches_single_process(world, n_decode, split):
+@pytest.mark.parametrize("world,n_decode,split,mult", [(2, 6, 0, 1), (2, 6, 7, 1), (3, 4, 5, 1),
+                                                        (2, 6, 0, 2), (2, 5, 9, 2), (3, 4, 11, 2), (3, 3, 1, 2)])
+def test_pipeline_schedule_matches_single_process(world, n_decode, split, mult):
+    """mult 1: lock-step schedule, `world` sequences; mult 2: 2*world sequences, stages two ticks apart, the exchange posted before
+    and completed after each tick's compute (what bench.py --gpus N runs)"""
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, n_decode, split, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, n_decode, split, q, mult)) for r in range(world)]
     for p in procs:
         p.start()
     res = {}
@@ -101,15 +104,16 @@ def test_pipeline_schedule_matches_single_process(world, n_decode, split):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    prompts = [np.arange(P, dtype=np.int32) * (s + 2) % VOCAB for s in range(world)]
+    n_seq = world * mult
+    prompts = [np.arange(P, dtype=np.int32) * (s + 2) % VOCAB for s in range(n_seq)]
     ref = reference(world, prompts, n_decode)
     assert res[world - 1][0] == ref                                   # tokens produced by the last stage
     assert res[0][1] == [r[:-1] for r in ref]                         # tokens rank 0 received back (all but the final one)
     for r in range(world):                                            # every rank ran every item exactly once, in item order
         log = res[r][2]
-        assert len(log) == world * (n_decode + 1)
-        assert log[:world] == [(s, P, 0) for s in range(world)]
-        assert log[world:2 * world] == [(s, 1, P) for s in range(world)]
+        assert len(log) == n_seq * (n_decode + 1)
+        assert log[:n_seq] == [(s, P, 0) for s in range(n_seq)]
+        assert log[n_seq:2 * n_seq] == [(s, 1, P) for s in range(n_seq)]
 
 
 def test_single_rank_pipeline_is_the_plain_greedy_loop():
