@@ -222,9 +222,15 @@ class LnbStage(Stage):
 
 def bench_main(args, cfg, name):
     """bench.py --gpus N under torchrun: weak scaling, N sequences in flight, one rank per GPU."""
+    import sys
     import torch
     import torch.distributed as dist
     import lnb
+    # librccl prints a version banner to the C stdout (flushed at exit, i.e. AFTER anything python printed): keep the process's
+    # stdout for the one JSON line and send everything else written to fd 1 to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
     if world != args.gpus:
@@ -232,9 +238,15 @@ def bench_main(args, cfg, name):
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")           # (only used by the single-process LNB_FORCE_PIPELINE=1 run)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    backend = os.environ.get("LNB_PIPELINE_BACKEND", "nccl")      # "gloo": ranks may share a GPU (tests); the exchange is staged on the host
+    if backend == "gloo":
+        local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
-    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))   # rank -> GPU mapping is explicit
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))   # rank -> GPU mapping is explicit
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     P, W, K = args.prompt_len, args.warmup, args.steps
     seq_len = P + W + K + 8
     # 2*world sequences: the exchange of a tick overlaps the compute of another sequence's item (run_ticks); LNB_PIPELINE_OVERLAP=0
@@ -252,7 +264,7 @@ def bench_main(args, cfg, name):
     run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, t_split, t_end, state)
     torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    tmax = torch.tensor([wall], dtype=torch.float64, device=device)
+    tmax = torch.tensor([wall], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
     dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     wall = float(tmax.item())
     if rank == 0:
@@ -273,7 +285,8 @@ def bench_main(args, cfg, name):
                "roofline": {"bound": "hbm", "achieved": round(tps * B / 1e9, 1), "peak": _b.PEAK_HBM_GBS * world, "unit": "GB/s",
                             "frac": round(tps * B / 1e9 / (_b.PEAK_HBM_GBS * world), 4), "traffic": None,
                             "note": "whole job: tokens/s x algorithmic bytes per token over N x 8 TB/s"}}
-        print(json.dumps(res))
+        os.write(json_fd, (json.dumps(res) + "\n").encode())
+    os.close(json_fd)
     stage.close()
     dist.destroy_process_group()
     return 0

@@ -375,6 +375,29 @@ def test_pipeline_two_processes_share_one_gpu(lnb, mult):
     assert r.returncode == 0 and "PIPELINE_TWO_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("overlap", ["1", "0"])
+def test_bench_two_ranks_prints_exactly_one_json_line(lnb, overlap):
+    """The driver's N > 1 launch line (torch.distributed.run ... bench.py --gpus 2) end to end -- timed windows, barrier, max over
+    ranks, rank-0 JSON -- with the two ranks sharing this GPU over gloo (LNB_PIPELINE_BACKEND; RCCL needs one GPU per rank)."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
+                        "--model", "tiny", "--prompt-len", "20"], capture_output=True, text=True, timeout=600, cwd=root,
+                       env=dict(os.environ, LNB_PIPELINE_BACKEND="gloo", LNB_PIPELINE_OVERLAP=overlap))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert d["config"]["sequences_in_flight"] == (4 if overlap == "1" else 2)
+    assert abs(d["value"] - 6 * d["config"]["sequences_in_flight"] / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-3
+
+
 def test_pipeline_stage_hidden_views_are_zero_copy_torch_tensors(lnb, tiny_pair):
     """pipeline.LnbStage (what `bench.py --gpus N` runs on every rank): the hidden state that RCCL sends/receives is a torch
     view of the library's own device buffer (CUDA array interface).  Two logical stages on this GPU, the hand-off done
