@@ -47,6 +47,11 @@ int lnb_device_count(int* out_count);
  * plus tok_embeddings when layer_begin == 0 and norm + output when layer_end == n_layers.
  * layer_begin=0, layer_end=n_layers is the whole model on one GPU. */
 int lnb_model_create(const lnb_model_args* args, int device, int layer_begin, int layer_end, lnb_model** out);
+/* The same with the range in HALF-block units (2l = attention half of block l: attention_norm, wq|wk|wv, attention, wo + residual,
+ * llamatransformer.go:222-232; 2l+1 = its feed-forward half: ffn_norm, w1|w3, w2 + residual, :237-248).  Between the halves the
+ * live state is again one [S, dim] vector, so a pipeline stage may start or end inside a block (pipeline.stage_halves balances
+ * the stages to half a block).  lnb_model_create(.., lb, le, ..) == lnb_model_create_halves(.., 2*lb, 2*le, ..). */
+int lnb_model_create_halves(const lnb_model_args* args, int device, int half_begin, int half_end, lnb_model** out);
 int lnb_model_destroy(lnb_model* m);
 
 /* FFN hidden size derivation (llamatransformer.go:569-577) */

@@ -57,7 +57,8 @@ struct LayerW {
 };
 struct lnb_model {
     lnb_model_args a{};
-    int device = 0, layer_begin = 0, layer_end = 0;
+    int device = 0, layer_begin = 0, layer_end = 0;      // layers this handle touches
+    int half_begin = 0, half_end = 0;                     // ... in half-block units: 2l = attention half of layer l, 2l+1 = its FFN half
     int head_dim = 0, n_rep = 0, ffn_hidden = 0, q_dim = 0, kv_dim = 0;
     uint16_t* tok_embd = nullptr; uint16_t* norm = nullptr; TiledDesc output{};
     std::vector<LayerW> layers;           // indexed by absolute layer id - layer_begin
@@ -67,8 +68,10 @@ struct lnb_model {
     hipStream_t stream = nullptr;
     bool finalized = false;
     int64_t weight_bytes = 0;
-    bool first() const { return layer_begin == 0; }
-    bool last() const { return layer_end == a.n_layers; }
+    bool first() const { return half_begin == 0; }
+    bool last() const { return half_end == 2 * a.n_layers; }
+    bool has_attn(int l) const { return 2 * l >= half_begin && 2 * l < half_end; }
+    bool has_ffn(int l) const { return 2 * l + 1 >= half_begin && 2 * l + 1 < half_end; }
 };
 struct lnb_ctx {
     lnb_model* m = nullptr; int seq_len = 0;
@@ -132,12 +135,19 @@ static void reg_tiled(lnb_model* m, const std::string& name, TiledDesc* td, int 
 }
 
 extern "C" int lnb_model_create(const lnb_model_args* args, int device, int layer_begin, int layer_end, lnb_model** out) {
+    return lnb_model_create_halves(args, device, 2 * layer_begin, 2 * layer_end, out);
+}
+// Pipeline stages may be cut INSIDE a block: between its attention half (attn_norm, wq|wk|wv, attention, wo + residual) and its FFN
+// half (ffn_norm, w1|w3, w2 + residual) the live state is again one [S, dim] vector (llamatransformer.go:232 -> :237), so the hand-off
+// is the same as between blocks and the stages can be balanced to half a block (pipeline.stage_halves).
+extern "C" int lnb_model_create_halves(const lnb_model_args* args, int device, int half_begin, int half_end, lnb_model** out) {
     if (!args || !out) return fail("null argument");
+    const int layer_begin = half_begin / 2, layer_end = (half_end + 1) / 2;
     lnb_model_args a = *args;
     if (a.n_kv_heads < 0) a.n_kv_heads = a.n_heads;                       // llamatransformer.go:73-75
     if (a.rope_theta <= 0) a.rope_theta = 500000.0;                       // :80-82
     if (a.dim <= 0 || a.n_heads <= 0 || a.dim % a.n_heads || a.n_heads % a.n_kv_heads) return fail("invalid head configuration");
-    if (layer_begin < 0 || layer_end > a.n_layers || layer_begin >= layer_end) return fail("invalid layer range [%d,%d)", layer_begin, layer_end);
+    if (half_begin < 0 || half_end > 2 * a.n_layers || half_begin >= half_end) return fail("invalid layer range [%d,%d)", half_begin / 2, (half_end + 1) / 2);
     int hd = a.dim / a.n_heads;
     if (a.dim % 8 || hd % 8) return fail("dim and head_dim must be multiples of 8");
     int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
@@ -147,7 +157,7 @@ extern "C" int lnb_model_create(const lnb_model_args* args, int device, int laye
     HIPCHK(lnbk_init());
     { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); if (prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount; }
     lnb_model* m = new lnb_model();
-    m->a = a; m->device = device; m->layer_begin = layer_begin; m->layer_end = layer_end;
+    m->a = a; m->device = device; m->layer_begin = layer_begin; m->layer_end = layer_end; m->half_begin = half_begin; m->half_end = half_end;
     m->head_dim = hd; m->n_rep = a.n_heads / a.n_kv_heads; m->ffn_hidden = lnb_model_ffn_hidden_dim(&a);
     if (m->ffn_hidden % 8) { delete m; return fail("ffn hidden dim must be a multiple of 8"); }
     m->q_dim = a.n_heads * hd; m->kv_dim = a.n_kv_heads * hd;
@@ -162,24 +172,29 @@ extern "C" int lnb_model_create(const lnb_model_args* args, int device, int laye
     for (int l = layer_begin; l < layer_end; l++) {
         LayerW& L = m->layers[l - layer_begin];
         char nm[128]; uint32_t base = 16u * (uint32_t)(l + 1);
-        if (alloc_linear(&L.attn_norm, dim, wb) || alloc_linear(&L.ffn_norm, dim, wb)) return -1;
-        if (alloc_tiled(L.wqkv, m->q_dim + 2 * m->kv_dim, dim, auto_rw(m->q_dim + 2 * m->kv_dim, "LNB_RW_QKV"), 1, wb)) return -1;
-        if (alloc_tiled(L.wo, dim, m->q_dim, auto_rw(dim, "LNB_RW_WO", m->q_dim, true), 1, wb)) return -1;
-        {   // two-chain gate|up matrix: when the rows split into exactly one 56-row block per CU, take it (all CUs stream)
-            int rw13 = auto_rw(F, "LNB_RW_W13");
-            if (env_int("LNB_RW_W13", 0) == 0 && F == 56 * g_num_cus) rw13 = 56;
-            if (alloc_tiled(L.w13, F, dim, rw13, 2, wb)) return -1;
+        if (m->has_attn(l)) {
+            if (alloc_linear(&L.attn_norm, dim, wb)) return -1;
+            if (alloc_tiled(L.wqkv, m->q_dim + 2 * m->kv_dim, dim, auto_rw(m->q_dim + 2 * m->kv_dim, "LNB_RW_QKV"), 1, wb)) return -1;
+            if (alloc_tiled(L.wo, dim, m->q_dim, auto_rw(dim, "LNB_RW_WO", m->q_dim, true), 1, wb)) return -1;
+            snprintf(nm, sizeof nm, "layers.%d.attention_norm.weight", l); reg_linear(m, nm, L.attn_norm, dim, base + 0, 1);
+            snprintf(nm, sizeof nm, "layers.%d.attention.wq.weight", l); reg_tiled(m, nm, &L.wqkv, m->q_dim, dim, 0, 0, base + 1);
+            snprintf(nm, sizeof nm, "layers.%d.attention.wk.weight", l); reg_tiled(m, nm, &L.wqkv, m->kv_dim, dim, m->q_dim, 0, base + 2);
+            snprintf(nm, sizeof nm, "layers.%d.attention.wv.weight", l); reg_tiled(m, nm, &L.wqkv, m->kv_dim, dim, m->q_dim + m->kv_dim, 0, base + 3);
+            snprintf(nm, sizeof nm, "layers.%d.attention.wo.weight", l); reg_tiled(m, nm, &L.wo, dim, m->q_dim, 0, 0, base + 4);
         }
-        if (alloc_tiled(L.w2, dim, F, auto_rw(dim, "LNB_RW_W2", F, true), 1, wb)) return -1;
-        snprintf(nm, sizeof nm, "layers.%d.attention_norm.weight", l); reg_linear(m, nm, L.attn_norm, dim, base + 0, 1);
-        snprintf(nm, sizeof nm, "layers.%d.attention.wq.weight", l); reg_tiled(m, nm, &L.wqkv, m->q_dim, dim, 0, 0, base + 1);
-        snprintf(nm, sizeof nm, "layers.%d.attention.wk.weight", l); reg_tiled(m, nm, &L.wqkv, m->kv_dim, dim, m->q_dim, 0, base + 2);
-        snprintf(nm, sizeof nm, "layers.%d.attention.wv.weight", l); reg_tiled(m, nm, &L.wqkv, m->kv_dim, dim, m->q_dim + m->kv_dim, 0, base + 3);
-        snprintf(nm, sizeof nm, "layers.%d.attention.wo.weight", l); reg_tiled(m, nm, &L.wo, dim, m->q_dim, 0, 0, base + 4);
-        snprintf(nm, sizeof nm, "layers.%d.ffn_norm.weight", l); reg_linear(m, nm, L.ffn_norm, dim, base + 5, 1);
-        snprintf(nm, sizeof nm, "layers.%d.feed_forward.w1.weight", l); reg_tiled(m, nm, &L.w13, F, dim, 0, 0, base + 6);
-        snprintf(nm, sizeof nm, "layers.%d.feed_forward.w2.weight", l); reg_tiled(m, nm, &L.w2, dim, F, 0, 0, base + 7);
-        snprintf(nm, sizeof nm, "layers.%d.feed_forward.w3.weight", l); reg_tiled(m, nm, &L.w13, F, dim, 0, 1, base + 8);
+        if (m->has_ffn(l)) {
+            if (alloc_linear(&L.ffn_norm, dim, wb)) return -1;
+            {   // two-chain gate|up matrix: when the rows split into exactly one 56-row block per CU, take it (all CUs stream)
+                int rw13 = auto_rw(F, "LNB_RW_W13");
+                if (env_int("LNB_RW_W13", 0) == 0 && F == 56 * g_num_cus) rw13 = 56;
+                if (alloc_tiled(L.w13, F, dim, rw13, 2, wb)) return -1;
+            }
+            if (alloc_tiled(L.w2, dim, F, auto_rw(dim, "LNB_RW_W2", F, true), 1, wb)) return -1;
+            snprintf(nm, sizeof nm, "layers.%d.ffn_norm.weight", l); reg_linear(m, nm, L.ffn_norm, dim, base + 5, 1);
+            snprintf(nm, sizeof nm, "layers.%d.feed_forward.w1.weight", l); reg_tiled(m, nm, &L.w13, F, dim, 0, 0, base + 6);
+            snprintf(nm, sizeof nm, "layers.%d.feed_forward.w2.weight", l); reg_tiled(m, nm, &L.w2, dim, F, 0, 0, base + 7);
+            snprintf(nm, sizeof nm, "layers.%d.feed_forward.w3.weight", l); reg_tiled(m, nm, &L.w13, F, dim, 0, 1, base + 8);
+        }
     }
     if (m->last()) {
         if (alloc_linear(&m->norm, dim, wb)) return -1;
@@ -399,7 +414,7 @@ extern "C" int lnb_ctx_reset(lnb_ctx* c) {
 extern "C" int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which, uint16_t* host) {
     if (!c || !host) return fail("null argument");
     HIPCHK(hipSetDevice(c->m->device));
-    if (layer < c->m->layer_begin || layer >= c->m->layer_end) return fail("layer %d is not owned by this stage", layer);
+    if (layer < c->m->layer_begin || layer >= c->m->layer_end || !c->m->has_attn(layer)) return fail("layer %d is not owned by this stage", layer);
     const size_t kvn = (size_t)c->seq_len * c->m->kv_dim;
     HIPCHK(hipStreamSynchronize(c->stream));
     if (which) { HIPCHK(hipMemcpy(host, c->cv[layer - c->m->layer_begin], kvn * 2, hipMemcpyDeviceToHost)); return 0; }
@@ -431,6 +446,10 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = c->stream;
     LayerW& L = m->layers[l - m->layer_begin];
     uint16_t* ck = c->ck[l - m->layer_begin]; uint16_t* cv = c->cv[l - m->layer_begin];
+    // h = x + attention (llamatransformer.go:232) normally has its own buffer; in a block this stage holds only one half of, it
+    // lives in x itself (the residual epilogues read and write element n from the same lane, so out may alias res): the half-block
+    // hand-off is then the same buffer as the block hand-off
+    uint16_t* const hbuf = (m->has_attn(l) && m->has_ffn(l)) ? c->h : c->x;
     if (use_mfma(S) && which != K_ATTN) {
         switch (which) {
         case K_QKV: {
@@ -438,12 +457,12 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
             GemmParams g = gemm_of(L.wqkv, c->xn, a.dim, L.wqkv.n_rows, S, c->st);
             g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.seq_len = c->seq_len; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
             HIPCHK(lnbk_gemm(&g, EPI_QKV_ROPE, st)); return 0; }
-        case K_WO: { GemmParams g = gemm_of(L.wo, c->att, m->q_dim, a.dim, S, c->st); g.out = c->h; g.res = c->x; HIPCHK(lnbk_gemm(&g, EPI_RESID, st)); return 0; }
+        case K_WO: { GemmParams g = gemm_of(L.wo, c->att, m->q_dim, a.dim, S, c->st); g.out = hbuf; g.res = c->x; HIPCHK(lnbk_gemm(&g, EPI_RESID, st)); return 0; }
         case K_W13: {
-            HIPCHK(lnbk_rmsnorm_rows(c->h, L.ffn_norm, c->xn, S, a.dim, a.norm_eps, st));
+            HIPCHK(lnbk_rmsnorm_rows(hbuf, L.ffn_norm, c->xn, S, a.dim, a.norm_eps, st));
             GemmParams g = gemm_of(L.w13, c->xn, a.dim, m->ffn_hidden, S, c->st); g.out = c->ffn; g.silu = m->silu;
             HIPCHK(lnbk_gemm(&g, EPI_SILU_MUL, st)); return 0; }
-        case K_W2: { GemmParams g = gemm_of(L.w2, c->ffn, m->ffn_hidden, a.dim, S, c->st); g.out = c->x; g.res = c->h; HIPCHK(lnbk_gemm(&g, EPI_RESID, st)); return 0; }
+        case K_W2: { GemmParams g = gemm_of(L.w2, c->ffn, m->ffn_hidden, a.dim, S, c->st); g.out = c->x; g.res = hbuf; HIPCHK(lnbk_gemm(&g, EPI_RESID, st)); return 0; }
         }
     }
     switch (which) {
@@ -458,14 +477,14 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
         ap.mfma = use_mfma(S) ? 1 : 0;
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
-        GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = c->h; o.res = c->x;
+        GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x;
         set_grid(o, L.wo); HIPCHK(lnbk_gemv(&o, L.wo.rw, 1, EPI_RESID, 0, st)); return 0; }
     case K_W13: {   // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
-        GemvParams f{}; f.w = L.w13.w; f.x = c->h; f.norm_w = L.ffn_norm; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
+        GemvParams f{}; f.w = L.w13.w; f.x = hbuf; f.norm_w = L.ffn_norm; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
         f.out = c->ffn; f.silu = m->silu;
         set_grid(f, L.w13); HIPCHK(lnbk_gemv(&f, L.w13.rw, 2, EPI_SILU_MUL, 1, st)); return 0; }
     case K_W2: {    // w2 + residual  (:619, :248)
-        GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = c->h;
+        GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = hbuf;
         set_grid(d, L.w2); HIPCHK(lnbk_gemv(&d, L.w2.rw, 1, EPI_RESID, 0, st)); return 0; }
     }
     return fail("bad kernel id");
@@ -474,7 +493,10 @@ static int enqueue_layers(lnb_ctx* c, int S, bool with_cb) {
     lnb_model* m = c->m;
     for (int l = m->layer_begin; l < m->layer_end; l++) {
         auto t0 = std::chrono::steady_clock::now();
-        for (int k = K_QKV; k <= K_W2; k++) if (enqueue_layer_kernel(c, l, S, k)) return -1;
+        for (int k = K_QKV; k <= K_W2; k++) {
+            if (!(k <= K_WO ? m->has_attn(l) : m->has_ffn(l))) continue;     // a stage may hold only one half of its first / last block
+            if (enqueue_layer_kernel(c, l, S, k)) return -1;
+        }
         if (with_cb && c->cb) {
             HIPCHK(hipStreamSynchronize(c->stream));
             double secs = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

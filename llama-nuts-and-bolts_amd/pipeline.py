@@ -182,6 +182,55 @@ def stage_layers(rank, world, n_layers, head_cost=1.2):
     return cuts[rank], cuts[rank + 1]
 
 
+def half_costs(cfg, ffn_hidden):
+    """(attention half, FFN half, head) in microseconds of one decode step: weight megabytes x the per-MB time of the kernel class
+    that streams them, measured on the 8B shape (thin fused-norm and row-broadcast GEMVs ~0.48, w2 0.38, the fat
+    w1|w3 0.20, the output projection 0.16 us/MB; ~8 us for the attention kernel itself)."""
+    dim, hd = cfg["dim"], cfg["dim"] // cfg["n_heads"]
+    kv = (cfg["n_kv_heads"] if cfg.get("n_kv_heads", -1) > 0 else cfg["n_heads"]) * hd
+    mb = 2.0 / 1e6
+    attn = 0.48 * (dim * (dim + 2 * kv) + dim * dim) * mb + 8.0
+    ffn = 0.20 * (2 * ffn_hidden * dim) * mb + 0.38 * (ffn_hidden * dim) * mb
+    head = 0.16 * (cfg["vocab_size"] * dim) * mb
+    return attn, ffn, head
+
+
+def stage_halves(rank, world, n_layers, attn_cost=0.35, ffn_cost=0.65, head_cost=1.2):
+    """[half_begin, half_end) of pipeline stage `rank` in half-block units (2l = attention half of block l, 2l+1 = its FFN half;
+    lnb_model_create_halves).  Contiguous partition of the 2*n_layers halves into `world` non-empty stages that minimises the slowest
+    stage (= the tick of the pipeline), the last stage also carrying the head: binary search on the bound + greedy fill.  8B shape
+    on 8 GPUs: the slowest stage drops from 5 blocks (698 us) to ~4.3 (~600 us)."""
+    n = 2 * n_layers
+    if world > n:
+        raise ValueError("more pipeline stages (%d) than half blocks (%d)" % (world, n))
+    cost = [attn_cost if u % 2 == 0 else ffn_cost for u in range(n)]
+    cost[-1] += head_cost
+
+    def cuts_for(bound):
+        cuts, acc = [0], 0.0
+        for u in range(n):
+            if acc > 0 and acc + cost[u] > bound:
+                cuts.append(u); acc = 0.0
+            acc += cost[u]
+            if cost[u] > bound:
+                return None
+        cuts.append(n)
+        return cuts if len(cuts) - 1 <= world else None
+
+    lo, hi = max(cost), sum(cost)
+    for _ in range(60):
+        mid = 0.5 * (lo + hi)
+        if cuts_for(mid) is None:
+            lo = mid
+        else:
+            hi = mid
+    cuts = cuts_for(hi)
+    while len(cuts) - 1 < world:                              # fewer stages than ranks: split the longest (in halves) splittable stage
+        j = max(range(len(cuts) - 1), key=lambda q: cuts[q + 1] - cuts[q])
+        cuts.insert(j + 1, (cuts[j] + cuts[j + 1] + 1) // 2)
+    return cuts[rank], cuts[rank + 1]
+
+
 class LnbStage(Stage):
     """One GPU's share of the model behind the C ABI (lnb_forward_stage)."""
 
@@ -189,9 +238,12 @@ class LnbStage(Stage):
         import ctypes as C
         self.lnb, self.torch, self.C = lnb, torch, C
         L = cfg["n_layers"]
-        lb, le = stage_layers(rank, world, L)
         self.first, self.last = rank == 0, rank == world - 1
-        self.model = lnb.LlamaTransformer(device=device_index, layer_begin=lb, layer_end=le, **cfg).fill_synthetic(1234)
+        probe = lnb.ModelArgs(**dict(lnb.LLAMA_8B, **cfg))
+        self.costs = half_costs(cfg, lnb.lib().lnb_model_ffn_hidden_dim(C.byref(probe)))
+        hb, he = stage_halves(rank, world, L, *self.costs)
+        self.halves = (hb, he)
+        self.model = lnb.LlamaTransformer(device=device_index, half_begin=hb, half_end=he, **cfg).fill_synthetic(1234)
         self.model.finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"]))
         self.ctx = [lnb.InferenceContext(self.model, seq_len) for _ in range(n_seq)]
         self.dim, self.device_index = cfg["dim"], device_index
@@ -278,8 +330,9 @@ def bench_main(args, cfg, name):
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "%s bf16, %dxMI355X layer pipeline (blocks per GPU %s), RCCL p2p hidden-state hand-off, %d sequences in flight, "
-                                      "prompt %d -> +%d tokens each" % (name, world, ",".join(str(stage_layers(r, world, cfg["n_layers"])[1] - stage_layers(r, world, cfg["n_layers"])[0])
-                                                                                                 for r in range(world)), n_seq, P, K),
+                                      "prompt %d -> +%d tokens each" % (name, world, ",".join("%g" % ((stage_halves(r, world, cfg["n_layers"], *stage.costs)[1]
+                                                                                                         - stage_halves(r, world, cfg["n_layers"], *stage.costs)[0]) / 2.0)
+                                                                                                for r in range(world)), n_seq, P, K),
                           "prompt_len": P, "sequences_in_flight": n_seq, "parallelism": "pp%d" % world,
                           "mode": "exact-order (token-id identical to the CPU reference path)"},
                "roofline": {"bound": "hbm", "achieved": round(tps * B / 1e9, 1), "peak": _b.PEAK_HBM_GBS * world, "unit": "GB/s",

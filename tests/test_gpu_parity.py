@@ -359,6 +359,50 @@ def test_pipeline_stages_on_one_device_equal_whole_model(lnb, tiny_pair):
     s0.close(); s1.close()
 
 
+@pytest.mark.parametrize("cuts,rows", [((0, 1, 3, 4), 6), ((0, 3, 4), 6), ((0, 1, 2, 3, 4), 24), ((0, 2, 3, 4), 1)])
+def test_pipeline_stages_cut_inside_a_block(lnb, tiny_pair, cuts, rows):
+    """lnb_model_create_halves: stages that start or end between a block's attention half and its FFN half (the hand-off there is again
+    one [S, dim] vector).  Prefill (GEMV rows and the matrix-core path) and a decode step through every chain of stages must give the
+    oracle's logits bit for bit; a stage refuses tensors of the half it does not hold."""
+    import ctypes as C
+    om, _ = tiny_pair
+    L = lnb.lib()
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    stages = [lnb.LlamaTransformer(half_begin=a, half_end=b, **TINY).fill_synthetic(1234).finalize() for a, b in zip(cuts[:-1], cuts[1:])]
+    ctxs = [lnb.InferenceContext(s, 64) for s in stages]
+    oc = orc.Context(om, 64)
+    toks = orc.synth_tokens(3, rows + 2, TINY["vocab_size"])
+
+    def through(tok, pos):
+        t = np.ascontiguousarray(tok, dtype=np.int32)
+        logits = np.empty((len(t), TINY["vocab_size"]), dtype=np.float32)
+        am = C.c_int32(-2)
+        for q, c in enumerate(ctxs):
+            lastq = q == len(ctxs) - 1
+            lnb._chk(L.lnb_forward_stage(c.h, lnb._p(t) if q == 0 else None, len(t), pos, lnb._p(logits) if lastq else None, C.byref(am) if lastq else None))
+            if not lastq:
+                assert hip.hipMemcpy(L.lnb_ctx_hidden_ptr(ctxs[q + 1].h, 0), L.lnb_ctx_hidden_ptr(c.h, 1), len(t) * TINY["dim"] * 2, 3) == 0
+        return logits, am.value
+
+    for lo_, hi_ in ((0, rows), (rows, rows + 1), (rows + 1, rows + 2)):
+        ref, ra = oc.forward(toks[lo_:hi_], lo_)
+        got, ga = through(toks[lo_:hi_], lo_)
+        assert (ref.view(np.uint32) == got.view(np.uint32)).all() and ra == ga
+    for s, (a, b) in zip(stages, zip(cuts[:-1], cuts[1:])):
+        held = {n for n, _ in s.tensor_infos()} if hasattr(s, "tensor_infos") else set()
+        for l in range(TINY["n_layers"]):
+            assert ("layers.%d.attention.wq.weight" % l in held) == (a <= 2 * l < b)
+            assert ("layers.%d.feed_forward.w2.weight" % l in held) == (a <= 2 * l + 1 < b)
+    with pytest.raises(lnb.LnbError):
+        lnb.LlamaTransformer(half_begin=3, half_end=3, **TINY)
+    oc.close()
+    for c in ctxs:
+        c.close()
+    for s in stages:
+        s.close()
+
+
 @pytest.mark.parametrize("mult", [2, 1])
 def test_pipeline_two_processes_share_one_gpu(lnb, mult):
     """bench.py --gpus 2 in miniature: two torch.distributed ranks (gloo), each with half of the blocks on cuda:0, exchanging the
