@@ -1700,7 +1700,8 @@ template <int EPI, int NCH> static hipError_t launch_gemm(const GemmParams* p, h
         return e != hipSuccess ? e : hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     }
     const unsigned mb = (unsigned)((p->S + GM_MB - 1) / GM_MB), nb4 = (unsigned)((p->n_rows + GM_NB - 1) / GM_NB);
-    if (nb4 * mb < 128)        // 64-row tiles would leave most CUs idle: 16-row tiles, the four waves split the batch rows
+    if (nb4 * mb <= 160)       // 64-row tiles would leave most CUs idle: 16-row tiles, the four waves split the batch rows
+                               // (tools/gemmbench.hip: 64 / 96 / 128 tiles: 1.4-2x faster; 256 tiles and up: 64-row tiles win)
         hipLaunchKernelGGL(k1, dim3((unsigned)((p->n_rows + 15) / 16), mb), dim3(256), lds1, st, *p);
     else
         hipLaunchKernelGGL(k4, dim3(nb4, mb), dim3(256), lds4, st, *p);
