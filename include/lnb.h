@@ -116,6 +116,11 @@ void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which);
  * hidden state must already be in hidden_ptr(0).  On the last stage logits_out/argmax_last_out behave as in
  * lnb_forward; on other stages they must be NULL and the result is left in hidden_ptr(1). */
 int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, float* logits_out, int32_t* argmax_last_out);
+/* The same in two halves, for a pipeline rank that exchanges hidden states with its neighbours WHILE the stage computes: _begin
+ * enqueues the stage on the ctx's stream and returns (want_argmax: last stage only, norm + output + argmax of the last row, as
+ * inference.go:207-211 needs); _end blocks until it has finished and returns the token.  One begin per end. */
+int lnb_forward_stage_begin(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, int want_argmax);
+int lnb_forward_stage_end(lnb_ctx* c, int32_t* argmax_last_out);
 /* block the calling thread until everything enqueued for this ctx has finished */
 int lnb_ctx_synchronize(lnb_ctx* c);
 /* raw HIP stream (hipStream_t) the ctx enqueues on, for event timing by the caller */

@@ -85,6 +85,8 @@ struct lnb_ctx {
     hipGraphExec_t graph = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     lnb_layer_cb cb = nullptr; void* cb_user = nullptr;
+    int32_t* h_io = nullptr;               // pinned host words of lnb_forward_stage_begin/_end: [0] argmax, [1] token error, [2..] tokens
+    bool pending = false, pending_tokens = false, pending_argmax = false;
 };
 
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
@@ -395,6 +397,7 @@ extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     for (auto p : c->ck) hipFree(p);
     for (auto p : c->cv) hipFree(p);
     hipFree(c->st); hipFree(c->dtok); hipFree(c->dnext); hipFree(c->derr); hipFree(c->dout);
+    if (c->h_io) hipHostFree(c->h_io);
     hipFree(c->x); hipFree(c->h); hipFree(c->xn); hipFree(c->q); hipFree(c->att); hipFree(c->ffn); if (c->logits) hipFree(c->logits);
     hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
     hipStreamDestroy(c->stream);
@@ -528,6 +531,52 @@ static int check_call(lnb_ctx* c, int seq, int start_pos) {
     if (T > c->m->cis_rows) return fail("incompatible locStart, locEnd values and tensor (position %d beyond the %d-row RoPE table)", T, c->m->cis_rows);
     if (T > c->seq_len) return fail("incompatible locStart, locEnd values and tensor (position %d beyond the KV cache of %d)", T, c->seq_len);
     if (seq > 1 && T % seq != 0) return fail("two tensor shapes cannot be broadcasted: [%d %d %d] and [%d %d]", c->m->a.n_heads, seq, T, seq, seq);
+    return 0;
+}
+
+// lnb_forward_stage split in two so that a pipeline rank can put its exchange with the neighbouring ranks in flight while the stage
+// computes: _begin enqueues the whole stage (embedding gather on the first stage, the blocks, norm + output + argmax on the last
+// when want_argmax) on the ctx's stream and returns; _end waits for it and reports the token / the vocabulary check.
+extern "C" int lnb_forward_stage_begin(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, int want_argmax) {
+    if (!c) return fail("null argument");
+    lnb_model* m = c->m; const int V = m->a.vocab_size;
+    HIPCHK(hipSetDevice(m->device));
+    if (c->pending) return fail("lnb_forward_stage_begin: the previous call has not been ended");
+    if (check_call(c, seq, start_pos)) return -1;
+    if (tokens && !m->first()) return fail("tokens given to a stage that does not own tok_embeddings");
+    if (!tokens && m->first()) return fail("first stage needs tokens");
+    if (want_argmax && !m->last()) return fail("logits requested from a stage that does not own output.weight");
+    if (!c->h_io) HIPCHK(hipHostMalloc((void**)&c->h_io, ((size_t)c->seq_len + 2) * 4, hipHostMallocDefault));
+    hipStream_t st = c->stream;
+    HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
+    if (tokens) {
+        memcpy(c->h_io + 2, tokens, (size_t)seq * 4);        // the caller's array need not outlive this call
+        HIPCHK(hipMemcpyAsync(c->dtok, c->h_io + 2, (size_t)seq * 4, hipMemcpyHostToDevice, st));
+        HIPCHK(hipMemsetAsync(c->derr, 0, 4, st));
+        HIPCHK(lnbk_embed(m->tok_embd, c->dtok, c->x, seq, m->a.dim, V, c->derr, st));       // Fwd_Get_Rows :118
+        HIPCHK(hipMemcpyAsync(c->h_io + 1, c->derr, 4, hipMemcpyDeviceToHost, st));
+    }
+    if (enqueue_layers(c, seq, false)) return -1;
+    if (want_argmax) {
+        if (c->logits_rows < 1) { HIPCHK(hipMalloc((void**)&c->logits, (size_t)V * 2)); c->logits_rows = 1; }
+        if (enqueue_head(c, seq - 1, 1)) return -1;
+        HIPCHK(lnbk_argmax(c->logits, V, c->dnext, c->st, c->dout, c->dout_cap, 0, st));        // inference.go:207-211
+        HIPCHK(hipMemcpyAsync(c->h_io, c->dnext, 4, hipMemcpyDeviceToHost, st));
+    }
+    c->pending = true; c->pending_tokens = tokens != nullptr; c->pending_argmax = want_argmax != 0;
+    return 0;
+}
+extern "C" int lnb_forward_stage_end(lnb_ctx* c, int32_t* argmax_last_out) {
+    if (!c) return fail("null argument");
+    if (!c->pending) return fail("lnb_forward_stage_end without a begin");
+    HIPCHK(hipSetDevice(c->m->device));
+    c->pending = false;
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->pending_tokens && c->h_io[1]) return fail("token id at index %d is outside the vocabulary", c->h_io[1] - 1);
+    if (argmax_last_out) {
+        if (!c->pending_argmax) return fail("lnb_forward_stage_end: no argmax was requested at begin");
+        *argmax_last_out = c->h_io[0];
+    }
     return 0;
 }
 

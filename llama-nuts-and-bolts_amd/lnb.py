@@ -46,7 +46,7 @@ EXPORTS = [
     "lnb_model_set_tensor", "lnb_model_get_tensor", "lnb_model_fill_synthetic", "lnb_model_finalize",
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
-    "lnb_forward_stage", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear",
+    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear",
     "lnb_profile_kernel", "lnb_model_num_tensors", "lnb_model_tensor_info",
     "lnb_checkpoint_open", "lnb_checkpoint_close", "lnb_checkpoint_num_tensors", "lnb_checkpoint_find", "lnb_checkpoint_tensor",
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
@@ -86,6 +86,8 @@ def lib():
     L.lnb_ctx_hidden_ptr.argtypes = [vp, C.c_int]
     L.lnb_ctx_hidden_ptr.restype = vp
     L.lnb_forward_stage.argtypes = [vp, vp, C.c_int, C.c_int, vp, i32p]
+    L.lnb_forward_stage_begin.argtypes = [vp, vp, C.c_int, C.c_int, C.c_int]
+    L.lnb_forward_stage_end.argtypes = [vp, i32p]
     L.lnb_ctx_synchronize.argtypes = [vp]
     L.lnb_ctx_stream.argtypes = [vp]
     L.lnb_ctx_stream.restype = vp

@@ -39,6 +39,15 @@ class Stage:
     def synchronize(self):
         pass
 
+    # non-blocking form used by the overlapped schedule: launch() starts the item, collect() waits for it and returns what run() would
+    def launch(self, seq, rows, start_pos, tokens):
+        self._result = self.run(seq, rows, start_pos, tokens)
+
+    def collect(self):
+        self.synchronize()
+        r, self._result = self._result, None
+        return r
+
 
 def schedule(rank, world, n_phases, n_seq=None, gap=1):
     """yield (tick, item_index or None) for this rank; item i = (phase i // n_seq, seq i % n_seq); rank r runs item t - gap*r at tick t"""
@@ -126,7 +135,7 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
         if works and device != "cpu":
             torch.cuda.synchronize()       # RCCL and the copies ran on torch's streams; the HIP library has its own
 
-    def compute(item):
+    def launch(item):                                         # starts the item on the stage's own stream and returns
         k, s = divmod(item, n_seq)
         if k == 0:
             rows, pos, toks = P, 0, (np.ascontiguousarray(prompts[s], dtype=np.int32) if first else None)
@@ -136,10 +145,12 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
                 tok = state["tok_next"] if world > 1 else state["produced"][s][-1]
                 state["received"][s].append(tok)
                 toks = np.array([tok], dtype=np.int32)
-        out = stage.run(s, rows, pos, toks)
+        stage.launch(s, rows, pos, toks)
+
+    def collect(item):
+        out = stage.collect()
         if last:
-            state["produced"][s].append(int(out))
-        stage.synchronize()
+            state["produced"][item % n_seq].append(int(out))
         return int(out) if last else None
 
     for t, item in schedule(rank, world, n_phases, n_seq, gap):
@@ -150,15 +161,18 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
         if overlap:
             nxt_item = t + 1 - gap * rank
             nxt_item = nxt_item if 0 <= nxt_item < n_items else None
-            pending = post(state["prev"], nxt_item)           # in flight during this tick's compute
-            tok = compute(item) if item is not None else None
+            if item is not None:
+                launch(item)                                  # the stage computes on its own stream ...
+            pending = post(state["prev"], nxt_item)           # ... while the exchange runs on the backend's
+            tok = collect(item) if item is not None else None
             finish(*pending)
             if tok is not None:
                 tok_out.fill_(tok)                            # (after the send of the previous token has completed)
         else:
             finish(*post(state["prev"], item))
             if item is not None:
-                tok = compute(item)
+                launch(item)
+                tok = collect(item)
                 if tok is not None:
                     tok_out.fill_(tok)
         state["prev"] = item
@@ -264,6 +278,16 @@ class LnbStage(Stage):
         am = C.c_int32(-2)
         tok_p = tokens.ctypes.data_as(C.c_void_p) if tokens is not None else None
         self.lnb._chk(L.lnb_forward_stage(self.ctx[seq].h, tok_p, rows, start_pos, None, C.byref(am) if self.last else None))
+        return am.value if self.last else None
+
+    def launch(self, seq, rows, start_pos, tokens):           # lnb_forward_stage_begin: enqueue and return
+        tok_p = tokens.ctypes.data_as(self.C.c_void_p) if tokens is not None else None
+        self.lnb._chk(self.lnb.lib().lnb_forward_stage_begin(self.ctx[seq].h, tok_p, rows, start_pos, 1 if self.last else 0))
+        self._inflight = seq
+
+    def collect(self):                                        # lnb_forward_stage_end: wait, return the last stage's token
+        am = self.C.c_int32(-2)
+        self.lnb._chk(self.lnb.lib().lnb_forward_stage_end(self.ctx[self._inflight].h, self.C.byref(am) if self.last else None))
         return am.value if self.last else None
 
     def close(self):

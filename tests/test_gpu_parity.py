@@ -403,6 +403,33 @@ def test_pipeline_stages_cut_inside_a_block(lnb, tiny_pair, cuts, rows):
         s.close()
 
 
+def test_forward_stage_begin_end_equals_forward_stage(lnb, tiny_pair):
+    """the non-blocking halves of lnb_forward_stage (what a pipeline rank overlaps its exchange with): same token, one begin per end"""
+    import ctypes as C
+    _, gm = tiny_pair
+    L = lnb.lib()
+    toks = np.ascontiguousarray(orc.synth_tokens(11, 20, TINY["vocab_size"]), dtype=np.int32)
+    a, b = lnb.InferenceContext(gm, 40), lnb.InferenceContext(gm, 40)
+    ref, got = C.c_int32(-2), C.c_int32(-3)
+    lnb._chk(L.lnb_forward_stage(a.h, lnb._p(toks), 20, 0, None, C.byref(ref)))
+    with pytest.raises(lnb.LnbError, match="without a begin"):
+        lnb._chk(L.lnb_forward_stage_end(b.h, C.byref(got)))
+    lnb._chk(L.lnb_forward_stage_begin(b.h, lnb._p(toks), 20, 0, 1))
+    with pytest.raises(lnb.LnbError, match="has not been ended"):
+        lnb._chk(L.lnb_forward_stage_begin(b.h, lnb._p(toks), 20, 0, 1))
+    lnb._chk(L.lnb_forward_stage_end(b.h, C.byref(got)))
+    assert ref.value == got.value
+    one = np.array([ref.value], dtype=np.int32)
+    lnb._chk(L.lnb_forward_stage(a.h, lnb._p(one), 1, 20, None, C.byref(ref)))
+    lnb._chk(L.lnb_forward_stage_begin(b.h, lnb._p(one), 1, 20, 1)); lnb._chk(L.lnb_forward_stage_end(b.h, C.byref(got)))
+    assert ref.value == got.value
+    bad = np.array([TINY["vocab_size"] + 5], dtype=np.int32)
+    lnb._chk(L.lnb_forward_stage_begin(b.h, lnb._p(bad), 1, 21, 0))
+    with pytest.raises(lnb.LnbError, match="outside the vocabulary"):
+        lnb._chk(L.lnb_forward_stage_end(b.h, None))
+    a.close(); b.close()
+
+
 @pytest.mark.parametrize("mult", [2, 1])
 def test_pipeline_two_processes_share_one_gpu(lnb, mult):
     """bench.py --gpus 2 in miniature: two torch.distributed ranks (gloo), each with half of the blocks on cuda:0, exchanging the
