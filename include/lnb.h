@@ -47,11 +47,13 @@ int lnb_device_count(int* out_count);
  * plus tok_embeddings when layer_begin == 0 and norm + output when layer_end == n_layers.
  * layer_begin=0, layer_end=n_layers is the whole model on one GPU. */
 int lnb_model_create(const lnb_model_args* args, int device, int layer_begin, int layer_end, lnb_model** out);
-/* The same with the range in HALF-block units (2l = attention half of block l: attention_norm, wq|wk|wv, attention, wo + residual,
- * llamatransformer.go:222-232; 2l+1 = its feed-forward half: ffn_norm, w1|w3, w2 + residual, :237-248).  Between the halves the
- * live state is again one [S, dim] vector, so a pipeline stage may start or end inside a block (pipeline.stage_halves balances
- * the stages to half a block).  lnb_model_create(.., lb, le, ..) == lnb_model_create_halves(.., 2*lb, 2*le, ..). */
-int lnb_model_create_halves(const lnb_model_args* args, int device, int half_begin, int half_end, lnb_model** out);
+/* The same with the range in THIRDS of a block: 3l = attention part of block l (attention_norm, wq|wk|wv, attention, wo + residual,
+ * llamatransformer.go:222-232), 3l+1 = gate/up part (ffn_norm, w1|w3, SiLU*up, :237, :601-617), 3l+2 = down part (w2 + residual,
+ * :619, :248).  A pipeline stage may start or end inside a block: after the attention part the live state is again one [S, dim]
+ * vector; after the gate/up part it is that vector plus the [S, ffn_hidden] activations (lnb_ctx_hidden_ptr(c, 2)).  The parts cost
+ * about the same HBM time, so pipeline.stage_parts balances the stages to a third of a block.
+ * lnb_model_create(.., lb, le, ..) == lnb_model_create_parts(.., 3*lb, 3*le, ..). */
+int lnb_model_create_parts(const lnb_model_args* args, int device, int part_begin, int part_end, lnb_model** out);
 int lnb_model_destroy(lnb_model* m);
 
 /* FFN hidden size derivation (llamatransformer.go:569-577) */
@@ -110,7 +112,8 @@ int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int
 
 /* ---- pipeline-stage form (layer-sharded multi-GPU) -------------------------------
  * hidden state buffers live on the device and are owned by the ctx: [seq_len, dim] bf16.
- * which: 0 = stage input, 1 = stage output.  RCCL send/recv (done by the host layer) targets these pointers. */
+ * which: 0 = stage input, 1 = stage output, 2 = the [seq_len, ffn_hidden] gate*up activations, part of the hand-off when the
+ * stage boundary lies between a block's gate/up and down parts.  RCCL send/recv (done by the host layer) targets these pointers. */
 void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which);
 /* Runs this stage's layers.  tokens != NULL only on the first stage (embedding gather); otherwise the input
  * hidden state must already be in hidden_ptr(0).  On the last stage logits_out/argmax_last_out behave as in

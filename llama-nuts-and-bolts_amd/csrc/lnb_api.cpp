@@ -58,7 +58,7 @@ struct LayerW {
 struct lnb_model {
     lnb_model_args a{};
     int device = 0, layer_begin = 0, layer_end = 0;      // layers this handle touches
-    int half_begin = 0, half_end = 0;                     // ... in half-block units: 2l = attention half of layer l, 2l+1 = its FFN half
+    int part_begin = 0, part_end = 0;                     // ... in thirds of a block: 3l = attention part of layer l, 3l+1 = gate/up, 3l+2 = down
     int head_dim = 0, n_rep = 0, ffn_hidden = 0, q_dim = 0, kv_dim = 0;
     uint16_t* tok_embd = nullptr; uint16_t* norm = nullptr; TiledDesc output{};
     std::vector<LayerW> layers;           // indexed by absolute layer id - layer_begin
@@ -68,10 +68,13 @@ struct lnb_model {
     hipStream_t stream = nullptr;
     bool finalized = false;
     int64_t weight_bytes = 0;
-    bool first() const { return half_begin == 0; }
-    bool last() const { return half_end == 2 * a.n_layers; }
-    bool has_attn(int l) const { return 2 * l >= half_begin && 2 * l < half_end; }
-    bool has_ffn(int l) const { return 2 * l + 1 >= half_begin && 2 * l + 1 < half_end; }
+    bool first() const { return part_begin == 0; }
+    bool last() const { return part_end == 3 * a.n_layers; }
+    bool has_part(int l, int q) const { return 3 * l + q >= part_begin && 3 * l + q < part_end; }
+    bool has_attn(int l) const { return has_part(l, 0); }
+    bool has_w13(int l) const { return has_part(l, 1); }
+    bool has_w2(int l) const { return has_part(l, 2); }
+    bool whole(int l) const { return has_attn(l) && has_w13(l) && has_w2(l); }
 };
 struct lnb_ctx {
     lnb_model* m = nullptr; int seq_len = 0;
@@ -137,19 +140,21 @@ static void reg_tiled(lnb_model* m, const std::string& name, TiledDesc* td, int 
 }
 
 extern "C" int lnb_model_create(const lnb_model_args* args, int device, int layer_begin, int layer_end, lnb_model** out) {
-    return lnb_model_create_halves(args, device, 2 * layer_begin, 2 * layer_end, out);
+    return lnb_model_create_parts(args, device, 3 * layer_begin, 3 * layer_end, out);
 }
-// Pipeline stages may be cut INSIDE a block: between its attention half (attn_norm, wq|wk|wv, attention, wo + residual) and its FFN
-// half (ffn_norm, w1|w3, w2 + residual) the live state is again one [S, dim] vector (llamatransformer.go:232 -> :237), so the hand-off
-// is the same as between blocks and the stages can be balanced to half a block (pipeline.stage_halves).
-extern "C" int lnb_model_create_halves(const lnb_model_args* args, int device, int half_begin, int half_end, lnb_model** out) {
+// Pipeline stages may be cut INSIDE a block, in thirds: 3l = attention part (attention_norm, wq|wk|wv, attention, wo + residual,
+// llamatransformer.go:222-232), 3l+1 = gate/up part (ffn_norm, w1|w3, SiLU*up, :237, :601-617), 3l+2 = down part (w2 + residual,
+// :619, :248).  After the attention part the live state is again one [S, dim] vector (h); after the gate/up part it is h plus the
+// [S, ffn_hidden] activations.  The three parts cost about the same HBM time (48 / 47 / 45 us for the 8B shape), so the stages of a
+// pipeline can be balanced to a third of a block (pipeline.stage_parts).
+extern "C" int lnb_model_create_parts(const lnb_model_args* args, int device, int part_begin, int part_end, lnb_model** out) {
     if (!args || !out) return fail("null argument");
-    const int layer_begin = half_begin / 2, layer_end = (half_end + 1) / 2;
+    const int layer_begin = part_begin / 3, layer_end = (part_end + 2) / 3;
     lnb_model_args a = *args;
     if (a.n_kv_heads < 0) a.n_kv_heads = a.n_heads;                       // llamatransformer.go:73-75
     if (a.rope_theta <= 0) a.rope_theta = 500000.0;                       // :80-82
     if (a.dim <= 0 || a.n_heads <= 0 || a.dim % a.n_heads || a.n_heads % a.n_kv_heads) return fail("invalid head configuration");
-    if (half_begin < 0 || half_end > 2 * a.n_layers || half_begin >= half_end) return fail("invalid layer range [%d,%d)", half_begin / 2, (half_end + 1) / 2);
+    if (part_begin < 0 || part_end > 3 * a.n_layers || part_begin >= part_end) return fail("invalid layer range [%d,%d)", part_begin / 3, (part_end + 2) / 3);
     int hd = a.dim / a.n_heads;
     if (a.dim % 8 || hd % 8) return fail("dim and head_dim must be multiples of 8");
     int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
@@ -159,7 +164,7 @@ extern "C" int lnb_model_create_halves(const lnb_model_args* args, int device, i
     HIPCHK(lnbk_init());
     { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); if (prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount; }
     lnb_model* m = new lnb_model();
-    m->a = a; m->device = device; m->layer_begin = layer_begin; m->layer_end = layer_end; m->half_begin = half_begin; m->half_end = half_end;
+    m->a = a; m->device = device; m->layer_begin = layer_begin; m->layer_end = layer_end; m->part_begin = part_begin; m->part_end = part_end;
     m->head_dim = hd; m->n_rep = a.n_heads / a.n_kv_heads; m->ffn_hidden = lnb_model_ffn_hidden_dim(&a);
     if (m->ffn_hidden % 8) { delete m; return fail("ffn hidden dim must be a multiple of 8"); }
     m->q_dim = a.n_heads * hd; m->kv_dim = a.n_kv_heads * hd;
@@ -184,18 +189,20 @@ extern "C" int lnb_model_create_halves(const lnb_model_args* args, int device, i
             snprintf(nm, sizeof nm, "layers.%d.attention.wv.weight", l); reg_tiled(m, nm, &L.wqkv, m->kv_dim, dim, m->q_dim + m->kv_dim, 0, base + 3);
             snprintf(nm, sizeof nm, "layers.%d.attention.wo.weight", l); reg_tiled(m, nm, &L.wo, dim, m->q_dim, 0, 0, base + 4);
         }
-        if (m->has_ffn(l)) {
+        if (m->has_w13(l)) {
             if (alloc_linear(&L.ffn_norm, dim, wb)) return -1;
             {   // two-chain gate|up matrix: when the rows split into exactly one 56-row block per CU, take it (all CUs stream)
                 int rw13 = auto_rw(F, "LNB_RW_W13");
                 if (env_int("LNB_RW_W13", 0) == 0 && F == 56 * g_num_cus) rw13 = 56;
                 if (alloc_tiled(L.w13, F, dim, rw13, 2, wb)) return -1;
             }
-            if (alloc_tiled(L.w2, dim, F, auto_rw(dim, "LNB_RW_W2", F, true), 1, wb)) return -1;
             snprintf(nm, sizeof nm, "layers.%d.ffn_norm.weight", l); reg_linear(m, nm, L.ffn_norm, dim, base + 5, 1);
             snprintf(nm, sizeof nm, "layers.%d.feed_forward.w1.weight", l); reg_tiled(m, nm, &L.w13, F, dim, 0, 0, base + 6);
-            snprintf(nm, sizeof nm, "layers.%d.feed_forward.w2.weight", l); reg_tiled(m, nm, &L.w2, dim, F, 0, 0, base + 7);
             snprintf(nm, sizeof nm, "layers.%d.feed_forward.w3.weight", l); reg_tiled(m, nm, &L.w13, F, dim, 0, 1, base + 8);
+        }
+        if (m->has_w2(l)) {
+            if (alloc_tiled(L.w2, dim, F, auto_rw(dim, "LNB_RW_W2", F, true), 1, wb)) return -1;
+            snprintf(nm, sizeof nm, "layers.%d.feed_forward.w2.weight", l); reg_tiled(m, nm, &L.w2, dim, F, 0, 0, base + 7);
         }
     }
     if (m->last()) {
@@ -433,7 +440,7 @@ extern "C" int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which, uint16_t* host)
 }
 
 extern "C" int lnb_ctx_set_layer_callback(lnb_ctx* c, lnb_layer_cb cb, void* user) { if (!c) return fail("null argument"); c->cb = cb; c->cb_user = user; return 0; }
-extern "C" void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which) { (void)which; return c ? (void*)c->x : nullptr; }
+extern "C" void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which) { return !c ? nullptr : which == 2 ? (void*)c->ffn : (void*)c->x; }
 extern "C" void* lnb_ctx_stream(lnb_ctx* c) { return c ? (void*)c->stream : nullptr; }
 extern "C" int lnb_ctx_synchronize(lnb_ctx* c) { if (!c) return fail("null argument"); HIPCHK(hipSetDevice(c->m->device)); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
 
@@ -449,10 +456,10 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = c->stream;
     LayerW& L = m->layers[l - m->layer_begin];
     uint16_t* ck = c->ck[l - m->layer_begin]; uint16_t* cv = c->cv[l - m->layer_begin];
-    // h = x + attention (llamatransformer.go:232) normally has its own buffer; in a block this stage holds only one half of, it
-    // lives in x itself (the residual epilogues read and write element n from the same lane, so out may alias res): the half-block
-    // hand-off is then the same buffer as the block hand-off
-    uint16_t* const hbuf = (m->has_attn(l) && m->has_ffn(l)) ? c->h : c->x;
+    // h = x + attention (llamatransformer.go:232) normally has its own buffer; in a block this stage holds only a part of, it lives
+    // in x itself (the residual epilogues read and write element n from the same lane, so out may alias res): the hand-off inside a
+    // block is then the same buffer as the hand-off between blocks (plus the ffn activations when the cut is in front of w2)
+    uint16_t* const hbuf = m->whole(l) ? c->h : c->x;
     if (use_mfma(S) && which != K_ATTN) {
         switch (which) {
         case K_QKV: {
@@ -497,7 +504,7 @@ static int enqueue_layers(lnb_ctx* c, int S, bool with_cb) {
     for (int l = m->layer_begin; l < m->layer_end; l++) {
         auto t0 = std::chrono::steady_clock::now();
         for (int k = K_QKV; k <= K_W2; k++) {
-            if (!(k <= K_WO ? m->has_attn(l) : m->has_ffn(l))) continue;     // a stage may hold only one half of its first / last block
+            if (!(k <= K_WO ? m->has_attn(l) : k == K_W13 ? m->has_w13(l) : m->has_w2(l))) continue;   // a stage may hold only parts of its first / last block
             if (enqueue_layer_kernel(c, l, S, k)) return -1;
         }
         if (with_cb && c->cb) {

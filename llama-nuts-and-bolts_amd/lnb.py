@@ -42,7 +42,7 @@ LLAMA_8B = dict(dim=4096, n_layers=32, n_heads=32, n_kv_heads=8, vocab_size=1282
 
 _lib = None
 EXPORTS = [
-    "lnb_last_error", "lnb_device_count", "lnb_model_create", "lnb_model_create_halves", "lnb_model_destroy", "lnb_model_ffn_hidden_dim",
+    "lnb_last_error", "lnb_device_count", "lnb_model_create", "lnb_model_create_parts", "lnb_model_destroy", "lnb_model_ffn_hidden_dim",
     "lnb_model_set_tensor", "lnb_model_get_tensor", "lnb_model_fill_synthetic", "lnb_model_finalize",
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
@@ -66,7 +66,7 @@ def lib():
     L.lnb_last_error.restype = C.c_char_p
     L.lnb_device_count.argtypes = [C.POINTER(C.c_int)]
     L.lnb_model_create.argtypes = [C.POINTER(ModelArgs), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
-    L.lnb_model_create_halves.argtypes = [C.POINTER(ModelArgs), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
+    L.lnb_model_create_parts.argtypes = [C.POINTER(ModelArgs), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.lnb_model_destroy.argtypes = [vp]
     L.lnb_model_ffn_hidden_dim.argtypes = [C.POINTER(ModelArgs)]
     L.lnb_model_set_tensor.argtypes = [vp, C.c_char_p, vp, C.POINTER(C.c_int64), C.c_int]
@@ -222,18 +222,19 @@ def model_args_from_json(path):
 class LlamaTransformer:
     """Device-resident model (one pipeline stage): model.NewLlamaTransformer, llamatransformer.go:64-113."""
 
-    def __init__(self, device=0, layer_begin=0, layer_end=None, half_begin=None, half_end=None, **kw):
-        """[layer_begin, layer_end) in blocks, or [half_begin, half_end) in half blocks (2l = attention half, 2l+1 = FFN half of block l)"""
+    def __init__(self, device=0, layer_begin=0, layer_end=None, part_begin=None, part_end=None, **kw):
+        """[layer_begin, layer_end) in blocks, or [part_begin, part_end) in thirds of a block (3l = attention part of block l,
+        3l+1 = gate/up part, 3l+2 = down part: lnb_model_create_parts)"""
         d = dict(LLAMA_8B)
         d.update(kw)
         self.args = ModelArgs(**d)
         self.L = lib()
         self.h = C.c_void_p()
-        if half_begin is None and half_end is None:
-            half_begin, half_end = 2 * layer_begin, 2 * (self.args.n_layers if layer_end is None else layer_end)
-        self.half_begin, self.half_end = int(half_begin), int(half_end)
-        self.layer_begin, self.layer_end = self.half_begin // 2, (self.half_end + 1) // 2
-        _chk(self.L.lnb_model_create_halves(C.byref(self.args), device, self.half_begin, self.half_end, C.byref(self.h)))
+        if part_begin is None and part_end is None:
+            part_begin, part_end = 3 * layer_begin, 3 * (self.args.n_layers if layer_end is None else layer_end)
+        self.part_begin, self.part_end = int(part_begin), int(part_end)
+        self.layer_begin, self.layer_end = self.part_begin // 3, (self.part_end + 2) // 3
+        _chk(self.L.lnb_model_create_parts(C.byref(self.args), device, self.part_begin, self.part_end, C.byref(self.h)))
         self.ffn_hidden = self.L.lnb_model_ffn_hidden_dim(C.byref(self.args))
         self.head_dim = self.args.dim // self.args.n_heads
 

@@ -1,8 +1,8 @@
 """Layer-sharded pipeline over the GPUs of one node (BASELINE.json configs[3], [4]).
 
 One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI).  Rank r owns a contiguous run of
-transformer blocks (`stage_layers`: split by cost, 4,4,4,5,4,4,4,3 for 32 blocks on 8 GPUs, because the last stage also runs the
-head) and their KV caches (`lnb_model_create(..., layer_begin, layer_end)`); rank 0 also owns
+transformer blocks, cut in thirds of a block and balanced by cost (`stage_parts`: 4 1/3 blocks on seven of 8 GPUs, 1 2/3 + the head
+on the last) and their KV caches (`lnb_model_create_parts(..., part_begin, part_end)`); rank 0 also owns
 tok_embeddings, rank N-1 also norm + output.  The only exchange of the path is point to point: the bf16 hidden
 state [S, dim] from rank r to r+1 (8 KiB per decoded token for dim 4096) and the 4-byte next-token id from rank N-1
 back to rank 0.  There is no all-reduce / all-gather anywhere (that would be tensor parallelism).
@@ -31,6 +31,9 @@ class Stage:
 
     def hidden_buffer(self, seq, rows):      # int16 [rows, dim] view of the stage's hidden state for sequence `seq`
         raise NotImplementedError
+
+    def hidden_buffers(self, seq, rows, side):   # everything that crosses the stage boundary: side "in" (from upstream) / "out" (downstream)
+        return [self.hidden_buffer(seq, rows)]
 
     def run(self, seq, rows, start_pos, tokens):   # tokens: np.int32[rows] on the first stage else None
         """consume hidden_buffer(seq) (or tokens), leave the output in hidden_buffer(seq); last stage returns the argmax token"""
@@ -92,33 +95,34 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
     def rows_of(item):
         return P if item // n_seq == 0 else 1
 
-    def staging(kind, like):                                  # one torch-allocated tensor per (direction, row count)
-        t_ = state[kind].get(like.shape[0])
+    def staging(kind, q, like):                               # one torch-allocated tensor per (direction, buffer index, row count)
+        key = (q, like.shape[0])
+        t_ = state[kind].get(key)
         if t_ is None:
-            t_ = state[kind][like.shape[0]] = torch.empty_like(like, device=comm)
+            t_ = state[kind][key] = torch.empty_like(like, device=comm)
         return t_
 
     def post(send_item, recv_item):
         """the exchange of one tick: result of `send_item` downstream (hidden state, or the token back to rank 0), input of `recv_item`
         from upstream.  Only tensors from torch's own allocator are handed to the backend: the stage's hidden state lives in memory
         the HIP library allocated, so it is copied (8 KiB per decoded token) into / out of a torch staging tensor."""
-        ops, landed, got_tok = [], None, False
+        ops, landed, got_tok = [], [], False
         if send_item is not None and world > 1:
             k, s = divmod(send_item, n_seq)
             if not last:
-                src = stage.hidden_buffer(s, rows_of(send_item))
-                out = staging("stage_out", src)
-                out.copy_(src)
-                ops.append(dist.P2POp(dist.isend, out, nxt))
+                for q, src in enumerate(stage.hidden_buffers(s, rows_of(send_item), "out")):
+                    out = staging("stage_out", q, src)
+                    out.copy_(src)
+                    ops.append(dist.P2POp(dist.isend, out, nxt))
             elif k + 1 < n_phases:        # the token of the final phase is not needed by rank 0
                 ops.append(dist.P2POp(dist.isend, tok_out, nxt))
         if recv_item is not None and world > 1:
             k, s = divmod(recv_item, n_seq)
             if not first:
-                dst = stage.hidden_buffer(s, rows_of(recv_item))
-                inn = staging("stage_in", dst)
-                ops.append(dist.P2POp(dist.irecv, inn, prv))
-                landed = (dst, inn)
+                for q, dst in enumerate(stage.hidden_buffers(s, rows_of(recv_item), "in")):
+                    inn = staging("stage_in", q, dst)
+                    ops.append(dist.P2POp(dist.irecv, inn, prv))
+                    landed.append((dst, inn))
             elif k > 0:
                 ops.append(dist.P2POp(dist.irecv, tok_in, prv))
                 got_tok = True
@@ -128,8 +132,8 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
     def finish(works, landed, got_tok):
         for req in works:
             req.wait()
-        if landed is not None:
-            landed[0].copy_(landed[1])
+        for dst, inn in landed:
+            dst.copy_(inn)
         if got_tok:
             state["tok_next"] = int(tok_in.item())
         if works and device != "cpu":
@@ -196,38 +200,39 @@ def stage_layers(rank, world, n_layers, head_cost=1.2):
     return cuts[rank], cuts[rank + 1]
 
 
-def half_costs(cfg, ffn_hidden):
-    """(attention half, FFN half, head) in microseconds of one decode step: weight megabytes x the per-MB time of the kernel class
-    that streams them, measured on the 8B shape (thin fused-norm and row-broadcast GEMVs ~0.48, w2 0.38, the fat
-    w1|w3 0.20, the output projection 0.16 us/MB; ~8 us for the attention kernel itself)."""
+def part_costs(cfg, ffn_hidden):
+    """(attention part, gate/up part, down part, head) in microseconds of one decode step: weight megabytes x the per-MB time of the
+    kernel class that streams them, measured on the 8B shape (thin fused-norm and row-broadcast GEMVs ~0.48, w2 0.38,
+    the fat w1|w3 0.20, the output projection 0.16 us/MB; ~8 us for the attention kernel itself)."""
     dim, hd = cfg["dim"], cfg["dim"] // cfg["n_heads"]
     kv = (cfg["n_kv_heads"] if cfg.get("n_kv_heads", -1) > 0 else cfg["n_heads"]) * hd
     mb = 2.0 / 1e6
     attn = 0.48 * (dim * (dim + 2 * kv) + dim * dim) * mb + 8.0
-    ffn = 0.20 * (2 * ffn_hidden * dim) * mb + 0.38 * (ffn_hidden * dim) * mb
+    w13 = 0.20 * (2 * ffn_hidden * dim) * mb
+    w2 = 0.38 * (ffn_hidden * dim) * mb
     head = 0.16 * (cfg["vocab_size"] * dim) * mb
-    return attn, ffn, head
+    return attn, w13, w2, head
 
 
-def stage_halves(rank, world, n_layers, attn_cost=0.35, ffn_cost=0.65, head_cost=1.2):
-    """[half_begin, half_end) of pipeline stage `rank` in half-block units (2l = attention half of block l, 2l+1 = its FFN half;
-    lnb_model_create_halves).  Contiguous partition of the 2*n_layers halves into `world` non-empty stages that minimises the slowest
-    stage (= the tick of the pipeline), the last stage also carrying the head: binary search on the bound + greedy fill.  8B shape
-    on 8 GPUs: the slowest stage drops from 5 blocks (698 us) to ~4.3 (~600 us)."""
-    n = 2 * n_layers
+def stage_parts(rank, world, n_layers, attn_cost=0.35, w13_cost=0.33, w2_cost=0.32, head_cost=1.2):
+    """[part_begin, part_end) of pipeline stage `rank` in thirds of a block (3l = attention part of block l, 3l+1 = gate/up part,
+    3l+2 = down part; lnb_model_create_parts).  Contiguous partition of the 3*n_layers parts into `world` non-empty stages that
+    minimises the slowest stage (= the tick of the pipeline), the last stage also carrying the head: binary search on the bound +
+    greedy fill (optimal for min-max).  8B shape on 8 GPUs: the slowest stage is 608 us (whole blocks: 699, ideal 580)."""
+    n = 3 * n_layers
     if world > n:
-        raise ValueError("more pipeline stages (%d) than half blocks (%d)" % (world, n))
-    cost = [attn_cost if u % 2 == 0 else ffn_cost for u in range(n)]
+        raise ValueError("more pipeline stages (%d) than block parts (%d)" % (world, n))
+    cost = [(attn_cost, w13_cost, w2_cost)[u % 3] for u in range(n)]
     cost[-1] += head_cost
 
     def cuts_for(bound):
         cuts, acc = [0], 0.0
         for u in range(n):
+            if cost[u] > bound:
+                return None
             if acc > 0 and acc + cost[u] > bound:
                 cuts.append(u); acc = 0.0
             acc += cost[u]
-            if cost[u] > bound:
-                return None
         cuts.append(n)
         return cuts if len(cuts) - 1 <= world else None
 
@@ -239,7 +244,7 @@ def stage_halves(rank, world, n_layers, attn_cost=0.35, ffn_cost=0.65, head_cost
         else:
             hi = mid
     cuts = cuts_for(hi)
-    while len(cuts) - 1 < world:                              # fewer stages than ranks: split the longest (in halves) splittable stage
+    while len(cuts) - 1 < world:                              # fewer stages than ranks: split the longest splittable stage
         j = max(range(len(cuts) - 1), key=lambda q: cuts[q + 1] - cuts[q])
         cuts.insert(j + 1, (cuts[j] + cuts[j + 1] + 1) // 2)
     return cuts[rank], cuts[rank + 1]
@@ -248,30 +253,41 @@ def stage_halves(rank, world, n_layers, attn_cost=0.35, ffn_cost=0.65, head_cost
 class LnbStage(Stage):
     """One GPU's share of the model behind the C ABI (lnb_forward_stage)."""
 
-    def __init__(self, lnb, torch, cfg, rank, world, n_seq, seq_len, device_index):
+    def __init__(self, lnb, torch, cfg, rank, world, n_seq, seq_len, device_index, parts=None):
         import ctypes as C
         self.lnb, self.torch, self.C = lnb, torch, C
         L = cfg["n_layers"]
         self.first, self.last = rank == 0, rank == world - 1
         probe = lnb.ModelArgs(**dict(lnb.LLAMA_8B, **cfg))
-        self.costs = half_costs(cfg, lnb.lib().lnb_model_ffn_hidden_dim(C.byref(probe)))
-        hb, he = stage_halves(rank, world, L, *self.costs)
-        self.halves = (hb, he)
-        self.model = lnb.LlamaTransformer(device=device_index, half_begin=hb, half_end=he, **cfg).fill_synthetic(1234)
+        self.ffn_hidden = lnb.lib().lnb_model_ffn_hidden_dim(C.byref(probe))
+        self.costs = part_costs(cfg, self.ffn_hidden)
+        pb, pe = parts if parts is not None else stage_parts(rank, world, L, *self.costs)     # (parts: a test's own cut)
+        self.parts = (pb, pe)
+        self.model = lnb.LlamaTransformer(device=device_index, part_begin=pb, part_end=pe, **cfg).fill_synthetic(1234)
         self.model.finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"]))
         self.ctx = [lnb.InferenceContext(self.model, seq_len) for _ in range(n_seq)]
         self.dim, self.device_index = cfg["dim"], device_index
         self._views = {}
 
-    def hidden_buffer(self, seq, rows):
-        key = (seq, rows)
+    def _view(self, seq, rows, which):
+        key = (seq, rows, which)
         if key not in self._views:
-            ptr = self.lnb.lib().lnb_ctx_hidden_ptr(self.ctx[seq].h, 0)
+            ptr = self.lnb.lib().lnb_ctx_hidden_ptr(self.ctx[seq].h, which)
+            width = self.ffn_hidden if which == 2 else self.dim
 
             class _Wrap:   # zero-copy view of the library's device buffer (CUDA array interface v2)
-                __cuda_array_interface__ = {"shape": (rows, self.dim), "typestr": "<i2", "data": (int(ptr), False), "version": 2}
+                __cuda_array_interface__ = {"shape": (rows, width), "typestr": "<i2", "data": (int(ptr), False), "version": 2}
             self._views[key] = self.torch.as_tensor(_Wrap(), device="cuda:%d" % self.device_index)
         return self._views[key]
+
+    def hidden_buffer(self, seq, rows):
+        return self._view(seq, rows, 0)
+
+    def hidden_buffers(self, seq, rows, side):
+        """the [rows, dim] hidden state, plus the [rows, ffn_hidden] gate*up activations when that boundary of the stage lies between a
+        block's gate/up part and its down part (part index 3l+2)"""
+        edge = self.parts[0] if side == "in" else self.parts[1]
+        return [self._view(seq, rows, 0)] + ([self._view(seq, rows, 2)] if edge % 3 == 2 else [])
 
     def run(self, seq, rows, start_pos, tokens):
         C, L = self.C, self.lnb.lib()
@@ -354,8 +370,8 @@ def bench_main(args, cfg, name):
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "%s bf16, %dxMI355X layer pipeline (blocks per GPU %s), RCCL p2p hidden-state hand-off, %d sequences in flight, "
-                                      "prompt %d -> +%d tokens each" % (name, world, ",".join("%g" % ((stage_halves(r, world, cfg["n_layers"], *stage.costs)[1]
-                                                                                                         - stage_halves(r, world, cfg["n_layers"], *stage.costs)[0]) / 2.0)
+                                      "prompt %d -> +%d tokens each" % (name, world, ",".join("%.3g" % ((stage_parts(r, world, cfg["n_layers"], *stage.costs)[1]
+                                                                                                           - stage_parts(r, world, cfg["n_layers"], *stage.costs)[0]) / 3.0)
                                                                                                 for r in range(world)), n_seq, P, K),
                           "prompt_len": P, "sequences_in_flight": n_seq, "parallelism": "pp%d" % world,
                           "mode": "exact-order (token-id identical to the CPU reference path)"},

@@ -19,7 +19,9 @@ dist.init_process_group("gloo", rank=rank, world_size=world)
 cfg = dict(orc.TINY)
 P, n_decode = 24, 9                                           # 24-row prefill: the matrix-core path on every stage
 n_seq = world * int(os.environ.get("LNB_TEST_MULT", "2"))     # 2: the overlapped schedule of bench.py --gpus N; 1: lock step
-stage = pipeline.LnbStage(lnb, torch, cfg, rank, world, n_seq, P + n_decode + 8, 0)
+cut = int(os.environ.get("LNB_TEST_CUT", "0"))               # > 0: rank 0 holds block parts [0, cut), rank 1 the rest (3 parts per block)
+parts = None if cut <= 0 else ((0, cut) if rank == 0 else (cut, 3 * cfg["n_layers"]))
+stage = pipeline.LnbStage(lnb, torch, cfg, rank, world, n_seq, P + n_decode + 8, 0, parts)
 prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
 st = pipeline.run_ticks(rank, world, stage, dist, torch, prompts, n_decode, "cuda:0")
 if rank == world - 1:

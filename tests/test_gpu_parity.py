@@ -359,20 +359,21 @@ def test_pipeline_stages_on_one_device_equal_whole_model(lnb, tiny_pair):
     s0.close(); s1.close()
 
 
-@pytest.mark.parametrize("cuts,rows", [((0, 1, 3, 4), 6), ((0, 3, 4), 6), ((0, 1, 2, 3, 4), 24), ((0, 2, 3, 4), 1)])
+@pytest.mark.parametrize("cuts,rows", [((0, 1, 4, 6), 6), ((0, 2, 6), 6), ((0, 1, 2, 3, 4, 5, 6), 24), ((0, 3, 5, 6), 1), ((0, 5, 6), 20)])
 def test_pipeline_stages_cut_inside_a_block(lnb, tiny_pair, cuts, rows):
-    """lnb_model_create_halves: stages that start or end between a block's attention half and its FFN half (the hand-off there is again
-    one [S, dim] vector).  Prefill (GEMV rows and the matrix-core path) and a decode step through every chain of stages must give the
-    oracle's logits bit for bit; a stage refuses tensors of the half it does not hold."""
+    """lnb_model_create_parts: stages that start or end inside a block -- after its attention part (hand-off: the [S, dim] vector) or
+    after its gate/up part (hand-off: that vector + the [S, ffn_hidden] activations).  Prefill (GEMV rows and the matrix-core path)
+    and decode steps through every chain of stages must give the oracle's logits bit for bit; a stage holds exactly its parts' tensors."""
     import ctypes as C
     om, _ = tiny_pair
     L = lnb.lib()
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
-    stages = [lnb.LlamaTransformer(half_begin=a, half_end=b, **TINY).fill_synthetic(1234).finalize() for a, b in zip(cuts[:-1], cuts[1:])]
+    stages = [lnb.LlamaTransformer(part_begin=a, part_end=b, **TINY).fill_synthetic(1234).finalize() for a, b in zip(cuts[:-1], cuts[1:])]
     ctxs = [lnb.InferenceContext(s, 64) for s in stages]
     oc = orc.Context(om, 64)
     toks = orc.synth_tokens(3, rows + 2, TINY["vocab_size"])
+    F = stages[0].ffn_hidden
 
     def through(tok, pos):
         t = np.ascontiguousarray(tok, dtype=np.int32)
@@ -383,6 +384,8 @@ def test_pipeline_stages_cut_inside_a_block(lnb, tiny_pair, cuts, rows):
             lnb._chk(L.lnb_forward_stage(c.h, lnb._p(t) if q == 0 else None, len(t), pos, lnb._p(logits) if lastq else None, C.byref(am) if lastq else None))
             if not lastq:
                 assert hip.hipMemcpy(L.lnb_ctx_hidden_ptr(ctxs[q + 1].h, 0), L.lnb_ctx_hidden_ptr(c.h, 1), len(t) * TINY["dim"] * 2, 3) == 0
+                if cuts[q + 1] % 3 == 2:                       # cut between gate/up and down: the activations travel too
+                    assert hip.hipMemcpy(L.lnb_ctx_hidden_ptr(ctxs[q + 1].h, 2), L.lnb_ctx_hidden_ptr(c.h, 2), len(t) * F * 2, 3) == 0
         return logits, am.value
 
     for lo_, hi_ in ((0, rows), (rows, rows + 1), (rows + 1, rows + 2)):
@@ -390,12 +393,13 @@ def test_pipeline_stages_cut_inside_a_block(lnb, tiny_pair, cuts, rows):
         got, ga = through(toks[lo_:hi_], lo_)
         assert (ref.view(np.uint32) == got.view(np.uint32)).all() and ra == ga
     for s, (a, b) in zip(stages, zip(cuts[:-1], cuts[1:])):
-        held = {n for n, _ in s.tensor_infos()} if hasattr(s, "tensor_infos") else set()
+        held = {n for n, _ in s.tensor_infos()}
         for l in range(TINY["n_layers"]):
-            assert ("layers.%d.attention.wq.weight" % l in held) == (a <= 2 * l < b)
-            assert ("layers.%d.feed_forward.w2.weight" % l in held) == (a <= 2 * l + 1 < b)
+            assert ("layers.%d.attention.wq.weight" % l in held) == (a <= 3 * l < b)
+            assert ("layers.%d.feed_forward.w3.weight" % l in held) == (a <= 3 * l + 1 < b) == ("layers.%d.ffn_norm.weight" % l in held)
+            assert ("layers.%d.feed_forward.w2.weight" % l in held) == (a <= 3 * l + 2 < b)
     with pytest.raises(lnb.LnbError):
-        lnb.LlamaTransformer(half_begin=3, half_end=3, **TINY)
+        lnb.LlamaTransformer(part_begin=3, part_end=3, **TINY)
     oc.close()
     for c in ctxs:
         c.close()
@@ -430,8 +434,8 @@ def test_forward_stage_begin_end_equals_forward_stage(lnb, tiny_pair):
     a.close(); b.close()
 
 
-@pytest.mark.parametrize("mult", [2, 1])
-def test_pipeline_two_processes_share_one_gpu(lnb, mult):
+@pytest.mark.parametrize("mult,cut", [(2, 0), (1, 0), (2, 5), (1, 2), (2, 1)])
+def test_pipeline_two_processes_share_one_gpu(lnb, mult, cut):
     """bench.py --gpus 2 in miniature: two torch.distributed ranks (gloo), each with half of the blocks on cuda:0, exchanging the
     hidden state and the token ring through pipeline.run_ticks; every generated token is checked against the oracle."""
     import socket
@@ -442,7 +446,7 @@ def test_pipeline_two_processes_share_one_gpu(lnb, mult):
     script = os.path.join(os.path.dirname(__file__), "native", "pipeline_two_rank.py")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), script], capture_output=True, text=True, timeout=600,
-                       env=dict(os.environ, LNB_TEST_MULT=str(mult)))
+                       env=dict(os.environ, LNB_TEST_MULT=str(mult), LNB_TEST_CUT=str(cut)))     # cut 5 / 2: the activations travel too
     assert r.returncode == 0 and "PIPELINE_TWO_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 

@@ -133,22 +133,22 @@ def test_stage_layers_cover_every_block_once_and_lighten_the_last_stage():
     assert pipeline.stage_layers(0, 1, 32) == (0, 32)
 
 
-def test_stage_halves_partition_is_contiguous_and_no_worse_than_whole_blocks():
+def test_stage_parts_partition_is_contiguous_and_no_worse_than_whole_blocks():
     import pipeline
-    costs = pipeline.half_costs(dict(dim=4096, n_heads=32, n_kv_heads=8, vocab_size=128256), 14336)
-    assert abs(costs[0] + costs[1] - 140) < 3 and abs(costs[2] - 170) < 5          # the measured 8B block / head times (us)
-    for world, L, c in [(1, 32, costs), (2, 32, costs), (4, 32, costs), (8, 32, costs), (8, 80, costs), (3, 2, (0.35, 0.65, 1.2)),
-                        (5, 7, (0.35, 0.65, 1.2)), (8, 8, (1, 1, 1)), (2, 1, (1, 1, 1)), (4, 2, (1, 2, 3))]:
-        cuts = [pipeline.stage_halves(r, world, L, *c) for r in range(world)]
-        assert cuts[0][0] == 0 and cuts[-1][1] == 2 * L
+    costs = pipeline.part_costs(dict(dim=4096, n_heads=32, n_kv_heads=8, vocab_size=128256), 14336)
+    assert abs(sum(costs[:3]) - 140) < 3 and abs(costs[3] - 170) < 5               # the measured 8B block / head times (us)
+    for world, L, c in [(1, 32, costs), (2, 32, costs), (4, 32, costs), (8, 32, costs), (8, 80, costs), (3, 2, (0.35, 0.33, 0.32, 1.2)),
+                        (5, 7, (0.35, 0.33, 0.32, 1.2)), (8, 8, (1, 1, 1, 1)), (2, 1, (1, 1, 1, 1)), (4, 2, (1, 2, 3, 4)), (6, 2, (1, 1, 1, 9))]:
+        cuts = [pipeline.stage_parts(r, world, L, *c) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == 3 * L
         for (a, b), (a2, b2) in zip(cuts, cuts[1:]):
             assert b == a2
         assert all(b > a for a, b in cuts)
 
         def tick(parts):
-            return max(sum(c[u % 2] for u in range(a, b)) + (c[2] if b == 2 * L else 0) for a, b in parts)
+            return max(sum(c[u % 3] for u in range(a, b)) + (c[3] if b == 3 * L else 0) for a, b in parts)
         if L >= world:
-            blocks = [pipeline.stage_layers(r, world, L, c[2] / (c[0] + c[1])) for r in range(world)]
-            assert tick(cuts) <= tick([(2 * a, 2 * b) for a, b in blocks]) + 1e-9
-    eight = [pipeline.stage_halves(r, 8, 32, *costs) for r in range(8)]
-    assert max(b - a for a, b in eight) <= 9                                        # no stage above 4.5 blocks (5 with whole blocks)
+            blocks = [pipeline.stage_layers(r, world, L, c[3] / sum(c[:3])) for r in range(world)]
+            assert tick(cuts) <= tick([(3 * a, 3 * b) for a, b in blocks]) + 1e-9
+    eight = [pipeline.stage_parts(r, 8, 32, *costs) for r in range(8)]
+    assert max(b - a for a, b in eight) <= 13                                       # no stage above 4 1/3 blocks (5 with whole blocks)
