@@ -899,7 +899,9 @@ __global__ __launch_bounds__(64) void rmsnorm_rows_kernel(const uint16_t* x, con
 }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
-constexpr int GM_NB = 64, GM_MB = 128, GM_KS = 128;
+constexpr int GM_NB = 64, GM_KS = 128;
+constexpr unsigned GM_MB64_UPTO = 0xFFFFFFFFu;              // 64-row batch tiles up to this many 64x128 tiles: always -- tools/gemmbench.hip, S = 256..2048:
+                                                            // 64 x 64 tiles are 2-28 % faster than 64 x 128 everywhere (more workgroups per CU to overlap staging)
 template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& g, const f32x4& u, int m, int n0) {
     // one lane: batch row m, four consecutive output rows n0..n0+3 (n0 % 4 == 0)
     if (m >= p.S) return;
@@ -941,21 +943,25 @@ template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& 
 //   B (x):       stream (kk, i) = [g/2][m-tile t][g&1] (512 B + 16 B pad): one ds_read_b128 = four m-tiles of two k-groups.
 // (An f32 k-major tile cost nine ds_reads per eight MFMAs and an LDS round trip in front of every pair; raw bf16 halves the LDS,
 // two workgroups fit a CU, and a staged 16 B unit -- 8 consecutive k = two k-groups -- lands as four packed words.)
-constexpr int GM_APAD = 80, GM_BPAD = 528;                  // stream strides in bytes: conflict-free 16 B reads across 16 lanes
+constexpr int GM_APAD = 80;                                 // stream strides in bytes: conflict-free 16 B reads across 16 lanes
+__host__ __device__ constexpr int gemm_bpad(int MB) { return 16 * (MB / 16) * 4 + 16; }       // 528 (128 batch rows) / 272 (64)
 __host__ __device__ constexpr size_t gemm_lds_a(int NCH, int WN) { return (size_t)NCH * WN * 64 * GM_APAD; }
-__host__ __device__ constexpr size_t gemm_lds_bytes(int NCH, int WN) { return gemm_lds_a(NCH, WN) + (size_t)64 * GM_BPAD; }
+__host__ __device__ constexpr size_t gemm_lds_bytes(int NCH, int WN, int MB = 128) { return gemm_lds_a(NCH, WN) + (size_t)64 * gemm_bpad(MB); }
 
 #ifndef GM_DBG
 #define GM_DBG 0                                            // tools/gemmbench.hip: 1 = stage only the first slab, 2 = no barriers, 4 = no LDS reads
 #endif
-template <int EPI, int NCH, int WN>
+// MB = batch rows per workgroup: 128, or 64 (WN = 4 only) when 128-row tiles would put at most one workgroup on a CU
+template <int EPI, int NCH, int WN, int MB = 128>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
+    static_assert(MB == 128 || (MB == 64 && WN == 4), "batch tile");
+    constexpr int GM_MB = MB, GM_BPAD = gemm_bpad(MB), TB = MB / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                                         // streams [(c*WN + w)*4 + kk][i] of GM_APAD bytes
     char* Bs = smem + gemm_lds_a(NCH, WN);                   // streams [kk][i] of GM_BPAD bytes
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    constexpr int NB = 16 * WN, MT = WN == 4 ? 8 : 2;       // output rows per workgroup, m-tiles per wave
+    constexpr int NB = 16 * WN, MT = WN == 4 ? TB : 2;      // output rows per workgroup, m-tiles per wave
     const int n0 = blockIdx.x * NB, m0 = blockIdx.y * GM_MB;
     const int nt_off = WN == 4 ? wave * 16 : 0, mt0 = WN == 4 ? 0 : wave * 2;
     const int K = p.K;
@@ -970,11 +976,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
     // of the slab; x = batch row tid % 128, unit tid / 128 + 2q.  Their addresses are a per-thread base + uniform strides (both tiled
     // layouts are affine in the slab, unit and chain index), so a full slab is staged without a compare, a select or a divergent
     // branch; only the last slab of a K that is not a multiple of 128 takes the checked path.
-    constexpr int WU = NB * (GM_KS / 8) / 256, XU = GM_MB * (GM_KS / 8) / 256, WQ = 256 / NB;   // 4 (or 1) and 8 units per thread
+    constexpr int WU = NB * (GM_KS / 8) / 256, XU = GM_MB * (GM_KS / 8) / 256, WQ = 256 / NB, XQ = 256 / GM_MB;   // 4 (or 1) and 8 (4) units per thread
     uint4 wreg[NCH][WU], xreg[XU];
     const bool rw4 = p.rw == 4;                              // row-broadcast layout: a 16 B unit holds k0 + 16e + kc, e = 0..7
     const int kst = rw4 ? 16 : 1;                            // k stride inside a 16 B weight unit
-    const int wrow = tid & (NB - 1), wkc = tid / NB, xrow = tid & (GM_MB - 1), xkc = tid >> 7;
+    const int wrow = tid & (NB - 1), wkc = tid / NB, xrow = tid & (GM_MB - 1), xkc = tid / GM_MB;
     int wn = n0 + wrow; wn = wn < p.n_rows ? wn : p.n_rows - 1;                             // clamped rows are computed and dropped
     int xm = m0 + xrow; xm = xm < p.S ? xm : p.S - 1;
     const uint16_t* wp = p.w + tiled_index(wn, rw4 ? wkc : 8 * wkc, 0, K, p.rw, p.nch);     // slab 0, unit q = 0, chain 0
@@ -989,7 +995,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
 #pragma unroll
                 for (int q = 0; q < WU; q++) wreg[c][q] = *(const uint4*)(wp + c * w_chain + q * w_unit);
 #pragma unroll
-            for (int q = 0; q < XU; q++) xreg[q] = *(const uint4*)(xp + 16 * q);
+            for (int q = 0; q < XU; q++) xreg[q] = *(const uint4*)(xp + 8 * XQ * q);
             wp += w_slab; xp += GM_KS;
             return;
         }
@@ -1004,7 +1010,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
             }
 #pragma unroll
         for (int q = 0; q < XU; q++) {
-            int kf = k0 + 8 * (xkc + 2 * q);
+            int kf = k0 + 8 * (xkc + XQ * q);
             kf = kf < K ? kf : 0;
             xreg[q] = *(const uint4*)(p.x + (size_t)xm * K + kf);
         }
@@ -1015,7 +1021,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
         w[2] = (v.y & 0xFFFFu) | (v.w << 16); w[3] = (v.y >> 16) | (v.w & 0xFFFF0000u);
     };
     char* const wblk = As + (size_t)((wrow >> 4) * 4) * 16 * GM_APAD + (size_t)(wrow & 15) * GM_APAD;   // (+ c*WN*64*GM_APAD per chain)
-    char* const xblk = Bs + (size_t)(xrow & 15) * GM_BPAD + (xkc * 8 + (xrow >> 4)) * 4;
+    char* const xblk = Bs + (size_t)(xrow & 15) * GM_BPAD + (xkc * TB + (xrow >> 4)) * 4;
     auto commit = [&](int k0) {                              // raw bf16, no conversion (beyond K: zeros)
         const bool full = k0 + GM_KS <= K;
 #pragma unroll
@@ -1040,10 +1046,10 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
 #pragma unroll
         for (int q = 0; q < XU; q++) {
             uint4 v = xreg[q];
-            if (!full && !(k0 + 8 * (xkc + 2 * q) < K)) v = make_uint4(0, 0, 0, 0);
+            if (!full && !(k0 + 8 * (xkc + XQ * q) < K)) v = make_uint4(0, 0, 0, 0);
             uint32_t w4[4]; pack4(v, w4);
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) *(uint32_t*)(xblk + (size_t)kk * 16 * GM_BPAD + q * 64) = w4[kk];
+            for (int kk = 0; kk < 4; kk++) *(uint32_t*)(xblk + (size_t)kk * 16 * GM_BPAD + q * XQ * TB * 4) = w4[kk];
         }
     };
     const char* ap = As + (size_t)(((WN == 4 ? wave : 0) * 4 + fk) * 16 + fi) * GM_APAD;       // (+ c*WN*64*GM_APAD for chain c)
@@ -1072,8 +1078,11 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
                 const uint4 lo = *(const uint4*)(bp + j * 32), hi = *(const uint4*)(bp + j * 32 + 16);
                 fb[sl][0] = lo.x; fb[sl][1] = lo.y; fb[sl][2] = lo.z; fb[sl][3] = lo.w;
                 fb[sl][4 % MT] = hi.x; fb[sl][5 % MT] = hi.y; fb[sl][6 % MT] = hi.z; fb[sl][7 % MT] = hi.w;
+            } else if (MT == 4) {
+                const uint4 lo = *(const uint4*)(bp + j * 16);
+                fb[sl][0] = lo.x; fb[sl][1] = lo.y; fb[sl][2 % MT] = lo.z; fb[sl][3 % MT] = lo.w;
             } else {
-                const uint2 v = *(const uint2*)(bp + j * 32);
+                const uint2 v = *(const uint2*)(bp + j * (TB * 4));
                 fb[sl][0] = v.x; fb[sl][1] = v.y;
             }
         };
@@ -1692,22 +1701,28 @@ extern "C" hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, i
 }
 
 template <int EPI, int NCH> static hipError_t launch_gemm(const GemmParams* p, hipStream_t st) {
-    auto k4 = gemm_mfma_kernel<EPI, NCH, 4>;
-    auto k1 = gemm_mfma_kernel<EPI, NCH, 1>;
-    const size_t lds4 = gemm_lds_bytes(NCH, 4), lds1 = gemm_lds_bytes(NCH, 1);                   // 53 / 73 KB (39 / 44 KB): two or more workgroups per CU
+    auto k4 = gemm_mfma_kernel<EPI, NCH, 4, 128>;
+    auto k2 = gemm_mfma_kernel<EPI, NCH, 4, 64>;
+    auto k1 = gemm_mfma_kernel<EPI, NCH, 1, 128>;
+    const size_t lds4 = gemm_lds_bytes(NCH, 4), lds2 = gemm_lds_bytes(NCH, 4, 64), lds1 = gemm_lds_bytes(NCH, 1);   // 53 / 73 KB (37 / 57, 39 / 44): >= two workgroups per CU
     if (!p) {
         hipError_t e = hipFuncSetAttribute((const void*)k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds4);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2);
         return e != hipSuccess ? e : hipFuncSetAttribute((const void*)k1, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds1);
     }
-    const unsigned mb = (unsigned)((p->S + GM_MB - 1) / GM_MB), nb4 = (unsigned)((p->n_rows + GM_NB - 1) / GM_NB);
-    if (nb4 * mb <= 160)       // 64-row tiles would leave most CUs idle: 16-row tiles, the four waves split the batch rows
+    const unsigned mb = (unsigned)((p->S + 127) / 128), nb4 = (unsigned)((p->n_rows + GM_NB - 1) / GM_NB);
+    static const int force = [] { const char* e = getenv("LNB_GEMM_TILE"); return e && *e ? atoi(e) : 0; }();       // 1 / 64 / 128: measurement aid
+    const int tile = force ? force : (nb4 * mb <= 160 ? 1 : nb4 * mb <= GM_MB64_UPTO ? 64 : 128);
+    if (tile == 1)             // 64 x 128 tiles would leave most CUs idle: 16-row tiles, the four waves split the batch rows
                                // (tools/gemmbench.hip: 64 / 96 / 128 tiles: 1.4-2x faster; 256 tiles and up: 64-row tiles win)
         hipLaunchKernelGGL(k1, dim3((unsigned)((p->n_rows + 15) / 16), mb), dim3(256), lds1, st, *p);
+    else if (tile == 64)       // about one 64 x 128 tile per CU: 64 x 64 tiles, two to three workgroups per CU overlap staging and MFMAs
+        hipLaunchKernelGGL(k2, dim3(nb4, (unsigned)((p->S + 63) / 64)), dim3(256), lds2, st, *p);
     else
         hipLaunchKernelGGL(k4, dim3(nb4, mb), dim3(256), lds4, st, *p);
     return hipGetLastError();
 }
-// exact-order prefill GEMM (f32 MFMA); p == nullptr prepares the kernel (dynamic LDS limit) outside any stream capture
+
 extern "C" hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st) {
     const int nch = p ? p->nch : 0;
     switch (epi) {
