@@ -1712,7 +1712,10 @@ template <int EPI, int NCH> static hipError_t launch_gemm(const GemmParams* p, h
     }
     const unsigned mb = (unsigned)((p->S + 127) / 128), nb4 = (unsigned)((p->n_rows + GM_NB - 1) / GM_NB);
     static const int force = [] { const char* e = getenv("LNB_GEMM_TILE"); return e && *e ? atoi(e) : 0; }();       // 1 / 64 / 128: measurement aid
-    const int tile = force ? force : (nb4 * mb <= 160 ? 1 : nb4 * mb <= GM_MB64_UPTO ? 64 : 128);
+    // the two-chain w1|w3 kernel already runs 2x the MFMAs per staged byte: with more than four 64 x 128 tiles per CU it keeps them
+    // (S = 2048: 3.90 ms against 4.11 ms with 64 x 64 tiles; the one-chain kernels gain 5 % from the smaller tile there;
+    // S = 512, 896 tiles: the small tile still wins, 74 against 77 ms per Forward)
+    const int tile = force ? force : (nb4 * mb <= 160 ? 1 : (NCH == 2 && nb4 * mb > 1024) ? 128 : nb4 * mb <= GM_MB64_UPTO ? 64 : 128);
     if (tile == 1)             // 64 x 128 tiles would leave most CUs idle: 16-row tiles, the four waves split the batch rows
                                // (tools/gemmbench.hip: 64 / 96 / 128 tiles: 1.4-2x faster; 256 tiles and up: 64-row tiles win)
         hipLaunchKernelGGL(k1, dim3((unsigned)((p->n_rows + 15) / 16), mb), dim3(256), lds1, st, *p);
