@@ -18,6 +18,7 @@
 extern "C" {
 hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st);
 hipError_t lnbk_attn(const AttnParams* p, hipStream_t st);
+hipError_t lnbk_exp_table(double* tab, float divisor, hipStream_t st);
 hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st);
 hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps, hipStream_t st);
 hipError_t lnbk_embed(const uint16_t* emb, const int32_t* tokens, uint16_t* x, int S, int dim, int vocab, int* err, hipStream_t st);
@@ -63,7 +64,7 @@ struct lnb_model {
     uint16_t* tok_embd = nullptr; uint16_t* norm = nullptr; TiledDesc output{};
     std::vector<LayerW> layers;           // indexed by absolute layer id - layer_begin
     std::map<std::string, TensorRef> tensors;
-    float* cis = nullptr; int cis_rows = 0; float* silu = nullptr;
+    float* cis = nullptr; int cis_rows = 0; float* silu = nullptr; double* exp_tab = nullptr;
     std::vector<float> cis_host;
     hipStream_t stream = nullptr;
     bool finalized = false;
@@ -226,6 +227,7 @@ extern "C" int lnb_model_destroy(lnb_model* m) {
     }
     if (m->cis) hipFree(m->cis);
     if (m->silu) hipFree(m->silu);
+    if (m->exp_tab) hipFree(m->exp_tab);
     if (m->stream) hipStreamDestroy(m->stream);
     delete m;
     return 0;
@@ -350,6 +352,9 @@ extern "C" int lnb_model_finalize(lnb_model* m, int rope_rows) {
     for (int i = 0; i < (1 << 16); i++) { double x = (double)bf_wide_h((uint16_t)i); silu[i] = (float)(x / (1.0 + std::exp(-x))); }
     if (!m->silu) HIPCHK(hipMalloc((void**)&m->silu, silu.size() * 4));
     HIPCHK(hipMemcpy(m->silu, silu.data(), silu.size() * 4, hipMemcpyHostToDevice));
+    if (!m->exp_tab) HIPCHK(hipMalloc((void**)&m->exp_tab, (size_t)(1 << 16) * 8));
+    HIPCHK(lnbk_exp_table(m->exp_tab, bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim))), m->stream));   // (attn_mfma_kernel)
+    HIPCHK(hipStreamSynchronize(m->stream));
     m->finalized = true;
     return 0;
 }
@@ -484,7 +489,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
         AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st; ap.dbg = g_dbg;
         ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len;
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
-        ap.mfma = use_mfma(S) ? 1 : 0;
+        ap.mfma = use_mfma(S) ? 1 : 0; ap.exp_tab = m->exp_tab;
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x;

@@ -113,4 +113,5 @@ struct AttnParams {
     float divisor;              // wide(trunc(f32(sqrt(hd))))  (llamatransformer.go:464)
     long long* dbg;             // LNB_GEMV_TIMING: phase stamps of workgroup (0,0)
     int mfma;                   // S >= 16: 16-row tiles on the f32 matrix cores (attn_mfma_kernel), same bits
+    const double* exp_tab;      // f64[65536]: exp(trunc(s / divisor)) of every raw bf16 score s (attn_mfma_kernel)
 };

@@ -1126,6 +1126,22 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
         gemm_epilogue4<EPI>(p, acc[0][t], acc[NCH - 1][t], m0 + (mt0 + t) * 16 + (lane & 15), n0 + nt_off + (lane >> 4) * 4);
 }
 
+// The softmax numerator of every possible raw score, in f64: a q.k chain is truncated to bf16 before anything else happens to it
+// (llamatransformer.go:459), so  s -> trunc(s / sqrt(hd)) -> (+ 0 where unmasked) -> exp  is a function of 16 bits.  The table is
+// filled by the DEVICE code path attn_exact_kernel evaluates inline (same __fdiv_rn, same exp), so a lookup is bit-identical to
+// computing it (adding the mask's +0 can only turn -0 into +0, and exp(-0) == exp(+0)); the prefill attention replaces ~130
+// instructions per element by one 8-byte load from 512 KB (the reference does the same for SiLU, activations.go:15-25).
+__global__ void exp_table_kernel(double* tab, float divisor) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (1 << 16)) return;
+    const uint16_t s16 = bf_trunc(__fdiv_rn(bf_wide((uint16_t)i), divisor));        // DivToScalar :464
+    tab[i] = exp((double)bf_wide(s16));                                              // Softmax impl:498
+}
+extern "C" hipError_t lnbk_exp_table(double* tab, float divisor, hipStream_t st) {
+    hipLaunchKernelGGL(exp_table_kernel, dim3(256), dim3(256), 0, st, tab, divisor);
+    return hipGetLastError();
+}
+
 // ------------------------------------------------------------------------------------------------
 // attn_mfma_kernel: the prefill form of the attention (S >= 16 query rows), the same arithmetic as attn_exact_kernel below with
 // both matrix products on the exact f32 matrix cores (v_mfma_f32_16x16x4_f32 == the reference's k-ordered chain, see gemm_mfma_kernel).
@@ -1195,11 +1211,9 @@ template <int HD> __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(Att
 #pragma unroll
         for (int r = 0; r < 4; r++) {
             const int j = j0 + 4 * fk + r;
-            const bool dead = j >= T || ((S > 1) && ((j % S) > irow));           // triu(-inf,1) broadcast by modulo (tensoriterators.go:47-55)
-            uint16_t s16 = bf_trunc(acc[r]);
-            s16 = bf_trunc(__fdiv_rn(bf_wide(s16), p.divisor));                  // DivToScalar :464
-            if (S > 1) s16 = bf_trunc(bf_wide(s16) + 0.0f);                      // Add(scores, mask) with mask == 0 :469-473
-            const double ev = exp((double)bf_wide(s16));                         // Softmax impl:498
+            const bool dead = j >= T || ((S > 1) && ((pos0 == 0 ? j : j % S) > irow));   // triu(-inf,1) broadcast by modulo (tensoriterators.go:47-55);
+                                                                                         // pos0 == 0: T == S, no wrap (uniform branch, saves the division)
+            const double ev = p.exp_tab[bf_trunc(acc[r])];                       // / sqrt(hd) :464, (+ mask 0 :469-473), exp impl:498: tabulated
             e[r] = dead ? 0.0 : ev;                                              // exp(-inf) == 0
         }
     };
