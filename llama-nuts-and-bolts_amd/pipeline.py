@@ -335,10 +335,12 @@ def bench_main(args, cfg, name):
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
+    import datetime
+    patience = datetime.timedelta(seconds=300)               # a lost peer fails the run instead of hanging it
     if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device))   # rank -> GPU mapping is explicit
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device), timeout=patience)   # rank -> GPU mapping is explicit
     else:
-        dist.init_process_group(backend, rank=rank, world_size=world)
+        dist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)
     P, W, K = args.prompt_len, args.warmup, args.steps
     seq_len = P + W + K + 8
     # 2*world sequences: the exchange of a tick overlaps the compute of another sequence's item (run_ticks); LNB_PIPELINE_OVERLAP=0
