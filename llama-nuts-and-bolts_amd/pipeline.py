@@ -214,6 +214,23 @@ def part_costs(cfg, ffn_hidden):
     return attn, w13, w2, head
 
 
+def probe_costs(lnb, cfg, device_index, pos, iters=24):
+    """(attention part, gate/up part, down part, head) measured on THIS GPU for THIS shape: a four-block model with the head, HIP-event
+    time of each decode kernel class (lnb_profile_kernel).  The table of part_costs is calibrated on the 8B shape; for other shapes
+    the thin kernels run at different fractions of the bandwidth (dim 8192: the attention part takes 93 us where the table says
+    153), and the partition should follow the machine, not the table."""
+    one = dict(cfg, n_layers=int(os.environ.get("LNB_PROBE_LAYERS", "4")))   # (the timing loop cycles through the blocks)
+    m = lnb.LlamaTransformer(device=device_index, **one).fill_synthetic(7).finalize(rope_rows=max(pos + 8, 2 * cfg.get("max_seq_len", 2048)))
+    c = lnb.InferenceContext(m, pos + 8)
+    _, tok = c.Forward(lnb.synth_tokens(3, 4, cfg["vocab_size"]), 0, want_logits=False)   # real activations in the buffers (an all-zero
+    c.decode_greedy(tok, 4, 2)                                                            # row sends the exact norm sum down its replay path)
+    for which in range(6):
+        c.profile_kernel(which, pos, 2)                       # first launches load code objects: not part of the measurement
+    t = [c.profile_kernel(which, pos, iters) * 1e3 for which in range(6)]          # qkv, attention, wo, w1|w3, w2, head (us)
+    c.close(); m.close()
+    return t[0] + t[1] + t[2], t[3], t[4], t[5]
+
+
 def stage_parts(rank, world, n_layers, attn_cost=0.35, w13_cost=0.33, w2_cost=0.32, head_cost=1.2):
     """[part_begin, part_end) of pipeline stage `rank` in thirds of a block (3l = attention part of block l, 3l+1 = gate/up part,
     3l+2 = down part; lnb_model_create_parts).  Contiguous partition of the 3*n_layers parts into `world` non-empty stages that
@@ -253,14 +270,14 @@ def stage_parts(rank, world, n_layers, attn_cost=0.35, w13_cost=0.33, w2_cost=0.
 class LnbStage(Stage):
     """One GPU's share of the model behind the C ABI (lnb_forward_stage)."""
 
-    def __init__(self, lnb, torch, cfg, rank, world, n_seq, seq_len, device_index, parts=None):
+    def __init__(self, lnb, torch, cfg, rank, world, n_seq, seq_len, device_index, parts=None, costs=None):
         import ctypes as C
         self.lnb, self.torch, self.C = lnb, torch, C
         L = cfg["n_layers"]
         self.first, self.last = rank == 0, rank == world - 1
         probe = lnb.ModelArgs(**dict(lnb.LLAMA_8B, **cfg))
         self.ffn_hidden = lnb.lib().lnb_model_ffn_hidden_dim(C.byref(probe))
-        self.costs = part_costs(cfg, self.ffn_hidden)
+        self.costs = tuple(costs) if costs is not None else part_costs(cfg, self.ffn_hidden)      # (costs: measured by probe_costs)
         pb, pe = parts if parts is not None else stage_parts(rank, world, L, *self.costs)     # (parts: a test's own cut)
         self.parts = (pb, pe)
         self.model = lnb.LlamaTransformer(device=device_index, part_begin=pb, part_end=pe, **cfg).fill_synthetic(1234)
@@ -346,7 +363,15 @@ def bench_main(args, cfg, name):
     # 2*world sequences: the exchange of a tick overlaps the compute of another sequence's item (run_ticks); LNB_PIPELINE_OVERLAP=0
     # falls back to the lock-step schedule with `world` sequences
     n_seq = world * (2 if world > 1 and os.environ.get("LNB_PIPELINE_OVERLAP", "1") != "0" else 1)
-    stage = LnbStage(lnb, torch, cfg, rank, world, n_seq, seq_len, local)
+    costs = None
+    if world > 1 and os.environ.get("LNB_PIPELINE_PROBE", "1") != "0":
+        # rank 0 times the three block parts and the head on its GPU; every rank cuts the model with the same numbers
+        t = torch.zeros(4, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        if rank == 0:
+            t += torch.tensor(probe_costs(lnb, cfg, local, P + W + K // 2), dtype=torch.float64).to(t.device)
+        dist.broadcast(t, 0)
+        costs = [float(v) for v in t.tolist()]
+    stage = LnbStage(lnb, torch, cfg, rank, world, n_seq, seq_len, local, costs=costs)
     prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
     n_decode = W + K
     t_split = n_seq * (1 + W)              # prefill phase + W warm-up decode rounds
@@ -376,6 +401,7 @@ def bench_main(args, cfg, name):
                                                                                                            - stage_parts(r, world, cfg["n_layers"], *stage.costs)[0]) / 3.0)
                                                                                                 for r in range(world)), n_seq, P, K),
                           "prompt_len": P, "sequences_in_flight": n_seq, "parallelism": "pp%d" % world,
+                          "part_costs_us": [round(v, 1) for v in stage.costs],
                           "mode": "exact-order (token-id identical to the CPU reference path)"},
                "roofline": {"bound": "hbm", "achieved": round(tps * B / 1e9, 1), "peak": _b.PEAK_HBM_GBS * world, "unit": "GB/s",
                             "frac": round(tps * B / 1e9 / (_b.PEAK_HBM_GBS * world), 4), "traffic": None,
