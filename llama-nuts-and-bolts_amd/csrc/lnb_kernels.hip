@@ -176,6 +176,7 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
     for (int w = 0; w < NH; w++) { const float v = wtot[w]; base += w < hw ? v : 0.0f; }
     SeqNode n; n.a = 0u; n.b = 0u;
     if (b < nleaf) n = seq_leaf(q, LEAF, base + (incl - bsum), base + incl);
+    if (b < nleaf && bsum == 0.0f && (n.a >> 24) == 0u) n.a = SEQ_ZERO_LEAF;      // nothing to add, whatever the running sum is
     SeqNode left; left.a = (uint32_t)dpp_wave_shr1((int)n.a, 0); left.b = 0u;
     int f = seq_is_start(lane, n, left, b == headleaf);
     const int fnext = dpp_wave_shl1(f, 1);
@@ -211,6 +212,8 @@ DEVINL uint32_t rms_walk_heap(uint32_t sb, const SeqNode& rc, unsigned long long
         const uint32_t ok = (uint32_t)((nb >> 24) == (uint32_t)pos) & (uint32_t)(e == es) & (uint32_t)(e != 0u) & (uint32_t)(Mn < 0x1000000u);
         const uint32_t snew = (es << 23) | (Mn & 0x7FFFFFu);
         if (__builtin_expect(!ok, 0)) {                                  // replay leaves pos..i term by term
+            if (na == SEQ_ZERO_LEAF && pos == i) { pos = i + 1; continue; }          // (a leaf of exact zeros in front of any binade: a row of zeros
+                                                                         //  used to replay every leaf, 2.7x the kernel time)
             float f = __uint_as_float(sb);
             const float* qe = sq + (size_t)(i + 1) * LEAF;
             for (const float* q = sq + (size_t)pos * LEAF; q < qe; q += 4) f = add4(f, *(const float4*)q);

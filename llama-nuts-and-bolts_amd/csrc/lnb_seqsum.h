@@ -76,6 +76,9 @@ SEQ_HD int32_t seq_guess(float lo, float hi) {
 // Packed in two words: a = (e << 24) | c0, b = c1, with c0, c1 < 2^24; e == 0 means "invalid, replay the terms".
 // Such maps compose:  (f then g)(par) = f.c[par] + g.c[par ^ (f.c[par] & 1)]  when both were evaluated for the same e.
 struct SeqNode { uint32_t a, b; };
+// an INVALID node (e == 0: no binade could be guessed) whose terms are all exactly +0: still cut out of every run, but the walker
+// skips it instead of replaying it (x + 0 == x).  Rows that start with zeros have no binade until the first non-zero term.
+#define SEQ_ZERO_LEAF 1u
 
 SEQ_HD SeqNode seq_pack(const SeqBlock& blk) {
     SeqNode n; n.a = 0; n.b = 0;

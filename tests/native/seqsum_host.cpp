@@ -68,6 +68,7 @@ extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, in
             const int b = g * 64 + l;
             n[l].a = 0; n[l].b = 0;
             if (b < nleaf) n[l] = seq_leaf(p + (size_t)b * LEAF, LEAF, lo[b], hi[b]);
+            if (b < nleaf && bs[b] == 0.0f && !(n[l].a >> 24)) n[l].a = SEQ_ZERO_LEAF;
         }
         for (int l = 0; l < 64; l++) f[l] = seq_is_start(l, n[l], l ? n[l - 1] : n[l], g * 64 + l == headleaf);
         uint64_t mask = 0;
@@ -99,6 +100,7 @@ extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, in
             nv++;
             SeqNode n = rec[(size_t)g * 64 + i];
             const int st = (int)(n.b >> 24); n.b &= 0xFFFFFFu;
+            if (n.a == SEQ_ZERO_LEAF && pos == i) { pos = i + 1; continue; }   // zeros: nothing to add
             if (!(st == pos && seq_apply_node(sb, n))) {
                 float f = seq_u2f(sb);
                 for (int l = pos; l <= i; l++) { const float* q = p + ((size_t)g * 64 + l) * LEAF; for (int t = 0; t < LEAF; t++) f += q[t]; nr++; }
