@@ -92,7 +92,9 @@ extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, in
     for (int g = 0; g < NH; g++) {
         int nloc = nleaf - g * 64; nloc = nloc < 0 ? 0 : (nloc > 64 ? 64 : nloc);
         int pos = headleaf - g * 64; pos = pos < 0 ? 0 : pos;
-        uint64_t mask = items[g];
+        uint64_t mask = items[g], zm = 0;
+        for (int l = 0; l < 64; l++) if (rec[(size_t)g * 64 + l].a == SEQ_ZERO_LEAF) zm |= 1ull << l;
+        mask &= ~zm;                                                       // leaves of exact zeros: stepped over, not visited
         while (mask) {
             const int i = __builtin_ctzll(mask); mask &= mask - 1;
             if (i < pos) continue;
@@ -100,7 +102,7 @@ extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, in
             nv++;
             SeqNode n = rec[(size_t)g * 64 + i];
             const int st = (int)(n.b >> 24); n.b &= 0xFFFFFFu;
-            if (n.a == SEQ_ZERO_LEAF && pos == i) { pos = i + 1; continue; }   // zeros: nothing to add
+            if (st > pos && ((((1ull << st) - 1ull) & (~0ull << pos)) & ~zm) == 0ull) pos = st;   // zeros: nothing to add
             if (!(st == pos && seq_apply_node(sb, n))) {
                 float f = seq_u2f(sb);
                 for (int l = pos; l <= i; l++) { const float* q = p + ((size_t)g * 64 + l) * LEAF; for (int t = 0; t < LEAF; t++) f += q[t]; nr++; }
