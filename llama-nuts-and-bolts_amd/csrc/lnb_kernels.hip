@@ -951,9 +951,14 @@ template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& 
 // (An f32 k-major tile cost nine ds_reads per eight MFMAs and an LDS round trip in front of every pair; raw bf16 halves the LDS,
 // two workgroups fit a CU, and a staged 16 B unit -- 8 consecutive k = two k-groups -- lands as four packed words.)
 constexpr int GM_APAD = 80;                                 // stream strides in bytes: conflict-free 16 B reads across 16 lanes
-__host__ __device__ constexpr int gemm_bpad(int MB) { return 16 * (MB / 16) * 4 + 16; }       // 528 (128 batch rows) / 272 (64)
+// The one-chain 64-row tiles (WN 4, NCH 1) keep x in the LDS as f32 (bf16 << 16, converted once per element while staging): the B
+// operand -- each value feeds ONE MFMA there -- then needs no widening op between matrix instructions (+6 % at S = 512).  The
+// two-chain w1|w3 kernel uses every B value twice and is faster with the compact tile (two workgroups per CU at 64 x 128); the
+// 16-row tiles (WN 1) keep raw bf16 pairs too.
+__host__ __device__ constexpr bool gemm_bf32(int NCH, int WN) { return WN == 4 && NCH == 1; }
+__host__ __device__ constexpr int gemm_bpad(int MB, bool f32 = false) { return (f32 ? 32 : 16) * (MB / 16) * 4 + 16; }   // stream bytes (+ pad)
 __host__ __device__ constexpr size_t gemm_lds_a(int NCH, int WN) { return (size_t)NCH * WN * 64 * GM_APAD; }
-__host__ __device__ constexpr size_t gemm_lds_bytes(int NCH, int WN, int MB = 128) { return gemm_lds_a(NCH, WN) + (size_t)64 * gemm_bpad(MB); }
+__host__ __device__ constexpr size_t gemm_lds_bytes(int NCH, int WN, int MB = 128) { return gemm_lds_a(NCH, WN) + (size_t)64 * gemm_bpad(MB, gemm_bf32(NCH, WN)); }
 
 #ifndef GM_DBG
 #define GM_DBG 0                                            // tools/gemmbench.hip: 1 = stage only the first slab, 2 = no barriers, 4 = no LDS reads
@@ -962,7 +967,8 @@ __host__ __device__ constexpr size_t gemm_lds_bytes(int NCH, int WN, int MB = 12
 template <int EPI, int NCH, int WN, int MB = 128>
 __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
     static_assert(MB == 128 || (MB == 64 && WN == 4), "batch tile");
-    constexpr int GM_MB = MB, GM_BPAD = gemm_bpad(MB), TB = MB / 16;
+    constexpr bool BF32 = gemm_bf32(NCH, WN);                // x tile as f32: stream (kk, i) = [g][m-tile t]
+    constexpr int GM_MB = MB, GM_BPAD = gemm_bpad(MB, BF32), TB = MB / 16;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* As = smem;                                         // streams [(c*WN + w)*4 + kk][i] of GM_APAD bytes
     char* Bs = smem + gemm_lds_a(NCH, WN);                   // streams [kk][i] of GM_BPAD bytes
@@ -1028,7 +1034,7 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
         w[2] = (v.y & 0xFFFFu) | (v.w << 16); w[3] = (v.y >> 16) | (v.w & 0xFFFF0000u);
     };
     char* const wblk = As + (size_t)((wrow >> 4) * 4) * 16 * GM_APAD + (size_t)(wrow & 15) * GM_APAD;   // (+ c*WN*64*GM_APAD per chain)
-    char* const xblk = Bs + (size_t)(xrow & 15) * GM_BPAD + (xkc * TB + (xrow >> 4)) * 4;
+    char* const xblk = Bs + (size_t)(xrow & 15) * GM_BPAD + ((BF32 ? 2 : 1) * xkc * TB + (xrow >> 4)) * 4;
     auto commit = [&](int k0) {                              // raw bf16, no conversion (beyond K: zeros)
         const bool full = k0 + GM_KS <= K;
 #pragma unroll
@@ -1054,9 +1060,19 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
         for (int q = 0; q < XU; q++) {
             uint4 v = xreg[q];
             if (!full && !(k0 + 8 * (xkc + XQ * q) < K)) v = make_uint4(0, 0, 0, 0);
-            uint32_t w4[4]; pack4(v, w4);
+            if (BF32) {                                      // element kk -> k-group 2kc, element 4+kk -> k-group 2kc+1, widened here
+                const uint32_t e0[4] = {v.x << 16, v.x & 0xFFFF0000u, v.y << 16, v.y & 0xFFFF0000u};
+                const uint32_t e1[4] = {v.z << 16, v.z & 0xFFFF0000u, v.w << 16, v.w & 0xFFFF0000u};
 #pragma unroll
-            for (int kk = 0; kk < 4; kk++) *(uint32_t*)(xblk + (size_t)kk * 16 * GM_BPAD + q * XQ * TB * 4) = w4[kk];
+                for (int kk = 0; kk < 4; kk++) {
+                    char* d = xblk + (size_t)kk * 16 * GM_BPAD + q * 2 * XQ * TB * 4;
+                    *(uint32_t*)d = e0[kk]; *(uint32_t*)(d + TB * 4) = e1[kk];
+                }
+            } else {
+                uint32_t w4[4]; pack4(v, w4);
+#pragma unroll
+                for (int kk = 0; kk < 4; kk++) *(uint32_t*)(xblk + (size_t)kk * 16 * GM_BPAD + q * XQ * TB * 4) = w4[kk];
+            }
         }
     };
     const char* ap = As + (size_t)(((WN == 4 ? wave : 0) * 4 + fk) * 16 + fi) * GM_APAD;       // (+ c*WN*64*GM_APAD for chain c)
@@ -1076,21 +1092,30 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
         // nops): 52 instead of 32 cycles per MFMA; ds_reads among MFMAs are free; an LDS round trip in front of each MFMA pair
         // (hipcc's other choice) costs 40 %.
         constexpr int NP = GM_KS / 8;
-        uint32_t fb[2][MT], fa[2][NCH][4];                    // raw ring: pair j+1 being widened, pair j+2 being read
-        float wa[2][2][NCH], wb[2][2][MT];                  // [pair parity][k-group parity]
+        uint32_t fb[2][BF32 ? 2 : 1][MT], fa[2][NCH][4];    // raw ring: pair j+1 (being widened / waiting), pair j+2 being read
+        float wa[2][2][NCH], wb[2][2][BF32 ? 1 : MT];        // [pair parity][k-group parity]
         auto read_b = [&](int j) {
             const int sl = j & 1;
-            if (GM_DBG & 4) { for (int t = 0; t < MT; t++) fb[sl][t] = (uint32_t)(k0 + j + t) * 0x10001u; return; }
-            if (MT == 8) {
+            if (GM_DBG & 4) { for (int h = 0; h < (BF32 ? 2 : 1); h++) for (int t = 0; t < MT; t++) fb[sl][h][t] = (uint32_t)(k0 + j + t) * 0x10001u; return; }
+            if (BF32) {                                      // two k-groups x MT f32 values
+#pragma unroll
+                for (int h = 0; h < 2; h++)
+#pragma unroll
+                    for (int t4 = 0; t4 < MT; t4 += 4) {
+                        const uint4 v = *(const uint4*)(bp + ((2 * j + h) * TB + t4) * 4);
+                        fb[sl][h % (BF32 ? 2 : 1)][t4] = v.x; fb[sl][h % (BF32 ? 2 : 1)][(t4 + 1) % MT] = v.y;
+                        fb[sl][h % (BF32 ? 2 : 1)][(t4 + 2) % MT] = v.z; fb[sl][h % (BF32 ? 2 : 1)][(t4 + 3) % MT] = v.w;
+                    }
+            } else if (MT == 8) {                            // raw bf16 pairs: one word = (k-group 2j | k-group 2j+1 << 16) of one m-tile
                 const uint4 lo = *(const uint4*)(bp + j * 32), hi = *(const uint4*)(bp + j * 32 + 16);
-                fb[sl][0] = lo.x; fb[sl][1] = lo.y; fb[sl][2] = lo.z; fb[sl][3] = lo.w;
-                fb[sl][4 % MT] = hi.x; fb[sl][5 % MT] = hi.y; fb[sl][6 % MT] = hi.z; fb[sl][7 % MT] = hi.w;
+                fb[sl][0][0] = lo.x; fb[sl][0][1] = lo.y; fb[sl][0][2 % MT] = lo.z; fb[sl][0][3 % MT] = lo.w;
+                fb[sl][0][4 % MT] = hi.x; fb[sl][0][5 % MT] = hi.y; fb[sl][0][6 % MT] = hi.z; fb[sl][0][7 % MT] = hi.w;
             } else if (MT == 4) {
                 const uint4 lo = *(const uint4*)(bp + j * 16);
-                fb[sl][0] = lo.x; fb[sl][1] = lo.y; fb[sl][2 % MT] = lo.z; fb[sl][3 % MT] = lo.w;
+                fb[sl][0][0] = lo.x; fb[sl][0][1] = lo.y; fb[sl][0][2 % MT] = lo.z; fb[sl][0][3 % MT] = lo.w;
             } else {
                 const uint2 v = *(const uint2*)(bp + j * (TB * 4));
-                fb[sl][0] = v.x; fb[sl][1] = v.y;
+                fb[sl][0][0] = v.x; fb[sl][0][1 % MT] = v.y;
             }
         };
         auto read_a = [&](int o) {                           // octet o: k-groups 8o .. 8o+7
@@ -1105,24 +1130,29 @@ __global__ __launch_bounds__(256) void gemm_mfma_kernel(GemmParams p) {
             const int sl = j & 1, q = j & 1;
 #pragma unroll
             for (int c = 0; c < NCH; c++) { const uint32_t w = fa[(j >> 2) & 1][c][j & 3]; wa[q][0][c] = bf_lo(w); wa[q][1][c] = bf_hi(w); }
+            if (!BF32) {
 #pragma unroll
-            for (int t = 0; t < MT; t++) { wb[q][0][t] = bf_lo(fb[sl][t]); wb[q][1][t] = bf_hi(fb[sl][t]); }
+                for (int t = 0; t < MT; t++) { wb[q][0][t % (BF32 ? 1 : MT)] = bf_lo(fb[sl][0][t]); wb[q][1][t % (BF32 ? 1 : MT)] = bf_hi(fb[sl][0][t]); }
+            }
         };
         read_a(0); read_b(0);
         widen(0);
-        read_b(1);
+        if (!BF32) read_b(1);
 #pragma unroll
         for (int j = 0; j < NP; j++) {
             if (j + 1 < NP) widen(j + 1);                    // (frees raw slot j+1 & 1 ... which pair j+2 then refills)
-            if (j + 2 < NP) read_b(j + 2);
+            if (BF32) { if (j + 1 < NP) read_b(j + 1); }     // f32 tile: pair j+1's values are read while pair j's MFMAs run, used as they are
+            else if (j + 2 < NP) read_b(j + 2);
             if ((j & 3) == 1 && j + 3 < NP) read_a(j / 4 + 1);   // octet o+1 is first widened at pair 4o+3, last use of octet o-1 was pair 4o-1
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int par = 0; par < 2; par++)
 #pragma unroll
-                for (int t = 0; t < MT; t++)
+                for (int t = 0; t < MT; t++) {
+                    const float bval = BF32 ? __uint_as_float(fb[j & 1][par % (BF32 ? 2 : 1)][t]) : wb[j & 1][par][t % (BF32 ? 1 : MT)];
 #pragma unroll
-                    for (int c = 0; c < NCH; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j & 1][par][c], wb[j & 1][par][t], acc[c][t], 0, 0, 0);
+                    for (int c = 0; c < NCH; c++) acc[c][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(wa[j & 1][par][c], bval, acc[c][t], 0, 0, 0);
+                }
             __builtin_amdgcn_sched_barrier(0);
         }
         if (!(GM_DBG & 2)) __syncthreads();
