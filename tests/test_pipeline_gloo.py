@@ -152,3 +152,34 @@ def test_stage_parts_partition_is_contiguous_and_no_worse_than_whole_blocks():
             assert tick(cuts) <= tick([(3 * a, 3 * b) for a, b in blocks]) + 1e-9
     eight = [pipeline.stage_parts(r, 8, 32, *costs) for r in range(8)]
     assert max(b - a for a, b in eight) <= 13                                       # no stage above 4 1/3 blocks (5 with whole blocks)
+
+
+def test_stage_parts_reaches_the_min_max_optimum():
+    """binary search + greedy fill against an exhaustive dynamic programme on small random instances"""
+    import functools
+    import random
+    import pipeline
+    rnd = random.Random(5)
+    for _ in range(200):
+        L, world = rnd.randint(1, 6), rnd.randint(1, 7)
+        c = (rnd.uniform(0.1, 3), rnd.uniform(0.1, 3), rnd.uniform(0.1, 3), rnd.uniform(0, 6))
+        n = 3 * L
+        if world > n:
+            with pytest.raises(ValueError):
+                pipeline.stage_parts(0, world, L, *c)
+            continue
+        cost = [c[u % 3] for u in range(n)]
+        cost[-1] += c[3]
+        pre = [0.0]
+        for x in cost:
+            pre.append(pre[-1] + x)
+
+        @functools.lru_cache(None)
+        def best(i, k):
+            if k == 1:
+                return pre[n] - pre[i]
+            return min(max(pre[j] - pre[i], best(j, k - 1)) for j in range(i + 1, n - k + 2))
+        cuts = [pipeline.stage_parts(r, world, L, *c) for r in range(world)]
+        assert cuts[0][0] == 0 and cuts[-1][1] == n and all(b > a for a, b in cuts) and all(x[1] == y[0] for x, y in zip(cuts, cuts[1:]))
+        got = max(pre[b] - pre[a] for a, b in cuts)
+        assert got <= best(0, world) * (1 + 1e-9) + 1e-12, (L, world, c, cuts)
