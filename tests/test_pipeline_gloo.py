@@ -87,7 +87,7 @@ def _free_port():
 
 
 @pytest.mark.parametrize("world,n_decode,split,mult", [(2, 6, 0, 1), (2, 6, 7, 1), (3, 4, 5, 1),
-                                                        (2, 6, 0, 2), (2, 5, 9, 2), (3, 4, 11, 2), (3, 3, 1, 2)])
+                                                        (2, 6, 0, 2), (2, 5, 9, 2), (3, 4, 11, 2), (3, 3, 1, 2), (4, 3, 17, 2)])
 def test_pipeline_schedule_matches_single_process(world, n_decode, split, mult):
     """mult 1: lock-step schedule, `world` sequences; mult 2: 2*world sequences, stages two ticks apart, the exchange posted before
     and completed after each tick's compute (what bench.py --gpus N runs)"""
