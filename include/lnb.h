@@ -86,6 +86,14 @@ int lnb_ctx_destroy(lnb_ctx* c);
 int lnb_ctx_reset(lnb_ctx* c);                                       /* zero the caches again */
 /* InferenceContext.CacheK/CacheV[layer] (exported, poked by llamatransformer_simulated_test.go:527-538) */
 int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which /*0=K 1=V*/, uint16_t* host_bf16);
+/* Arithmetic mode of a context.  LNB_MODE_EXACT (default): every matmul output is the reference's single k-ordered f32 chain
+ * (src/ml/operations_lineartransform.go:46-65), every intermediate bit-identical to the Go CPU path.  LNB_MODE_FAST: the same
+ * operators and bf16 truncation points with split-K f32 sums (decode) and bf16 matrix-core GEMMs (prefill): HBM / MFMA bound instead
+ * of add-latency bound, logits within the 1e-2 tolerance of the north star but NOT bit-identical, token ids may diverge (measured:
+ * DESIGN.md 6.2).  Opt-in, per context, switchable between calls; the KV cache is shared by both modes. */
+enum { LNB_MODE_EXACT = 0, LNB_MODE_FAST = 1 };
+int lnb_ctx_set_mode(lnb_ctx* c, int mode);
+int lnb_ctx_get_mode(const lnb_ctx* c);
 /* optional per-layer progress hook = infContext.Logf("Transformer block layer %d / %d was run, took %.4f sec(s)")
  * (llamatransformer.go:157-163); forces a per-layer stream sync, so it is off by default */
 typedef void (*lnb_layer_cb)(int layer_1based, int n_layers, double secs, void* user);
@@ -142,6 +150,13 @@ int lnb_op_linear(int device, const uint16_t* x, const uint16_t* w, uint16_t* y,
 /* RMSNorm.Forward (llamatransformer.go:633-639) followed by a linear layer, as the fused kernel computes it */
 int lnb_op_rmsnorm_linear(int device, const uint16_t* x, const uint16_t* norm_w, float eps, const uint16_t* w,
                           uint16_t* y, int rows, int n_out, int k_in, int rw);
+
+/* either operator in a given arithmetic mode (norm_w == NULL: plain linear); LNB_MODE_FAST runs the split-K kernels */
+int lnb_op_linear_mode(int device, const uint16_t* x, const uint16_t* norm_w, float eps, const uint16_t* w, uint16_t* y,
+                       int rows, int n_out, int k_in, int rw, int mode);
+/* ml.Argmax (operations_impl.go:513-548) of n bf16 values: strict '<' scan from -MaxFloat32, so the FIRST maximum wins and
+ * NaN / -inf are never selected (-1 when nothing qualifies); the kernel the device greedy loop uses (inference.go:207-211) */
+int lnb_op_argmax(int device, const uint16_t* logits_bf16, int n, int32_t* out);
 
 /* ---- weight ingestion: replaces torch.TorchModelReader + model.loadModelArgsFromFile (SURVEY.md 8f "next" #2) -------
  * src/torch/torchmodelreader.go:39-145, src/torch/types.go:9-56, src/pickle/pickledispatch.go:13-78,

@@ -27,6 +27,8 @@ hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st);
 hipError_t lnbk_tile(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, int gather, hipStream_t st);
 hipError_t lnbk_synth_fill(uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, uint64_t seed, uint32_t tensor_id, int kind, float sigma, hipStream_t st);
 hipError_t lnbk_init(void);
+hipError_t lnbk_fast_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st);
+hipError_t lnbk_fast_init(void);
 }
 
 static thread_local char g_err[1024] = "";
@@ -91,6 +93,7 @@ struct lnb_ctx {
     lnb_layer_cb cb = nullptr; void* cb_user = nullptr;
     int32_t* h_io = nullptr;               // pinned host words of lnb_forward_stage_begin/_end: [0] argmax, [1] token error, [2..] tokens
     bool pending = false, pending_tokens = false, pending_argmax = false;
+    int mode = LNB_MODE_EXACT;             // LNB_MODE_FAST: split-K kernels of lnb_fast.hip (tolerance mode, opt-in)
 };
 
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
@@ -148,13 +151,18 @@ extern "C" int lnb_model_create(const lnb_model_args* args, int device, int laye
 // :619, :248).  After the attention part the live state is again one [S, dim] vector (h); after the gate/up part it is h plus the
 // [S, ffn_hidden] activations.  The three parts cost about the same HBM time (48 / 47 / 45 us for the 8B shape), so the stages of a
 // pipeline can be balanced to a third of a block (pipeline.stage_parts).
+static int model_alloc(lnb_model* m);
 extern "C" int lnb_model_create_parts(const lnb_model_args* args, int device, int part_begin, int part_end, lnb_model** out) {
     if (!args || !out) return fail("null argument");
+    *out = nullptr;
     const int layer_begin = part_begin / 3, layer_end = (part_end + 2) / 3;
     lnb_model_args a = *args;
     if (a.n_kv_heads < 0) a.n_kv_heads = a.n_heads;                       // llamatransformer.go:73-75
     if (a.rope_theta <= 0) a.rope_theta = 500000.0;                       // :80-82
-    if (a.dim <= 0 || a.n_heads <= 0 || a.dim % a.n_heads || a.n_heads % a.n_kv_heads) return fail("invalid head configuration");
+    if (a.n_layers <= 0) return fail("n_layers must be positive (got %d)", a.n_layers);
+    if (a.vocab_size <= 0) return fail("vocab_size must be positive (got %d; params.json without the key gives -1: take it from tok_embeddings)", a.vocab_size);
+    if (a.multiple_of <= 0) return fail("multiple_of must be positive (got %d)", a.multiple_of);
+    if (a.dim <= 0 || a.n_heads <= 0 || a.n_kv_heads <= 0 || a.dim % a.n_heads || a.n_heads % a.n_kv_heads) return fail("invalid head configuration");
     if (part_begin < 0 || part_end > 3 * a.n_layers || part_begin >= part_end) return fail("invalid layer range [%d,%d)", part_begin / 3, (part_end + 2) / 3);
     int hd = a.dim / a.n_heads;
     if (a.dim % 8 || hd % 8) return fail("dim and head_dim must be multiples of 8");
@@ -163,12 +171,20 @@ extern "C" int lnb_model_create_parts(const lnb_model_args* args, int device, in
     if (device < 0 || device >= ndev) return fail("device %d out of range (%d devices)", device, ndev);
     HIPCHK(hipSetDevice(device));
     HIPCHK(lnbk_init());
+    HIPCHK(lnbk_fast_init());
     { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); if (prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount; }
     lnb_model* m = new lnb_model();
     m->a = a; m->device = device; m->layer_begin = layer_begin; m->layer_end = layer_end; m->part_begin = part_begin; m->part_end = part_end;
     m->head_dim = hd; m->n_rep = a.n_heads / a.n_kv_heads; m->ffn_hidden = lnb_model_ffn_hidden_dim(&a);
-    if (m->ffn_hidden % 8) { delete m; return fail("ffn hidden dim must be a multiple of 8"); }
     m->q_dim = a.n_heads * hd; m->kv_dim = a.n_kv_heads * hd;
+    if (m->ffn_hidden <= 0 || m->ffn_hidden % 8) { delete m; return fail("ffn hidden dim must be a positive multiple of 8"); }
+    if (model_alloc(m)) { lnb_model_destroy(m); return -1; }             // (the error text survives: destroy does not touch it)
+    *out = m;
+    return 0;
+}
+static int model_alloc(lnb_model* m) {
+    const lnb_model_args& a = m->a;
+    const int layer_begin = m->layer_begin, layer_end = m->layer_end;
     HIPCHK(hipStreamCreate(&m->stream));
     int64_t& wb = m->weight_bytes;
     const int dim = a.dim, F = m->ffn_hidden;
@@ -212,7 +228,6 @@ extern "C" int lnb_model_create_parts(const lnb_model_args* args, int device, in
         if (alloc_tiled(m->output, a.vocab_size, dim, auto_rw(a.vocab_size, "LNB_RW_OUT"), 1, wb)) return -1;
         reg_tiled(m, "output.weight", &m->output, a.vocab_size, dim, 0, 0, 2);
     }
-    *out = m;
     return 0;
 }
 
@@ -370,22 +385,34 @@ extern "C" int lnb_model_rope_table(lnb_model* m, float* out, int64_t nfloats, i
 }
 
 // ---------------------------------------------------------------------------------------------------
+static int ctx_alloc(lnb_ctx* c);
 extern "C" int lnb_ctx_create(lnb_model* m, int seq_len, lnb_ctx** out) {
     if (!m || !out) return fail("null argument");
+    *out = nullptr;
     if (!m->finalized) return fail("model not finalized");
     HIPCHK(hipSetDevice(m->device));
     lnb_ctx* c = new lnb_ctx();
     c->m = m; c->seq_len = seq_len > 0 ? seq_len : m->a.max_seq_len;        // inferencecontext.go:22-26
+    // the one-workgroup-per-head decode attention stages e (f64) and p (f32) of every cached position in the LDS: 12 bytes per
+    // position next to the product ring -> about 7.8K positions at head_dim 128 (documented in include/lnb.h)
     if ((size_t)c->seq_len * 12 + 2 * 64 * (size_t)m->head_dim * 4 + 4096 > 160 * 1024 || (m->head_dim != 128 && m->head_dim != 64 && m->head_dim != 32))
         { delete c; return fail("seq_len %d too long for the LDS staging of the attention kernel, or head_dim %d not one of 32/64/128", c->seq_len, m->head_dim); }
+    if (ctx_alloc(c)) { lnb_ctx_destroy(c); return -1; }
+    *out = c;
+    return 0;
+}
+static int ctx_alloc(lnb_ctx* c) {
+    lnb_model* m = c->m;
     HIPCHK(hipStreamCreate(&c->stream));
     HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
     const size_t kvn = (size_t)c->seq_len * m->kv_dim;
     for (size_t l = 0; l < m->layers.size(); l++) {
         uint16_t *k = nullptr, *v = nullptr;
-        HIPCHK(hipMalloc((void**)&k, kvn * 2)); HIPCHK(hipMalloc((void**)&v, kvn * 2));
-        HIPCHK(hipMemset(k, 0, kvn * 2)); HIPCHK(hipMemset(v, 0, kvn * 2));     // ml.Zeros, inferencecontext.go:32-42
-        c->ck.push_back(k); c->cv.push_back(v);
+        if (m->has_attn(m->layer_begin + (int)l)) {                         // a stage that holds only FFN parts of a block keeps no cache for it
+            HIPCHK(hipMalloc((void**)&k, kvn * 2)); c->ck.push_back(k); c->cv.push_back(nullptr);
+            HIPCHK(hipMalloc((void**)&v, kvn * 2)); c->cv.back() = v;
+            HIPCHK(hipMemset(k, 0, kvn * 2)); HIPCHK(hipMemset(v, 0, kvn * 2));     // ml.Zeros, inferencecontext.go:32-42
+        } else { c->ck.push_back(nullptr); c->cv.push_back(nullptr); }
     }
     HIPCHK(hipMalloc((void**)&c->st, sizeof(StepState))); HIPCHK(hipMemset(c->st, 0, sizeof(StepState)));
     HIPCHK(hipMalloc((void**)&c->dtok, (size_t)c->seq_len * 4));
@@ -397,22 +424,22 @@ extern "C" int lnb_ctx_create(lnb_model* m, int seq_len, lnb_ctx** out) {
     HIPCHK(hipMalloc((void**)&c->q, S * m->q_dim * 2)); HIPCHK(hipMalloc((void**)&c->att, S * m->q_dim * 2));
     HIPCHK(hipMalloc((void**)&c->ffn, S * m->ffn_hidden * 2));
     if (m->last()) { HIPCHK(hipMalloc((void**)&c->logits, (size_t)m->a.vocab_size * 2)); c->logits_rows = 1; }
-    *out = c;
     return 0;
 }
 
 extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->m->device);
-    hipStreamSynchronize(c->stream);
+    if (c->stream) hipStreamSynchronize(c->stream);
     if (c->graph) hipGraphExecDestroy(c->graph);
-    for (auto p : c->ck) hipFree(p);
-    for (auto p : c->cv) hipFree(p);
+    for (auto p : c->ck) if (p) hipFree(p);
+    for (auto p : c->cv) if (p) hipFree(p);
     hipFree(c->st); hipFree(c->dtok); hipFree(c->dnext); hipFree(c->derr); hipFree(c->dout);
     if (c->h_io) hipHostFree(c->h_io);
     hipFree(c->x); hipFree(c->h); hipFree(c->xn); hipFree(c->q); hipFree(c->att); hipFree(c->ffn); if (c->logits) hipFree(c->logits);
-    hipEventDestroy(c->ev0); hipEventDestroy(c->ev1);
-    hipStreamDestroy(c->stream);
+    if (c->ev0) hipEventDestroy(c->ev0);
+    if (c->ev1) hipEventDestroy(c->ev1);
+    if (c->stream) hipStreamDestroy(c->stream);
     delete c;
     return 0;
 }
@@ -421,7 +448,7 @@ extern "C" int lnb_ctx_reset(lnb_ctx* c) {
     if (!c) return fail("null argument");
     HIPCHK(hipSetDevice(c->m->device));
     const size_t kvn = (size_t)c->seq_len * c->m->kv_dim;
-    for (size_t l = 0; l < c->ck.size(); l++) { HIPCHK(hipMemsetAsync(c->ck[l], 0, kvn * 2, c->stream)); HIPCHK(hipMemsetAsync(c->cv[l], 0, kvn * 2, c->stream)); }
+    for (size_t l = 0; l < c->ck.size(); l++) if (c->ck[l]) { HIPCHK(hipMemsetAsync(c->ck[l], 0, kvn * 2, c->stream)); HIPCHK(hipMemsetAsync(c->cv[l], 0, kvn * 2, c->stream)); }
     HIPCHK(hipStreamSynchronize(c->stream));
     return 0;
 }
@@ -444,6 +471,18 @@ extern "C" int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which, uint16_t* host)
     return 0;
 }
 
+// exact-order (default) or tolerance mode for everything this context runs afterwards; the captured decode graph is per mode
+extern "C" int lnb_ctx_set_mode(lnb_ctx* c, int mode) {
+    if (!c) return fail("null argument");
+    if (mode != LNB_MODE_EXACT && mode != LNB_MODE_FAST) return fail("unknown mode %d (LNB_MODE_EXACT = 0, LNB_MODE_FAST = 1)", mode);
+    if (mode == c->mode) return 0;
+    HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    c->mode = mode;
+    return 0;
+}
+extern "C" int lnb_ctx_get_mode(const lnb_ctx* c) { return c ? c->mode : -1; }
 extern "C" int lnb_ctx_set_layer_callback(lnb_ctx* c, lnb_layer_cb cb, void* user) { if (!c) return fail("null argument"); c->cb = cb; c->cb_user = user; return 0; }
 extern "C" void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which) { return !c ? nullptr : which == 2 ? (void*)c->ffn : (void*)c->x; }
 extern "C" void* lnb_ctx_stream(lnb_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -456,6 +495,10 @@ enum { K_QKV = 0, K_ATTN = 1, K_WO = 2, K_W13 = 3, K_W2 = 4, K_HEAD = 5, K_LAYER
 static bool use_mfma(int S) { static const int on = env_int("LNB_PREFILL_MFMA", 1); return on && S >= 16; }
 static GemmParams gemm_of(const TiledDesc& t, const uint16_t* x, int K, int n_rows, int S, const StepState* st) {
     GemmParams g{}; g.w = t.w; g.rw = t.rw; g.nch = t.nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = S; g.st = st; return g;
+}
+// S < 16 rows: the exact-order chain kernels, or (LNB_MODE_FAST) the split-K kernels over the same resident weights
+static hipError_t gemv_dispatch(const lnb_ctx* c, const GemvParams* g, int rw, int nch, int epi, int norm, hipStream_t st) {
+    return c->mode == LNB_MODE_FAST ? lnbk_fast_gemv(g, rw, nch, epi, norm, st) : lnbk_gemv(g, rw, nch, epi, norm, st);
 }
 static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = c->stream;
@@ -484,7 +527,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     case K_QKV: {   // attn_norm + wq|wk|wv + RoPE + KV append  (llamatransformer.go:222, :297-403)
         GemvParams g{}; g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
         g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.seq_len = c->seq_len; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
-        set_grid(g, L.wqkv); HIPCHK(lnbk_gemv(&g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, st)); return 0; }
+        set_grid(g, L.wqkv); HIPCHK(gemv_dispatch(c, &g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, st)); return 0; }
     case K_ATTN: {  // scores / softmax / PV  (:409-514)
         AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st; ap.dbg = g_dbg;
         ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len;
@@ -493,14 +536,14 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x;
-        set_grid(o, L.wo); HIPCHK(lnbk_gemv(&o, L.wo.rw, 1, EPI_RESID, 0, st)); return 0; }
+        set_grid(o, L.wo); HIPCHK(gemv_dispatch(c, &o, L.wo.rw, 1, EPI_RESID, 0, st)); return 0; }
     case K_W13: {   // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
         GemvParams f{}; f.w = L.w13.w; f.x = hbuf; f.norm_w = L.ffn_norm; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
         f.out = c->ffn; f.silu = m->silu;
-        set_grid(f, L.w13); HIPCHK(lnbk_gemv(&f, L.w13.rw, 2, EPI_SILU_MUL, 1, st)); return 0; }
+        set_grid(f, L.w13); HIPCHK(gemv_dispatch(c, &f, L.w13.rw, 2, EPI_SILU_MUL, 1, st)); return 0; }
     case K_W2: {    // w2 + residual  (:619, :248)
         GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = hbuf;
-        set_grid(d, L.w2); HIPCHK(lnbk_gemv(&d, L.w2.rw, 1, EPI_RESID, 0, st)); return 0; }
+        set_grid(d, L.w2); HIPCHK(gemv_dispatch(c, &d, L.w2.rw, 1, EPI_RESID, 0, st)); return 0; }
     }
     return fail("bad kernel id");
 }
@@ -532,7 +575,7 @@ static int enqueue_head(lnb_ctx* c, int first, int rows) {
     GemvParams g{}; g.w = m->output.w; g.x = c->x + (size_t)first * m->a.dim; g.norm_w = m->norm; g.eps = m->a.norm_eps; g.K = m->a.dim;
     g.n_rows = m->a.vocab_size; g.S = rows; g.st = c->st; g.out = c->logits;
     set_grid(g, m->output);
-    HIPCHK(lnbk_gemv(&g, m->output.rw, 1, EPI_STORE, 1, c->stream));
+    HIPCHK(gemv_dispatch(c, &g, m->output.rw, 1, EPI_STORE, 1, c->stream));
     return 0;
 }
 
@@ -612,7 +655,9 @@ extern "C" int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int
         const int rows = logits_out ? seq : 1;
         if (rows > c->logits_rows) {
             HIPCHK(hipStreamSynchronize(st));
-            hipFree(c->logits); c->logits = nullptr;
+            // the captured decode graph has the old buffer baked into its head GEMV / argmax nodes: drop it with the buffer
+            if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+            hipFree(c->logits); c->logits = nullptr; c->logits_rows = 0;
             HIPCHK(hipMalloc((void**)&c->logits, (size_t)rows * V * 2)); c->logits_rows = rows;
         }
         if (enqueue_head(c, logits_out ? 0 : seq - 1, rows)) return -1;
@@ -754,7 +799,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
 
 // ---- single-op entry points for the parity tests ------------------------------------------------------
 static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w, float eps, const uint16_t* w, uint16_t* y,
-                          int rows, int n_out, int k_in, int rw) {
+                          int rows, int n_out, int k_in, int rw, int mode = LNB_MODE_EXACT) {
     if (!x || !w || !y) return fail("null argument");
     if (rows <= 0 || n_out <= 0 || k_in <= 0) return fail("empty operand");
     if (k_in % 8) return fail("in_features must be a multiple of 8");
@@ -762,6 +807,8 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     if (ndev == 0) return fail("no HIP device: liblnb_hip.so has no CPU fallback");
     HIPCHK(hipSetDevice(device));
     HIPCHK(lnbk_init());
+    HIPCHK(lnbk_fast_init());
+    if (mode != LNB_MODE_EXACT && mode != LNB_MODE_FAST) return fail("unknown mode %d", mode);
     if (rw == 0) rw = auto_rw(n_out, "LNB_RW_OP", k_in, norm_w == nullptr);
     if (rw != 16 && rw != 32 && rw != 64 && !(rw == 4 && !norm_w && k_in % 128 == 0 && k_in <= 16384)) return fail("rw must be 16, 32 or 64 (or 4: row-broadcast layout, no fused norm, in_features a multiple of 128)");
     if ((size_t)k_in * 4 > 120 * 1024) return fail("in_features %d does not fit the LDS staging", k_in);
@@ -785,15 +832,39 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     } else {
     GemvParams g{}; g.w = t.w; g.x = dx; g.norm_w = dn; g.eps = eps; g.K = k_in; g.n_rows = n_out; g.S = rows; g.st = st; g.out = dy;
     set_grid(g, t);
-    HIPCHK(lnbk_gemv(&g, rw, 1, EPI_STORE, norm_w ? 1 : 0, nullptr));
+    if (mode == LNB_MODE_FAST) HIPCHK(lnbk_fast_gemv(&g, rw, 1, EPI_STORE, norm_w ? 1 : 0, nullptr));
+    else HIPCHK(lnbk_gemv(&g, rw, 1, EPI_STORE, norm_w ? 1 : 0, nullptr));
     }
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(y, dy, (size_t)rows * n_out * 2, hipMemcpyDeviceToHost));
     hipFree(dx); hipFree(dw); hipFree(dy); hipFree(st); hipFree(t.w); if (dn) hipFree(dn);
     return 0;
 }
+// ml.Argmax (operations_impl.go:513-548) of one row of bf16 logits through argmax_kernel, the kernel of the greedy loop
+extern "C" int lnb_op_argmax(int device, const uint16_t* logits_bf16, int n, int32_t* out) {
+    if (!logits_bf16 || !out) return fail("null argument");
+    if (n <= 0) return fail("empty operand");
+    int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev == 0) return fail("no HIP device: liblnb_hip.so has no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    uint16_t* d = nullptr; int32_t* dn = nullptr; StepState* st = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)n * 2 + 16)); HIPCHK(hipMalloc((void**)&dn, 16)); HIPCHK(hipMalloc((void**)&st, sizeof(StepState)));
+    HIPCHK(hipMemset(st, 0, sizeof(StepState)));
+    HIPCHK(hipMemcpy(d, logits_bf16, (size_t)n * 2, hipMemcpyHostToDevice));
+    hipError_t e = lnbk_argmax(d, n, dn, st, nullptr, 0, 0, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out, dn, 4, hipMemcpyDeviceToHost);
+    hipFree(d); hipFree(dn); hipFree(st);
+    HIPCHK(e);
+    return 0;
+}
 extern "C" int lnb_op_linear(int device, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int n_out, int k_in, int rw) {
     return op_linear_impl(device, x, nullptr, 0.0f, w, y, rows, n_out, k_in, rw);
+}
+// the same two operators in a given arithmetic mode (LNB_MODE_FAST: the split-K kernels; norm_w may be NULL)
+extern "C" int lnb_op_linear_mode(int device, const uint16_t* x, const uint16_t* norm_w, float eps, const uint16_t* w, uint16_t* y,
+                                  int rows, int n_out, int k_in, int rw, int mode) {
+    return op_linear_impl(device, x, norm_w, eps, w, y, rows, n_out, k_in, rw, mode);
 }
 extern "C" int lnb_op_rmsnorm_linear(int device, const uint16_t* x, const uint16_t* norm_w, float eps, const uint16_t* w, uint16_t* y,
                                      int rows, int n_out, int k_in, int rw) {

@@ -16,13 +16,17 @@ _SO = os.path.join(_HERE, "liblnb_hip.so")
 _CSRC = os.path.join(_HERE, "csrc")
 
 
+MODE_EXACT, MODE_FAST = 0, 1
+
+
 class LnbError(RuntimeError):
     pass
 
 
 def build(force=False):
     """hipcc --offload-arch=gfx950 build of the library, in-tree (the .so travels with the repo snapshot)."""
-    srcs = [os.path.join(_CSRC, f) for f in ("lnb_kernels.hip", "lnb_api.cpp", "lnb_device.h", "Makefile")]
+    # every source and header under csrc/ plus the ABI header: a stale git-ignored .so must never be what the tests validate
+    srcs = [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith((".hip", ".cpp", ".h", ".hpp")) or f == "Makefile"]
     srcs.append(os.path.join(_HERE, "..", "include", "lnb.h"))
     if force or not os.path.exists(_SO) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs):
         subprocess.check_call(["make", "-C", _CSRC, "-s"])
@@ -46,7 +50,7 @@ EXPORTS = [
     "lnb_model_set_tensor", "lnb_model_get_tensor", "lnb_model_fill_synthetic", "lnb_model_finalize",
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
-    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear",
+    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear", "lnb_op_argmax", "lnb_op_linear_mode", "lnb_ctx_set_mode", "lnb_ctx_get_mode",
     "lnb_profile_kernel", "lnb_model_num_tensors", "lnb_model_tensor_info",
     "lnb_checkpoint_open", "lnb_checkpoint_close", "lnb_checkpoint_num_tensors", "lnb_checkpoint_find", "lnb_checkpoint_tensor",
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
@@ -94,6 +98,10 @@ def lib():
     L.lnb_profile_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p]
     L.lnb_op_linear.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_op_rmsnorm_linear.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lnb_ctx_set_mode.argtypes = [vp, C.c_int]
+    L.lnb_ctx_get_mode.argtypes = [vp]
+    L.lnb_op_linear_mode.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
+    L.lnb_op_argmax.argtypes = [C.c_int, vp, C.c_int, i32p]
     L.lnb_model_num_tensors.argtypes = [vp]
     L.lnb_model_tensor_info.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.lnb_checkpoint_open.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -296,6 +304,11 @@ class InferenceContext:
         self.h = C.c_void_p()
         _chk(self.L.lnb_ctx_create(transformer.h, seq_len, C.byref(self.h)))
 
+    def set_mode(self, mode):
+        """MODE_EXACT (default, bit-identical to the reference) or MODE_FAST (split-K / bf16-MFMA tolerance mode)"""
+        _chk(self.L.lnb_ctx_set_mode(self.h, {"exact": 0, "fast": 1}.get(mode, mode)))
+        return self
+
     def Forward(self, tokens, start_pos, want_logits=True):
         """(*LlamaTransformer).Forward (llamatransformer.go:145-180) -> (logits f32 [S,V] | None, argmax of last row)."""
         tok = np.ascontiguousarray(tokens, dtype=np.int32)
@@ -383,6 +396,24 @@ def op_rmsnorm_linear(x_u16, norm_w_u16, eps, w_u16, rw=0, device=0):
     y = np.empty((rows, n), dtype=np.uint16)
     _chk(lib().lnb_op_rmsnorm_linear(device, _p(x), _p(nw), np.float32(eps), _p(w), _p(y), rows, n, k, rw))
     return y
+
+
+def op_linear_mode(x_u16, w_u16, mode, norm_w_u16=None, eps=1e-5, rw=0, device=0):
+    x = np.ascontiguousarray(x_u16, dtype=np.uint16)
+    w = np.ascontiguousarray(w_u16, dtype=np.uint16)
+    nw = None if norm_w_u16 is None else np.ascontiguousarray(norm_w_u16, dtype=np.uint16)
+    rows, k = x.shape
+    n = w.shape[0]
+    y = np.empty((rows, n), dtype=np.uint16)
+    _chk(lib().lnb_op_linear_mode(device, _p(x), None if nw is None else _p(nw), np.float32(eps), _p(w), _p(y), rows, n, k, rw, mode))
+    return y
+
+
+def op_argmax(logits_u16, device=0):
+    a = np.ascontiguousarray(logits_u16, dtype=np.uint16).ravel()
+    out = C.c_int32(-2)
+    _chk(lib().lnb_op_argmax(device, _p(a), a.size, C.byref(out)))
+    return out.value
 
 
 _M64 = (1 << 64) - 1

@@ -1,0 +1,201 @@
+"""GPU parity at the geometries of BASELINE.json's other configs (run with -m gpu on an MI355X), HIP path vs the CPU oracle, bit for bit:
+
+* configs[2] (long context): contexts that cross every branch of the decode attention (second K register set above 512 cached
+  positions, third pass above 1024, more than eight PV chunks) and of the prefill attention (hundreds of 16-position tiles), with
+  RoPE rows beyond the reference's 4096-row table and bf16-quantised positions (llamatransformer.go:409-514, :109);
+* configs[4] (70B-like shape cut to two layers): dim 8192, 64/8 heads, FFN 28672 as a whole Forward (the four-helper long-K w2
+  kernel, the dim-8192 norm, 64-head attention);
+* ml.Argmax edge cases through the kernel of the device greedy loop (operations_impl.go:513-548);
+* decode -> multi-row Forward -> decode on ONE context (the captured decode graph must not outlive the logits buffer it was
+  captured with).
+"""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def lnb():
+    import lnb as _lnb
+    _lnb.build()
+    assert _lnb.device_count() >= 1
+    return _lnb
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+# head_dim 64 (4 query heads on 2 KV heads) and head_dim 128 (2 on 1); max_seq_len 2304 -> a 4608-row RoPE table
+LONG_CFGS = {
+    "hd64": dict(orc.TINY, max_seq_len=2304),
+    "hd128": dict(orc.TINY, n_heads=2, n_kv_heads=1, max_seq_len=2304),
+}
+
+
+@pytest.fixture(scope="module", params=sorted(LONG_CFGS))
+def long_pair(lnb, request):
+    cfg = LONG_CFGS[request.param]
+    om = orc.Model(**cfg).fill_synthetic(4321).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(4321).finalize()
+    assert gm.PrecomputedFreqsCis.shape[0] == 4608
+    assert (_bits(om.rope_table()) == _bits(gm.PrecomputedFreqsCis)).all()
+    yield cfg, om, gm
+    gm.close(); om.close()
+
+
+@pytest.mark.parametrize("chunks,steps", [
+    ((510,), 4),            # decode at T = 511, 512, 513, 514: the scores loop's second K register set switches on at 513
+    ((1023,), 3),           # T = 1024, 1025, 1026: third scores pass, 17 PV chunks
+    ((1535,), 3),           # T = 1536, 1537, 1538
+    ((4094,), 3),           # T = 4095, 4096, 4097: positions quantised to bf16 (4095 -> 4080), RoPE row 4096 = first row past the reference's table
+    ((2080, 2080), 3),      # chunked prefill, second chunk at start_pos 2080 (T % S == 0: modulo-broadcast mask), then T = 4161..4163
+])
+def test_long_context_prefill_and_decode_bit_exact(lnb, long_pair, chunks, steps):
+    cfg, om, gm = long_pair
+    total = sum(chunks)
+    seq_len = total + steps + 1
+    toks = orc.synth_tokens(1000 + total, total, cfg["vocab_size"])
+    oc, gc = orc.Context(om, seq_len), lnb.InferenceContext(gm, seq_len)
+    pos = 0
+    for n in chunks:
+        lo, ao = oc.forward(toks[pos:pos + n], pos)
+        lg, ag = gc.Forward(toks[pos:pos + n], pos)
+        assert np.abs(lo - lg).max() <= 1e-2                                   # north_star tolerance
+        assert (_bits(lo) == _bits(lg)).all() and ao == ag                     # expected: bit-identical
+        pos += n
+    tok = ag
+    for i in range(steps):                                                     # S = 1 kernels (attn_exact_kernel) over the long cache
+        lo, ao = oc.forward([tok], pos)
+        lg, ag = gc.Forward(np.array([tok], dtype=np.int32), pos)
+        assert (_bits(lo) == _bits(lg)).all() and ao == ag, "decode step at T = %d" % (pos + 1)
+        tok, pos = ao, pos + 1
+    for layer in range(cfg["n_layers"]):
+        assert (oc.cache(layer, 0)[:pos] == gc.CacheK(layer)[:pos]).all()
+        assert (oc.cache(layer, 1)[:pos] == gc.CacheV(layer)[:pos]).all()
+    # the device greedy loop (hipGraph replays) continues from the same cache and gives the tokens of the step-by-step path
+    gc2 = lnb.InferenceContext(gm, seq_len)
+    p2 = 0
+    for n in chunks:
+        _, first = gc2.Forward(toks[p2:p2 + n], p2, want_logits=False)
+        p2 += n
+    got, _ = gc2.decode_greedy(first, total, steps)
+    oc2 = orc.Context(om, seq_len)
+    p2 = 0
+    for n in chunks:
+        _, t = oc2.forward(toks[p2:p2 + n], p2, want_logits=False)
+        p2 += n
+    ref = []
+    for i in range(steps):
+        _, t = oc2.forward([t], total + i, want_logits=False)
+        ref.append(t)
+    assert [int(x) for x in got] == ref
+    for c in (oc, oc2):
+        c.close()
+    for c in (gc, gc2):
+        c.close()
+
+
+def test_llama70b_like_geometry_two_layers_bit_exact(lnb):
+    """configs[4]'s shape (dim 8192, 64 query heads on 8 KV heads, FFN 28672) cut to two layers and a 2048-token vocabulary:
+    a 24-row prefill (matrix-core path) and 32 one-token steps, logits and KV cache against the oracle."""
+    cfg = dict(orc.LLAMA_8B, dim=8192, n_layers=2, n_heads=64, n_kv_heads=8, vocab_size=2048, multiple_of=4096)
+    om = orc.Model(**cfg).fill_synthetic(70).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(70).finalize()
+    assert gm.ffn_hidden == om.ffn_hidden == 28672 and gm.head_dim == 128
+    P, N = 24, 32
+    toks = orc.synth_tokens(170, P, cfg["vocab_size"])
+    oc, gc = orc.Context(om, P + N + 1), lnb.InferenceContext(gm, P + N + 1)
+    lo, ao = oc.forward(toks, 0)
+    lg, ag = gc.Forward(toks, 0)
+    assert np.abs(lo - lg).max() <= 1e-2
+    assert (_bits(lo) == _bits(lg)).all() and ao == ag
+    tok = ao
+    for i in range(N):
+        lo, ao = oc.forward([tok], P + i)
+        lg, ag = gc.Forward(np.array([tok], dtype=np.int32), P + i)
+        assert (_bits(lo) == _bits(lg)).all() and ao == ag, "decode step %d" % i
+        tok = ao
+    for layer in range(2):
+        assert (oc.cache(layer, 0)[:P + N] == gc.CacheK(layer)[:P + N]).all()
+        assert (oc.cache(layer, 1)[:P + N] == gc.CacheV(layer)[:P + N]).all()
+    # and the hipGraph-replayed loop
+    gc2 = lnb.InferenceContext(gm, P + N + 1)
+    _, first = gc2.Forward(toks, 0, want_logits=False)
+    got, _ = gc2.decode_greedy(first, P, N)
+    ref, _ = orc.Context(om, P + N + 1).generate(toks, N + 1)
+    assert [first] + [int(t) for t in got] == [int(t) for t in ref]
+    gc.close(); gc2.close(); oc.close(); gm.close(); om.close()
+
+
+def _argmax_ref(u16):
+    f = orc.bf16_to_f32(np.asarray(u16, dtype=np.uint16))
+    return int(orc.lib().orc_argmax_f32(orc._p(f), f.size))
+
+
+def test_argmax_kernel_edge_cases(lnb):
+    """ml.Argmax (operations_impl.go:529-541): strict '<' from -MaxFloat32: first maximum wins, NaN / -inf never selected."""
+    NAN, NINF, PINF = 0x7FC0, 0xFF80, 0x7F80
+    bf = orc.f32_to_bf16
+    rng = np.random.default_rng(5)
+    cases = []
+    a = bf(rng.standard_normal(128256).astype(np.float32)); a[[100000, 7, 60000]] = bf(np.float32(9.0)); cases.append(("ties at distant indices", a, 7))
+    a = bf(rng.standard_normal(128256).astype(np.float32)); a[[128255, 128248]] = bf(np.float32(8.5)); cases.append(("tie inside the last 16 B unit", a, 128248))
+    a = bf(rng.standard_normal(4099).astype(np.float32)); a[4098] = bf(np.float32(50.0)); cases.append(("maximum in the scalar tail (V % 8 != 0)", a, 4098))
+    a = bf(rng.standard_normal(13).astype(np.float32)); cases.append(("V smaller than one 16 B unit x threads", a, None))
+    a = bf(rng.standard_normal(1001).astype(np.float32)); a[::3] = NAN; cases.append(("NaNs are skipped", a, None))
+    a = np.full(1024, NAN, dtype=np.uint16); a[777] = bf(np.float32(-3.0)); cases.append(("one number among NaNs", a, 777))
+    cases.append(("all NaN", np.full(2048, NAN, dtype=np.uint16), -1))
+    cases.append(("all -inf", np.full(128256, NINF, dtype=np.uint16), -1))
+    a = np.full(5000, NINF, dtype=np.uint16); a[4321] = 0xFF7F; cases.append(("most negative finite bf16 beats -inf", a, 4321))
+    a = bf(rng.standard_normal(9000).astype(np.float32)); a[[8000, 1234]] = PINF; cases.append(("+inf, first one", a, 1234))
+    a = np.zeros(777, dtype=np.uint16); a[5] = 0x8000; cases.append(("+0 / -0 tie: index 0", a, 0))
+    a = bf(rng.standard_normal(128256).astype(np.float32)); a[:] = np.minimum(a.view(np.int16), 0x3F00).view(np.uint16); cases.append(("saturated plateau", a, None))
+    for name, arr, want in cases:
+        ref = _argmax_ref(arr)
+        if want is not None:
+            assert ref == want, name                                    # the oracle itself on the constructed case
+        assert lnb.op_argmax(arr) == ref, name
+    for V in (8, 9, 1023, 1024, 4096 * 8, 4096 * 8 + 1, 128256):      # random rows with heavy ties (few distinct values)
+        for rep in range(3):
+            arr = bf(rng.integers(-3, 4, V).astype(np.float32))
+            assert lnb.op_argmax(arr) == _argmax_ref(arr), (V, rep)
+
+
+def test_decode_graph_survives_a_multi_row_forward_on_the_same_context(lnb):
+    """multi-turn use of ONE InferenceContext: greedy decode (captures the hipGraph with the 1-row logits buffer), then a Forward
+    that asks for the logits of 8 rows (the buffer is re-allocated), then greedy decode again -- every token and the 8 logits rows
+    against the oracle."""
+    cfg = dict(orc.TINY)
+    om = orc.Model(**cfg).fill_synthetic(1234).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1234).finalize()
+    oc, gc = orc.Context(om, 64), lnb.InferenceContext(gm, 64)
+    p1 = orc.synth_tokens(41, 8, cfg["vocab_size"])
+    p2 = orc.synth_tokens(42, 8, cfg["vocab_size"])
+    _, t0 = gc.Forward(p1, 0, want_logits=False)
+    got1, _ = gc.decode_greedy(t0, 8, 8)                              # positions 8..15
+    lg, t1 = gc.Forward(p2, 16, want_logits=True)                     # T = 24, S = 8
+    got2, _ = gc.decode_greedy(t1, 24, 6)
+    _, r0 = oc.forward(p1, 0, want_logits=False)
+    ref1, tok = [], r0
+    for i in range(8):
+        _, tok = oc.forward([tok], 8 + i, want_logits=False)
+        ref1.append(tok)
+    lo, r1 = oc.forward(p2, 16)
+    ref2, tok = [], r1
+    for i in range(6):
+        _, tok = oc.forward([tok], 24 + i, want_logits=False)
+        ref2.append(tok)
+    assert t0 == r0 and [int(t) for t in got1] == ref1
+    assert (_bits(lo) == _bits(lg)).all() and t1 == r1
+    assert [int(t) for t in got2] == ref2
+    gc.close(); oc.close(); gm.close(); om.close()
+
+
+def test_create_rejects_degenerate_arguments_without_crashing(lnb):
+    for bad in (dict(n_kv_heads=0), dict(vocab_size=-1), dict(vocab_size=0), dict(n_layers=0), dict(multiple_of=0), dict(dim=0), dict(n_heads=0)):
+        with pytest.raises(lnb.LnbError):
+            lnb.LlamaTransformer(**dict(orc.TINY, **bad))
