@@ -28,6 +28,7 @@ hipError_t lnbk_tile(const uint16_t* src, uint16_t* dst, int rows, int K, int ro
 hipError_t lnbk_synth_fill(uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, uint64_t seed, uint32_t tensor_id, int kind, float sigma, hipStream_t st);
 hipError_t lnbk_init(void);
 hipError_t lnbk_fast_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st);
+hipError_t lnbk_fast_gemm(const GemmParams* p, int epi, hipStream_t st);
 hipError_t lnbk_fast_init(void);
 }
 
@@ -500,6 +501,12 @@ static GemmParams gemm_of(const TiledDesc& t, const uint16_t* x, int K, int n_ro
 static hipError_t gemv_dispatch(const lnb_ctx* c, const GemvParams* g, int rw, int nch, int epi, int norm, hipStream_t st) {
     return c->mode == LNB_MODE_FAST ? lnbk_fast_gemv(g, rw, nch, epi, norm, st) : lnbk_gemv(g, rw, nch, epi, norm, st);
 }
+// S >= 16 rows: the exact chains on the f32 matrix cores, or (LNB_MODE_FAST) the bf16 matrix-core GEMM; shapes the fast kernel does not
+// take (K not a multiple of 64) stay on the exact one
+static hipError_t gemm_dispatch(int mode, const GemmParams* g, int epi, hipStream_t st) {
+    if (mode == LNB_MODE_FAST) { hipError_t e = lnbk_fast_gemm(g, epi, st); if (e != hipErrorNotSupported) return e; }
+    return lnbk_gemm(g, epi, st);
+}
 static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = c->stream;
     LayerW& L = m->layers[l - m->layer_begin];
@@ -514,13 +521,13 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
             HIPCHK(lnbk_rmsnorm_rows(c->x, L.attn_norm, c->xn, S, a.dim, a.norm_eps, st));
             GemmParams g = gemm_of(L.wqkv, c->xn, a.dim, L.wqkv.n_rows, S, c->st);
             g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.seq_len = c->seq_len; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
-            HIPCHK(lnbk_gemm(&g, EPI_QKV_ROPE, st)); return 0; }
-        case K_WO: { GemmParams g = gemm_of(L.wo, c->att, m->q_dim, a.dim, S, c->st); g.out = hbuf; g.res = c->x; HIPCHK(lnbk_gemm(&g, EPI_RESID, st)); return 0; }
+            HIPCHK(gemm_dispatch(c->mode, &g, EPI_QKV_ROPE, st)); return 0; }
+        case K_WO: { GemmParams g = gemm_of(L.wo, c->att, m->q_dim, a.dim, S, c->st); g.out = hbuf; g.res = c->x; HIPCHK(gemm_dispatch(c->mode, &g, EPI_RESID, st)); return 0; }
         case K_W13: {
             HIPCHK(lnbk_rmsnorm_rows(hbuf, L.ffn_norm, c->xn, S, a.dim, a.norm_eps, st));
             GemmParams g = gemm_of(L.w13, c->xn, a.dim, m->ffn_hidden, S, c->st); g.out = c->ffn; g.silu = m->silu;
-            HIPCHK(lnbk_gemm(&g, EPI_SILU_MUL, st)); return 0; }
-        case K_W2: { GemmParams g = gemm_of(L.w2, c->ffn, m->ffn_hidden, a.dim, S, c->st); g.out = c->x; g.res = hbuf; HIPCHK(lnbk_gemm(&g, EPI_RESID, st)); return 0; }
+            HIPCHK(gemm_dispatch(c->mode, &g, EPI_SILU_MUL, st)); return 0; }
+        case K_W2: { GemmParams g = gemm_of(L.w2, c->ffn, m->ffn_hidden, a.dim, S, c->st); g.out = c->x; g.res = hbuf; HIPCHK(gemm_dispatch(c->mode, &g, EPI_RESID, st)); return 0; }
         }
     }
     switch (which) {
@@ -569,7 +576,7 @@ static int enqueue_head(lnb_ctx* c, int first, int rows) {
     if (use_mfma(rows)) {
         HIPCHK(lnbk_rmsnorm_rows(c->x + (size_t)first * m->a.dim, m->norm, c->xn, rows, m->a.dim, m->a.norm_eps, c->stream));
         GemmParams gm = gemm_of(m->output, c->xn, m->a.dim, m->a.vocab_size, rows, c->st); gm.out = c->logits;
-        HIPCHK(lnbk_gemm(&gm, EPI_STORE, c->stream));
+        HIPCHK(gemm_dispatch(c->mode, &gm, EPI_STORE, c->stream));
         return 0;
     }
     GemvParams g{}; g.w = m->output.w; g.x = c->x + (size_t)first * m->a.dim; g.norm_w = m->norm; g.eps = m->a.norm_eps; g.K = m->a.dim;
@@ -826,7 +833,7 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
         uint16_t* dxn = nullptr;
         if (norm_w) { HIPCHK(hipMalloc((void**)&dxn, (size_t)rows * k_in * 2)); HIPCHK(lnbk_rmsnorm_rows(dx, dn, dxn, rows, k_in, eps, nullptr)); }
         GemmParams gm = gemm_of(t, norm_w ? dxn : dx, k_in, n_out, rows, st); gm.out = dy;
-        HIPCHK(lnbk_gemm(&gm, EPI_STORE, nullptr));
+        HIPCHK(gemm_dispatch(mode, &gm, EPI_STORE, nullptr));
         HIPCHK(hipDeviceSynchronize());
         if (dxn) hipFree(dxn);
     } else {

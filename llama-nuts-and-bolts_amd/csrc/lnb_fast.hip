@@ -246,10 +246,212 @@ __global__ __launch_bounds__(256) void fast_gemv_b(GemvParams p) {
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// fast_gemm_kernel: the prefill GEMM of the tolerance mode on the bf16 matrix cores, Y[m][n] = sum_k X[m][k] W[n][k], f32 accumulate.
+//
+// v_mfma_f32_32x32x16_bf16: A lane (row = lane & 31, kg = lane >> 5) supplies 8 bf16 of its row, k = 8 kg .. 8 kg + 7 of the
+// 16-step; B likewise per column; D[row][col]: lane holds col = lane & 31, rows (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// A = the WEIGHTS, straight from HBM/L2 into the operand registers: a 16 B unit of either resident layout IS 8 k-values of one
+// weight row (layout A: consecutive k; layout B: k = 128c + 16e + j, e = 0..7 -- the k order inside an instruction does not matter
+// for a sum, the X tile is staged in the matching order), a 32-row tile of layout A is one 512 B run per k-group, and every weight
+// unit is consumed by exactly one wave, so an LDS stage would buy nothing.  B = X, staged through the LDS (shared by the four
+// waves): 128 batch rows x 64 k per slab, row pitch 144 B (conflict-free ds_read_b128), double-buffered, one barrier per slab.
+// Wave w owns 64 output rows (two 32-row tiles; one 32-row tile of BOTH chains for the gate|up matrix) x 128 batch rows:
+// 8 MFMAs per 16-step on 2 weight loads + 4 LDS reads.  The next slab's weights and X rows are in flight during a slab's 32 MFMAs.
+// Epilogues = the reference's rounding points, four consecutive output rows per lane (RoPE partner in the same lane).
+// grid (ceil(N / 256 or 128), ceil(S / 128)), block 256, static LDS 36 KB: two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int FG_BK = 64, FG_PITCH = 144;
+
+template <int EPI> DEVINL void fast_gemm_epilogue4(const GemmParams& p, const f32x4& g, const f32x4& u, int m, int n0) {
+    if (m >= p.S) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int n = n0 + r;
+        if (n >= p.n_rows) continue;
+        const size_t o = (size_t)m * p.n_rows + n;
+        if (EPI == EPI_STORE) p.out[o] = bf_trunc(g[r]);
+        else if (EPI == EPI_RESID) p.out[o] = bf_trunc(bf_wide(p.res[o]) + bf_wide(bf_trunc(g[r])));
+        else if (EPI == EPI_SILU_MUL) {
+            const uint16_t gs = bf_trunc(p.silu[bf_trunc(g[r])]);
+            p.out[o] = bf_trunc(bf_wide(gs) * bf_wide(bf_trunc(u[r])));
+        } else if (EPI == EPI_QKV_ROPE) {
+            const int pos = p.st->pos + m;
+            const uint16_t mine = bf_trunc(g[r]), other = bf_trunc(g[r ^ 1]);
+            if (n < p.q_dim + p.kv_dim) {
+                const int d = n % p.head_dim, i = d >> 1;
+                const float2 cs = *(const float2*)(p.cis + ((size_t)pos * (p.head_dim >> 1) + i) * 2);
+                const double cr = (double)cs.x, ci = (double)cs.y;
+                uint16_t r16;
+                if ((n & 1) == 0) { const double a = (double)bf_wide(mine), bb = (double)bf_wide(other); r16 = bf_trunc((float)(a * cr - bb * ci)); }
+                else              { const double a = (double)bf_wide(other), bb = (double)bf_wide(mine); r16 = bf_trunc((float)(a * ci + bb * cr)); }
+                if (n < p.q_dim) p.q_out[(size_t)m * p.q_dim + n] = r16;
+                else {
+                    const int kc = n - p.q_dim, kh = kc / p.head_dim;
+                    p.cache_k[(((size_t)kh * (p.head_dim >> 3) + (d >> 3)) * p.seq_len + pos) * 8 + (d & 7)] = r16;
+                }
+            } else p.cache_v[(size_t)pos * p.kv_dim + (n - p.q_dim - p.kv_dim)] = mine;
+        }
+    }
+}
+
+template <int EPI, int NCH, bool LAYB, int MT>
+__global__ __launch_bounds__(256, 1) void fast_gemm_kernel(GemmParams p) {
+    constexpr int AT = NCH == 2 ? 1 : 2;                     // 32-row weight tiles per wave and chain
+    constexpr int NWG = 4 * 32 * AT;                         // output rows per workgroup
+    constexpr int MB = 32 * MT, XQ = MB / 32;                // batch rows per workgroup; X units per thread and slab
+    extern __shared__ __attribute__((aligned(16))) char lds_raw[];
+    char* const lds0 = lds_raw; char* const lds1 = lds_raw + (size_t)MB * FG_PITCH;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 31, kg = lane >> 5;
+    // blockIdx.x = batch tile (fastest): the workgroups that stream the same weight rows run at the same time and share them in L2
+    const int n0 = blockIdx.y * NWG + wave * 32 * AT, m0 = blockIdx.x * MB;
+    const int K = p.K, nslabs = K / FG_BK;
+    // ---- weight stream: per-lane byte offset of k-step 0 of slab 0 from the wave-uniform base; uniform strides per k-step and slab
+    // (32-bit offsets: a matrix is < 4 GB, and offsets cost half the registers of pointers)
+    uint32_t wp[NCH][AT];
+    const char* const wbase = (const char*)p.w;
+    uint32_t w_step, w_slab0, w_slab1;                       // slab s -> s+1 advances by w_slab0 (s even) / w_slab1 (s odd)
+    if (LAYB) { w_step = 32; w_slab0 = 128; w_slab1 = 1024 - 128; }
+    else { w_step = (uint32_t)(2 * p.nch * p.rw * 16); w_slab0 = w_slab1 = (uint32_t)(8 * p.nch * p.rw * 16); }
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int a = 0; a < AT; a++) {
+            int n = n0 + 32 * a + ln; n = n < p.n_rows ? n : p.n_rows - 1;         // clamped rows are computed and dropped
+            if (LAYB) wp[c][a] = (uint32_t)((((size_t)(n >> 2) * (size_t)(K >> 7) * 64 + (size_t)((n & 3) * 16 + kg)) * 16));
+            else wp[c][a] = (uint32_t)((((((size_t)(n / p.rw) * (size_t)(K >> 3) + (size_t)kg) * p.nch + c) * p.rw + (size_t)(n % p.rw)) * 16));
+        }
+    // ---- X staging: thread = (row = tid / 8 + 32 q, unit = tid % 8) of the MB x 64 slab
+    const int xr_row = tid >> 3, xr_u = tid & 7;
+    uint32_t xp[XQ];                                         // element offsets of this thread's rows (S * K < 2^31)
+#pragma unroll
+    for (int q = 0; q < XQ; q++) { int m = m0 + xr_row + 32 * q; m = m < p.S ? m : p.S - 1; xp[q] = (uint32_t)m * (uint32_t)K; }
+    uint4 xr[XQ];
+    auto x_issue = [&](int s) {                              // layout A: 8 consecutive k; layout B: the unit whose k % 16 lies in this slab's half
+        const int off = LAYB ? ((s >> 1) * 128 + (2 * xr_u + (s & 1)) * 8) : (s * FG_BK + xr_u * 8);
+#pragma unroll
+        for (int q = 0; q < XQ; q++) xr[q] = *(const uint4*)(p.x + (size_t)(xp[q] + (uint32_t)off));
+    };
+    auto x_commit = [&](char* buf) {
+#pragma unroll
+        for (int q = 0; q < XQ; q++) {
+            char* row = buf + (size_t)(xr_row + 32 * q) * FG_PITCH;
+            if (LAYB) {                                      // element i of the loaded unit = k % 16 = 8 h + i -> LDS unit i, slot e = xr_u
+                const uint32_t wd[4] = {xr[q].x, xr[q].y, xr[q].z, xr[q].w};
+#pragma unroll
+                for (int i = 0; i < 8; i++) *(uint16_t*)(row + i * 16 + xr_u * 2) = (uint16_t)(wd[i >> 1] >> ((i & 1) * 16));
+            } else *(uint4*)(row + xr_u * 16) = make_uint4(xr[q].x, xr[q].y, xr[q].z, xr[q].w);   // (component reads: a whole-struct copy keeps xr on the stack)
+        }
+    };
+    typedef uint4 wbuf_t[4][NCH][AT];
+    wbuf_t w0, w1, w2;                                       // weights of three consecutive slabs: two slabs of prefetch distance
+    int s_w = 0;                                             // slab the pointers stand on
+    auto w_issue = [&](wbuf_t& w) {                          // loads the slab the pointers stand on, then steps them to the next
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int a = 0; a < AT; a++) w[ks][c][a] = *(const uint4*)(wbase + (size_t)(wp[c][a] + (uint32_t)ks * w_step));
+        const uint32_t d = (s_w & 1) ? w_slab1 : w_slab0;
+#pragma unroll
+        for (int c = 0; c < NCH; c++)
+#pragma unroll
+            for (int a = 0; a < AT; a++) wp[c][a] += d;
+        s_w++;
+    };
+    f32x16 acc[NCH][AT][MT];
+#pragma unroll
+    for (int c = 0; c < NCH; c++)
+#pragma unroll
+        for (int a = 0; a < AT; a++)
+#pragma unroll
+            for (int t = 0; t < MT; t++)
+#pragma unroll
+                for (int i = 0; i < 16; i++) acc[c][a][t][i] = 0.0f;
+    // slab s: X of slab s+1 and the weights of slab s+2 go in flight (X first: its wait must not drain the younger weight loads),
+    // 32 MT MFMAs on slab s, then X(s+1) is written to the other LDS buffer; one barrier
+    auto slab = [&](int s, const wbuf_t& wa, wbuf_t& wc) {
+        const bool more = s + 1 < nslabs;                    // (uniform)
+        if (more) x_issue(s + 1);
+        if (s + 2 < nslabs) w_issue(wc);
+        const char* bl = ((s & 1) ? lds1 : lds0) + (size_t)ln * FG_PITCH + kg * 16;
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+            bf16x8 bfr[MT];
+#pragma unroll
+            for (int t = 0; t < MT; t++) bfr[t] = *(const bf16x8*)(bl + (size_t)t * 32 * FG_PITCH + ks * 32);
+#pragma unroll
+            for (int c = 0; c < NCH; c++)
+#pragma unroll
+                for (int a = 0; a < AT; a++) {
+                    const bf16x8 af = __builtin_bit_cast(bf16x8, wa[ks][c][a]);
+#pragma unroll
+                    for (int t = 0; t < MT; t++) acc[c][a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af, bfr[t], acc[c][a][t], 0, 0, 0);
+                }
+        }
+        if (more) x_commit((s & 1) ? lds0 : lds1);
+        __syncthreads();
+    };
+    x_issue(0); w_issue(w0); if (nslabs > 1) w_issue(w1);
+    x_commit(lds0);
+    __syncthreads();
+    for (int s = 0; s < nslabs; s += 3) {
+        slab(s, w0, w2);
+        if (s + 1 < nslabs) slab(s + 1, w1, w0);
+        if (s + 2 < nslabs) slab(s + 2, w2, w1);
+    }
+    // D: lane holds batch column m0 + 32 t + ln, output rows 8 g + 4 kg + r (g = 0..3, r = 0..3) of each 32-row tile
+#pragma unroll
+    for (int a = 0; a < AT; a++)
+#pragma unroll
+        for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const f32x16& A0 = acc[0][a][t]; const f32x16& A1 = acc[NCH - 1][a][t];
+                const f32x4 gv = {A0[4 * g], A0[4 * g + 1], A0[4 * g + 2], A0[4 * g + 3]};
+                const f32x4 uv = {A1[4 * g], A1[4 * g + 1], A1[4 * g + 2], A1[4 * g + 3]};
+                fast_gemm_epilogue4<EPI>(p, gv, uv, m0 + 32 * t + ln, n0 + 32 * a + 8 * g + 4 * kg);
+            }
+}
+
+template <int EPI, int NCH, bool LAYB, int MT> hipError_t launch_gemm_fast_t(const GemmParams* p, hipStream_t st) {
+    auto kfn = fast_gemm_kernel<EPI, NCH, LAYB, MT>;
+    const size_t lds = 2 * (size_t)32 * MT * FG_PITCH;
+    if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    const int nwg = NCH == 2 ? 128 : 256;
+    const dim3 grid((unsigned)((p->S + 32 * MT - 1) / (32 * MT)), (unsigned)((p->n_rows + nwg - 1) / nwg));
+    hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, *p);
+    return hipGetLastError();
+}
+template <int EPI, int NCH> hipError_t launch_gemm_fast(const GemmParams* p, int layb, hipStream_t st) {
+    if (!p) {                                                // raise the dynamic-LDS limits (72 KB for the 256-row batch tile)
+        hipError_t e = launch_gemm_fast_t<EPI, NCH, false, 4>(nullptr, nullptr);
+        if (e == hipSuccess) e = launch_gemm_fast_t<EPI, NCH, false, 8>(nullptr, nullptr);
+        if (NCH == 1 && e == hipSuccess) e = launch_gemm_fast_t<EPI, NCH, true, 4>(nullptr, nullptr);
+        if (NCH == 1 && e == hipSuccess) e = launch_gemm_fast_t<EPI, NCH, true, 8>(nullptr, nullptr);
+        return e;
+    }
+    const bool big = p->S > 128;                             // 256 batch rows per workgroup: twice the MFMAs per weight byte and per slab
+    if constexpr (NCH == 1) if (layb) return big ? launch_gemm_fast_t<EPI, NCH, true, 8>(p, st) : launch_gemm_fast_t<EPI, NCH, true, 4>(p, st);
+    return big ? launch_gemm_fast_t<EPI, NCH, false, 8>(p, st) : launch_gemm_fast_t<EPI, NCH, false, 4>(p, st);
+}
+
 int fast_rg(int rw, int nch, int n_blocks) {
     static const int force = [] { const char* e = getenv("LNB_FAST_RG"); return e && *e ? atoi(e) : 0; }();
     if (force && rw % force == 0 && (force == 8 || force == 16 || force == 32 || force == 64)) return force;
-    if (rw % 16 == 0 && (long)n_blocks * (rw / 16) >= 1024) return 16;       // enough 16-row units to fill the chip: 256 B segments
+    // measured on MI355X (8B shape, gpurun call A of round 2): LM head (2004 blocks of 64) 181 / 170 / 154 us with 8 / 16 / 32 rows per unit,
+    // wq|wk|wv (192 blocks of 32) 14.1 / 13.0 / 17.0 us: the longer the contiguous run per wave load the better, as long as the
+    // matrix still splits into a few units per CU
+    if (rw % 64 == 0 && n_blocks >= 1024) return 64;
+    if (rw % 32 == 0 && (long)n_blocks * (rw / 32) >= 1024) return 32;
+    if (rw % 16 == 0 && (long)n_blocks * (rw / 16) >= 256) return 16;
     return 8;
 }
 
@@ -309,6 +511,20 @@ extern "C" hipError_t lnbk_fast_gemv(const GemvParams* p, int rw, int nch, int e
         default: return hipErrorInvalidValue;
     }
 }
+// S >= 16 rows on the bf16 matrix cores.  K must be a multiple of 64 (128 for the row-broadcast layout): the caller falls back to the
+// exact GEMM otherwise (hipErrorNotSupported).
+extern "C" hipError_t lnbk_fast_gemm(const GemmParams* p, int epi, hipStream_t st) {
+    if (!p) return hipErrorInvalidValue;
+    if (p->K % FG_BK || (p->rw == 4 && (p->K & 127 || p->nch != 1)) || (p->rw != 4 && p->rw % 8)) return hipErrorNotSupported;
+    const int layb = p->rw == 4;
+    switch (epi) {
+        case EPI_STORE: return p->nch == 1 ? launch_gemm_fast<EPI_STORE, 1>(p, layb, st) : hipErrorInvalidValue;
+        case EPI_RESID: return p->nch == 1 ? launch_gemm_fast<EPI_RESID, 1>(p, layb, st) : hipErrorInvalidValue;
+        case EPI_QKV_ROPE: return p->nch == 1 ? launch_gemm_fast<EPI_QKV_ROPE, 1>(p, layb, st) : hipErrorInvalidValue;
+        case EPI_SILU_MUL: return p->nch == 2 ? launch_gemm_fast<EPI_SILU_MUL, 2>(p, layb, st) : hipErrorInvalidValue;
+        default: return hipErrorInvalidValue;
+    }
+}
 extern "C" hipError_t lnbk_fast_init(void) {
     static bool done = false;
     if (done) return hipSuccess;
@@ -320,6 +536,10 @@ extern "C" hipError_t lnbk_fast_init(void) {
     if ((e = lnbk_fast_gemv(nullptr, 64, 1, EPI_STORE, 0, nullptr)) != hipSuccess) return e;
     if ((e = lnbk_fast_gemv(nullptr, 64, 1, EPI_QKV_ROPE, 1, nullptr)) != hipSuccess) return e;
     if ((e = lnbk_fast_gemv(nullptr, 64, 1, EPI_RESID, 0, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm_fast<EPI_STORE, 1>(nullptr, 0, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm_fast<EPI_RESID, 1>(nullptr, 0, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm_fast<EPI_QKV_ROPE, 1>(nullptr, 0, nullptr)) != hipSuccess) return e;
+    if ((e = launch_gemm_fast<EPI_SILU_MUL, 2>(nullptr, 0, nullptr)) != hipSuccess) return e;
     done = true;
     return hipSuccess;
 }

@@ -78,6 +78,33 @@ def test_fast_rmsnorm_linear_close_to_the_oracle(lnb, rows, n, k, rw):
     assert (ulp_distance(y, ref) <= 1).mean() > 0.995
 
 
+@pytest.mark.parametrize("rows,n,k,rw", [
+    (128, 256, 256, 64), (16, 64, 128, 16), (33, 100, 896, 32), (64, 300, 512, 32), (200, 4096, 4096, 4), (130, 96, 14336, 4),
+    (256, 512, 4096, 64), (300, 1000, 1024, 16), (129, 260, 2048, 4), (40, 192, 4096, 32),
+])
+def test_fast_prefill_gemm_on_the_bf16_matrix_cores(lnb, rows, n, k, rw):
+    """16 or more rows in the tolerance mode: fast_gemm_kernel (v_mfma_f32_32x32x16_bf16, f32 accumulate; weights straight from either
+    resident layout, ragged M / N, both batch-tile sizes).  Every output within one bf16 ulp of the chain's or within the f32
+    summation-order bound of the exact value."""
+    rng = np.random.default_rng(rows * 7 + n + k + rw)
+    x = bf(rng.standard_normal((rows, k)))
+    w = bf(rng.standard_normal((n, k)) * 0.05)
+    y = lnb.op_linear_mode(x, w, lnb.MODE_FAST, rw=rw)
+    ref = orc_linear(x, w)
+    xf, wf = orc.bf16_to_f32(x).astype(np.float64), orc.bf16_to_f32(w).astype(np.float64)
+    exact, scale = xf @ wf.T, np.abs(xf) @ np.abs(wf).T
+    d = ulp_distance(y, ref)
+    ok = (d <= 1) | (np.abs(orc.bf16_to_f32(y).astype(np.float64) - exact) <= 4e-6 * scale + np.abs(exact) * 2.0 ** -7)
+    assert ok.all(), "worst: %d ulps at %s" % (d.max(), np.unravel_index(d.argmax(), d.shape))
+    assert (d == 0).mean() > 0.97
+
+
+def test_fast_prefill_gemm_k_not_a_multiple_of_64_falls_back_to_the_exact_kernel(lnb):
+    rng = np.random.default_rng(1)
+    x = bf(rng.standard_normal((20, 40))); w = bf(rng.standard_normal((17, 40)) * 0.05)
+    assert (lnb.op_linear_mode(x, w, lnb.MODE_FAST, rw=64) == orc_linear(x, w)).all()
+
+
 @pytest.fixture(scope="module")
 def tiny_pair(lnb):
     om = orc.Model(**TINY).fill_synthetic(1234).finalize()
@@ -114,6 +141,23 @@ def test_fast_mode_forward_is_within_tolerance_and_opt_in(lnb, tiny_pair):
     gc.reset(); gc.set_mode("exact")
     lg2, _ = gc.Forward(toks, 0)
     assert (lo.view(np.uint32) == lg2.view(np.uint32)).all()
+    gc.close(); oc.close()
+
+
+def test_fast_mode_long_prefill_through_the_bf16_matrix_cores(lnb, tiny_pair):
+    """48 + 48 rows (chunked at start_pos 48) through rmsnorm_rows + fast_gemm_kernel with all four epilogues (RoPE + KV append into
+    the position-contiguous K layout, residual, SiLU*up, store): logits within tolerance of the oracle's, the K/V rows it wrote within
+    a bf16 ulp or two, and the exact-mode decode that follows on the same cache runs."""
+    om, gm = tiny_pair
+    oc, gc = orc.Context(om, 128), lnb.InferenceContext(gm, 128).set_mode("fast")
+    toks = orc.synth_tokens(77, 96, TINY["vocab_size"])
+    for lo_, hi_ in ((0, 48), (48, 96)):
+        lo, ao = oc.forward(toks[lo_:hi_], lo_)
+        lf, af = gc.Forward(toks[lo_:hi_], lo_)
+        assert np.abs(lf - lo).max() <= 3.2e-2 and np.abs(lf - lo).mean() <= 2e-3
+    k0, k1 = orc.bf16_to_f32(oc.cache(0, 0)[:96]), orc.bf16_to_f32(gc.CacheK(0)[:96])
+    assert np.abs(k0 - k1).max() <= 2.0 ** -6 * max(1.0, float(np.abs(k0).max()))
+    assert (oc.cache(0, 1)[:96] == gc.CacheV(0)[:96]).mean() > 0.97       # layer 0's V rows: one GEMM away from exact inputs
     gc.close(); oc.close()
 
 
