@@ -94,6 +94,12 @@ int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which /*0=K 1=V*/, uint16_t* host
 enum { LNB_MODE_EXACT = 0, LNB_MODE_FAST = 1 };
 int lnb_ctx_set_mode(lnb_ctx* c, int mode);
 int lnb_ctx_get_mode(const lnb_ctx* c);
+/* Decode attention form (both bit-identical to the reference arithmetic): one-token calls whose context exceeds long_threshold
+ * positions use the long-context kernels (scores over all CUs, PV per (head, 16-dim slice), softmax denominator certified against
+ * the reference's serial f64 sum instead of walked).  long_threshold < 0: keep (default 512, env LNB_ATTN_LONG_T); force_zseq = 1:
+ * always walk the serial sum (test hook).  lnb_ctx_zseq_count: rows that could not be certified and walked it. */
+int lnb_ctx_set_attention(lnb_ctx* c, int long_threshold, int force_zseq);
+int lnb_ctx_zseq_count(lnb_ctx* c, int* out);
 /* optional per-layer progress hook = infContext.Logf("Transformer block layer %d / %d was run, took %.4f sec(s)")
  * (llamatransformer.go:157-163); forces a per-layer stream sync, so it is off by default */
 typedef void (*lnb_layer_cb)(int layer_1based, int n_layers, double secs, void* user);

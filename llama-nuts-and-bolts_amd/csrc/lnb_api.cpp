@@ -95,6 +95,11 @@ struct lnb_ctx {
     int32_t* h_io = nullptr;               // pinned host words of lnb_forward_stage_begin/_end: [0] argmax, [1] token error, [2..] tokens
     bool pending = false, pending_tokens = false, pending_argmax = false;
     int mode = LNB_MODE_EXACT;             // LNB_MODE_FAST: split-K kernels of lnb_fast.hip (tolerance mode, opt-in)
+    // long-context decode attention (attn_long_*_kernel): used for one-token calls whose context exceeds attn_long_T
+    double* e_buf = nullptr; double* z_part = nullptr; int* zseq_count = nullptr;
+    int attn_long_T = 0; int force_zseq = 0;
+    bool attn_long = false;                // selection for the launches being enqueued (set per call / per captured graph)
+    hipGraphExec_t graph_long = nullptr;   // the decode step captured with the long-context attention
 };
 
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
@@ -425,6 +430,11 @@ static int ctx_alloc(lnb_ctx* c) {
     HIPCHK(hipMalloc((void**)&c->q, S * m->q_dim * 2)); HIPCHK(hipMalloc((void**)&c->att, S * m->q_dim * 2));
     HIPCHK(hipMalloc((void**)&c->ffn, S * m->ffn_hidden * 2));
     if (m->last()) { HIPCHK(hipMalloc((void**)&c->logits, (size_t)m->a.vocab_size * 2)); c->logits_rows = 1; }
+    HIPCHK(hipMalloc((void**)&c->e_buf, (size_t)m->a.n_heads * S * 8));
+    HIPCHK(hipMalloc((void**)&c->z_part, (size_t)m->a.n_heads * ((S + 255) / 256) * 8));
+    HIPCHK(hipMalloc((void**)&c->zseq_count, 16)); HIPCHK(hipMemset(c->zseq_count, 0, 16));
+    // crossover measured on MI355X (tools/att_timing.py): the one-workgroup-per-head kernel wins below a few hundred positions
+    c->attn_long_T = env_int("LNB_ATTN_LONG_T", 512);
     return 0;
 }
 
@@ -433,6 +443,8 @@ extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     hipSetDevice(c->m->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->graph) hipGraphExecDestroy(c->graph);
+    if (c->graph_long) hipGraphExecDestroy(c->graph_long);
+    hipFree(c->e_buf); hipFree(c->z_part); hipFree(c->zseq_count);
     for (auto p : c->ck) if (p) hipFree(p);
     for (auto p : c->cv) if (p) hipFree(p);
     hipFree(c->st); hipFree(c->dtok); hipFree(c->dnext); hipFree(c->derr); hipFree(c->dout);
@@ -480,10 +492,32 @@ extern "C" int lnb_ctx_set_mode(lnb_ctx* c, int mode) {
     HIPCHK(hipSetDevice(c->m->device));
     HIPCHK(hipStreamSynchronize(c->stream));
     if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    if (c->graph_long) { hipGraphExecDestroy(c->graph_long); c->graph_long = nullptr; }
     c->mode = mode;
     return 0;
 }
 extern "C" int lnb_ctx_get_mode(const lnb_ctx* c) { return c ? c->mode : -1; }
+// Decode attention form: one-token calls at contexts above long_threshold run the chip-wide long-context kernels (bit-identical to the
+// one-workgroup-per-head kernel, tests/test_gpu_configs.py).  long_threshold < 0 keeps the current value; force_zseq = 1 makes the
+// long-context kernel always walk the reference's serial f64 sum instead of certifying the tree estimate (test hook).
+extern "C" int lnb_ctx_set_attention(lnb_ctx* c, int long_threshold, int force_zseq) {
+    if (!c) return fail("null argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    if (c->graph_long) { hipGraphExecDestroy(c->graph_long); c->graph_long = nullptr; }
+    if (long_threshold >= 0) c->attn_long_T = long_threshold;
+    c->force_zseq = force_zseq ? 1 : 0;
+    return 0;
+}
+// how many (head, token, layer) rows of the long-context attention had to walk the serial Z chain because the estimate could not be certified
+extern "C" int lnb_ctx_zseq_count(lnb_ctx* c, int* out) {
+    if (!c || !out) return fail("null argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    HIPCHK(hipMemcpy(out, c->zseq_count, 4, hipMemcpyDeviceToHost));
+    return 0;
+}
 extern "C" int lnb_ctx_set_layer_callback(lnb_ctx* c, lnb_layer_cb cb, void* user) { if (!c) return fail("null argument"); c->cb = cb; c->cb_user = user; return 0; }
 extern "C" void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which) { return !c ? nullptr : which == 2 ? (void*)c->ffn : (void*)c->x; }
 extern "C" void* lnb_ctx_stream(lnb_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -540,6 +574,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
         ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len;
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
         ap.mfma = use_mfma(S) ? 1 : 0; ap.exp_tab = m->exp_tab;
+        ap.longctx = (S == 1 && c->attn_long) ? 1 : 0; ap.force_zseq = c->force_zseq; ap.e_buf = c->e_buf; ap.z_part = c->z_part; ap.zseq_count = c->zseq_count;
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x;
@@ -610,6 +645,7 @@ extern "C" int lnb_forward_stage_begin(lnb_ctx* c, const int32_t* tokens, int se
     if (want_argmax && !m->last()) return fail("logits requested from a stage that does not own output.weight");
     if (!c->h_io) HIPCHK(hipHostMalloc((void**)&c->h_io, ((size_t)c->seq_len + 2) * 4, hipHostMallocDefault));
     hipStream_t st = c->stream;
+    c->attn_long = seq == 1 && start_pos + 1 > c->attn_long_T;
     HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
     if (tokens) {
         memcpy(c->h_io + 2, tokens, (size_t)seq * 4);        // the caller's array need not outlive this call
@@ -651,6 +687,7 @@ extern "C" int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int
     if (!tokens && m->first()) return fail("first stage needs tokens");
     if ((logits_out || argmax_last_out) && !m->last()) return fail("logits requested from a stage that does not own output.weight");
     hipStream_t st = c->stream;
+    c->attn_long = seq == 1 && start_pos + 1 > c->attn_long_T;
     HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
     if (tokens) {
         HIPCHK(hipMemcpyAsync(c->dtok, tokens, (size_t)seq * 4, hipMemcpyHostToDevice, st));
@@ -664,6 +701,7 @@ extern "C" int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int
             HIPCHK(hipStreamSynchronize(st));
             // the captured decode graph has the old buffer baked into its head GEMV / argmax nodes: drop it with the buffer
             if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+            if (c->graph_long) { hipGraphExecDestroy(c->graph_long); c->graph_long = nullptr; }
             hipFree(c->logits); c->logits = nullptr; c->logits_rows = 0;
             HIPCHK(hipMalloc((void**)&c->logits, (size_t)rows * V * 2)); c->logits_rows = rows;
         }
@@ -712,23 +750,31 @@ extern "C" int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n
     if (token < 0 || token >= m->a.vocab_size) return fail("token id at index 0 is outside the vocabulary");
     hipStream_t st = c->stream;
     const bool use_graph = env_int("LNB_NO_GRAPH", 0) == 0;
-    if (use_graph && !c->graph) {
+    // one captured graph per attention form: the step at context T replays the long-context one when T exceeds the crossover
+    auto capture = [&](hipGraphExec_t* slot, bool longctx) -> int {
+        if (*slot) return 0;
         hipGraph_t g = nullptr;
+        c->attn_long = longctx;
         HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
         int rc = enqueue_decode_step(c);
         hipError_t e = hipStreamEndCapture(st, &g);
         if (rc) { if (g) hipGraphDestroy(g); return -1; }
         HIPCHK(e);
-        HIPCHK(hipGraphInstantiate(&c->graph, g, nullptr, nullptr, 0));
+        HIPCHK(hipGraphInstantiate(slot, g, nullptr, nullptr, 0));
         HIPCHK(hipGraphDestroy(g));
-    }
+        return 0;
+    };
+    const bool any_short = start_pos + 1 <= c->attn_long_T, any_long = start_pos + n_steps > c->attn_long_T;
+    if (use_graph && any_short && capture(&c->graph, false)) return -1;
+    if (use_graph && any_long && capture(&c->graph_long, true)) return -1;
     HIPCHK(hipMemcpyAsync(c->dtok, &token, 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(c->derr, 0, 4, st));
     HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
     HIPCHK(hipEventRecord(c->ev0, st));
     for (int i = 0; i < n_steps; i++) {
-        if (use_graph) HIPCHK(hipGraphLaunch(c->graph, st));
-        else if (enqueue_decode_step(c)) return -1;
+        const bool longctx = start_pos + i + 1 > c->attn_long_T;
+        if (use_graph) HIPCHK(hipGraphLaunch(longctx ? c->graph_long : c->graph, st));
+        else { c->attn_long = longctx; if (enqueue_decode_step(c)) return -1; }
     }
     HIPCHK(hipEventRecord(c->ev1, st));
     HIPCHK(hipMemcpyAsync(out_tokens, c->dout, (size_t)n_steps * 4, hipMemcpyDeviceToHost, st));
@@ -747,6 +793,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     if (check_call(c, 1, pos)) return -1;
     if (which == K_HEAD && !m->last()) return fail("this stage does not own output.weight");
     hipStream_t st = c->stream;
+    c->attn_long = pos + 1 > c->attn_long_T;
     HIPCHK(lnbk_set_state(c->st, pos, 0, st));
     const int nl = m->layer_end - m->layer_begin;
     // consecutive launches walk through the layers so that every launch streams its weights from HBM

@@ -114,4 +114,10 @@ struct AttnParams {
     long long* dbg;             // LNB_GEMV_TIMING: phase stamps of workgroup (0,0)
     int mfma;                   // S >= 16: 16-row tiles on the f32 matrix cores (attn_mfma_kernel), same bits
     const double* exp_tab;      // f64[65536]: exp(trunc(s / divisor)) of every raw bf16 score s (attn_mfma_kernel)
+    // long-context decode (S == 1, attn_long_scores_kernel + attn_long_pv_kernel): scores over all CUs, PV per (head, 16-dim slice)
+    int longctx;                // 1: use the two-kernel form
+    int force_zseq;             // 1: always take the sequential-Z path of attn_long_pv_kernel (tests)
+    double* e_buf;              // [H][seq_len] f64: exp of every score of the current token
+    double* z_part;             // [H][ceil(seq_len / 256)] f64: per-block tree sums of e (only an ESTIMATE of Z, see the kernel)
+    int* zseq_count;            // counts workgroups that had to fall back to the sequential Z chain (diagnostics)
 };

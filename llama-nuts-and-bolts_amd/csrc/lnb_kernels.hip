@@ -1576,6 +1576,182 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
 }
 
 // ------------------------------------------------------------------------------------------------
+// Long-context decode attention (S == 1, thousands of cached positions): the same arithmetic as attn_exact_kernel, spread over the
+// chip.  attn_exact_kernel is one workgroup per head: at T = 4100 its scores take 12 us, the serial f64 Z chain 16 us and PV 31 us
+// (one CU pulls a whole head's V rows).  Here:
+//   attn_long_scores_kernel  grid (H, ceil(seq_len / 256)): one cached position per thread, the 128-long q.k chain, /sqrt(hd), exp
+//       in f64 -> e_buf[h][j]; plus a tree sum of the block's 256 values -> z_part (an ESTIMATE of the row sum, see below);
+//   attn_long_pv_kernel      grid (H, hd / 16): p_j for the whole row, then out[d] = sum_j p_j v[j][d] for 16 output dims with the
+//       role split of the short kernel (four producer waves: V rows -> exact products in an LDS ring, one adder wave: one chain per
+//       lane, j ascending).  256 workgroups instead of 32, each pulls 32 B per position instead of 256 B.
+// Z WITHOUT the serial chain, still bit-exact:  the reference adds the T exponentials one by one in f64 (operations_impl.go:492-499).
+// Every way of summing T non-negative doubles is within (T-1) u of the exact sum (u = 2^-53), so the tree estimate Zt and the
+// reference's Zs differ by less than eps = 4 T u relatively -- and p_j = trunc_bf16(f32(e_j / Z)) is a MONOTONE step function of Z
+// whose steps are 2^-8 wide relative to p.  So p_j is evaluated with Zt and CERTIFIED: the f64 quotient q must not lie within
+// 4 T + 4 f64 ulps of the one point per bf16 cell where the result changes (the f32 rounding boundary just below a bf16 grid
+// point: low 45 mantissa bits == 2^45 - 2^28); quotients in the f32 denormal range are certified by evaluating the step function at
+// both ends of [Zt (1 - eps), Zt (1 + eps)].  If every p_j of the row is certified, they equal the reference's bits whatever Zs is
+// (monotonicity); otherwise -- about once in 10^9 elements -- the workgroup walks the reference's serial sum itself (16 us, exact)
+// and re-evaluates.  force_zseq runs that path always (tests/test_gpu_configs.py compares both with the oracle).
+// ------------------------------------------------------------------------------------------------
+constexpr int ALS_NT = 256;                                  // positions per scores workgroup
+template <int NK> DEVINL double attn_score_value(const uint4 (&k)[NK], const float* qf, float divisor) {   // attn_score for S == 1 (no mask)
+    float acc = 0.0f;
+#pragma unroll
+    for (int c = 0; c < NK; c++) {                           // MatMul q.k, d ascending (operations_matmul.go:37-55)
+        const float4 xa = *(const float4*)(qf + c * 8), xb = *(const float4*)(qf + c * 8 + 4);
+        acc = mac8(acc, xa, xb, k[c]);
+    }
+    uint16_t s = bf_trunc(acc);
+    s = bf_trunc(__fdiv_rn(bf_wide(s), divisor));           // DivToScalar :464
+    return exp((double)bf_wide(s));                          // Softmax impl:498
+}
+template <int HD> __global__ __launch_bounds__(ALS_NT) void attn_long_scores_kernel(AttnParams p) {
+    constexpr int NK = HD / 8;
+    __shared__ __attribute__((aligned(16))) float qf[HD];
+    __shared__ double wsum[ALS_NT / 64];
+    const int tid = threadIdx.x, h = blockIdx.x, blk = blockIdx.y;
+    const int T = p.st->pos + 1, j0 = blk * ALS_NT;
+    if (j0 >= T) return;                                     // (uniform: the grid is sized for seq_len, the captured graph serves every T)
+    const int kvh = h / (p.H / p.KVH);
+    const uint4* kbase = (const uint4*)p.cache_k + (size_t)kvh * NK * p.seq_len;
+    const uint16_t* q = p.q + (size_t)h * HD;
+    const uint16_t q16 = q[tid < HD ? tid : 0];
+    const int j = j0 + tid;
+    uint4 k[NK];
+    attn_load_k<NK>(k, kbase, p.seq_len, j < T ? j : T - 1);
+    if (tid < HD) qf[tid] = bf_wide(q16);
+    __syncthreads();
+    double ev = 0.0;
+    if (j < T) { ev = attn_score_value<NK>(k, qf, p.divisor); p.e_buf[(size_t)h * p.seq_len + j] = ev; }
+    // tree sum of the block (fixed shape: deterministic); only ever used as an estimate with a rigorous error bound
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) ev += __shfl_xor(ev, o);
+    if ((tid & 63) == 0) wsum[tid >> 6] = ev;
+    __syncthreads();
+    if (tid == 0) p.z_part[(size_t)h * ((p.seq_len + ALS_NT - 1) / ALS_NT) + blk] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+}
+
+constexpr int ALP_DS = 16;                                   // output dims per workgroup
+constexpr int ALP_BATCH = 512;                               // cached positions per PV batch (one barrier per batch)
+constexpr int ALP_NT = 320;                                  // wave 0: adder; waves 1..4: producers
+__host__ __device__ inline size_t alp_lds_bytes(int seq_len) { return (size_t)((seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4 + 2 * (size_t)ALP_BATCH * ALP_DS * 4 + 64; }
+DEVINL float alp_p(double e, double z) { return bf_wide(bf_trunc((float)(e / z))); }     // impl:506 + ToBFloat16 :493
+template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int h = blockIdx.x, ds = blockIdx.y;
+    const int T = p.st->pos + 1, nblk = (T + ALS_NT - 1) / ALS_NT, nbatch = (T + ALP_BATCH - 1) / ALP_BATCH;
+    const int Tpad = (nbatch + 1) * ALP_BATCH;               // the producers of the last iteration read one batch ahead: zeros
+    float* pw = (float*)smem;                                // [Tpad] p_j (+0 beyond T)
+    float* ring = (float*)(smem + (size_t)((p.seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4);   // [2][ALP_BATCH][ALP_DS] products
+    double* zsh = (double*)(ring + 2 * ALP_BATCH * ALP_DS);
+    const double* E = p.e_buf + (size_t)h * p.seq_len;
+    const int kvh = h / (p.H / p.KVH);
+    // ---- Z estimate: the per-block tree sums, added in block order (same value in every thread)
+    double zt = 0.0;
+    {
+        const double* zp = p.z_part + (size_t)h * ((p.seq_len + ALS_NT - 1) / ALS_NT);
+        for (int b = 0; b < nblk; b++) zt += zp[b];
+    }
+    // ---- p_j with the estimate, certified (header comment)
+    const unsigned long long delta = 4ull * (unsigned long long)T + 4ull;
+    const double epsr = (double)(4 * T + 8) * 1.1102230246251565e-16;          // relative half-width of the interval that holds the reference's Z
+    const double zlo = zt * (1.0 - epsr), zhi = zt * (1.0 + epsr);
+    int bad = p.force_zseq;
+    for (int j = tid; j < Tpad; j += ALP_NT) {
+        float pj = 0.0f;
+        if (j < T) {
+            const double e = E[j];
+            const double q = e / zt;
+            pj = bf_wide(bf_trunc((float)q));
+            const unsigned long long b = (unsigned long long)__double_as_longlong(q);
+            const unsigned eq = (unsigned)(b >> 52) & 0x7FFu;
+            if (q != 0.0) {
+                if (eq >= 1023u - 126u && eq <= 1023u) {     // f32-normal quotient (q <= 1): distance from the step point of its bf16 cell
+                    const unsigned long long lo45 = b & ((1ull << 45) - 1ull), thr = (1ull << 45) - (1ull << 28);
+                    const unsigned long long d = lo45 > thr ? lo45 - thr : thr - lo45;
+                    if (d <= delta) bad = 1;
+                } else if (alp_p(e, zlo) != alp_p(e, zhi)) bad = 1;   // f32 denormals (or q > 1, impossible): both ends of the interval
+            }
+        }
+        pw[j] = pj;
+    }
+    if (__syncthreads_or(bad)) {
+        // the reference's serial sum, j ascending, f64 (operations_impl.go:492-499): one wave, 16 values in flight ahead of the adds
+        if (wave == 0) {
+            double z = 0.0;
+            for (int j0 = 0; j0 < T; j0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = E[j0 + u < T ? j0 + u : T - 1];
+#pragma unroll
+                for (int u = 0; u < 16; u++) z += (j0 + u < T) ? v[u] : 0.0;
+            }
+            if (lane == 0) { zsh[0] = z; if (p.zseq_count && ds == 0) atomicAdd(p.zseq_count, 1); }
+        }
+        __syncthreads();
+        const double z = zsh[0];
+        for (int j = tid; j < T; j += ALP_NT) pw[j] = alp_p(E[j], z);
+        __syncthreads();
+    }
+    // ---- PV: out[d] = trunc(sum_{j ascending} p_j * v[j][d]) for d = ds*16 .. +15 (llamatransformer.go:504-514)
+    // iteration it: producers turn batch it (rows already in registers) into exact products in ring[it & 1] after putting batch it+1's
+    // rows in flight; the adder walks batch it-1.  Positions past T carry p == +0 (products +-0, acc is never -0).
+    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD + (size_t)ds * ALP_DS;
+    const size_t vrow = (size_t)p.KVH * HD;
+    float acc = 0.0f;
+    if (wave == 0) {
+        const int d = lane & (ALP_DS - 1);
+        for (int it = 0; it <= nbatch; it++) {
+            if (it > 0) {
+                const float* src = ring + (size_t)((it - 1) & 1) * ALP_BATCH * ALP_DS + d;
+                for (int c = 0; c < ALP_BATCH; c += ATT_JC) {
+                    float a[ATT_JC];
+#pragma unroll
+                    for (int j = 0; j < ATT_JC; j++) a[j] = src[(c + j) * ALP_DS];          // a whole 64-position chunk in flight
+#pragma unroll
+                    for (int j = 0; j < ATT_JC; j++) acc += a[j];
+                }
+            }
+            __syncthreads();
+        }
+        if (lane < ALP_DS) p.out[(size_t)h * HD + ds * ALP_DS + lane] = bf_trunc(acc);
+    } else {
+        const int pl = tid - 64, half = pl & 1, prow = pl >> 1;            // 128 positions x two 8-dim halves per round, 4 rounds per batch
+        auto load = [&](uint4 (&v)[4], int b) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                int j = b * ALP_BATCH + r * 128 + prow; j = j < T ? j : T - 1;
+                v[r] = *(const uint4*)(vbase + (size_t)j * vrow + half * 8);
+            }
+        };
+        auto produce = [&](const uint4 (&v)[4], int b) {
+            float* dst = ring + (size_t)(b & 1) * ALP_BATCH * ALP_DS + half * 8;
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const int jl = r * 128 + prow;
+                const float pj = pw[b * ALP_BATCH + jl];
+                const uint4 w = v[r];                        // exact products: 8-bit x 8-bit significands
+                *(float4*)(dst + jl * ALP_DS) = make_float4(pj * bf_lo(w.x), pj * bf_hi(w.x), pj * bf_lo(w.y), pj * bf_hi(w.y));
+                *(float4*)(dst + jl * ALP_DS + 4) = make_float4(pj * bf_lo(w.z), pj * bf_hi(w.z), pj * bf_lo(w.w), pj * bf_hi(w.w));
+            }
+        };
+        uint4 va[4], vb[4];
+        load(va, 0);
+        for (int it = 0; it <= nbatch; it += 2) {
+            if (it < nbatch) { load(vb, it + 1); produce(va, it); }
+            __syncthreads();
+            if (it + 1 <= nbatch) {
+                if (it + 1 < nbatch) { load(va, it + 2); produce(vb, it + 1); }
+                __syncthreads();
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
 // Fwd_Get_Rows (operations_impl.go:142-173): byte copy of embedding rows
@@ -1794,6 +1970,7 @@ extern "C" hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, ui
 }
 
 static size_t attn_lds_bytes(int seq_len, int hd) { return attn_off_ring(seq_len, hd) + 2 * (size_t)ATT_JC * hd * 4; }
+extern "C" size_t lnbk_attn_short_lds(int seq_len, int hd) { return attn_lds_bytes(seq_len, hd); }
 extern "C" hipError_t lnbk_init(void) {
     static bool done = false;
     if (done) return hipSuccess;
@@ -1819,11 +1996,30 @@ extern "C" hipError_t lnbk_init(void) {
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     done = true;
     return hipSuccess;
 }
 
+static hipError_t launch_attn_long(const AttnParams* p, hipStream_t st) {
+    const size_t lds = alp_lds_bytes(p->seq_len);
+    if (lds > 160 * 1024 || p->hd % ALP_DS || !p->e_buf || !p->z_part) return hipErrorInvalidValue;
+    const dim3 gs(p->H, (p->seq_len + ALS_NT - 1) / ALS_NT), gp(p->H, p->hd / ALP_DS);
+    switch (p->hd) {
+    case 128: hipLaunchKernelGGL(attn_long_scores_kernel<128>, gs, dim3(ALS_NT), 0, st, *p); hipLaunchKernelGGL(attn_long_pv_kernel<128>, gp, dim3(ALP_NT), lds, st, *p); break;
+    case 64: hipLaunchKernelGGL(attn_long_scores_kernel<64>, gs, dim3(ALS_NT), 0, st, *p); hipLaunchKernelGGL(attn_long_pv_kernel<64>, gp, dim3(ALP_NT), lds, st, *p); break;
+    case 32: hipLaunchKernelGGL(attn_long_scores_kernel<32>, gs, dim3(ALS_NT), 0, st, *p); hipLaunchKernelGGL(attn_long_pv_kernel<32>, gp, dim3(ALP_NT), lds, st, *p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+extern "C" size_t lnbk_attn_long_lds(int seq_len) { return alp_lds_bytes(seq_len); }
+extern "C" size_t lnbk_attn_short_lds(int seq_len, int hd);
+
 extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
+    if (p->longctx && p->S == 1) return launch_attn_long(p, st);
     if (p->mfma && p->S >= 16 && (p->hd == 128 || p->hd == 64)) {       // prefill: 16 query rows per wave on the matrix cores
         if (p->hd == 128) hipLaunchKernelGGL(attn_mfma_kernel<128>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
         else hipLaunchKernelGGL(attn_mfma_kernel<64>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);

@@ -50,7 +50,7 @@ EXPORTS = [
     "lnb_model_set_tensor", "lnb_model_get_tensor", "lnb_model_fill_synthetic", "lnb_model_finalize",
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
-    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear", "lnb_op_argmax", "lnb_op_linear_mode", "lnb_ctx_set_mode", "lnb_ctx_get_mode",
+    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear", "lnb_op_argmax", "lnb_op_linear_mode", "lnb_ctx_set_mode", "lnb_ctx_get_mode", "lnb_ctx_set_attention", "lnb_ctx_zseq_count",
     "lnb_profile_kernel", "lnb_model_num_tensors", "lnb_model_tensor_info",
     "lnb_checkpoint_open", "lnb_checkpoint_close", "lnb_checkpoint_num_tensors", "lnb_checkpoint_find", "lnb_checkpoint_tensor",
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
@@ -100,6 +100,8 @@ def lib():
     L.lnb_op_rmsnorm_linear.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_ctx_set_mode.argtypes = [vp, C.c_int]
     L.lnb_ctx_get_mode.argtypes = [vp]
+    L.lnb_ctx_set_attention.argtypes = [vp, C.c_int, C.c_int]
+    L.lnb_ctx_zseq_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.lnb_op_linear_mode.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_op_argmax.argtypes = [C.c_int, vp, C.c_int, i32p]
     L.lnb_model_num_tensors.argtypes = [vp]
@@ -308,6 +310,16 @@ class InferenceContext:
         """MODE_EXACT (default, bit-identical to the reference) or MODE_FAST (split-K / bf16-MFMA tolerance mode)"""
         _chk(self.L.lnb_ctx_set_mode(self.h, {"exact": 0, "fast": 1}.get(mode, mode)))
         return self
+
+    def set_attention(self, long_threshold=-1, force_zseq=0):
+        """contexts above long_threshold use the long-context decode attention; force_zseq: always walk the serial f64 sum"""
+        _chk(self.L.lnb_ctx_set_attention(self.h, long_threshold, force_zseq))
+        return self
+
+    def zseq_count(self):
+        n = C.c_int(0)
+        _chk(self.L.lnb_ctx_zseq_count(self.h, C.byref(n)))
+        return n.value
 
     def Forward(self, tokens, start_pos, want_logits=True):
         """(*LlamaTransformer).Forward (llamatransformer.go:145-180) -> (logits f32 [S,V] | None, argmax of last row)."""

@@ -99,6 +99,51 @@ def test_long_context_prefill_and_decode_bit_exact(lnb, long_pair, chunks, steps
         c.close()
 
 
+@pytest.mark.parametrize("P", [3, 70, 300, 700])
+def test_long_context_attention_kernels_equal_the_oracle_at_every_context(lnb, long_pair, P):
+    """attn_long_scores_kernel + attn_long_pv_kernel forced on at every T (threshold 0), with the certified tree estimate of the
+    softmax denominator and with the serial f64 sum forced (force_zseq), against the one-workgroup-per-head kernel (threshold off)
+    and the oracle: identical logits bits, identical KV."""
+    cfg, om, gm = long_pair
+    toks = orc.synth_tokens(5000 + P, P, cfg["vocab_size"])
+    oc = orc.Context(om, P + 8)
+    _, tok0 = oc.forward(toks, 0, want_logits=False)
+    ref, tok = [], tok0
+    for i in range(4):
+        lo, tok_n = oc.forward([tok], P + i)
+        ref.append((lo, tok_n)); tok = tok_n
+    for thr, zseq in ((10 ** 9, 0), (0, 0), (0, 1)):
+        gc = lnb.InferenceContext(gm, P + 8).set_attention(thr, zseq)
+        _, t0 = gc.Forward(toks, 0, want_logits=False)
+        assert t0 == tok0
+        tok = t0
+        for i in range(4):
+            lg, tg = gc.Forward(np.array([tok], dtype=np.int32), P + i)
+            assert (_bits(ref[i][0]) == _bits(lg)).all() and tg == ref[i][1], (thr, zseq, i)
+            tok = tg
+        n = gc.zseq_count()
+        if thr == 0:                                                          # 4 steps x layers x heads rows went through the long kernels
+            assert (n == 4 * cfg["n_layers"] * cfg["n_heads"]) if zseq else (n == 0), n
+        for layer in range(cfg["n_layers"]):
+            assert (oc.cache(layer, 0)[:P + 4] == gc.CacheK(layer)[:P + 4]).all() and (oc.cache(layer, 1)[:P + 4] == gc.CacheV(layer)[:P + 4]).all()
+        gc.close()
+    oc.close()
+
+
+def test_greedy_loop_switches_graphs_at_the_attention_crossover(lnb, long_pair):
+    """lnb_decode_greedy replays the short-attention graph up to the crossover context and the long-attention graph beyond it: a run
+    that starts below and ends above (default crossover 512, and a crossover in the middle of a short run) equals the oracle's tokens."""
+    cfg, om, gm = long_pair
+    for P, steps, thr in ((500, 30, -1), (20, 24, 30)):
+        toks = orc.synth_tokens(7000 + P, P, cfg["vocab_size"])
+        ref, _ = orc.Context(om, P + steps + 2).generate(toks, steps + 1)
+        gc = lnb.InferenceContext(gm, P + steps + 2).set_attention(thr, 0)
+        _, first = gc.Forward(toks, 0, want_logits=False)
+        got, _ = gc.decode_greedy(first, P, steps)
+        assert [first] + [int(t) for t in got] == [int(t) for t in ref]
+        gc.close()
+
+
 def test_llama70b_like_geometry_two_layers_bit_exact(lnb):
     """configs[4]'s shape (dim 8192, 64 query heads on 8 KV heads, FFN 28672) cut to two layers and a 2048-token vocabulary:
     a 24-row prefill (matrix-core path) and 32 one-token steps, logits and KV cache against the oracle."""

@@ -1,7 +1,15 @@
-import lnb, os
+"""decode attention time per layer at several contexts, both kernel forms (8B head geometry, two layers)
+    python tools/att_timing.py"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "llama-nuts-and-bolts_amd"))
+import lnb
 cfg = dict(lnb.LLAMA_8B); cfg.update(n_layers=2)
 m = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize(rope_rows=8192)
 c = lnb.InferenceContext(m, 4400)
-for pos in (271, 1023, 2047, 4100):
-    ms = c.profile_kernel(1, pos, 32)
-    print("attention at T=%d: %.2f us" % (pos + 1, ms * 1e3), flush=True)
+for pos in (63, 127, 271, 383, 511, 767, 1023, 2047, 4100):
+    row = []
+    for thr, z in ((10 ** 9, 0), (0, 0), (0, 1)):
+        c.set_attention(thr, z)
+        row.append(c.profile_kernel(1, pos, 32) * 1e3)
+    print("attention at T=%5d: one workgroup per head %7.2f us | long-context kernels %7.2f us | with the serial Z walk %7.2f us" % (pos + 1, *row), flush=True)
