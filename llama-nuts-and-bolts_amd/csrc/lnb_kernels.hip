@@ -1660,6 +1660,9 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
     const double epsr = (double)(4 * T + 8) * 1.1102230246251565e-16;          // relative half-width of the interval that holds the reference's Z
     const double zlo = zt * (1.0 - epsr), zhi = zt * (1.0 + epsr);
     int bad = p.force_zseq;
+    int* const flag = (int*)(zsh + 1);                       // (own flag instead of __syncthreads_or: its library reduction takes static LDS)
+    if (tid == 0) *flag = 0;
+    __syncthreads();
     for (int j = tid; j < Tpad; j += ALP_NT) {
         float pj = 0.0f;
         if (j < T) {
@@ -1678,7 +1681,9 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
         }
         pw[j] = pj;
     }
-    if (__syncthreads_or(bad)) {
+    if (bad) *flag = 1;
+    __syncthreads();
+    if (*flag) {
         // the reference's serial sum, j ascending, f64 (operations_impl.go:492-499): one wave, 16 values in flight ahead of the adds
         if (wave == 0) {
             double z = 0.0;
