@@ -143,6 +143,30 @@ int lnb_ctx_synchronize(lnb_ctx* c);
 /* raw HIP stream (hipStream_t) the ctx enqueues on, for event timing by the caller */
 void* lnb_ctx_stream(lnb_ctx* c);
 
+/* ---- the pipeline's exchange behind the boundary (RCCL point-to-point over xGMI; librccl.so.1 is loaded on first use) -----------
+ * The reference runs its blocks in one loop (llamatransformer.go:156-164); here rank r of `world` holds the stage created with
+ * lnb_model_create_parts and one lnb_ctx per sequence in flight.  A host layer in any language only needs a way to hand rank 0's
+ * 128-byte id to the other ranks (a file, a socket, MPI, torch.distributed ...).
+ * lnb_pipeline_tick ENQUEUES and returns (no stream is synchronised):
+ *   run   != NULL: the stage step of that sequence -- run_rows rows at position run_pos; run_tokens: host token ids (rank 0, prompt rows)
+ *                  or NULL (other ranks: the input is the received hidden state; rank 0, one-token steps: the token received from the
+ *                  last rank, already on the device).  One-token steps replay a captured hipGraph.  On the last rank the argmax token is
+ *                  appended to a pinned log; *token_slot_out = its slot (lnb_pipeline_read_tokens).
+ *   send  != NULL: ncclSend of that context's result to rank+1 (hidden state [send_rows, dim], plus the [send_rows, ffn_hidden]
+ *                  activations when the stage ends between a block's gate/up and down parts); on the LAST rank: the 4-byte token to rank 0.
+ *   recv  != NULL: ncclRecv from rank-1 into that context's input buffers; on rank 0: the token from the last rank.
+ * send and recv go into ONE ncclGroupStart/End on the pipe's exchange stream, ordered against the compute streams by events; the
+ * schedule (which sequence runs / is sent / is received in which tick) belongs to the host layer -- every rank must post matching
+ * sends and receives in the same tick order (llama-nuts-and-bolts_amd/pipeline.py: run_ticks_native). */
+typedef struct lnb_pipe lnb_pipe;
+int lnb_pipeline_unique_id(void* id128);                       /* rank 0: ncclGetUniqueId */
+int lnb_pipeline_init(lnb_model* stage, int rank, int world, const void* id128, lnb_pipe** out);   /* world == 1: no communicator, the token ring is a device copy */
+int lnb_pipeline_destroy(lnb_pipe* p);
+int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,
+                      lnb_ctx* send, int send_rows, lnb_ctx* recv, int recv_rows, int* token_slot_out);
+int lnb_pipeline_sync(lnb_pipe* p);
+int lnb_pipeline_read_tokens(lnb_pipe* p, int first_slot, int n, int32_t* out);
+
 /* ---- measurement aid (bench.py roofline leg): average HIP-event time of ONE kernel class of the decode step.
  * which: 0 attn_norm+QKV+RoPE GEMV, 1 attention, 2 wo GEMV, 3 ffn_norm+w1|w3 GEMV, 4 w2 GEMV, 5 norm+output GEMV,
  * 6 the five kernels of a whole block.  Consecutive launches cycle through this stage's layers so every launch

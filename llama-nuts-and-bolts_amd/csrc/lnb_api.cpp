@@ -14,6 +14,7 @@
 #include <vector>
 #include "../../include/lnb.h"
 #include "lnb_device.h"
+#include "lnb_rccl.h"
 
 extern "C" {
 hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st);
@@ -24,6 +25,7 @@ hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out
 hipError_t lnbk_embed(const uint16_t* emb, const int32_t* tokens, uint16_t* x, int S, int dim, int vocab, int* err, hipStream_t st);
 hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_token, StepState* state, int32_t* out_tokens, int out_cap, int advance, hipStream_t st);
 hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st);
+hipError_t lnbk_advance_state(StepState* state, int rows, hipStream_t st);
 hipError_t lnbk_tile(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, int gather, hipStream_t st);
 hipError_t lnbk_synth_fill(uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, uint64_t seed, uint32_t tensor_id, int kind, float sigma, hipStream_t st);
 hipError_t lnbk_init(void);
@@ -100,6 +102,11 @@ struct lnb_ctx {
     int attn_long_T = 0; int force_zseq = 0;
     bool attn_long = false;                // selection for the launches being enqueued (set per call / per captured graph)
     hipGraphExec_t graph_long = nullptr;   // the decode step captured with the long-context attention
+    // pipeline stage (lnb_pipeline_tick): one-token stage step as a captured graph per attention form, events towards / from the exchange stream
+    hipGraphExec_t stage_graph[2] = {nullptr, nullptr};
+    hipEvent_t ev_done = nullptr, ev_in = nullptr, ev_sent = nullptr;
+    bool in_pending = false, sent_pending = false;
+    int dev_pos = -1;                      // position the device-side StepState will hold when the stream reaches this point (-1: unknown)
 };
 
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
@@ -444,6 +451,10 @@ extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     if (c->stream) hipStreamSynchronize(c->stream);
     if (c->graph) hipGraphExecDestroy(c->graph);
     if (c->graph_long) hipGraphExecDestroy(c->graph_long);
+    for (int i = 0; i < 2; i++) if (c->stage_graph[i]) hipGraphExecDestroy(c->stage_graph[i]);
+    if (c->ev_done) hipEventDestroy(c->ev_done);
+    if (c->ev_in) hipEventDestroy(c->ev_in);
+    if (c->ev_sent) hipEventDestroy(c->ev_sent);
     hipFree(c->e_buf); hipFree(c->z_part); hipFree(c->zseq_count);
     for (auto p : c->ck) if (p) hipFree(p);
     for (auto p : c->cv) if (p) hipFree(p);
@@ -848,6 +859,190 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
             if (cnt) fprintf(stderr, "[timing]   wave %d: n=%d total=%.0f (max %.0f) barrier_wait=%.0f x_or_vmwait=%.0f rms_fold_or_walk=%.0f\n", w, cnt, tot / cnt, mx, wait / cnt, tx / cnt, aux / cnt);
         }
     }
+    return 0;
+}
+
+// ---- layer-sharded pipeline: the exchange behind the C ABI ---------------------------------------------------------------------
+// The reference runs its 32 blocks in one loop (llamatransformer.go:156-164); a pipeline cuts that loop over the GPUs of a node.  Rank r
+// holds a stage (lnb_model_create_parts) and one lnb_ctx per sequence in flight; a TICK enqueues, without ever blocking the host:
+//   * the stage step of one sequence on that context's stream (one-token steps replay a captured hipGraph; the position lives on the
+//     device), gated by the event of the receive that delivered its input;
+//   * ONE RCCL group on the pipe's exchange stream: ncclSend of the previous result to rank r+1 straight from the context's hidden
+//     state buffer (the last rank sends the 4-byte argmax token to rank 0 straight from device memory) and ncclRecv of the next input
+//     from rank r-1 straight into the target context's buffer (rank 0: the token, into the device word the embedding gather reads).
+// No staging copies, no host round trip for the token ring, no stream synchronisation per tick: the host only enqueues, and reads the
+// generated tokens from a pinned log after lnb_pipeline_sync.  RCCL is loaded on first use (lnb_pipeline.cpp).
+struct lnb_pipe {
+    lnb_model* m = nullptr; int rank = 0, world = 1;
+    void* comm = nullptr; const lnb_rccl_api* api = nullptr;
+    hipStream_t xs = nullptr;              // exchange stream
+    int32_t* h_tok = nullptr; int tok_cap = 0, tok_n = 0;   // pinned log of the tokens the last stage produced, in tick order
+    bool use_graph = true;
+};
+#define NCCLCHK(p_, expr) do { int r_ = (expr); if (r_ != 0) return fail("%s failed: %s (%s:%d)", #expr, (p_)->api->GetErrorString(r_), __FILE__, __LINE__); } while (0)
+
+extern "C" int lnb_pipeline_unique_id(void* id128) {
+    if (!id128) return fail("null argument");
+    const lnb_rccl_api* api = lnb_rccl_load();
+    if (!api) return -1;
+    lnb_nccl_id id; memset(&id, 0, sizeof id);
+    int r = api->GetUniqueId(&id);
+    if (r != 0) return fail("ncclGetUniqueId failed: %s", api->GetErrorString(r));
+    memcpy(id128, &id, sizeof id);
+    return 0;
+}
+extern "C" int lnb_pipeline_init(lnb_model* m, int rank, int world, const void* id128, lnb_pipe** out) {
+    if (!m || !out) return fail("null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail("rank %d out of range for %d pipeline stages", rank, world);
+    if (!m->finalized) return fail("model not finalized");
+    if ((rank == 0) != m->first()) return fail("pipeline rank %d: only the first stage owns tok_embeddings (this stage starts at block part %d)", rank, m->part_begin);
+    if ((rank == world - 1) != m->last()) return fail("pipeline rank %d of %d: only the last stage owns norm + output (this stage ends at block part %d)", rank, world, m->part_end);
+    if (world > 1 && !id128) return fail("null unique id");
+    HIPCHK(hipSetDevice(m->device));
+    lnb_pipe* p = new lnb_pipe();
+    p->m = m; p->rank = rank; p->world = world; p->use_graph = env_int("LNB_PIPELINE_GRAPH", 1) != 0;
+    if (world > 1) {
+        p->api = lnb_rccl_load();
+        if (!p->api) { delete p; return -1; }
+        lnb_nccl_id id; memcpy(&id, id128, sizeof id);
+        int r = p->api->CommInitRank(&p->comm, world, id, rank);
+        if (r != 0) { fail("ncclCommInitRank failed: %s", p->api->GetErrorString(r)); delete p; return -1; }
+    }
+    hipError_t e = hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking);
+    if (e == hipSuccess) { p->tok_cap = 1 << 16; e = hipHostMalloc((void**)&p->h_tok, (size_t)p->tok_cap * 4, hipHostMallocDefault); }
+    if (e != hipSuccess) { fail("pipeline init: %s", hipGetErrorString(e)); if (p->comm) p->api->CommDestroy(p->comm); if (p->xs) hipStreamDestroy(p->xs); delete p; return -1; }
+    *out = p;
+    return 0;
+}
+extern "C" int lnb_pipeline_destroy(lnb_pipe* p) {
+    if (!p) return 0;
+    hipSetDevice(p->m->device);
+    hipDeviceSynchronize();
+    if (p->comm) p->api->CommDestroy(p->comm);
+    if (p->xs) hipStreamDestroy(p->xs);
+    if (p->h_tok) hipHostFree(p->h_tok);
+    delete p;
+    return 0;
+}
+static int pipe_events(lnb_ctx* c) {
+    if (!c->ev_done) { HIPCHK(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&c->ev_in, hipEventDisableTiming));
+                       HIPCHK(hipEventCreateWithFlags(&c->ev_sent, hipEventDisableTiming)); }
+    return 0;
+}
+// one stage step on the context's stream; tokens != NULL: host tokens (prefill on rank 0); NULL on rank 0: the token already sits in
+// c->dtok (received from the last rank).  The last stage leaves the argmax token in c->dnext.
+static int enqueue_stage_step(lnb_pipe* p, lnb_ctx* c, const int32_t* tokens, int rows, int pos) {
+    lnb_model* m = c->m; const int V = m->a.vocab_size; hipStream_t st = c->stream;
+    const bool longctx = rows == 1 && pos + 1 > c->attn_long_T;
+    auto body = [&](bool host_tokens) -> int {
+        if (m->first()) {
+            if (host_tokens) {
+                if (!c->h_io) HIPCHK(hipHostMalloc((void**)&c->h_io, ((size_t)c->seq_len + 2) * 4, hipHostMallocDefault));
+                memcpy(c->h_io + 2, tokens, (size_t)rows * 4);
+                HIPCHK(hipMemcpyAsync(c->dtok, c->h_io + 2, (size_t)rows * 4, hipMemcpyHostToDevice, st));
+            }
+            HIPCHK(lnbk_embed(m->tok_embd, c->dtok, c->x, rows, m->a.dim, V, c->derr, st));   // Fwd_Get_Rows :118
+        }
+        if (enqueue_layers(c, rows, false)) return -1;
+        if (m->last()) {
+            if (enqueue_head(c, rows - 1, 1)) return -1;
+            HIPCHK(lnbk_argmax(c->logits, V, c->dnext, c->st, c->dout, c->dout_cap, 0, st));   // inference.go:207-211
+        }
+        return 0;
+    };
+    c->attn_long = longctx;
+    if (rows == 1 && !tokens && p->use_graph) {
+        hipGraphExec_t* slot = &c->stage_graph[longctx ? 1 : 0];
+        if (!*slot) {
+            hipGraph_t g = nullptr;
+            HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+            int rc = body(false);
+            if (!rc && lnbk_advance_state(c->st, 1, st) != hipSuccess) rc = fail("advance_state launch failed");
+            hipError_t e = hipStreamEndCapture(st, &g);
+            if (rc) { if (g) hipGraphDestroy(g); return -1; }
+            HIPCHK(e);
+            HIPCHK(hipGraphInstantiate(slot, g, nullptr, nullptr, 0));
+            HIPCHK(hipGraphDestroy(g));
+        }
+        if (c->dev_pos != pos) HIPCHK(lnbk_set_state(c->st, pos, 0, st));
+        HIPCHK(hipGraphLaunch(*slot, st));
+        c->dev_pos = pos + 1;
+        return 0;
+    }
+    HIPCHK(lnbk_set_state(c->st, pos, 0, st));
+    c->dev_pos = pos;
+    return body(tokens != nullptr);
+}
+// What crosses the boundary behind this stage (towards rank+1) / in front of it: the [rows, dim] hidden state, plus the [rows, ffn_hidden]
+// gate*up activations when the cut lies between a block's gate/up and down parts.
+static int pipe_xfer(lnb_pipe* p, lnb_ctx* c, int rows, bool sending) {
+    lnb_model* m = c->m;
+    const int edge = sending ? m->part_end : m->part_begin, peer = sending ? p->rank + 1 : p->rank - 1;
+    const size_t nx = (size_t)rows * m->a.dim * 2, nf = (size_t)rows * m->ffn_hidden * 2;
+    if (sending) { NCCLCHK(p, p->api->Send(c->x, nx, LNB_NCCL_INT8, peer, p->comm, p->xs)); if (edge % 3 == 2) NCCLCHK(p, p->api->Send(c->ffn, nf, LNB_NCCL_INT8, peer, p->comm, p->xs)); }
+    else { NCCLCHK(p, p->api->Recv(c->x, nx, LNB_NCCL_INT8, peer, p->comm, p->xs)); if (edge % 3 == 2) NCCLCHK(p, p->api->Recv(c->ffn, nf, LNB_NCCL_INT8, peer, p->comm, p->xs)); }
+    return 0;
+}
+extern "C" int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,
+                                 lnb_ctx* send, int send_rows, lnb_ctx* recv, int recv_rows, int* token_slot_out) {
+    if (!p) return fail("null argument");
+    lnb_model* m = p->m;
+    HIPCHK(hipSetDevice(m->device));
+    const bool first = p->rank == 0, last = p->rank == p->world - 1;
+    for (lnb_ctx* c : {run, send, recv}) if (c) { if (c->m != m) return fail("context of another model stage"); if (pipe_events(c)) return -1; }
+    if (token_slot_out) *token_slot_out = -1;
+    if (run) {
+        if (check_call(run, run_rows, run_pos)) return -1;
+        if (run_tokens && !first) return fail("tokens given to a stage that does not own tok_embeddings");
+        if (!run_tokens && first && run_rows != 1) return fail("the first stage needs host tokens for a multi-row step");
+        if (run->in_pending) { HIPCHK(hipStreamWaitEvent(run->stream, run->ev_in, 0)); run->in_pending = false; }      // its input has arrived
+        if (run->sent_pending) { HIPCHK(hipStreamWaitEvent(run->stream, run->ev_sent, 0)); run->sent_pending = false; }  // its previous output has left
+        if (enqueue_stage_step(p, run, run_tokens, run_rows, run_pos)) return -1;
+        if (last) {
+            if (p->tok_n >= p->tok_cap) return fail("pipeline token log full (%d): call lnb_pipeline_read_tokens", p->tok_cap);
+            HIPCHK(hipMemcpyAsync(p->h_tok + p->tok_n, run->dnext, 4, hipMemcpyDeviceToHost, run->stream));
+            if (token_slot_out) *token_slot_out = p->tok_n;
+            p->tok_n++;
+            if (p->world == 1) HIPCHK(hipMemcpyAsync(run->dtok, run->dnext, 4, hipMemcpyDeviceToDevice, run->stream));    // the ring of a one-stage pipe
+        }
+        HIPCHK(hipEventRecord(run->ev_done, run->stream));
+    }
+    if (p->world > 1 && (send || recv)) {
+        if (send) HIPCHK(hipStreamWaitEvent(p->xs, send->ev_done, 0));                 // the result being sent has been computed
+        if (recv) { HIPCHK(hipEventRecord(recv->ev_done, recv->stream)); HIPCHK(hipStreamWaitEvent(p->xs, recv->ev_done, 0)); }   // nothing still reads the buffer being overwritten
+        NCCLCHK(p, p->api->GroupStart());
+        int rc = 0;
+        if (send) {
+            if (last) { int r_ = p->api->Send(send->dnext, 4, LNB_NCCL_INT8, 0, p->comm, p->xs); if (r_) rc = fail("ncclSend failed: %s", p->api->GetErrorString(r_)); }
+            else rc = pipe_xfer(p, send, send_rows, true);
+        }
+        if (!rc && recv) {
+            if (first) { int r_ = p->api->Recv(recv->dtok, 4, LNB_NCCL_INT8, p->world - 1, p->comm, p->xs); if (r_) rc = fail("ncclRecv failed: %s", p->api->GetErrorString(r_)); }
+            else rc = pipe_xfer(p, recv, recv_rows, false);
+        }
+        int re = p->api->GroupEnd();
+        if (rc) return -1;
+        if (re != 0) return fail("ncclGroupEnd failed: %s", p->api->GetErrorString(re));
+        if (send) { HIPCHK(hipEventRecord(send->ev_sent, p->xs)); send->sent_pending = true; }
+        if (recv) { HIPCHK(hipEventRecord(recv->ev_in, p->xs)); recv->in_pending = true; }
+    }
+    return 0;
+}
+// block until everything enqueued so far (stage steps and exchanges) has finished
+extern "C" int lnb_pipeline_sync(lnb_pipe* p) {
+    if (!p) return fail("null argument");
+    HIPCHK(hipSetDevice(p->m->device));
+    HIPCHK(hipDeviceSynchronize());
+    return 0;
+}
+// tokens the last stage produced, by log slot (lnb_pipeline_tick's token_slot_out); valid after lnb_pipeline_sync
+extern "C" int lnb_pipeline_read_tokens(lnb_pipe* p, int first_slot, int n, int32_t* out) {
+    if (!p || !out) return fail("null argument");
+    if (first_slot < 0 || n < 0 || first_slot + n > p->tok_n) return fail("token slots [%d, %d) out of range (%d logged)", first_slot, first_slot + n, p->tok_n);
+    HIPCHK(hipSetDevice(p->m->device));
+    HIPCHK(hipDeviceSynchronize());
+    memcpy(out, p->h_tok + first_slot, (size_t)n * 4);
     return 0;
 }
 

@@ -1649,13 +1649,18 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
     double* zsh = (double*)(ring + 2 * ALP_BATCH * ALP_DS);
     const double* E = p.e_buf + (size_t)h * p.seq_len;
     const int kvh = h / (p.H / p.KVH);
-    // ---- Z estimate: the per-block tree sums, added in block order (same value in every thread)
+    // ---- Z estimate: the per-block tree sums, added in block order (same value in every thread).  One partial per lane, all loads
+    // in flight at once, then a register walk (a load-use loop paid one L2 round trip per block: 12 us at T = 4100)
     double zt = 0.0;
     {
         const double* zp = p.z_part + (size_t)h * ((p.seq_len + ALS_NT - 1) / ALS_NT);
-        for (int b = 0; b < nblk; b++) zt += zp[b];
+        for (int b0 = 0; b0 < nblk; b0 += 64) {
+            const double mine = zp[b0 + lane < nblk ? b0 + lane : nblk - 1];
+            const int nb = nblk - b0 < 64 ? nblk - b0 : 64;
+            for (int b = 0; b < nb; b++) zt += __shfl(mine, b);
+        }
     }
-    // ---- p_j with the estimate, certified (header comment)
+    // ---- p_j with the estimate, certified (header comment); eight e_j per thread in flight at a time
     const unsigned long long delta = 4ull * (unsigned long long)T + 4ull;
     const double epsr = (double)(4 * T + 8) * 1.1102230246251565e-16;          // relative half-width of the interval that holds the reference's Z
     const double zlo = zt * (1.0 - epsr), zhi = zt * (1.0 + epsr);
@@ -1663,23 +1668,31 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
     int* const flag = (int*)(zsh + 1);                       // (own flag instead of __syncthreads_or: its library reduction takes static LDS)
     if (tid == 0) *flag = 0;
     __syncthreads();
-    for (int j = tid; j < Tpad; j += ALP_NT) {
-        float pj = 0.0f;
-        if (j < T) {
-            const double e = E[j];
-            const double q = e / zt;
-            pj = bf_wide(bf_trunc((float)q));
-            const unsigned long long b = (unsigned long long)__double_as_longlong(q);
-            const unsigned eq = (unsigned)(b >> 52) & 0x7FFu;
-            if (q != 0.0) {
-                if (eq >= 1023u - 126u && eq <= 1023u) {     // f32-normal quotient (q <= 1): distance from the step point of its bf16 cell
-                    const unsigned long long lo45 = b & ((1ull << 45) - 1ull), thr = (1ull << 45) - (1ull << 28);
-                    const unsigned long long d = lo45 > thr ? lo45 - thr : thr - lo45;
-                    if (d <= delta) bad = 1;
-                } else if (alp_p(e, zlo) != alp_p(e, zhi)) bad = 1;   // f32 denormals (or q > 1, impossible): both ends of the interval
+    for (int j0 = 0; j0 < Tpad; j0 += 8 * ALP_NT) {
+        double ev[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) { const int j = j0 + u * ALP_NT + tid; ev[u] = E[j < T ? j : T - 1]; }    // unconditional (clamped) loads
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int j = j0 + u * ALP_NT + tid;
+            if (j >= Tpad) continue;
+            float pj = 0.0f;
+            if (j < T) {
+                const double e = ev[u];
+                const double q = e / zt;
+                pj = bf_wide(bf_trunc((float)q));
+                const unsigned long long b = (unsigned long long)__double_as_longlong(q);
+                const unsigned eq = (unsigned)(b >> 52) & 0x7FFu;
+                if (q != 0.0) {
+                    if (eq >= 1023u - 126u && eq <= 1023u) {     // f32-normal quotient (q <= 1): distance from the step point of its bf16 cell
+                        const unsigned long long lo45 = b & ((1ull << 45) - 1ull), thr = (1ull << 45) - (1ull << 28);
+                        const unsigned long long d = lo45 > thr ? lo45 - thr : thr - lo45;
+                        if (d <= delta) bad = 1;
+                    } else if (alp_p(e, zlo) != alp_p(e, zhi)) bad = 1;   // f32 denormals: both ends of the interval
+                }
             }
+            pw[j] = pj;
         }
-        pw[j] = pj;
     }
     if (bad) *flag = 1;
     __syncthreads();
@@ -1698,7 +1711,13 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
         }
         __syncthreads();
         const double z = zsh[0];
-        for (int j = tid; j < T; j += ALP_NT) pw[j] = alp_p(E[j], z);
+        for (int j0 = 0; j0 < T; j0 += 8 * ALP_NT) {
+            double ev[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int j = j0 + u * ALP_NT + tid; ev[u] = E[j < T ? j : T - 1]; }
+#pragma unroll
+            for (int u = 0; u < 8; u++) { const int j = j0 + u * ALP_NT + tid; if (j < T) pw[j] = alp_p(ev[u], z); }
+        }
         __syncthreads();
     }
     // ---- PV: out[d] = trunc(sum_{j ascending} p_j * v[j][d]) for d = ds*16 .. +15 (llamatransformer.go:504-514)
@@ -1825,6 +1844,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, in
 }
 
 __global__ void set_state_kernel(StepState* st, int pos, int n_out) { st->pos = pos; st->n_out = n_out; }
+__global__ void advance_state_kernel(StepState* st, int rows) { st->pos = st->pos + rows; }   // end of a captured pipeline-stage step
 
 // ---- weight re-tiling (load time, once) ------------------------------------------------------------
 __global__ void tile_scatter_kernel(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH) {
@@ -2052,6 +2072,10 @@ extern "C" hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_t
 }
 extern "C" hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st) {
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, state, pos, n_out);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_advance_state(StepState* state, int rows, hipStream_t st) {
+    hipLaunchKernelGGL(advance_state_kernel, dim3(1), dim3(1), 0, st, state, rows);
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_tile(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, int gather, hipStream_t st) {

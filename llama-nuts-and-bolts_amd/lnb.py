@@ -56,6 +56,7 @@ EXPORTS = [
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
     "lnb_tokenizer_load", "lnb_tokenizer_free", "lnb_tokenizer_vocab_size", "lnb_tokenizer_special", "lnb_tokenizer_token_id",
     "lnb_tokenizer_piece", "lnb_tokenizer_encode", "lnb_tokenizer_encode_chat",
+    "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens",
 ]
 
 
@@ -102,6 +103,12 @@ def lib():
     L.lnb_ctx_get_mode.argtypes = [vp]
     L.lnb_ctx_set_attention.argtypes = [vp, C.c_int, C.c_int]
     L.lnb_ctx_zseq_count.argtypes = [vp, C.POINTER(C.c_int)]
+    L.lnb_pipeline_unique_id.argtypes = [vp]
+    L.lnb_pipeline_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.lnb_pipeline_destroy.argtypes = [vp]
+    L.lnb_pipeline_tick.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
+    L.lnb_pipeline_sync.argtypes = [vp]
+    L.lnb_pipeline_read_tokens.argtypes = [vp, C.c_int, C.c_int, vp]
     L.lnb_op_linear_mode.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_op_argmax.argtypes = [C.c_int, vp, C.c_int, i32p]
     L.lnb_model_num_tensors.argtypes = [vp]
@@ -359,6 +366,43 @@ class InferenceContext:
     def close(self):
         if self.h:
             self.L.lnb_ctx_destroy(self.h)
+            self.h = C.c_void_p()
+
+
+class Pipeline:
+    """One rank of the layer-sharded pipeline behind the C ABI (lnb_pipeline_*): RCCL send / recv straight from / into the stage's
+    device buffers, stage steps as captured graphs, nothing synchronised per tick."""
+
+    def __init__(self, transformer, rank, world, unique_id=None):
+        self.L, self.rank, self.world = transformer.L, rank, world
+        self.h = C.c_void_p()
+        idp = C.c_char_p(bytes(unique_id)) if unique_id is not None else None
+        _chk(self.L.lnb_pipeline_init(transformer.h, rank, world, idp, C.byref(self.h)))
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        _chk(lib().lnb_pipeline_unique_id(buf))
+        return bytes(buf.raw)
+
+    def tick(self, run=None, run_rows=0, run_pos=0, run_tokens=None, send=None, send_rows=0, recv=None, recv_rows=0):
+        slot = C.c_int(-1)
+        tok = None if run_tokens is None else np.ascontiguousarray(run_tokens, dtype=np.int32)
+        _chk(self.L.lnb_pipeline_tick(self.h, run.h if run else None, run_rows, run_pos, _p(tok) if tok is not None else None,
+                                      send.h if send else None, send_rows, recv.h if recv else None, recv_rows, C.byref(slot)))
+        return slot.value
+
+    def sync(self):
+        _chk(self.L.lnb_pipeline_sync(self.h))
+
+    def read_tokens(self, first_slot, n):
+        out = np.empty(n, dtype=np.int32)
+        _chk(self.L.lnb_pipeline_read_tokens(self.h, first_slot, n, _p(out)))
+        return out
+
+    def close(self):
+        if self.h:
+            self.L.lnb_pipeline_destroy(self.h)
             self.h = C.c_void_p()
 
 

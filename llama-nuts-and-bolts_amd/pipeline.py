@@ -183,6 +183,53 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
     return state
 
 
+def run_ticks_native(rank, world, pipe, ctxs, prompts, n_decode, lo=0, hi=None, state=None):
+    """The overlapped schedule of run_ticks driven through the C ABI (lnb_pipeline_tick): rank r runs item t - 2r at tick t, sends the
+    result of the item it ran in the previous tick and receives the input of the item of the next tick -- all ENQUEUED; nothing is
+    synchronised here (the caller calls pipe.sync() where it needs the device to have caught up).  2*world sequences in flight
+    (world == 1: the token ring is a device copy inside the library, any number of sequences).
+    state["slots"][s] on the last rank = token-log slots of sequence s's tokens, in order (pipe.read_tokens)."""
+    P, n_seq = len(prompts[0]), len(prompts)
+    n_phases = 1 + n_decode
+    n_items = n_phases * n_seq
+    gap = 2 if world > 1 else 1
+    assert world == 1 or n_seq == 2 * world, "the overlapped schedule keeps 2*world sequences in flight"
+    first, last = rank == 0, rank == world - 1
+    if state is None:
+        state = {"prev": None, "slots": [[] for _ in range(n_seq)]}
+    if hi is None:
+        hi = n_items + gap * (world - 1)
+
+    def rows_of(item):
+        return P if item // n_seq == 0 else 1
+
+    for t, item in schedule(rank, world, n_phases, n_seq, gap):
+        if t < lo:
+            continue
+        if t >= hi:
+            break
+        kw = {}
+        if item is not None:
+            k, s = divmod(item, n_seq)
+            kw.update(run=ctxs[s], run_rows=rows_of(item), run_pos=0 if k == 0 else P + k - 1,
+                      run_tokens=(np.ascontiguousarray(prompts[s], dtype=np.int32) if (first and k == 0) else None))
+        prev = state["prev"]
+        if prev is not None and world > 1:
+            k, s = divmod(prev, n_seq)
+            if not last or k + 1 < n_phases:                  # the token of the final phase is not needed by rank 0
+                kw.update(send=ctxs[s], send_rows=rows_of(prev))
+        nxt_item = t + 1 - gap * rank
+        if 0 <= nxt_item < n_items and world > 1:
+            k, s = divmod(nxt_item, n_seq)
+            if not first or k > 0:
+                kw.update(recv=ctxs[s], recv_rows=rows_of(nxt_item))
+        slot = pipe.tick(**kw)
+        if item is not None and last:
+            state["slots"][item % n_seq].append(slot)
+        state["prev"] = item
+    return state
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 def stage_layers(rank, world, n_layers, head_cost=1.2):
     """[layer_begin, layer_end) of pipeline stage `rank`.  The last stage also runs the final norm + LM head, which costs about
@@ -330,7 +377,12 @@ class LnbStage(Stage):
 
 
 def bench_main(args, cfg, name):
-    """bench.py --gpus N under torchrun: weak scaling, N sequences in flight, one rank per GPU."""
+    """bench.py --gpus N under torchrun: weak scaling, 2N sequences in flight, one rank per GPU.
+
+    Control plane (rendezvous, the 128-byte RCCL id, barriers, max over ranks): torch.distributed over gloo.  Data plane: RCCL
+    point-to-point INSIDE the library (lnb_pipeline_tick: ncclSend / ncclRecv straight from / into the stage's device buffers, stage
+    steps as captured graphs, no per-tick synchronisation).  LNB_PIPELINE_EXCHANGE=torch (or a failed native init on any rank) runs the
+    exchange through torch.distributed instead (run_ticks: staging tensors + batch_isend_irecv), which is also what the gloo tests use."""
     import sys
     import torch
     import torch.distributed as dist
@@ -348,44 +400,109 @@ def bench_main(args, cfg, name):
     os.environ.setdefault("MASTER_PORT", "29531")           # (only used by the single-process LNB_FORCE_PIPELINE=1 run)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     backend = os.environ.get("LNB_PIPELINE_BACKEND", "nccl")      # "gloo": ranks may share a GPU (tests); the exchange is staged on the host
+    exchange = os.environ.get("LNB_PIPELINE_EXCHANGE", "native" if backend == "nccl" else "torch")
     if backend == "gloo":
         local %= torch.cuda.device_count()
     torch.cuda.set_device(local)
     device = "cuda:%d" % local
     import datetime
     patience = datetime.timedelta(seconds=300)               # a lost peer fails the run instead of hanging it
-    if backend == "nccl":
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device), timeout=patience)   # rank -> GPU mapping is explicit
-    else:
-        dist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)
     P, W, K = args.prompt_len, args.warmup, args.steps
     seq_len = P + W + K + 8
-    # 2*world sequences: the exchange of a tick overlaps the compute of another sequence's item (run_ticks); LNB_PIPELINE_OVERLAP=0
-    # falls back to the lock-step schedule with `world` sequences
-    n_seq = world * (2 if world > 1 and os.environ.get("LNB_PIPELINE_OVERLAP", "1") != "0" else 1)
-    costs = None
-    if world > 1 and os.environ.get("LNB_PIPELINE_PROBE", "1") != "0":
+    mode = getattr(args, "mode", "exact")
+
+    def probe(bcast_device):
+        if not (world > 1 and os.environ.get("LNB_PIPELINE_PROBE", "1") != "0"):
+            return None
         # rank 0 times the three block parts and the head on its GPU; every rank cuts the model with the same numbers
-        t = torch.zeros(4, dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        t = torch.zeros(4, dtype=torch.float64, device=bcast_device)
         if rank == 0:
             t += torch.tensor(probe_costs(lnb, cfg, local, P + W + K // 2), dtype=torch.float64).to(t.device)
         dist.broadcast(t, 0)
-        costs = [float(v) for v in t.tolist()]
-    stage = LnbStage(lnb, torch, cfg, rank, world, n_seq, seq_len, local, costs=costs)
-    prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
-    n_decode = W + K
-    t_split = n_seq * (1 + W)              # prefill phase + W warm-up decode rounds
-    t_end = n_seq * (1 + W + K)
-    state = run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, 0, t_split)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    # the timed window: every rank runs exactly K*n_seq items (K decode steps of each sequence in flight)
-    run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, t_split, t_end, state)
-    torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
-    wall = time.perf_counter() - t0
-    tmax = torch.tensor([wall], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
-    dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    wall = float(tmax.item())
+        return [float(v) for v in t.tolist()]
+
+    stage = None
+    if exchange == "native":
+        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=patience)          # control plane only
+        n_seq = 2 * world if world > 1 else int(os.environ.get("LNB_PIPELINE_SEQS", "2"))
+        costs = probe("cpu")
+        stage = LnbStage(lnb, torch, cfg, rank, world, n_seq, seq_len, local, costs=costs)
+        for c in stage.ctx:
+            c.set_mode(mode)
+        ok, pipe = 1, None
+        try:
+            idt = torch.zeros(128, dtype=torch.uint8)
+            if rank == 0 and world > 1:
+                idt = torch.frombuffer(bytearray(lnb.Pipeline.unique_id()), dtype=torch.uint8).clone()
+            if world > 1:
+                dist.broadcast(idt, 0)
+            pipe = lnb.Pipeline(stage.model, rank, world, bytes(idt.numpy().tobytes()) if world > 1 else None)
+        except Exception as e:                                # (every rank must take the same path: agree below)
+            sys.stderr.write("[rank %d] native RCCL exchange unavailable: %s\n" % (rank, e))
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32)
+        if world > 1:
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if pipe is not None:
+                pipe.close()
+            stage.close(); stage = None
+            dist.destroy_process_group()
+            exchange = "torch (native RCCL init failed on some rank)"
+    if exchange == "native":
+        prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
+        n_decode = W + K
+        t_split, t_end = n_seq * (1 + W), n_seq * (1 + W + K)
+        st = run_ticks_native(rank, world, pipe, stage.ctx, prompts, n_decode, 0, t_split)
+        pipe.sync()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        t_host = time.perf_counter()
+        run_ticks_native(rank, world, pipe, stage.ctx, prompts, n_decode, t_split, t_end, st)
+        t_host = time.perf_counter() - t_host                # host time of ENQUEUEING the K*n_seq ticks of the timed window
+        pipe.sync()
+        if world > 1:
+            dist.barrier()
+        wall = time.perf_counter() - t0
+        tmax = torch.tensor([wall], dtype=torch.float64)
+        if world > 1:
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+        extra = {"exchange": "RCCL point-to-point inside the library (lnb_pipeline_tick), stage steps as captured graphs",
+                 "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * n_seq), 1)}
+        if rank == world - 1 and os.environ.get("LNB_PIPELINE_DUMP_TOKENS"):
+            toks = {s: [int(t) for t in pipe.read_tokens(sl[0], len(sl))] if sl and sl == list(range(sl[0], sl[0] + len(sl))) else
+                    [int(pipe.read_tokens(q, 1)[0]) for q in sl] for s, sl in enumerate(st["slots"])}
+            json.dump(toks, open(os.environ["LNB_PIPELINE_DUMP_TOKENS"], "w"))
+        pipe.close()
+    else:
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device), timeout=patience)   # rank -> GPU mapping is explicit
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=patience)
+        # 2*world sequences: the exchange of a tick overlaps the compute of another sequence's item (run_ticks); LNB_PIPELINE_OVERLAP=0
+        # falls back to the lock-step schedule with `world` sequences
+        n_seq = world * (2 if world > 1 and os.environ.get("LNB_PIPELINE_OVERLAP", "1") != "0" else 1)
+        costs = probe(device if backend == "nccl" else "cpu")
+        stage = LnbStage(lnb, torch, cfg, rank, world, n_seq, seq_len, local, costs=costs)
+        for c in stage.ctx:
+            c.set_mode(mode)
+        prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
+        n_decode = W + K
+        t_split = n_seq * (1 + W)              # prefill phase + W warm-up decode rounds
+        t_end = n_seq * (1 + W + K)
+        state = run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, 0, t_split)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        # the timed window: every rank runs exactly K*n_seq items (K decode steps of each sequence in flight)
+        run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, t_split, t_end, state)
+        torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        tmax = torch.tensor([wall], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        wall = float(tmax.item())
+        extra = {"exchange": "torch.distributed batch_isend_irecv through staging tensors (%s)" % exchange}
     if rank == 0:
         import bench as _b
         tokens = K * n_seq
@@ -396,13 +513,13 @@ def bench_main(args, cfg, name):
         res = {"metric": "decode tokens/s Llama-3.1-8B bf16 @1/2/4/8 MI355X; % HBM roofline", "value": round(tps, 2), "unit": "tokens/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "%s bf16, %dxMI355X layer pipeline (blocks per GPU %s), RCCL p2p hidden-state hand-off, %d sequences in flight, "
-                                      "prompt %d -> +%d tokens each" % (name, world, ",".join("%.3g" % ((stage_parts(r, world, cfg["n_layers"], *stage.costs)[1]
-                                                                                                           - stage_parts(r, world, cfg["n_layers"], *stage.costs)[0]) / 3.0)
-                                                                                                for r in range(world)), n_seq, P, K),
-                          "prompt_len": P, "sequences_in_flight": n_seq, "parallelism": "pp%d" % world,
-                          "part_costs_us": [round(v, 1) for v in stage.costs],
-                          "mode": "exact-order (token-id identical to the CPU reference path)"},
+               "config": dict({"workload": "%s bf16, %dxMI355X layer pipeline (blocks per GPU %s), RCCL p2p hidden-state hand-off, %d sequences in flight, "
+                                           "prompt %d -> +%d tokens each" % (name, world, ",".join("%.3g" % ((stage_parts(r, world, cfg["n_layers"], *stage.costs)[1]
+                                                                                                                - stage_parts(r, world, cfg["n_layers"], *stage.costs)[0]) / 3.0)
+                                                                                                     for r in range(world)), n_seq, P, K),
+                                "prompt_len": P, "sequences_in_flight": n_seq, "parallelism": "pp%d" % world,
+                                "part_costs_us": [round(v, 1) for v in stage.costs],
+                                "mode": "exact-order (token-id identical to the CPU reference path)" if mode == "exact" else "fast (opt-in tolerance mode)"}, **extra),
                "roofline": {"bound": "hbm", "achieved": round(tps * B / 1e9, 1), "peak": _b.PEAK_HBM_GBS * world, "unit": "GB/s",
                             "frac": round(tps * B / 1e9 / (_b.PEAK_HBM_GBS * world), 4), "traffic": None,
                             "note": "whole job: tokens/s x algorithmic bytes per token over N x 8 TB/s"}}

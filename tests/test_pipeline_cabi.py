@@ -1,0 +1,149 @@
+"""The pipeline's exchange behind the C ABI (lnb_pipeline_*, include/lnb.h): what can be checked without a second GPU.
+
+CPU: the library resolves RCCL on first use (dlopen of librccl.so.1 + every entry point the pipeline calls) and reports its errors
+through lnb_last_error; argument validation; the native tick schedule (pipeline.run_ticks_native) posts MATCHING sends and receives
+on every pair of neighbouring ranks in every tick, never runs an item before its input was received, and closes the token ring.
+GPU (-m gpu): a one-stage pipe on one GPU -- stage steps as captured graphs, device-side token ring, pinned token log -- generates
+the oracle's tokens for several sequences in flight.  (Ranks > 1 need one GPU each: the driver's multi-GPU run.)"""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lnb():
+    import lnb as _lnb
+    _lnb.build()
+    return _lnb
+
+
+def _gpu_here():
+    import glob
+    return os.path.exists("/dev/kfd") and bool(glob.glob("/dev/dri/renderD*"))
+
+
+def test_rccl_is_resolved_on_first_use_and_errors_surface(lnb):
+    L = lnb.lib()
+    assert L.lnb_pipeline_unique_id(None) != 0 and b"null argument" in L.lnb_last_error()
+    buf = C.create_string_buffer(128)
+    rc = L.lnb_pipeline_unique_id(buf)
+    if _gpu_here():
+        assert rc == 0 and any(buf.raw)
+    else:                                       # librccl was loaded and called: it is RCCL that reports the missing device, not the loader
+        msg = L.lnb_last_error().decode()
+        assert rc != 0 and "ncclGetUniqueId failed" in msg, msg
+    # the loader mapped the library with every symbol the pipeline needs
+    maps = open("/proc/self/maps").read()
+    assert "librccl" in maps
+
+
+def test_pipeline_init_validates_its_arguments(lnb):
+    L = lnb.lib()
+    out = C.c_void_p()
+    assert L.lnb_pipeline_init(None, 0, 1, None, C.byref(out)) != 0 and b"null argument" in L.lnb_last_error()
+    assert L.lnb_pipeline_tick(None, None, 0, 0, None, None, 0, None, 0, None) != 0 and b"null argument" in L.lnb_last_error()
+    assert L.lnb_pipeline_sync(None) != 0
+    assert L.lnb_pipeline_destroy(None) == 0
+
+
+class _FakePipe:
+    def __init__(self, rank):
+        self.rank, self.ticks = rank, []
+
+    def tick(self, **kw):
+        self.ticks.append(kw)
+        return len(self.ticks) - 1
+
+
+@pytest.mark.parametrize("world,n_decode", [(2, 3), (3, 2), (4, 4), (8, 2)])
+def test_native_schedule_posts_matching_sends_and_receives(world, n_decode):
+    import pipeline
+    P, n_seq = 5, 2 * world
+    prompts = [np.arange(P, dtype=np.int32) + s for s in range(n_seq)]
+    pipes = [_FakePipe(r) for r in range(world)]
+    ctxs = [["ctx%d_%d" % (r, s) for s in range(n_seq)] for r in range(world)]
+    for r in range(world):
+        pipeline.run_ticks_native(r, world, pipes[r], ctxs[r], prompts, n_decode)
+    n_ticks = len(pipes[0].ticks)
+    assert all(len(p.ticks) == n_ticks for p in pipes)
+    seq_of = lambda name: int(name.split("_")[1])
+    got_input = [set() for _ in range(world)]           # (rank) -> {(seq, phase)} inputs received so far
+    phase = [[0] * n_seq for _ in range(world)]         # next phase each rank will run per sequence
+    ran = [[] for _ in range(world)]
+    for t in range(n_ticks):
+        for r in range(world):
+            kw = pipes[r].ticks[t]
+            if kw.get("run") is not None:
+                s = seq_of(kw["run"]); k = phase[r][s]
+                assert kw["run_rows"] == (P if k == 0 else 1) and kw["run_pos"] == (0 if k == 0 else P + k - 1)
+                if r == 0:
+                    assert (kw["run_tokens"] is not None) == (k == 0)
+                    if k > 0:
+                        assert (s, k) in got_input[0], "rank 0 ran a decode step before its token arrived"
+                else:
+                    assert kw["run_tokens"] is None and (s, k) in got_input[r], "rank %d ran (%d,%d) before its input arrived" % (r, s, k)
+                ran[r].append((s, k)); phase[r][s] += 1
+        for r in range(world):                           # every send of rank r in tick t is received by its peer in the SAME tick
+            kw, peer = pipes[r].ticks[t], pipes[(r + 1) % world].ticks[t]
+            if kw.get("send") is not None:
+                assert peer.get("recv") is not None and seq_of(peer["recv"]) == seq_of(kw["send"])
+                assert r == world - 1 or peer["recv_rows"] == kw["send_rows"]      # (the last rank sends the 4-byte token whatever the row count)
+                s = seq_of(kw["send"])
+                assert (s, phase[r][s] - 1) in ran[r]                      # it sends something it has computed
+                got_input[(r + 1) % world].add((s, phase[r][s] - 1 + (1 if r == world - 1 else 0)))
+            else:
+                assert peer.get("recv") is None
+    for r in range(world):
+        assert sorted(ran[r]) == sorted((s, k) for s in range(n_seq) for k in range(1 + n_decode))
+
+
+@pytest.mark.gpu
+def test_one_stage_pipe_on_one_gpu_generates_the_oracle_tokens(lnb):
+    """world == 1: no communicator, but everything else of lnb_pipeline_tick -- prefill with host tokens, one-token steps as replays of
+    the captured stage graph with the position on the device, the device-side token ring, the pinned token log."""
+    import pipeline
+    from oracle import oracle as orc
+    cfg = dict(orc.TINY)
+    om = orc.Model(**cfg).fill_synthetic(1234).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1234).finalize()
+    P, n_seq, n_decode = 6, 3, 9
+    prompts = [orc.synth_tokens(50 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
+    ctxs = [lnb.InferenceContext(gm, P + n_decode + 2) for _ in range(n_seq)]
+    pipe = lnb.Pipeline(gm, 0, 1)
+    st = pipeline.run_ticks_native(0, 1, pipe, ctxs, prompts, n_decode, 0, n_seq * 4)      # two windows, like bench.py
+    pipe.sync()
+    pipeline.run_ticks_native(0, 1, pipe, ctxs, prompts, n_decode, n_seq * 4, None, st)
+    pipe.sync()
+    for s in range(n_seq):
+        got = [int(pipe.read_tokens(q, 1)[0]) for q in st["slots"][s]]
+        ref, _ = orc.Context(om, P + n_decode + 2).generate(prompts[s], n_decode + 1)
+        assert got == [int(t) for t in ref], s
+    with pytest.raises(lnb.LnbError, match="out of range"):
+        pipe.read_tokens(0, 10 ** 6)
+    s1 = lnb.LlamaTransformer(layer_begin=0, layer_end=1, **cfg).fill_synthetic(1234).finalize()
+    with pytest.raises(lnb.LnbError, match="only the last stage owns"):
+        lnb.Pipeline(s1, 0, 1)
+    with pytest.raises(lnb.LnbError, match="out of range"):
+        lnb.Pipeline(gm, 2, 2)
+    s1.close(); pipe.close()
+    for c in ctxs:
+        c.close()
+    gm.close(); om.close()
+
+
+@pytest.mark.gpu
+def test_bench_force_pipeline_on_one_gpu_runs_the_native_tick_path(lnb):
+    import json
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "6", "--warmup", "2", "--model", "tiny", "--prompt-len", "20"],
+                       capture_output=True, text=True, timeout=600, cwd=ROOT, env=dict(os.environ, LNB_FORCE_PIPELINE="1", MASTER_PORT="29577"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["value"] > 0 and "lnb_pipeline_tick" in d["config"]["exchange"] and d["config"]["host_enqueue_us_per_tick"] > 0
