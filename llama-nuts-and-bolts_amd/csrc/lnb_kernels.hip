@@ -1635,7 +1635,8 @@ template <int HD> __global__ __launch_bounds__(ALS_NT) void attn_long_scores_ker
 constexpr int ALP_DS = 16;                                   // output dims per workgroup
 constexpr int ALP_BATCH = 512;                               // cached positions per PV batch (one barrier per batch)
 constexpr int ALP_NT = 320;                                  // wave 0: adder; waves 1..4: producers
-__host__ __device__ inline size_t alp_lds_bytes(int seq_len) { return (size_t)((seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4 + 2 * (size_t)ALP_BATCH * ALP_DS * 4 + 64; }
+constexpr int ALP_PITCH = ALP_BATCH + 20;                    // floats per dim row of a ring slot: 16 B reads of the 16 dims hit distinct banks; + read-ahead slack
+__host__ __device__ inline size_t alp_lds_bytes(int seq_len) { return (size_t)((seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4 + 2 * (size_t)ALP_DS * ALP_PITCH * 4 + 64; }
 DEVINL float alp_p(double e, double z) { return bf_wide(bf_trunc((float)(e / z))); }     // impl:506 + ToBFloat16 :493
 template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1645,8 +1646,8 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
     const int T = p.st->pos + 1, nblk = (T + ALS_NT - 1) / ALS_NT, nbatch = (T + ALP_BATCH - 1) / ALP_BATCH;
     const int Tpad = (nbatch + 1) * ALP_BATCH;               // the producers of the last iteration read one batch ahead: zeros
     float* pw = (float*)smem;                                // [Tpad] p_j (+0 beyond T)
-    float* ring = (float*)(smem + (size_t)((p.seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4);   // [2][ALP_BATCH][ALP_DS] products
-    double* zsh = (double*)(ring + 2 * ALP_BATCH * ALP_DS);
+    float* ring = (float*)(smem + (size_t)((p.seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4);   // [2][ALP_DS][ALP_PITCH] products
+    double* zsh = (double*)(ring + 2 * ALP_DS * ALP_PITCH);
     const double* E = p.e_buf + (size_t)h * p.seq_len;
     const int kvh = h / (p.H / p.KVH);
     // ---- Z estimate: the per-block tree sums, added in block order (same value in every thread).  One partial per lane, all loads
@@ -1721,8 +1722,10 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
         __syncthreads();
     }
     // ---- PV: out[d] = trunc(sum_{j ascending} p_j * v[j][d]) for d = ds*16 .. +15 (llamatransformer.go:504-514)
-    // iteration it: producers turn batch it (rows already in registers) into exact products in ring[it & 1] after putting batch it+1's
-    // rows in flight; the adder walks batch it-1.  Positions past T carry p == +0 (products +-0, acc is never -0).
+    // iteration it: producers turn batch it (rows already in registers, loaded three batches ahead) into exact products in ring[it & 1],
+    // laid out [dim][position] (pitch ALP_PITCH: conflict-free 16 B reads across the 16 dims); the adder walks batch it-1 with the
+    // chain wave's pipeline of the GEMV: 64 positions = 16 ds_read_b128 in flight behind the 64 dependent adds of the previous chunk.
+    // Positions past T carry p == +0 (products +-0, acc is never -0).
     const uint16_t* vbase = p.cache_v + (size_t)kvh * HD + (size_t)ds * ALP_DS;
     const size_t vrow = (size_t)p.KVH * HD;
     float acc = 0.0f;
@@ -1730,13 +1733,25 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
         const int d = lane & (ALP_DS - 1);
         for (int it = 0; it <= nbatch; it++) {
             if (it > 0) {
-                const float* src = ring + (size_t)((it - 1) & 1) * ALP_BATCH * ALP_DS + d;
-                for (int c = 0; c < ALP_BATCH; c += ATT_JC) {
-                    float a[ATT_JC];
+                const float* src = ring + (size_t)((it - 1) & 1) * ALP_DS * ALP_PITCH + (size_t)d * ALP_PITCH;
+                float4 pa[4], pb[4];
 #pragma unroll
-                    for (int j = 0; j < ATT_JC; j++) a[j] = src[(c + j) * ALP_DS];          // a whole 64-position chunk in flight
+                for (int u = 0; u < 4; u++) pa[u] = *(const float4*)(src + 4 * u);
+                for (int c = 0; c < ALP_BATCH; c += 32) {    // 16 positions per half-step, the other half's reads in flight
 #pragma unroll
-                    for (int j = 0; j < ATT_JC; j++) acc += a[j];
+                    for (int u = 0; u < 4; u++) pb[u] = *(const float4*)(src + c + 16 + 4 * u);
+                    __builtin_amdgcn_sched_barrier(0);
+                    touch16(pa[0], pa[1], pa[2], pa[3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = add4(acc, pa[0]); acc = add4(acc, pa[1]); acc = add4(acc, pa[2]); acc = add4(acc, pa[3]);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int u = 0; u < 4; u++) pa[u] = *(const float4*)(src + c + 32 + 4 * u);       // (the pitch has room for the read past the batch)
+                    __builtin_amdgcn_sched_barrier(0);
+                    touch16(pb[0], pb[1], pb[2], pb[3]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    acc = add4(acc, pb[0]); acc = add4(acc, pb[1]); acc = add4(acc, pb[2]); acc = add4(acc, pb[3]);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
             __syncthreads();
@@ -1752,26 +1767,26 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
             }
         };
         auto produce = [&](const uint4 (&v)[4], int b) {
-            float* dst = ring + (size_t)(b & 1) * ALP_BATCH * ALP_DS + half * 8;
+            float* dst = ring + (size_t)(b & 1) * ALP_DS * ALP_PITCH + (size_t)(half * 8) * ALP_PITCH;
 #pragma unroll
             for (int r = 0; r < 4; r++) {
                 const int jl = r * 128 + prow;
                 const float pj = pw[b * ALP_BATCH + jl];
                 const uint4 w = v[r];                        // exact products: 8-bit x 8-bit significands
-                *(float4*)(dst + jl * ALP_DS) = make_float4(pj * bf_lo(w.x), pj * bf_hi(w.x), pj * bf_lo(w.y), pj * bf_hi(w.y));
-                *(float4*)(dst + jl * ALP_DS + 4) = make_float4(pj * bf_lo(w.z), pj * bf_hi(w.z), pj * bf_lo(w.w), pj * bf_hi(w.w));
+                float* q = dst + jl;
+                q[0 * ALP_PITCH] = pj * bf_lo(w.x); q[1 * ALP_PITCH] = pj * bf_hi(w.x); q[2 * ALP_PITCH] = pj * bf_lo(w.y); q[3 * ALP_PITCH] = pj * bf_hi(w.y);
+                q[4 * ALP_PITCH] = pj * bf_lo(w.z); q[5 * ALP_PITCH] = pj * bf_hi(w.z); q[6 * ALP_PITCH] = pj * bf_lo(w.w); q[7 * ALP_PITCH] = pj * bf_hi(w.w);
             }
         };
-        uint4 va[4], vb[4];
-        load(va, 0);
-        for (int it = 0; it <= nbatch; it += 2) {
-            if (it < nbatch) { load(vb, it + 1); produce(va, it); }
-            __syncthreads();
-            if (it + 1 <= nbatch) {
-                if (it + 1 < nbatch) { load(va, it + 2); produce(vb, it + 1); }
+        auto step = [&](int it, const uint4 (&cur)[4], uint4 (&nxt)[4]) {
+            if (it <= nbatch) {                              // (uniform; one barrier per iteration, like the adder)
+                if (it < nbatch) { load(nxt, it + 3); produce(cur, it); }
                 __syncthreads();
             }
-        }
+        };
+        uint4 v0[4], v1[4], v2[4], v3[4];
+        load(v0, 0); load(v1, 1); load(v2, 2);
+        for (int it = 0; it <= nbatch; it += 4) { step(it, v0, v3); step(it + 1, v1, v0); step(it + 2, v2, v1); step(it + 3, v3, v2); }
     }
 }
 

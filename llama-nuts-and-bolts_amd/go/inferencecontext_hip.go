@@ -1,0 +1,139 @@
+//go:build hip
+
+// inferencecontext_hip.go -- package model's InferenceContext on the MI355X library, selected with `-tags hip` (see
+// llamatransformer_hip.go for how the two files slot under the reference's types).  Same exported names as
+// src/model/inferencecontext.go:8-52: SequenceLength, CacheK, CacheV, NewInferenceContext(model, inferenceArgs, logFn), Logf.
+//
+// The KV cache lives on the device.  CacheK / CacheV are HOST MIRRORS with the reference's shape [SequenceLength, N_KVHeads, HeadDim]
+// DT_BF16, allocated zero-filled like the reference (inferencecontext.go:32-42) and refreshed from the device by
+// SyncCachesFromDevice -- after every Forward when MirrorCaches is set (what a test that reads CacheK, as
+// llamatransformer_simulated_test.go:534-538 does, switches on), never otherwise (the copy is 2 x 64 KiB per token and layer).
+//
+// NOT COMPILED IN THIS REPOSITORY'S CI (no Go toolchain in the build image).
+
+package model
+
+/*
+#include <stdint.h>
+#include "lnb.h"
+extern void lnbGoLayerCallback(int layer, int nLayers, double secs, void* user);
+*/
+import "C"
+
+import (
+	"runtime"
+	"runtime/cgo"
+	"unsafe"
+
+	"github.com/adalkiran/llama-nuts-and-bolts/src/common"
+	"github.com/adalkiran/llama-nuts-and-bolts/src/ml"
+)
+
+type InferenceContext struct {
+	SequenceLength int // context size used during inference
+
+	CacheK []*ml.Tensor // host mirrors, see SyncCachesFromDevice
+	CacheV []*ml.Tensor
+
+	MirrorCaches bool // refresh CacheK / CacheV after every Forward
+
+	logFn func(format string, v ...any)
+
+	handle *C.lnb_ctx
+	lt     *LlamaTransformer // keeps the transformer alive (and finalized after this context)
+	self   cgo.Handle
+}
+
+// NewInferenceContext: same signature and defaults as src/model/inferencecontext.go:17-46.  The device side is created on the first
+// Forward (the reference's constructor has no error return, and the context does not know its transformer until then).
+func NewInferenceContext(model *Model, inferenceArgs common.InferenceArgs, logFn func(format string, v ...any)) *InferenceContext {
+	context := &InferenceContext{logFn: logFn}
+	if inferenceArgs.SequenceLength > 0 {
+		context.SequenceLength = inferenceArgs.SequenceLength
+	} else {
+		context.SequenceLength = model.ModelArgs.MaxSequenceLength
+	}
+	modelArgs := model.ModelArgs
+	context.CacheK = make([]*ml.Tensor, modelArgs.N_Layers)
+	context.CacheV = make([]*ml.Tensor, modelArgs.N_Layers)
+	for layerIdx := 0; layerIdx < modelArgs.N_Layers; layerIdx++ {
+		context.CacheK[layerIdx], _ = ml.Zeros([]int{context.SequenceLength, modelArgs.N_KVHeads, modelArgs.HeadDim}, ml.DT_BF16)
+		context.CacheV[layerIdx], _ = ml.Zeros([]int{context.SequenceLength, modelArgs.N_KVHeads, modelArgs.HeadDim}, ml.DT_BF16)
+	}
+	common.GLogger.DebugPrintf("Inference Context created with SequenceLength: %d", context.SequenceLength)
+	return context
+}
+
+func (ic *InferenceContext) Logf(format string, v ...any) {
+	if ic.logFn != nil {
+		ic.logFn(format, v...)
+	}
+}
+
+// The library's per-layer hook (lnb_ctx_set_layer_callback) lands here and becomes the reference's
+// infContext.Logf("Transformer block layer %d / %d was run, took %.4f sec(s)", ...) of llamatransformer.go:163.
+//
+//export lnbGoLayerCallback
+func lnbGoLayerCallback(layer C.int, nLayers C.int, secs C.double, user unsafe.Pointer) {
+	ic := cgo.Handle(uintptr(user)).Value().(*InferenceContext)
+	ic.Logf("Transformer block layer %d / %d was run, took %.4f sec(s)", int(layer), int(nLayers), float64(secs))
+}
+
+// attach creates the device-side context on the first Forward.
+func (ic *InferenceContext) attach(lt *LlamaTransformer) error {
+	if ic.handle != nil {
+		return nil
+	}
+	if err := lnbCall(func() C.int { return C.lnb_ctx_create(lt.handle, C.int(ic.SequenceLength), &ic.handle) }); err != nil {
+		return err
+	}
+	lt.mu.Lock()
+	lt.ctxs++
+	lt.mu.Unlock()
+	ic.lt = lt
+	if ic.logFn != nil { // the hook forces a per-layer stream sync: only when somebody listens
+		ic.self = cgo.NewHandle(ic)
+		if err := lnbCall(func() C.int {
+			return C.lnb_ctx_set_layer_callback(ic.handle, C.lnb_layer_cb(C.lnbGoLayerCallback), unsafe.Pointer(uintptr(ic.self)))
+		}); err != nil {
+			return err
+		}
+	}
+	runtime.SetFinalizer(ic, func(c *InferenceContext) { c.Close() })
+	return nil
+}
+
+// SyncCachesFromDevice copies every layer's K and V cache into the host mirrors, in the reference's [position, kv head, dim] order
+// (the library stores K position-contiguous on the device and hands it back transposed: lnb_ctx_read_kv).
+func (ic *InferenceContext) SyncCachesFromDevice() error {
+	if ic.handle == nil {
+		return nil
+	}
+	for layer := range ic.CacheK {
+		for which, t := range []*ml.Tensor{ic.CacheK[layer], ic.CacheV[layer]} {
+			if err := lnbCall(func() C.int {
+				return C.lnb_ctx_read_kv(ic.handle, C.int(layer), C.int(which), (*C.uint16_t)(unsafe.Pointer(&t.RawData[0])))
+			}); err != nil {
+				return err
+			}
+		}
+	}
+	return nil
+}
+
+// Close frees the device buffers of this context (idempotent; also run by the finalizer, before the transformer's).
+func (ic *InferenceContext) Close() error {
+	if ic.handle == nil {
+		return nil
+	}
+	C.lnb_ctx_destroy(ic.handle)
+	ic.handle = nil
+	if ic.self != 0 {
+		ic.self.Delete()
+		ic.self = 0
+	}
+	ic.lt.mu.Lock()
+	ic.lt.ctxs--
+	ic.lt.mu.Unlock()
+	return nil
+}

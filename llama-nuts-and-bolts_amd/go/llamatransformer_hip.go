@@ -1,20 +1,26 @@
-// llamatransformer_hip.go -- cgo binding of the MI355X-native LlamaTransformer.Forward path (liblnb_hip.so).
-//
-// UNTESTED SOURCE: no Go toolchain exists in the build image (`go: command not found`), so this file has never been
-// compiled.  It shows the exact binding a maintainer of adalkiran/llama-nuts-and-bolts adds to package `model`
-// (src/model/) to swap the CPU path for the HIP library while keeping every exported Go signature:
-//
-//   NewLlamaTransformer(model *Model) (*LlamaTransformer, error)                       src/model/llamatransformer.go:64
-//   (*LlamaTransformer).Forward(infContext, inputTokens *ml.Tensor, startPos int)       src/model/llamatransformer.go:145
-//   NewInferenceContext(model, inferenceArgs, logFn) *InferenceContext                  src/model/inferencecontext.go:17
-//
-// Build:  CGO_CFLAGS="-I<repo>/include" CGO_LDFLAGS="-L<repo>/llama-nuts-and-bolts_amd -llnb_hip" go build -tags hip ./...
 //go:build hip
+
+// llamatransformer_hip.go -- package model's LlamaTransformer on the MI355X library (liblnb_hip.so), selected with `-tags hip`.
+//
+// This file and inferencecontext_hip.go define THE SAME exported names as the reference's src/model/llamatransformer.go and
+// src/model/inferencecontext.go, so that everything that uses them compiles unchanged:
+//     Model.Transformer *LlamaTransformer                                   src/model/model.go:48
+//     NewLlamaTransformer(model *Model) (*LlamaTransformer, error)          src/model/llamatransformer.go:64   (called by the loader)
+//     (*LlamaTransformer).Forward(infContext, inputTokens, startPos)        src/model/llamatransformer.go:145  (called at src/inference/inference.go:202)
+//     LlamaTransformer.PrecomputedFreqsCis                                  src/model/llamatransformer.go:24
+// To adopt: copy both files into src/model/, add the line `//go:build !hip` at the top of the two reference files they replace (and of
+// llamatransformer_simulated_test.go, which pokes the CPU implementation's private fields), and build with
+//     CGO_CFLAGS="-I<repo>/include" CGO_LDFLAGS="-L<repo>/llama-nuts-and-bolts_amd -llnb_hip -Wl,-rpath,<repo>/llama-nuts-and-bolts_amd" go build -tags hip ./...
+// scripts/check_go.sh runs `go vet -tags hip ./src/model/` against a checkout of the reference when a Go toolchain exists.
+//
+// NOT COMPILED IN THIS REPOSITORY'S CI: the build image has no Go toolchain (`go: command not found`).  The C side of every call
+// below is exercised through the same ABI by tests/ (ctypes) and tests/native/host_mirror_test.cpp (C++).
 
 package model
 
 /*
 #cgo LDFLAGS: -llnb_hip
+#include <stdint.h>
 #include <stdlib.h>
 #include "lnb.h"
 */
@@ -24,107 +30,39 @@ import (
 	"errors"
 	"fmt"
 	"runtime"
+	"sync"
 	"unsafe"
 
-	"github.com/adalkiran/llama-nuts-and-bolts/src/common"
 	"github.com/adalkiran/llama-nuts-and-bolts/src/ml"
 )
 
-func lastError() error { return errors.New(C.GoString(C.lnb_last_error())) }
+// lnb_last_error() is thread-local in the library and a goroutine may migrate between OS threads: the failing call and the fetch of
+// its message run with the goroutine pinned to one thread.
+func lnbCall(f func() C.int) error {
+	runtime.LockOSThread()
+	defer runtime.UnlockOSThread()
+	if f() != 0 {
+		return errors.New(C.GoString(C.lnb_last_error()))
+	}
+	return nil
+}
 
-// LlamaTransformerHIP replaces the weight-holding fields of LlamaTransformer; the exported fields the tests read
-// (Layers, PrecomputedFreqsCis) are kept on the embedding struct.
-type LlamaTransformerHIP struct {
+// LlamaTransformer keeps the exported surface of the reference struct.  The weights live on the device behind `handle`
+// (re-tiled once by lnb_model_set_tensor); Layers stays exported with one entry per block for code that ranges over it.
+type LlamaTransformer struct {
+	Layers []*LlamaTransformerBlock
+
+	PrecomputedFreqsCis *ml.Tensor // [2*MaxSequenceLength, HeadDim/2] complex64, as the reference computes it (read back from the library)
+
 	handle *C.lnb_model
 	args   *ModelArgs
+	mu     sync.Mutex
+	ctxs   int // live InferenceContexts (Close refuses while > 0)
 }
 
-func newLlamaTransformerHIP(model *Model, device int) (*LlamaTransformerHIP, error) {
-	a := model.ModelArgs
-	cargs := C.lnb_model_args{
-		dim: C.int32_t(a.Dim), n_layers: C.int32_t(a.N_Layers), n_heads: C.int32_t(a.N_Heads), n_kv_heads: C.int32_t(a.N_KVHeads),
-		vocab_size: C.int32_t(a.VocabSize), multiple_of: C.int32_t(a.MultipleOf), ffn_dim_multiplier: C.double(a.FFNDimMultiplier),
-		norm_eps: C.float(a.NormEpsilon), use_scaled_rope: boolToC(a.UseScaledRope), rope_theta: C.double(a.RopeTheta),
-		max_seq_len: C.int32_t(a.MaxSequenceLength),
-	}
-	t := &LlamaTransformerHIP{args: a}
-	if C.lnb_model_create(&cargs, C.int(device), 0, C.int(a.N_Layers), &t.handle) != 0 {
-		return nil, lastError()
-	}
-	// bind every checkpoint tensor by its Meta key: same names and shapes getTensor/getLayerTensor check (loader.go:183-192).
-	// RawData is a sub-slice of the mmap (src/torch/types.go:51-55): the library copies it to the device and keeps nothing.
-	for _, name := range model.Tensors.GetKeys() {
-		tensor, _ := model.Tensors.Get(name)
-		shape := make([]C.int64_t, len(tensor.Size))
-		for i, s := range tensor.Size {
-			shape[i] = C.int64_t(s)
-		}
-		cname := C.CString(name)
-		rc := C.lnb_model_set_tensor(t.handle, cname, (*C.uint16_t)(unsafe.Pointer(&tensor.RawData[0])), &shape[0], C.int(len(shape)))
-		C.free(unsafe.Pointer(cname))
-		if rc != 0 {
-			C.lnb_model_destroy(t.handle)
-			return nil, lastError()
-		}
-	}
-	if C.lnb_model_finalize(t.handle, 0) != 0 { // PrecomputedFreqsCis, llamatransformer.go:109
-		C.lnb_model_destroy(t.handle)
-		return nil, lastError()
-	}
-	runtime.SetFinalizer(t, func(t *LlamaTransformerHIP) { C.lnb_model_destroy(t.handle) })
-	return t, nil
-}
-
-// InferenceContextHIP is the device KV cache behind model.InferenceContext (inferencecontext.go:8-15).
-type InferenceContextHIP struct {
-	handle         *C.lnb_ctx
-	SequenceLength int
-}
-
-func newInferenceContextHIP(t *LlamaTransformerHIP, inferenceArgs common.InferenceArgs) (*InferenceContextHIP, error) {
-	c := &InferenceContextHIP{SequenceLength: inferenceArgs.SequenceLength}
-	if C.lnb_ctx_create(t.handle, C.int(inferenceArgs.SequenceLength), &c.handle) != 0 {
-		return nil, lastError()
-	}
-	runtime.SetFinalizer(c, func(c *InferenceContextHIP) { C.lnb_ctx_destroy(c.handle) })
-	return c, nil
-}
-
-// Forward is the body of (*LlamaTransformer).Forward (llamatransformer.go:145-180) on the HIP path:
-// inputTokens is the DT_INT32 tensor the generation loop slices (inference.go:195), the result is the
-// [sequenceLength, VocabSize] DT_F32 logits tensor the caller argmaxes (inference.go:207-211).
-func (t *LlamaTransformerHIP) Forward(infContext *InferenceContextHIP, inputTokens *ml.Tensor, startPos int) (*ml.Tensor, error) {
-	if inputTokens.Size[0] == 0 {
-		return nil, fmt.Errorf("empty token array")
-	}
-	if inputTokens.DataType != ml.DT_INT32 {
-		return nil, fmt.Errorf("tensor is not in data type %s: \"%s\" is %s", ml.DT_INT32, inputTokens.Name, inputTokens.DataType)
-	}
-	seq := inputTokens.Size[0]
-	logits := ml.NewEmptyTensor([]int{seq, t.args.VocabSize}, ml.DT_F32)
-	var pinner runtime.Pinner // Go memory handed to C for the duration of the call
-	pinner.Pin(&inputTokens.RawData[0])
-	pinner.Pin(&logits.RawData[0])
-	defer pinner.Unpin()
-	rc := C.lnb_forward(infContext.handle, (*C.int32_t)(unsafe.Pointer(&inputTokens.RawData[0])), C.int(seq), C.int(startPos),
-		(*C.float)(unsafe.Pointer(&logits.RawData[0])), nil)
-	if rc != 0 {
-		return nil, lastError()
-	}
-	return logits, nil
-}
-
-// DecodeGreedy runs n one-token Forward+Argmax steps on the device (the loop body of inference.go:194-252).
-func (t *LlamaTransformerHIP) DecodeGreedy(infContext *InferenceContextHIP, token TokenId, startPos int, n int) ([]TokenId, error) {
-	out := make([]int32, n)
-	if C.lnb_decode_greedy(infContext.handle, C.int32_t(token), C.int(startPos), C.int(n), (*C.int32_t)(unsafe.Pointer(&out[0])), nil) != 0 {
-		return nil, lastError()
-	}
-	res := make([]TokenId, n)
-	for i, v := range out {
-		res[i] = TokenId(v)
-	}
-	return res, nil
+// LlamaTransformerBlock: the reference's blocks hold weight tensors; here a block is its index (the weights are on the device).
+type LlamaTransformerBlock struct {
+	LayerIndex int
 }
 
 func boolToC(b bool) C.int32_t {
@@ -132,4 +70,113 @@ func boolToC(b bool) C.int32_t {
 		return 1
 	}
 	return 0
+}
+
+// NewLlamaTransformer binds every checkpoint tensor by its Meta key (the names and shapes getTensor / getLayerTensor check,
+// src/model/loader.go:183-192) and builds the RoPE table; same signature and error behaviour as src/model/llamatransformer.go:64-113.
+func NewLlamaTransformer(model *Model) (*LlamaTransformer, error) {
+	a := model.ModelArgs
+	cargs := C.lnb_model_args{
+		dim: C.int32_t(a.Dim), n_layers: C.int32_t(a.N_Layers), n_heads: C.int32_t(a.N_Heads), n_kv_heads: C.int32_t(a.N_KVHeads),
+		vocab_size: C.int32_t(a.VocabSize), multiple_of: C.int32_t(a.MultipleOf), ffn_dim_multiplier: C.double(a.FFNDimMultiplier),
+		norm_eps: C.float(a.NormEpsilon), use_scaled_rope: boolToC(a.UseScaledRope), rope_theta: C.double(a.RopeTheta),
+		max_seq_len: C.int32_t(a.MaxSequenceLength),
+	}
+	lt := &LlamaTransformer{args: a}
+	if err := lnbCall(func() C.int { return C.lnb_model_create(&cargs, 0, 0, C.int(a.N_Layers), &lt.handle) }); err != nil {
+		return nil, err
+	}
+	n := int(C.lnb_model_num_tensors(lt.handle))
+	for k := 0; k < n; k++ {
+		var cname *C.char
+		var shape [2]C.int64_t
+		var rank C.int
+		if err := lnbCall(func() C.int { return C.lnb_model_tensor_info(lt.handle, C.int(k), &cname, &shape[0], &rank) }); err != nil {
+			lt.Close()
+			return nil, err
+		}
+		name := C.GoString(cname)
+		tensor, ok := model.Tensors.Get(name)
+		if !ok {
+			lt.Close()
+			return nil, fmt.Errorf("tensor \"%s\" not found", name) // loader.go:185
+		}
+		tshape := make([]C.int64_t, len(tensor.Size))
+		for i, s := range tensor.Size {
+			tshape[i] = C.int64_t(s)
+		}
+		// RawData is a sub-slice of the checkpoint mmap (src/torch/types.go:51-55): copied to the device, not retained
+		if err := lnbCall(func() C.int {
+			return C.lnb_model_set_tensor(lt.handle, cname, (*C.uint16_t)(unsafe.Pointer(&tensor.RawData[0])), &tshape[0], C.int(len(tshape)))
+		}); err != nil {
+			lt.Close()
+			return nil, err
+		}
+	}
+	if err := lnbCall(func() C.int { return C.lnb_model_finalize(lt.handle, 0) }); err != nil {
+		lt.Close()
+		return nil, err
+	}
+	// PrecomputedFreqsCis (exported field, llamatransformer.go:24,109): [rows, HeadDim/2] complex64 = f32 pairs
+	var rows C.int
+	if err := lnbCall(func() C.int { return C.lnb_model_rope_table(lt.handle, nil, 0, &rows) }); err != nil {
+		lt.Close()
+		return nil, err
+	}
+	lt.PrecomputedFreqsCis = ml.NewEmptyTensor([]int{int(rows), a.HeadDim / 2}, ml.DT_COMPLEX)
+	nf := C.int64_t(int(rows) * (a.HeadDim / 2) * 2)
+	if err := lnbCall(func() C.int {
+		return C.lnb_model_rope_table(lt.handle, (*C.float)(unsafe.Pointer(&lt.PrecomputedFreqsCis.RawData[0])), nf, &rows)
+	}); err != nil {
+		lt.Close()
+		return nil, err
+	}
+	lt.Layers = make([]*LlamaTransformerBlock, a.N_Layers)
+	for i := range lt.Layers {
+		lt.Layers[i] = &LlamaTransformerBlock{LayerIndex: i}
+	}
+	runtime.SetFinalizer(lt, func(t *LlamaTransformer) { t.Close() })
+	return lt, nil
+}
+
+// Close frees the device copy.  It refuses while InferenceContexts created on this transformer are alive (they hold device
+// buffers that refer to it); contexts keep a Go reference to the transformer, so the garbage collector finalizes them first.
+func (lt *LlamaTransformer) Close() error {
+	lt.mu.Lock()
+	defer lt.mu.Unlock()
+	if lt.handle == nil {
+		return nil
+	}
+	if lt.ctxs > 0 {
+		return fmt.Errorf("LlamaTransformer.Close: %d InferenceContext(s) still open", lt.ctxs)
+	}
+	C.lnb_model_destroy(lt.handle)
+	lt.handle = nil
+	return nil
+}
+
+// Forward: same contract as src/model/llamatransformer.go:145-180 -- inputTokens [seq] DT_INT32, logits [seq, VocabSize] DT_F32
+// (bf16-representable values), errors for an empty token array and for positions beyond the RoPE table / KV cache.
+func (lt *LlamaTransformer) Forward(infContext *InferenceContext, inputTokens *ml.Tensor, startPos int) (*ml.Tensor, error) {
+	if inputTokens.Size[0] == 0 {
+		return nil, fmt.Errorf("empty token array") // llamatransformer.go:146-148
+	}
+	if err := infContext.attach(lt); err != nil {
+		return nil, err
+	}
+	seq := inputTokens.Size[0]
+	output := ml.NewEmptyTensor([]int{seq, lt.args.VocabSize}, ml.DT_F32)
+	if err := lnbCall(func() C.int {
+		return C.lnb_forward(infContext.handle, (*C.int32_t)(unsafe.Pointer(&inputTokens.RawData[0])), C.int(seq), C.int(startPos),
+			(*C.float)(unsafe.Pointer(&output.RawData[0])), nil)
+	}); err != nil {
+		return nil, err
+	}
+	if infContext.MirrorCaches {
+		if err := infContext.SyncCachesFromDevice(); err != nil {
+			return nil, err
+		}
+	}
+	runtime.KeepAlive(inputTokens)
+	return output, nil
 }
