@@ -65,9 +65,11 @@ def cpu_baseline(model_cfg, prompt, n_steps):
     t2 = time.time()
     oc.close(); om.close()
     return {"value": round(n_steps / (t2 - t1), 4), "unit": "tokens/s", "cores": ncores, "kind": "port",
-            "sample": "Llama-3.1-8B shape, synthetic weights seed 1234: %d-token prefill (%.1f s incl. weight generation) then %d greedy "
-                      "decode steps timed (%.2f s/token); C restatement of the Go reference (no Go toolchain on this box)"
-                      % (len(prompt), t1 - t0, n_steps, (t2 - t1) / n_steps)}
+            "sample": "configs[0]-sized run (context %d = %d-token prompt + %d greedy steps) of the Llama-3.1-8B shape with synthetic weights seed 1234: "
+                      "prefill %.1f s incl. weight generation, then the %d one-token Forward+Argmax steps timed (%.2f s/token).  C restatement of the Go "
+                      "reference (no Go toolchain on this box), parallel over output elements like the reference's goroutine fan-out but with 8 outputs "
+                      "interleaved per thread and capped at 64 threads -- faster than one goroutine per output; a stand-in, not the Go binary"
+                      % (len(prompt) + n_steps, len(prompt), n_steps, t1 - t0, n_steps, (t2 - t1) / n_steps)}
 
 
 # kernel symbol (prefix) of each decode kernel class of the 8B shape, for the PMC traffic lookup
@@ -204,7 +206,7 @@ def main():
                        "bound": "mfma (f32, exact order: v_mfma_f32_16x16x4_f32 is the k-ordered chain; the bf16 instructions are not)" if args.mode == "exact"
                                 else "mfma (bf16, tolerance mode) / HBM at small row counts"}}
     if args.cpu_steps > 0:
-        res["cpu_baseline"] = cpu_baseline(cfg, prompt[:4], args.cpu_steps)
+        res["cpu_baseline"] = cpu_baseline(cfg, prompt[:8], args.cpu_steps)        # 8 + 24 = configs[0]'s seq_len of 32
     ctx.close(); model.close()
     print(json.dumps(res))
     return 0

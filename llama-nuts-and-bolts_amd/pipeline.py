@@ -183,6 +183,92 @@ def run_ticks(rank, world, stage, dist, torch, prompts, n_decode, device, lo=0, 
     return state
 
 
+class TcpGroup:
+    """Minimal control plane for one node: rank 0 listens on (addr, port), the others connect; broadcast / all-reduce / barrier of small
+    python values over that star.  It exists so that the NATIVE exchange path never imports torch: PyTorch bundles its own HIP runtime
+    and RCCL, and an RCCL bound to one runtime must not be handed streams created by another (liblnb_hip.so uses /opt/rocm's)."""
+
+    def __init__(self, rank, world, addr, port, timeout=300.0):
+        import pickle
+        import socket
+        import struct
+        self.rank, self.world, self._pickle, self._struct = rank, world, pickle, struct
+        self.peers = []
+        if world == 1:
+            return
+        if rank == 0:
+            srv = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            srv.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+            srv.bind((addr, port)); srv.listen(world); srv.settimeout(timeout)
+            conns = {}
+            while len(conns) < world - 1:
+                c, _ = srv.accept()
+                c.settimeout(timeout)
+                r = struct.unpack("<i", self._recvn(c, 4))[0]
+                conns[r] = c
+            srv.close()
+            self.peers = [conns[r] for r in range(1, world)]
+        else:
+            deadline = time.time() + timeout
+            while True:
+                try:
+                    c = socket.create_connection((addr, port), timeout=5.0)
+                    break
+                except OSError:
+                    if time.time() > deadline:
+                        raise
+                    time.sleep(0.2)
+            c.settimeout(timeout)
+            c.sendall(struct.pack("<i", rank))
+            self.peers = [c]
+
+    @staticmethod
+    def _recvn(c, n):
+        buf = b""
+        while len(buf) < n:
+            part = c.recv(n - len(buf))
+            if not part:
+                raise ConnectionError("peer closed the control connection")
+            buf += part
+        return buf
+
+    def _send(self, c, obj):
+        raw = self._pickle.dumps(obj)
+        c.sendall(self._struct.pack("<q", len(raw)) + raw)
+
+    def _recv(self, c):
+        n = self._struct.unpack("<q", self._recvn(c, 8))[0]
+        return self._pickle.loads(self._recvn(c, n))
+
+    def broadcast(self, obj):
+        """value of rank 0 on every rank"""
+        if self.world == 1:
+            return obj
+        if self.rank == 0:
+            for c in self.peers:
+                self._send(c, obj)
+            return obj
+        return self._recv(self.peers[0])
+
+    def all_reduce(self, value, op):
+        """op(values of all ranks) on every rank (op: min / max / sum)"""
+        if self.world == 1:
+            return value
+        if self.rank == 0:
+            vals = [value] + [self._recv(c) for c in self.peers]
+            return self.broadcast(op(vals))
+        self._send(self.peers[0], value)
+        return self._recv(self.peers[0])
+
+    def barrier(self):
+        self.all_reduce(0, max)
+
+    def close(self):
+        for c in self.peers:
+            c.close()
+        self.peers = []
+
+
 def run_ticks_native(rank, world, pipe, ctxs, prompts, n_decode, lo=0, hi=None, state=None):
     """The overlapped schedule of run_ticks driven through the C ABI (lnb_pipeline_tick): rank r runs item t - 2r at tick t, sends the
     result of the item it ran in the previous tick and receives the input of the item of the next tick -- all ENQUEUED; nothing is
@@ -319,7 +405,7 @@ class LnbStage(Stage):
 
     def __init__(self, lnb, torch, cfg, rank, world, n_seq, seq_len, device_index, parts=None, costs=None):
         import ctypes as C
-        self.lnb, self.torch, self.C = lnb, torch, C
+        self.lnb, self.torch, self.C = lnb, torch, C      # torch may be None (native exchange path): only the zero-copy views need it
         L = cfg["n_layers"]
         self.first, self.last = rank == 0, rank == world - 1
         probe = lnb.ModelArgs(**dict(lnb.LLAMA_8B, **cfg))
@@ -379,13 +465,12 @@ class LnbStage(Stage):
 def bench_main(args, cfg, name):
     """bench.py --gpus N under torchrun: weak scaling, 2N sequences in flight, one rank per GPU.
 
-    Control plane (rendezvous, the 128-byte RCCL id, barriers, max over ranks): torch.distributed over gloo.  Data plane: RCCL
-    point-to-point INSIDE the library (lnb_pipeline_tick: ncclSend / ncclRecv straight from / into the stage's device buffers, stage
-    steps as captured graphs, no per-tick synchronisation).  LNB_PIPELINE_EXCHANGE=torch (or a failed native init on any rank) runs the
-    exchange through torch.distributed instead (run_ticks: staging tensors + batch_isend_irecv), which is also what the gloo tests use."""
+    Data plane: RCCL point-to-point INSIDE the library (lnb_pipeline_tick: ncclSend / ncclRecv straight from / into the stage's device
+    buffers, stage steps as captured graphs, no per-tick synchronisation).  Control plane (the 128-byte RCCL id, barriers, max over
+    ranks, the measured part costs): a small TCP star (TcpGroup) -- the native path never imports torch, so the process holds exactly one
+    HIP runtime and one RCCL.  LNB_PIPELINE_EXCHANGE=torch (or a failed native init on any rank) runs the exchange through
+    torch.distributed instead (run_ticks: staging tensors + batch_isend_irecv), which is also what the gloo tests use."""
     import sys
-    import torch
-    import torch.distributed as dist
     import lnb
     # librccl prints a version banner to the C stdout (flushed at exit, i.e. AFTER anything python printed): keep the process's
     # stdout for the one JSON line and send everything else written to fd 1 to stderr
@@ -401,53 +486,35 @@ def bench_main(args, cfg, name):
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     backend = os.environ.get("LNB_PIPELINE_BACKEND", "nccl")      # "gloo": ranks may share a GPU (tests); the exchange is staged on the host
     exchange = os.environ.get("LNB_PIPELINE_EXCHANGE", "native" if backend == "nccl" else "torch")
-    if backend == "gloo":
-        local %= torch.cuda.device_count()
-    torch.cuda.set_device(local)
-    device = "cuda:%d" % local
-    import datetime
-    patience = datetime.timedelta(seconds=300)               # a lost peer fails the run instead of hanging it
     P, W, K = args.prompt_len, args.warmup, args.steps
     seq_len = P + W + K + 8
     mode = getattr(args, "mode", "exact")
-
-    def probe(bcast_device):
-        if not (world > 1 and os.environ.get("LNB_PIPELINE_PROBE", "1") != "0"):
-            return None
-        # rank 0 times the three block parts and the head on its GPU; every rank cuts the model with the same numbers
-        t = torch.zeros(4, dtype=torch.float64, device=bcast_device)
-        if rank == 0:
-            t += torch.tensor(probe_costs(lnb, cfg, local, P + W + K // 2), dtype=torch.float64).to(t.device)
-        dist.broadcast(t, 0)
-        return [float(v) for v in t.tolist()]
-
-    stage = None
+    stage, dist, torch = None, None, None
     if exchange == "native":
-        dist.init_process_group("gloo", rank=rank, world_size=world, timeout=patience)          # control plane only
+        n_dev = lnb.device_count()
+        local %= max(1, n_dev)
+        # the torchrun agent's own store listens on MASTER_PORT: the control star takes a port next to it
+        grp = TcpGroup(rank, world, os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + int(os.environ.get("LNB_CONTROL_PORT_OFFSET", "23")))
         n_seq = 2 * world if world > 1 else int(os.environ.get("LNB_PIPELINE_SEQS", "2"))
-        costs = probe("cpu")
-        stage = LnbStage(lnb, torch, cfg, rank, world, n_seq, seq_len, local, costs=costs)
+        costs = None
+        if world > 1 and os.environ.get("LNB_PIPELINE_PROBE", "1") != "0":
+            # rank 0 times the three block parts and the head on its GPU; every rank cuts the model with the same numbers
+            costs = grp.broadcast([float(v) for v in probe_costs(lnb, cfg, local, P + W + K // 2)] if rank == 0 else None)
+        stage = LnbStage(lnb, None, cfg, rank, world, n_seq, seq_len, local, costs=costs)
         for c in stage.ctx:
             c.set_mode(mode)
         ok, pipe = 1, None
         try:
-            idt = torch.zeros(128, dtype=torch.uint8)
-            if rank == 0 and world > 1:
-                idt = torch.frombuffer(bytearray(lnb.Pipeline.unique_id()), dtype=torch.uint8).clone()
-            if world > 1:
-                dist.broadcast(idt, 0)
-            pipe = lnb.Pipeline(stage.model, rank, world, bytes(idt.numpy().tobytes()) if world > 1 else None)
+            uid = grp.broadcast(lnb.Pipeline.unique_id() if (rank == 0 and world > 1) else None)
+            pipe = lnb.Pipeline(stage.model, rank, world, uid)
         except Exception as e:                                # (every rank must take the same path: agree below)
             sys.stderr.write("[rank %d] native RCCL exchange unavailable: %s\n" % (rank, e))
             ok = 0
-        flag = torch.tensor([ok], dtype=torch.int32)
-        if world > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-        if int(flag.item()) == 0:
+        if grp.all_reduce(ok, min) == 0:
             if pipe is not None:
                 pipe.close()
             stage.close(); stage = None
-            dist.destroy_process_group()
+            grp.close()
             exchange = "torch (native RCCL init failed on some rank)"
     if exchange == "native":
         prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
@@ -455,20 +522,14 @@ def bench_main(args, cfg, name):
         t_split, t_end = n_seq * (1 + W), n_seq * (1 + W + K)
         st = run_ticks_native(rank, world, pipe, stage.ctx, prompts, n_decode, 0, t_split)
         pipe.sync()
-        if world > 1:
-            dist.barrier()
+        grp.barrier()
         t0 = time.perf_counter()
         t_host = time.perf_counter()
         run_ticks_native(rank, world, pipe, stage.ctx, prompts, n_decode, t_split, t_end, st)
         t_host = time.perf_counter() - t_host                # host time of ENQUEUEING the K*n_seq ticks of the timed window
         pipe.sync()
-        if world > 1:
-            dist.barrier()
-        wall = time.perf_counter() - t0
-        tmax = torch.tensor([wall], dtype=torch.float64)
-        if world > 1:
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        wall = float(tmax.item())
+        grp.barrier()
+        wall = grp.all_reduce(time.perf_counter() - t0, max)
         extra = {"exchange": "RCCL point-to-point inside the library (lnb_pipeline_tick), stage steps as captured graphs",
                  "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * n_seq), 1)}
         if rank == world - 1 and os.environ.get("LNB_PIPELINE_DUMP_TOKENS"):
@@ -476,7 +537,26 @@ def bench_main(args, cfg, name):
                     [int(pipe.read_tokens(q, 1)[0]) for q in sl] for s, sl in enumerate(st["slots"])}
             json.dump(toks, open(os.environ["LNB_PIPELINE_DUMP_TOKENS"], "w"))
         pipe.close()
+        grp.close()
     else:
+        import datetime
+        import torch
+        import torch.distributed as dist
+        if backend == "gloo":
+            local %= torch.cuda.device_count()
+        torch.cuda.set_device(local)
+        device = "cuda:%d" % local
+        patience = datetime.timedelta(seconds=300)               # a lost peer fails the run instead of hanging it
+
+        def probe(bcast_device):
+            if not (world > 1 and os.environ.get("LNB_PIPELINE_PROBE", "1") != "0"):
+                return None
+            t = torch.zeros(4, dtype=torch.float64, device=bcast_device)
+            if rank == 0:
+                t += torch.tensor(probe_costs(lnb, cfg, local, P + W + K // 2), dtype=torch.float64).to(t.device)
+            dist.broadcast(t, 0)
+            return [float(v) for v in t.tolist()]
+
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device(device), timeout=patience)   # rank -> GPU mapping is explicit
         else:
@@ -526,5 +606,6 @@ def bench_main(args, cfg, name):
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     os.close(json_fd)
     stage.close()
-    dist.destroy_process_group()
+    if dist is not None:
+        dist.destroy_process_group()
     return 0

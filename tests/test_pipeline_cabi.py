@@ -50,6 +50,36 @@ def test_pipeline_init_validates_its_arguments(lnb):
     assert L.lnb_pipeline_destroy(None) == 0
 
 
+def _tcp_worker(rank, world, port, q):
+    import pipeline
+    g = pipeline.TcpGroup(rank, world, "127.0.0.1", port, timeout=30.0)
+    got = g.broadcast(b"\x07" * 128 if rank == 0 else None)
+    mx = g.all_reduce(float(rank) + 0.5, max)
+    mn = g.all_reduce(1 if rank != 1 else 0, min)
+    g.barrier()
+    costs = g.broadcast([1.0, 2.0, 3.0, 4.0] if rank == 0 else None)
+    g.close()
+    q.put((rank, got, mx, mn, costs))
+
+
+def test_tcp_control_plane_broadcast_reduce_barrier():
+    """the torch-free control plane of the native bench path: three processes on 127.0.0.1"""
+    import multiprocessing as mp
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_tcp_worker, args=(r, 3, port, q)) for r in range(3)]
+    for p_ in procs:
+        p_.start()
+    res = sorted(q.get(timeout=60) for _ in range(3))
+    for p_ in procs:
+        p_.join(30)
+    for r, got, mx, mn, costs in res:
+        assert got == b"\x07" * 128 and mx == 2.5 and mn == 0 and costs == [1.0, 2.0, 3.0, 4.0]
+
+
 class _FakePipe:
     def __init__(self, rank):
         self.rank, self.ticks = rank, []
