@@ -80,7 +80,10 @@ int lnb_model_rope_table(lnb_model* m, float* out, int64_t nfloats, int* rows_ou
 int64_t lnb_model_weight_bytes(lnb_model* m);
 
 /* ---- context: replaces model.NewInferenceContext (src/model/inferencecontext.go:17-46) ---------------
- * device-resident, zero-filled CacheK/CacheV [seq_len, n_kv_heads, head_dim] bf16 per owned layer */
+ * device-resident, zero-filled CacheK/CacheV [seq_len, n_kv_heads, head_dim] bf16 per owned layer.
+ * Context length: up to about 23000 positions (the long-context decode attention keeps 4 bytes per position in the LDS); head_dim 32, 64
+ * or 128.  Calls of 2..15 rows use a kernel that stages 12 bytes per position and fail beyond ~7800 positions (head_dim 128; ~10800 at 64):
+ * one-token calls and calls of 16 or more rows have no such limit. */
 int lnb_ctx_create(lnb_model* m, int seq_len, lnb_ctx** out);
 int lnb_ctx_destroy(lnb_ctx* c);
 int lnb_ctx_reset(lnb_ctx* c);                                       /* zero the caches again */

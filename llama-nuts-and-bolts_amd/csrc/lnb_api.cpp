@@ -19,6 +19,8 @@
 extern "C" {
 hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st);
 hipError_t lnbk_attn(const AttnParams* p, hipStream_t st);
+int lnbk_attn_short_max_T(int hd);
+size_t lnbk_attn_long_lds(int seq_len);
 hipError_t lnbk_exp_table(double* tab, float divisor, hipStream_t st);
 hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st);
 hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps, hipStream_t st);
@@ -31,6 +33,7 @@ hipError_t lnbk_synth_fill(uint16_t* dst, int rows, int K, int row_off, int chai
 hipError_t lnbk_init(void);
 hipError_t lnbk_fast_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hipStream_t st);
 hipError_t lnbk_fast_gemm(const GemmParams* p, int epi, hipStream_t st);
+hipError_t lnbk_fast_attn(const AttnParams* p, hipStream_t st);
 hipError_t lnbk_fast_init(void);
 }
 
@@ -100,6 +103,7 @@ struct lnb_ctx {
     // long-context decode attention (attn_long_*_kernel): used for one-token calls whose context exceeds attn_long_T
     double* e_buf = nullptr; double* z_part = nullptr; int* zseq_count = nullptr;
     int attn_long_T = 0; int force_zseq = 0;
+    int attn_short_cap = 0;                // longest context the one-workgroup-per-head kernel can stage in the LDS
     bool attn_long = false;                // selection for the launches being enqueued (set per call / per captured graph)
     hipGraphExec_t graph_long = nullptr;   // the decode step captured with the long-context attention
     // pipeline stage (lnb_pipeline_tick): one-token stage step as a captured graph per attention form, events towards / from the exchange stream
@@ -406,10 +410,12 @@ extern "C" int lnb_ctx_create(lnb_model* m, int seq_len, lnb_ctx** out) {
     HIPCHK(hipSetDevice(m->device));
     lnb_ctx* c = new lnb_ctx();
     c->m = m; c->seq_len = seq_len > 0 ? seq_len : m->a.max_seq_len;        // inferencecontext.go:22-26
-    // the one-workgroup-per-head decode attention stages e (f64) and p (f32) of every cached position in the LDS: 12 bytes per
-    // position next to the product ring -> about 7.8K positions at head_dim 128 (documented in include/lnb.h)
-    if ((size_t)c->seq_len * 12 + 2 * 64 * (size_t)m->head_dim * 4 + 4096 > 160 * 1024 || (m->head_dim != 128 && m->head_dim != 64 && m->head_dim != 32))
-        { delete c; return fail("seq_len %d too long for the LDS staging of the attention kernel, or head_dim %d not one of 32/64/128", c->seq_len, m->head_dim); }
+    // Context length: one-token calls above the attention crossover and calls of 16 or more rows run kernels without a per-position LDS
+    // array that would not fit (the long-context PV kernel keeps 4 bytes per position: ~23 K positions); the one-workgroup-per-head kernel
+    // (12 bytes per position: ~7.8 K at head_dim 128) then only serves calls of 2..15 rows, which fail beyond its reach (lnb.h)
+    if (m->head_dim != 128 && m->head_dim != 64 && m->head_dim != 32) { delete c; return fail("head_dim %d not one of 32/64/128", m->head_dim); }
+    if (lnbk_attn_long_lds(c->seq_len) > 160 * 1024)
+        { const int sl = c->seq_len; delete c; return fail("seq_len %d too long for the LDS staging of the attention kernels (about 23000 positions)", sl); }
     if (ctx_alloc(c)) { lnb_ctx_destroy(c); return -1; }
     *out = c;
     return 0;
@@ -442,6 +448,7 @@ static int ctx_alloc(lnb_ctx* c) {
     HIPCHK(hipMalloc((void**)&c->zseq_count, 16)); HIPCHK(hipMemset(c->zseq_count, 0, 16));
     // crossover measured on MI355X (tools/att_timing.py): the one-workgroup-per-head kernel wins below a few hundred positions
     c->attn_long_T = env_int("LNB_ATTN_LONG_T", 512);
+    c->attn_short_cap = lnbk_attn_short_max_T(m->head_dim);
     return 0;
 }
 
@@ -549,7 +556,11 @@ static hipError_t gemv_dispatch(const lnb_ctx* c, const GemvParams* g, int rw, i
 // S >= 16 rows: the exact chains on the f32 matrix cores, or (LNB_MODE_FAST) the bf16 matrix-core GEMM; shapes the fast kernel does not
 // take (K not a multiple of 64) stay on the exact one
 static hipError_t gemm_dispatch(int mode, const GemmParams* g, int epi, hipStream_t st) {
-    if (mode == LNB_MODE_FAST) { hipError_t e = lnbk_fast_gemm(g, epi, st); if (e != hipErrorNotSupported) return e; }
+    // below ~200 rows the bf16 GEMM's 256-row weight tiles leave most CUs without work (wq|wk|wv: 24 workgroups) and the exact
+    // kernel with its 16-row tiles is the faster one (128 rows: 29.6 ms against 36.6 ms per Forward): the tolerance mode may always
+    // use an exact kernel
+    static const int min_rows = env_int("LNB_FAST_GEMM_MIN_ROWS", 192);
+    if (mode == LNB_MODE_FAST && g->S >= min_rows) { hipError_t e = lnbk_fast_gemm(g, epi, st); if (e != hipErrorNotSupported) return e; }
     return lnbk_gemm(g, epi, st);
 }
 static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
@@ -583,9 +594,14 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
     case K_ATTN: {  // scores / softmax / PV  (:409-514)
         AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st; ap.dbg = g_dbg;
         ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len;
+        ap.lds_T = c->seq_len < c->attn_short_cap ? c->seq_len : c->attn_short_cap;
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
         ap.mfma = use_mfma(S) ? 1 : 0; ap.exp_tab = m->exp_tab;
         ap.longctx = (S == 1 && c->attn_long) ? 1 : 0; ap.force_zseq = c->force_zseq; ap.e_buf = c->e_buf; ap.z_part = c->z_part; ap.zseq_count = c->zseq_count;
+        if (c->mode == LNB_MODE_FAST && ap.mfma) {           // tolerance mode prefill: flash form on the bf16 matrix cores
+            hipError_t e = lnbk_fast_attn(&ap, st);
+            if (e != hipErrorNotSupported) { HIPCHK(e); return 0; }
+        }
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x;
@@ -632,6 +648,10 @@ static int enqueue_head(lnb_ctx* c, int first, int rows) {
     return 0;
 }
 
+// one-token call at context T: the long-context kernels above the crossover, and always beyond the short kernel's LDS reach
+static bool want_long_attention(const lnb_ctx* c, int seq, int start_pos) {
+    return seq == 1 && (start_pos + 1 > c->attn_long_T || start_pos + 1 > c->attn_short_cap);
+}
 static int check_call(lnb_ctx* c, int seq, int start_pos) {
     if (seq == 0) return fail("empty token array");                                            // llamatransformer.go:146-148
     if (seq < 0 || start_pos < 0) return fail("negative sequence length or start position");
@@ -639,6 +659,9 @@ static int check_call(lnb_ctx* c, int seq, int start_pos) {
     if (T > c->m->cis_rows) return fail("incompatible locStart, locEnd values and tensor (position %d beyond the %d-row RoPE table)", T, c->m->cis_rows);
     if (T > c->seq_len) return fail("incompatible locStart, locEnd values and tensor (position %d beyond the KV cache of %d)", T, c->seq_len);
     if (seq > 1 && T % seq != 0) return fail("two tensor shapes cannot be broadcasted: [%d %d %d] and [%d %d]", c->m->a.n_heads, seq, T, seq, seq);
+    if (seq > 1 && !use_mfma(seq) && T > c->attn_short_cap)
+        return fail("a call of %d rows (2..15) at context %d: the row-per-workgroup attention kernel stages at most %d positions in the LDS; "
+                    "use one-token calls or 16 or more rows there", seq, T, c->attn_short_cap);
     return 0;
 }
 
@@ -656,7 +679,7 @@ extern "C" int lnb_forward_stage_begin(lnb_ctx* c, const int32_t* tokens, int se
     if (want_argmax && !m->last()) return fail("logits requested from a stage that does not own output.weight");
     if (!c->h_io) HIPCHK(hipHostMalloc((void**)&c->h_io, ((size_t)c->seq_len + 2) * 4, hipHostMallocDefault));
     hipStream_t st = c->stream;
-    c->attn_long = seq == 1 && start_pos + 1 > c->attn_long_T;
+    c->attn_long = want_long_attention(c, seq, start_pos);
     HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
     if (tokens) {
         memcpy(c->h_io + 2, tokens, (size_t)seq * 4);        // the caller's array need not outlive this call
@@ -698,7 +721,7 @@ extern "C" int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int
     if (!tokens && m->first()) return fail("first stage needs tokens");
     if ((logits_out || argmax_last_out) && !m->last()) return fail("logits requested from a stage that does not own output.weight");
     hipStream_t st = c->stream;
-    c->attn_long = seq == 1 && start_pos + 1 > c->attn_long_T;
+    c->attn_long = want_long_attention(c, seq, start_pos);
     HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
     if (tokens) {
         HIPCHK(hipMemcpyAsync(c->dtok, tokens, (size_t)seq * 4, hipMemcpyHostToDevice, st));
@@ -775,7 +798,7 @@ extern "C" int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n
         HIPCHK(hipGraphDestroy(g));
         return 0;
     };
-    const bool any_short = start_pos + 1 <= c->attn_long_T, any_long = start_pos + n_steps > c->attn_long_T;
+    const bool any_short = !want_long_attention(c, 1, start_pos), any_long = want_long_attention(c, 1, start_pos + n_steps - 1);
     if (use_graph && any_short && capture(&c->graph, false)) return -1;
     if (use_graph && any_long && capture(&c->graph_long, true)) return -1;
     HIPCHK(hipMemcpyAsync(c->dtok, &token, 4, hipMemcpyHostToDevice, st));
@@ -783,7 +806,7 @@ extern "C" int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n
     HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
     HIPCHK(hipEventRecord(c->ev0, st));
     for (int i = 0; i < n_steps; i++) {
-        const bool longctx = start_pos + i + 1 > c->attn_long_T;
+        const bool longctx = want_long_attention(c, 1, start_pos + i);
         if (use_graph) HIPCHK(hipGraphLaunch(longctx ? c->graph_long : c->graph, st));
         else { c->attn_long = longctx; if (enqueue_decode_step(c)) return -1; }
     }
@@ -804,7 +827,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     if (check_call(c, 1, pos)) return -1;
     if (which == K_HEAD && !m->last()) return fail("this stage does not own output.weight");
     hipStream_t st = c->stream;
-    c->attn_long = pos + 1 > c->attn_long_T;
+    c->attn_long = want_long_attention(c, 1, pos);
     HIPCHK(lnbk_set_state(c->st, pos, 0, st));
     const int nl = m->layer_end - m->layer_begin;
     // consecutive launches walk through the layers so that every launch streams its weights from HBM
@@ -934,7 +957,7 @@ static int pipe_events(lnb_ctx* c) {
 // c->dtok (received from the last rank).  The last stage leaves the argmax token in c->dnext.
 static int enqueue_stage_step(lnb_pipe* p, lnb_ctx* c, const int32_t* tokens, int rows, int pos) {
     lnb_model* m = c->m; const int V = m->a.vocab_size; hipStream_t st = c->stream;
-    const bool longctx = rows == 1 && pos + 1 > c->attn_long_T;
+    const bool longctx = want_long_attention(c, rows, pos);
     auto body = [&](bool host_tokens) -> int {
         if (m->first()) {
             if (host_tokens) {

@@ -110,6 +110,7 @@ struct AttnParams {
     uint16_t* out;              // [S][H*hd]
     const StepState* st;
     int S, H, KVH, hd, seq_len;
+    int lds_T;                  // positions the LDS arrays of attn_exact_kernel are sized for (min(seq_len, what fits 160 KB)); the call's T must not exceed it
     float divisor;              // wide(trunc(f32(sqrt(hd))))  (llamatransformer.go:464)
     long long* dbg;             // LNB_GEMV_TIMING: phase stamps of workgroup (0,0)
     int mfma;                   // S >= 16: 16-row tiles on the f32 matrix cores (attn_mfma_kernel), same bits

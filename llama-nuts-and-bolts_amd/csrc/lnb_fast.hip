@@ -138,26 +138,33 @@ __global__ __launch_bounds__(256) void fast_gemv_a(GemvParams p, int RW) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int m = blockIdx.y, K = p.K, nunits = K >> 3;
-    stage_x<NORM>(p, p.x + (size_t)m * K, xs, red, tid);
     const int groups = RW / RG, n_units = p.n_blocks * groups;
     const size_t chunk_stride = (size_t)NCH * RW * 16, block_bytes = (size_t)nunits * chunk_stride;
     const int r = lane & (RG - 1), ph = lane / RG;
+    // the first round of weight loads of the first unit does not depend on x: in flight while x is staged (and normalised)
+    uint4 wv[FA_UNR][NCH];
+    auto issue = [&](const char* base, int kb) {
+        const int kc0 = kb + wave * PH + ph;
+#pragma unroll
+        for (int j = 0; j < FA_UNR; j++) {
+            const int kc = kc0 + j * CPI;
+            const char* a = base + (size_t)(kc < nunits ? kc : nunits - 1) * chunk_stride;
+#pragma unroll
+            for (int c = 0; c < NCH; c++) wv[j][c] = ld_stream(a + (size_t)c * RW * 16);
+        }
+    };
+    auto base_of = [&](int u) { const int b = u / groups, g = u - b * groups; return (const char*)p.w + (size_t)b * block_bytes + (size_t)(g * RG + r) * 16; };
+    if ((int)blockIdx.x < n_units) issue(base_of(blockIdx.x), 0);
+    stage_x<NORM>(p, p.x + (size_t)m * K, xs, red, tid);
     for (int u = blockIdx.x; u < n_units; u += gridDim.x) {
         const int b = u / groups, g = u - b * groups;
-        const char* base = (const char*)p.w + (size_t)b * block_bytes + (size_t)(g * RG + r) * 16;
+        const char* base = base_of(u);
         float acc[NCH];
 #pragma unroll
         for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
         for (int kb = 0; kb < nunits; kb += CPI * FA_UNR) {     // (uniform trip count)
             const int kc0 = kb + wave * PH + ph;
-            uint4 wv[FA_UNR][NCH];
-#pragma unroll
-            for (int j = 0; j < FA_UNR; j++) {
-                const int kc = kc0 + j * CPI;
-                const char* a = base + (size_t)(kc < nunits ? kc : nunits - 1) * chunk_stride;
-#pragma unroll
-                for (int c = 0; c < NCH; c++) wv[j][c] = ld_stream(a + (size_t)c * RW * 16);
-            }
+            if (kb != 0 || u != (int)blockIdx.x) issue(base, kb);
 #pragma unroll
             for (int j = 0; j < FA_UNR; j++) {
                 const int kc = kc0 + j * CPI;
@@ -309,8 +316,14 @@ __global__ __launch_bounds__(256, 1) void fast_gemm_kernel(GemmParams p) {
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 31, kg = lane >> 5;
-    // blockIdx.x = batch tile (fastest): the workgroups that stream the same weight rows run at the same time and share them in L2
-    const int n0 = blockIdx.y * NWG + wave * 32 * AT, m0 = blockIdx.x * MB;
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the workgroups that stream the SAME
+    // weight rows (one per batch tile) are given linear ids 8 apart: they run at the same time on ONE XCD and share the rows in its L2
+    // (measured neutral at S = 4096 on the 8B shape -- 93.7 against 95.5 ms per Forward: the weight stream is not the limiter there)
+    const int gx = (p.S + MB - 1) / MB, ny = (p.n_rows + NWG - 1) / NWG;
+    const int lin = blockIdx.x, chunk = lin / (8 * gx), within = lin - chunk * (8 * gx);
+    const int by = chunk * 8 + (within & 7), bx = within >> 3;
+    if (by >= ny) return;                                    // (uniform: padding of the last group of 8 weight tiles)
+    const int n0 = by * NWG + wave * 32 * AT, m0 = bx * MB;
     const int K = p.K, nslabs = K / FG_BK;
     // ---- weight stream: per-lane byte offset of k-step 0 of slab 0 from the wave-uniform base; uniform strides per k-step and slab
     // (32-bit offsets: a matrix is < 4 GB, and offsets cost half the registers of pointers)
@@ -426,7 +439,8 @@ template <int EPI, int NCH, bool LAYB, int MT> hipError_t launch_gemm_fast_t(con
     const size_t lds = 2 * (size_t)32 * MT * FG_PITCH;
     if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int nwg = NCH == 2 ? 128 : 256;
-    const dim3 grid((unsigned)((p->S + 32 * MT - 1) / (32 * MT)), (unsigned)((p->n_rows + nwg - 1) / nwg));
+    const unsigned gx = (unsigned)((p->S + 32 * MT - 1) / (32 * MT)), ny = (unsigned)((p->n_rows + nwg - 1) / nwg);
+    const dim3 grid(((ny + 7) / 8) * 8 * gx);                // (padded to whole groups of 8 weight tiles: see the tile order in the kernel)
     hipLaunchKernelGGL(kfn, grid, dim3(256), lds, st, *p);
     return hipGetLastError();
 }
@@ -441,6 +455,147 @@ template <int EPI, int NCH> hipError_t launch_gemm_fast(const GemmParams* p, int
     const bool big = p->S > 128;                             // 256 batch rows per workgroup: twice the MFMAs per weight byte and per slab
     if constexpr (NCH == 1) if (layb) return big ? launch_gemm_fast_t<EPI, NCH, true, 8>(p, st) : launch_gemm_fast_t<EPI, NCH, true, 4>(p, st);
     return big ? launch_gemm_fast_t<EPI, NCH, false, 8>(p, st) : launch_gemm_fast_t<EPI, NCH, false, 4>(p, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fast_attn_prefill_kernel: the prefill attention of the tolerance mode (S >= 16 query rows) on the bf16 matrix cores, flash form:
+// one pass over the cached positions in tiles of 32 with an online softmax (running maximum and sum per query row, f32), instead of
+// the reference's f64 softmax without maximum subtraction over materialised scores (llamatransformer.go:456-514).
+//   S^T tile [32 j][32 q] = K Q^T: A = K rows straight from the position-contiguous cache (a 16 B unit = 8 dims of one position: the MFMA
+//       operand as it lies in HBM), B = Q rows held in registers; D: lane = query row q (lane & 31), 16 positions per lane
+//       (j = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)) -- everything per query row (mask, maximum, sum, rescale) is lane-local plus ONE
+//       exchange with lane ^ 32;
+//   O^T [d][q] += V^T P^T: B = the lane's own 16 probabilities packed to bf16 (its k-slots are its own positions: no transpose), A = V^T from
+//       the LDS, where the workgroup stages the tile TRANSPOSED ([d][j], the positions of a 16-group permuted into the order the lanes
+//       hold them, pitch 80 B: conflict-free 16 B reads); D: lane = query row again, so the softmax rescale of O is lane-local too.
+// A wave owns 32 query rows of one head, a workgroup 128 (the V tile is shared); causal tiles only; heavy workgroups first.
+// The mask is the reference's modulo-broadcast triu (tensoriterators.go:47-55): (j mod S) > i is masked.
+// grid (H, ceil(S / 128)), block 256, static LDS 20 KB (hd 128).
+// ------------------------------------------------------------------------------------------------
+constexpr int FA_VP = 80;                                    // bytes per d row of the staged V tile (32 positions x 2 B + pad)
+template <int HD> __global__ __launch_bounds__(256, 2) void fast_attn_prefill_kernel(AttnParams p) {
+    constexpr int NKS = HD / 16, DT = HD / 32, VU = 32 * (HD / 8) / 256;     // QK k-steps, 32-dim output tiles, V units per thread
+    static_assert(VU >= 1, "head_dim >= 64");
+    __shared__ __attribute__((aligned(16))) char vl[2][HD * FA_VP];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ln = lane & 31, kg = lane >> 5;
+    const int h = blockIdx.x, qb = (int)gridDim.y - 1 - (int)blockIdx.y;
+    const int S = p.S, H = p.H, KVH = p.KVH;
+    const int pos0 = p.st->pos, T = pos0 + S;
+    const int kvh = h / (H / KVH);
+    const int q0 = qb * 128 + wave * 32, i = q0 + ln;         // this lane's query row
+    const float scale = 1.4426950408889634f / p.divisor;      // scores in log2 units: exp(x) = exp2(x * log2 e)
+    // ---- Q operand: 8 consecutive dims of row i per k-step
+    bf16x8 qf[NKS];
+    {
+        const uint16_t* qr = p.q + ((size_t)(i < S ? i : S - 1) * H + h) * HD + 8 * kg;
+#pragma unroll
+        for (int s2 = 0; s2 < NKS; s2++) qf[s2] = __builtin_bit_cast(bf16x8, *(const uint4*)(qr + 16 * s2));
+    }
+    const int qmax = (qb * 128 + 127 < S ? qb * 128 + 127 : S - 1);
+    const int jlast = (pos0 == 0) ? qmax : T - 1;            // last position any row of this workgroup can see
+    const int ntiles = jlast / 32 + 1;
+    const uint4* kbase = (const uint4*)p.cache_k + (size_t)kvh * (HD / 8) * p.seq_len;
+    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD;
+    const size_t vrow = (size_t)KVH * HD;
+    auto load_k = [&](uint4 (&k)[NKS], int jt) {
+        int j = jt * 32 + ln; j = j < T ? j : T - 1;
+#pragma unroll
+        for (int s2 = 0; s2 < NKS; s2++) k[s2] = kbase[(size_t)(2 * s2 + kg) * p.seq_len + j];
+    };
+    uint4 vr[VU];
+    auto load_v = [&](int jt) {
+#pragma unroll
+        for (int u = 0; u < VU; u++) {
+            const int un = tid + 256 * u, jr = un / (HD / 8), dc = un % (HD / 8);
+            int j = jt * 32 + jr; j = j < T ? j : T - 1;
+            vr[u] = *(const uint4*)(vbase + (size_t)j * vrow + 8 * dc);
+        }
+    };
+    auto store_v = [&](int buf) {                            // transposed, positions permuted into the lanes' order
+#pragma unroll
+        for (int u = 0; u < VU; u++) {
+            const int un = tid + 256 * u, jr = un / (HD / 8), dc = un % (HD / 8);
+            const int w = jr & 15, pj = (jr & 16) + 8 * ((w >> 2) & 1) + (w & 3) + 4 * (w >> 3);
+            char* d = vl[buf] + (size_t)(8 * dc) * FA_VP + pj * 2;
+            const uint32_t wd[4] = {vr[u].x, vr[u].y, vr[u].z, vr[u].w};
+#pragma unroll
+            for (int e = 0; e < 8; e++) *(uint16_t*)(d + e * FA_VP) = (uint16_t)(wd[e >> 1] >> ((e & 1) * 16));
+        }
+    };
+    f32x16 o[DT];
+#pragma unroll
+    for (int t = 0; t < DT; t++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) o[t][r] = 0.0f;
+    float m = -INFINITY, l = 0.0f;
+    uint4 kt[NKS];
+    load_v(0); store_v(0); load_k(kt, 0);
+    for (int jt = 0; jt < ntiles; jt++) {
+        __syncthreads();                                     // V(jt) is staged; everybody is done with the buffer V(jt+1) goes to
+        const bool more = jt + 1 < ntiles;
+        if (more) load_v(jt + 1);
+        f32x16 sc;
+#pragma unroll
+        for (int r = 0; r < 16; r++) sc[r] = 0.0f;
+#pragma unroll
+        for (int s2 = 0; s2 < NKS; s2++) sc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, kt[s2]), qf[s2], sc, 0, 0, 0);
+        if (more) load_k(kt, jt + 1);
+        // ---- online softmax of this lane's 16 positions of row i
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int j = jt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kg;
+            const bool dead = j >= T || i >= S || ((pos0 == 0 ? j : j % S) > i);
+            sc[r] = dead ? -INFINITY : sc[r] * scale;
+            mx = fmaxf(mx, sc[r]);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float mn = fmaxf(m, mx);
+        const float msafe = mn == -INFINITY ? 0.0f : mn;      // a row with nothing visible yet: every p is exp2(-inf) = 0
+        const float alpha = __builtin_amdgcn_exp2f(m - msafe);   // m == -inf -> 0
+        float rs = 0.0f;
+        uint32_t pk[8];
+#pragma unroll
+        for (int r = 0; r < 16; r += 2) {
+            const float p0 = __builtin_amdgcn_exp2f(sc[r] - msafe), p1 = __builtin_amdgcn_exp2f(sc[r + 1] - msafe);
+            rs += p0 + p1;
+            pk[r >> 1] = __builtin_amdgcn_perm(__float_as_uint(p1), __float_as_uint(p0), 0x07060302u);   // two truncated bf16
+        }
+        rs += __shfl_xor(rs, 32);
+        l = l * alpha + rs; m = mn;
+#pragma unroll
+        for (int t = 0; t < DT; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) o[t][r] *= alpha;
+        // ---- O^T += V^T P^T: two 16-position k-steps
+        const char* vb = vl[jt & 1] + (size_t)ln * FA_VP + kg * 16;
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+            const uint4 pu = make_uint4(pk[4 * ks], pk[4 * ks + 1], pk[4 * ks + 2], pk[4 * ks + 3]);
+            const bf16x8 pf = __builtin_bit_cast(bf16x8, pu);
+#pragma unroll
+            for (int t = 0; t < DT; t++) {
+                const bf16x8 vf = *(const bf16x8*)(vb + (size_t)t * 32 * FA_VP + ks * 32);
+                o[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf, o[t], 0, 0, 0);
+            }
+        }
+        if (more) store_v((jt + 1) & 1);
+    }
+    // ---- out[i][h][d] = trunc(O^T[d][i] / l): lane = row i, dims 32 t + 8 g + 4 kg + (0..3)
+    if (i < S) {
+        const float inv = 1.0f / l;
+        uint16_t* dst = p.out + ((size_t)i * H + h) * HD + 4 * kg;
+#pragma unroll
+        for (int t = 0; t < DT; t++)
+#pragma unroll
+            for (int g = 0; g < 4; g++) {
+                const uint32_t lo = (uint32_t)bf_trunc(o[t][4 * g] * inv) | ((uint32_t)bf_trunc(o[t][4 * g + 1] * inv) << 16);
+                const uint32_t hi = (uint32_t)bf_trunc(o[t][4 * g + 2] * inv) | ((uint32_t)bf_trunc(o[t][4 * g + 3] * inv) << 16);
+                *(uint2*)(dst + 32 * t + 8 * g) = make_uint2(lo, hi);
+            }
+    }
 }
 
 int fast_rg(int rw, int nch, int n_blocks) {
@@ -524,6 +679,15 @@ extern "C" hipError_t lnbk_fast_gemm(const GemmParams* p, int epi, hipStream_t s
         case EPI_SILU_MUL: return p->nch == 2 ? launch_gemm_fast<EPI_SILU_MUL, 2>(p, layb, st) : hipErrorInvalidValue;
         default: return hipErrorInvalidValue;
     }
+}
+// prefill attention of the tolerance mode; head_dim 64 / 128 (others: hipErrorNotSupported -> the caller keeps the exact kernel)
+extern "C" hipError_t lnbk_fast_attn(const AttnParams* p, hipStream_t st) {
+    if (!p || p->S < 16) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)p->H, (unsigned)((p->S + 127) / 128));
+    if (p->hd == 128) hipLaunchKernelGGL(fast_attn_prefill_kernel<128>, grid, dim3(256), 0, st, *p);
+    else if (p->hd == 64) hipLaunchKernelGGL(fast_attn_prefill_kernel<64>, grid, dim3(256), 0, st, *p);
+    else return hipErrorNotSupported;
+    return hipGetLastError();
 }
 extern "C" hipError_t lnbk_fast_init(void) {
     static bool done = false;

@@ -1457,10 +1457,10 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     const int pos0 = p.st->pos, T = pos0 + S;
     const int kvh = h / (p.H / KVH);
     double* e = (double*)smem;
-    float* pw = (float*)(smem + attn_off_pw(p.seq_len));
-    float* qf = (float*)(smem + attn_off_q(p.seq_len));
-    double* zb = (double*)(smem + attn_off_z(p.seq_len, HD));
-    char* ring = smem + attn_off_ring(p.seq_len, HD);
+    float* pw = (float*)(smem + attn_off_pw(p.lds_T));
+    float* qf = (float*)(smem + attn_off_q(p.lds_T));
+    double* zb = (double*)(smem + attn_off_z(p.lds_T, HD));
+    char* ring = smem + attn_off_ring(p.lds_T, HD);
     const uint32_t row_bytes = (uint32_t)KVH * HD * 2;
     // K cache is stored [kv head][d/8][position][8] so that "one position per lane" reads are contiguous across the wave
     const uint4* kbase = (const uint4*)p.cache_k + (size_t)kvh * NK * p.seq_len;
@@ -1650,6 +1650,8 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
     double* zsh = (double*)(ring + 2 * ALP_DS * ALP_PITCH);
     const double* E = p.e_buf + (size_t)h * p.seq_len;
     const int kvh = h / (p.H / p.KVH);
+#define ALP_STAMP(n) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wave < 4) p.dbg[wave * 16 + (n)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    ALP_STAMP(0);
     // ---- Z estimate: the per-block tree sums, added in block order (same value in every thread).  One partial per lane, all loads
     // in flight at once, then a register walk (a load-use loop paid one L2 round trip per block: 12 us at T = 4100)
     double zt = 0.0;
@@ -1695,8 +1697,10 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
             pw[j] = pj;
         }
     }
+    ALP_STAMP(1);
     if (bad) *flag = 1;
     __syncthreads();
+    ALP_STAMP(2);
     if (*flag) {
         // the reference's serial sum, j ascending, f64 (operations_impl.go:492-499): one wave, 16 values in flight ahead of the adds
         if (wave == 0) {
@@ -1731,7 +1735,9 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
     float acc = 0.0f;
     if (wave == 0) {
         const int d = lane & (ALP_DS - 1);
+        ALP_STAMP(3);
         for (int it = 0; it <= nbatch; it++) {
+            if (it == 2) ALP_STAMP(4);
             if (it > 0) {
                 const float* src = ring + (size_t)((it - 1) & 1) * ALP_DS * ALP_PITCH + (size_t)d * ALP_PITCH;
                 float4 pa[4], pb[4];
@@ -1756,7 +1762,9 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
             }
             __syncthreads();
         }
+        ALP_STAMP(5);
         if (lane < ALP_DS) p.out[(size_t)h * HD + ds * ALP_DS + lane] = bf_trunc(acc);
+        ALP_STAMP(6);
     } else {
         const int pl = tid - 64, half = pl & 1, prow = pl >> 1;            // 128 positions x two 8-dim halves per round, 4 rounds per batch
         auto load = [&](uint4 (&v)[4], int b) {
@@ -1785,8 +1793,10 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
             }
         };
         uint4 v0[4], v1[4], v2[4], v3[4];
+        ALP_STAMP(3);
         load(v0, 0); load(v1, 1); load(v2, 2);
-        for (int it = 0; it <= nbatch; it += 4) { step(it, v0, v3); step(it + 1, v1, v0); step(it + 2, v2, v1); step(it + 3, v3, v2); }
+        for (int it = 0; it <= nbatch; it += 4) { step(it, v0, v3); if (it == 0) ALP_STAMP(4); step(it + 1, v1, v0); step(it + 2, v2, v1); step(it + 3, v3, v2); }
+        ALP_STAMP(5); ALP_STAMP(6);
     }
 }
 
@@ -2011,6 +2021,12 @@ extern "C" hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, ui
 
 static size_t attn_lds_bytes(int seq_len, int hd) { return attn_off_ring(seq_len, hd) + 2 * (size_t)ATT_JC * hd * 4; }
 extern "C" size_t lnbk_attn_short_lds(int seq_len, int hd) { return attn_lds_bytes(seq_len, hd); }
+// the longest context the one-workgroup-per-head kernel can stage in 160 KB of LDS (e f64 + p f32 per position + q + the product ring)
+extern "C" int lnbk_attn_short_max_T(int hd) {
+    int lo = 64, hi = 1 << 20;
+    while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (attn_lds_bytes(mid, hd) <= 160 * 1024) lo = mid; else hi = mid - 1; }
+    return lo;
+}
 extern "C" hipError_t lnbk_init(void) {
     static bool done = false;
     if (done) return hipSuccess;
@@ -2065,8 +2081,8 @@ extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
         else hipLaunchKernelGGL(attn_mfma_kernel<64>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
         return hipGetLastError();
     }
-    size_t lds = attn_lds_bytes(p->seq_len, p->hd);
-    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    size_t lds = attn_lds_bytes(p->lds_T, p->hd);
+    if (lds > 160 * 1024 || p->lds_T <= 0 || p->lds_T > p->seq_len) return hipErrorInvalidValue;
     switch (p->hd) {
     case 128: hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
     case 64: hipLaunchKernelGGL(attn_exact_kernel<64>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;

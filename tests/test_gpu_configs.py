@@ -130,6 +130,37 @@ def test_long_context_attention_kernels_equal_the_oracle_at_every_context(lnb, l
     oc.close()
 
 
+def test_context_beyond_the_reach_of_the_one_workgroup_per_head_kernel(lnb):
+    """head_dim 128, 8192+ positions: more than the 12-bytes-per-position LDS staging of attn_exact_kernel holds.  The prefill runs on the
+    matrix-core attention, one-token steps on the long-context kernels (whatever the crossover says); a call of 2..15 rows there is refused."""
+    cfg = dict(LONG_CFGS["hd128"], max_seq_len=4200)
+    om = orc.Model(**cfg).fill_synthetic(77).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(77).finalize()
+    P, steps = 8188, 3
+    toks = orc.synth_tokens(9, P, cfg["vocab_size"])
+    oc, gc = orc.Context(om, P + 16), lnb.InferenceContext(gm, P + 16).set_attention(10 ** 9, 0)      # crossover "never": the reach decides
+    lo, ao = oc.forward(toks, 0, want_logits=False)
+    lg, ag = gc.Forward(toks, 0, want_logits=False)
+    assert ao == ag
+    tok = ao
+    for i in range(steps):
+        lo, ao = oc.forward([tok], P + i)
+        lg, ag = gc.Forward(np.array([tok], dtype=np.int32), P + i)
+        assert (_bits(lo) == _bits(lg)).all() and ao == ag, i
+        tok = ao
+    got, _ = gc.decode_greedy(tok, P + steps, 2)
+    ref = []
+    for i in range(2):
+        _, tok = oc.forward([tok], P + steps + i, want_logits=False)
+        ref.append(tok)
+    assert [int(t) for t in got] == ref
+    with pytest.raises(lnb.LnbError, match="2..15"):
+        gc.Forward(np.zeros(2, dtype=np.int32), P + steps + 2 + 1)              # start 8194, T = 8196 = 2 * 4098
+    with pytest.raises(lnb.LnbError, match="too long"):
+        lnb.InferenceContext(gm, 40000)
+    gc.close(); oc.close(); gm.close(); om.close()
+
+
 def test_greedy_loop_switches_graphs_at_the_attention_crossover(lnb, long_pair):
     """lnb_decode_greedy replays the short-attention graph up to the crossover context and the long-attention graph beyond it: a run
     that starts below and ends above (default crossover 512, and a crossover in the middle of a short run) equals the oracle's tokens."""

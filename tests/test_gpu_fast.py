@@ -8,6 +8,8 @@ differs in its last bits, and a truncation to bf16 turns that into a whole bf16 
     agreement on all but near-tied rows; the KV cache, the greedy loop and the mode switch behave like the exact mode's;
   * the mode is opt-in: a fresh context is exact, and switching back gives the oracle's bits again.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -15,6 +17,7 @@ from oracle import oracle as orc
 
 pytestmark = pytest.mark.gpu
 TINY = dict(orc.TINY)
+os.environ.setdefault("LNB_FAST_GEMM_MIN_ROWS", "16")     # (the library keeps the exact GEMM below 192 rows by default: exercise the bf16 one)
 
 
 @pytest.fixture(scope="module")
@@ -159,6 +162,24 @@ def test_fast_mode_long_prefill_through_the_bf16_matrix_cores(lnb, tiny_pair):
     assert np.abs(k0 - k1).max() <= 2.0 ** -6 * max(1.0, float(np.abs(k0).max()))
     assert (oc.cache(0, 1)[:96] == gc.CacheV(0)[:96]).mean() > 0.97       # layer 0's V rows: one GEMM away from exact inputs
     gc.close(); oc.close()
+
+
+@pytest.mark.parametrize("heads,kv_heads,rows", [(4, 2, 300), (2, 1, 300), (2, 1, 37), (4, 4, 130)])
+def test_fast_prefill_flash_attention_head_dims_and_ragged_rows(lnb, heads, kv_heads, rows):
+    """fast_attn_prefill_kernel (bf16 matrix cores, online softmax): head_dim 64 and 128, GQA and MHA, row counts that leave partial
+    32-row waves / 128-row workgroups / 32-position tiles, then the same number of rows again at start_pos = rows (the reference's
+    modulo-broadcast mask over T = 2 S): logits within the tolerance-mode bound of the oracle's."""
+    cfg = dict(TINY, n_heads=heads, n_kv_heads=kv_heads, n_layers=2, vocab_size=512)
+    om = orc.Model(**cfg).fill_synthetic(31).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(31).finalize()
+    toks = orc.synth_tokens(8, 2 * rows, cfg["vocab_size"])
+    oc, gc = orc.Context(om, 2 * rows + 8), lnb.InferenceContext(gm, 2 * rows + 8).set_mode("fast")
+    for lo_, hi_ in ((0, rows), (rows, 2 * rows)):
+        lo, ao = oc.forward(toks[lo_:hi_], lo_)
+        lf, af = gc.Forward(toks[lo_:hi_], lo_)
+        d = np.abs(lf - lo)
+        assert d.max() <= 4e-2 and d.mean() <= 3e-3, (d.max(), d.mean())
+    gc.close(); oc.close(); gm.close(); om.close()
 
 
 def test_fast_mode_greedy_loop_runs_as_a_graph_and_is_deterministic(lnb, tiny_pair):
