@@ -31,11 +31,12 @@ def test_rccl_is_resolved_on_first_use_and_errors_surface(lnb):
     assert L.lnb_pipeline_unique_id(None) != 0 and b"null argument" in L.lnb_last_error()
     buf = C.create_string_buffer(128)
     rc = L.lnb_pipeline_unique_id(buf)
-    if _gpu_here():
-        assert rc == 0 and any(buf.raw)
+    if rc == 0:                                 # a GPU box -- or an RCCL build that hands out ids without touching a device (PyTorch's
+        assert any(buf.raw)                     # bundled one does, and it is the one the process holds when torch was imported first)
     else:                                       # librccl was loaded and called: it is RCCL that reports the missing device, not the loader
+        assert not _gpu_here()
         msg = L.lnb_last_error().decode()
-        assert rc != 0 and "ncclGetUniqueId failed" in msg, msg
+        assert "ncclGetUniqueId failed" in msg, msg
     # the loader mapped the library with every symbol the pipeline needs
     maps = open("/proc/self/maps").read()
     assert "librccl" in maps
