@@ -306,8 +306,10 @@ template <int EPI> DEVINL void fast_gemm_epilogue4(const GemmParams& p, const f3
     }
 }
 
-template <int EPI, int NCH, bool LAYB, int MT>
-__global__ __launch_bounds__(256, 1) void fast_gemm_kernel(GemmParams p) {
+// WB = weight register sets: 3 (two slabs of prefetch distance, one workgroup per CU, accumulators for 256 batch rows) or 2 (one slab, two
+// workgroups per CU within 256 registers per wave: a second wave per SIMD issues MFMAs while the first is parked on a wait)
+template <int EPI, int NCH, bool LAYB, int MT, int WB>
+__global__ __launch_bounds__(256, WB == 2 ? 2 : 1) void fast_gemm_kernel(GemmParams p) {
     constexpr int AT = NCH == 2 ? 1 : 2;                     // 32-row weight tiles per wave and chain
     constexpr int NWG = 4 * 32 * AT;                         // output rows per workgroup
     constexpr int MB = 32 * MT, XQ = MB / 32;                // batch rows per workgroup; X units per thread and slab
@@ -363,7 +365,7 @@ __global__ __launch_bounds__(256, 1) void fast_gemm_kernel(GemmParams p) {
         }
     };
     typedef uint4 wbuf_t[4][NCH][AT];
-    wbuf_t w0, w1, w2;                                       // weights of three consecutive slabs: two slabs of prefetch distance
+    wbuf_t w0, w1, w2;                                       // weights of WB consecutive slabs (w2 unused when WB == 2)
     int s_w = 0;                                             // slab the pointers stand on
     auto w_issue = [&](wbuf_t& w) {                          // loads the slab the pointers stand on, then steps them to the next
 #pragma unroll
@@ -393,7 +395,7 @@ __global__ __launch_bounds__(256, 1) void fast_gemm_kernel(GemmParams p) {
     auto slab = [&](int s, const wbuf_t& wa, wbuf_t& wc) {
         const bool more = s + 1 < nslabs;                    // (uniform)
         if (more) x_issue(s + 1);
-        if (s + 2 < nslabs) w_issue(wc);
+        if (s + WB - 1 < nslabs) w_issue(wc);
         const char* bl = ((s & 1) ? lds1 : lds0) + (size_t)ln * FG_PITCH + kg * 16;
 #pragma unroll
         for (int ks = 0; ks < 4; ks++) {
@@ -412,13 +414,20 @@ __global__ __launch_bounds__(256, 1) void fast_gemm_kernel(GemmParams p) {
         if (more) x_commit((s & 1) ? lds0 : lds1);
         __syncthreads();
     };
-    x_issue(0); w_issue(w0); if (nslabs > 1) w_issue(w1);
+    x_issue(0); w_issue(w0); if (WB == 3 && nslabs > 1) w_issue(w1);
     x_commit(lds0);
     __syncthreads();
-    for (int s = 0; s < nslabs; s += 3) {
-        slab(s, w0, w2);
-        if (s + 1 < nslabs) slab(s + 1, w1, w0);
-        if (s + 2 < nslabs) slab(s + 2, w2, w1);
+    if constexpr (WB == 3) {
+        for (int s = 0; s < nslabs; s += 3) {
+            slab(s, w0, w2);
+            if (s + 1 < nslabs) slab(s + 1, w1, w0);
+            if (s + 2 < nslabs) slab(s + 2, w2, w1);
+        }
+    } else {
+        for (int s = 0; s < nslabs; s += 2) {
+            slab(s, w0, w1);
+            if (s + 1 < nslabs) slab(s + 1, w1, w0);
+        }
     }
     // D: lane holds batch column m0 + 32 t + ln, output rows 8 g + 4 kg + r (g = 0..3, r = 0..3) of each 32-row tile
 #pragma unroll
@@ -434,8 +443,8 @@ __global__ __launch_bounds__(256, 1) void fast_gemm_kernel(GemmParams p) {
             }
 }
 
-template <int EPI, int NCH, bool LAYB, int MT> hipError_t launch_gemm_fast_t(const GemmParams* p, hipStream_t st) {
-    auto kfn = fast_gemm_kernel<EPI, NCH, LAYB, MT>;
+template <int EPI, int NCH, bool LAYB, int MT, int WB = 3> hipError_t launch_gemm_fast_t(const GemmParams* p, hipStream_t st) {
+    auto kfn = fast_gemm_kernel<EPI, NCH, LAYB, MT, WB>;
     const size_t lds = 2 * (size_t)32 * MT * FG_PITCH;
     if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     const int nwg = NCH == 2 ? 128 : 256;
@@ -450,7 +459,16 @@ template <int EPI, int NCH> hipError_t launch_gemm_fast(const GemmParams* p, int
         if (e == hipSuccess) e = launch_gemm_fast_t<EPI, NCH, false, 8>(nullptr, nullptr);
         if (NCH == 1 && e == hipSuccess) e = launch_gemm_fast_t<EPI, NCH, true, 4>(nullptr, nullptr);
         if (NCH == 1 && e == hipSuccess) e = launch_gemm_fast_t<EPI, NCH, true, 8>(nullptr, nullptr);
+        if (e == hipSuccess) e = launch_gemm_fast_t<EPI, NCH, false, 4, 2>(nullptr, nullptr);
+        if (NCH == 1 && e == hipSuccess) e = launch_gemm_fast_t<EPI, NCH, true, 4, 2>(nullptr, nullptr);
         return e;
+    }
+    // 128-row batch tiles with two workgroups per CU win while there are few tiles (512 rows: 35.6 against 42.5 ms per Forward of the 8B
+    // shape), 256-row tiles with one workgroup per CU from ~1000 rows up (2048: 61.8 against 67.5 ms; 4096: 94.8 against 128.7)
+    static const int two = [] { const char* e = getenv("LNB_FAST_GEMM_2WG"); return e && *e ? atoi(e) : -1; }();   // -1: by row count
+    if (two == 1 || (two < 0 && p->S < 1024)) {              // 128 batch rows, two workgroups per CU
+        if constexpr (NCH == 1) if (layb) return launch_gemm_fast_t<EPI, NCH, true, 4, 2>(p, st);
+        return launch_gemm_fast_t<EPI, NCH, false, 4, 2>(p, st);
     }
     const bool big = p->S > 128;                             // 256 batch rows per workgroup: twice the MFMAs per weight byte and per slab
     if constexpr (NCH == 1) if (layb) return big ? launch_gemm_fast_t<EPI, NCH, true, 8>(p, st) : launch_gemm_fast_t<EPI, NCH, true, 4>(p, st);
