@@ -164,6 +164,10 @@ void* lnb_ctx_stream(lnb_ctx* c);
 typedef struct lnb_pipe lnb_pipe;
 int lnb_pipeline_unique_id(void* id128);                       /* rank 0: ncclGetUniqueId */
 int lnb_pipeline_init(lnb_model* stage, int rank, int world, const void* id128, lnb_pipe** out);   /* world == 1: no communicator, the token ring is a device copy */
+/* the same pipe with an IN-PROCESS transport instead of RCCL: every stage lives in this process (pipes that name the same `group`), a send
+ * meets its receive in a mailbox and becomes a device-to-device copy.  Same ticks, events and graphs; for single-process hosts and for
+ * testing a schedule where RCCL cannot run (it wants one GPU per rank) */
+int lnb_pipeline_init_loopback(lnb_model* stage, int rank, int world, const char* group, lnb_pipe** out);
 int lnb_pipeline_destroy(lnb_pipe* p);
 int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,
                       lnb_ctx* send, int send_rows, lnb_ctx* recv, int recv_rows, int* token_slot_out);

@@ -9,7 +9,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <deque>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/lnb.h"
@@ -895,8 +897,18 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
 //     from rank r-1 straight into the target context's buffer (rank 0: the token, into the device word the embedding gather reads).
 // No staging copies, no host round trip for the token ring, no stream synchronisation per tick: the host only enqueues, and reads the
 // generated tokens from a pinned log after lnb_pipeline_sync.  RCCL is loaded on first use (lnb_pipeline.cpp).
+// In-process transport (lnb_pipeline_init_loopback): every stage of a pipeline lives in ONE process (all on one GPU, or one per GPU) and a
+// "send" meets its "receive" in a mailbox; whichever side is posted second enqueues the device copy.  Same tick code, same events, same
+// graphs as the RCCL transport -- what it replaces is only ncclSend / ncclRecv.  Used to test host schedules where RCCL cannot run
+// (two ranks need two GPUs) and by single-process multi-GPU hosts.
+struct LoopMsg { lnb_ctx* ctx; int rows; };
+struct LoopGroup { std::map<std::pair<int, int>, std::deque<LoopMsg>> sends, recvs; int users = 0; };
+static std::map<std::string, LoopGroup> g_loops;
+static std::mutex g_loops_mu;
+
 struct lnb_pipe {
     lnb_model* m = nullptr; int rank = 0, world = 1;
+    LoopGroup* loop = nullptr; std::string loop_tag;
     void* comm = nullptr; const lnb_rccl_api* api = nullptr;
     hipStream_t xs = nullptr;              // exchange stream
     int32_t* h_tok = nullptr; int tok_cap = 0, tok_n = 0;   // pinned log of the tokens the last stage produced, in tick order
@@ -938,10 +950,31 @@ extern "C" int lnb_pipeline_init(lnb_model* m, int rank, int world, const void* 
     *out = p;
     return 0;
 }
+extern "C" int lnb_pipeline_init_loopback(lnb_model* m, int rank, int world, const char* group, lnb_pipe** out) {
+    if (!m || !out || !group) return fail("null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail("rank %d out of range for %d pipeline stages", rank, world);
+    if (!m->finalized) return fail("model not finalized");
+    if ((rank == 0) != m->first()) return fail("pipeline rank %d: only the first stage owns tok_embeddings (this stage starts at block part %d)", rank, m->part_begin);
+    if ((rank == world - 1) != m->last()) return fail("pipeline rank %d of %d: only the last stage owns norm + output (this stage ends at block part %d)", rank, world, m->part_end);
+    HIPCHK(hipSetDevice(m->device));
+    lnb_pipe* p = new lnb_pipe();
+    p->m = m; p->rank = rank; p->world = world; p->use_graph = env_int("LNB_PIPELINE_GRAPH", 1) != 0;
+    hipError_t e = hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking);
+    if (e == hipSuccess) { p->tok_cap = 1 << 16; e = hipHostMalloc((void**)&p->h_tok, (size_t)p->tok_cap * 4, hipHostMallocDefault); }
+    if (e != hipSuccess) { fail("pipeline init: %s", hipGetErrorString(e)); if (p->xs) hipStreamDestroy(p->xs); delete p; return -1; }
+    if (world > 1) {
+        std::lock_guard<std::mutex> lock(g_loops_mu);
+        p->loop_tag = group; p->loop = &g_loops[p->loop_tag]; p->loop->users++;
+    }
+    *out = p;
+    return 0;
+}
 extern "C" int lnb_pipeline_destroy(lnb_pipe* p) {
     if (!p) return 0;
     hipSetDevice(p->m->device);
     hipDeviceSynchronize();
+    if (p->loop) { std::lock_guard<std::mutex> lock(g_loops_mu); if (--p->loop->users == 0) g_loops.erase(p->loop_tag); }
     if (p->comm) p->api->CommDestroy(p->comm);
     if (p->xs) hipStreamDestroy(p->xs);
     if (p->h_tok) hipHostFree(p->h_tok);
@@ -1007,6 +1040,31 @@ static int pipe_xfer(lnb_pipe* p, lnb_ctx* c, int rows, bool sending) {
     else { NCCLCHK(p, p->api->Recv(c->x, nx, LNB_NCCL_INT8, peer, p->comm, p->xs)); if (edge % 3 == 2) NCCLCHK(p, p->api->Recv(c->ffn, nf, LNB_NCCL_INT8, peer, p->comm, p->xs)); }
     return 0;
 }
+// mailbox transport: `mine` is posted now; if its counterpart is already waiting, enqueue the copy on this pipe's exchange stream
+static int loop_copy(lnb_pipe* p, const LoopMsg& s, const LoopMsg& r, bool token) {
+    HIPCHK(hipStreamWaitEvent(p->xs, s.ctx->ev_done, 0));   // the result has been computed
+    HIPCHK(hipStreamWaitEvent(p->xs, r.ctx->ev_done, 0));   // nothing still reads the buffer being overwritten
+    if (token) HIPCHK(hipMemcpyAsync(r.ctx->dtok, s.ctx->dnext, 4, hipMemcpyDeviceToDevice, p->xs));
+    else {
+        if (s.rows != r.rows) return fail("loopback exchange: %d rows sent, %d rows expected", s.rows, r.rows);
+        lnb_model* sm = s.ctx->m;
+        HIPCHK(hipMemcpyAsync(r.ctx->x, s.ctx->x, (size_t)s.rows * sm->a.dim * 2, hipMemcpyDeviceToDevice, p->xs));
+        if (sm->part_end % 3 == 2) HIPCHK(hipMemcpyAsync(r.ctx->ffn, s.ctx->ffn, (size_t)s.rows * sm->ffn_hidden * 2, hipMemcpyDeviceToDevice, p->xs));
+    }
+    HIPCHK(hipEventRecord(s.ctx->ev_sent, p->xs)); s.ctx->sent_pending = true;
+    HIPCHK(hipEventRecord(r.ctx->ev_in, p->xs)); r.ctx->in_pending = true;
+    return 0;
+}
+static int loop_post(lnb_pipe* p, bool sending, lnb_ctx* c, int rows, int peer, bool token) {
+    std::lock_guard<std::mutex> lock(g_loops_mu);
+    const std::pair<int, int> key = sending ? std::make_pair(p->rank, peer) : std::make_pair(peer, p->rank);   // (source rank, destination rank)
+    auto& mine = sending ? p->loop->sends[key] : p->loop->recvs[key];
+    auto& theirs = sending ? p->loop->recvs[key] : p->loop->sends[key];
+    const LoopMsg msg{c, rows};
+    if (theirs.empty()) { mine.push_back(msg); return 0; }
+    const LoopMsg other = theirs.front(); theirs.pop_front();
+    return sending ? loop_copy(p, msg, other, token) : loop_copy(p, other, msg, token);
+}
 extern "C" int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,
                                  lnb_ctx* send, int send_rows, lnb_ctx* recv, int recv_rows, int* token_slot_out) {
     if (!p) return fail("null argument");
@@ -1030,6 +1088,12 @@ extern "C" int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int ru
             if (p->world == 1) HIPCHK(hipMemcpyAsync(run->dtok, run->dnext, 4, hipMemcpyDeviceToDevice, run->stream));    // the ring of a one-stage pipe
         }
         HIPCHK(hipEventRecord(run->ev_done, run->stream));
+    }
+    if (p->world > 1 && p->loop && (send || recv)) {         // in-process transport
+        if (recv) HIPCHK(hipEventRecord(recv->ev_done, recv->stream));
+        if (send && loop_post(p, true, send, send_rows, last ? 0 : p->rank + 1, last)) return -1;
+        if (recv && loop_post(p, false, recv, recv_rows, first ? p->world - 1 : p->rank - 1, first)) return -1;
+        return 0;
     }
     if (p->world > 1 && (send || recv)) {
         if (send) HIPCHK(hipStreamWaitEvent(p->xs, send->ev_done, 0));                 // the result being sent has been computed

@@ -56,7 +56,7 @@ EXPORTS = [
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
     "lnb_tokenizer_load", "lnb_tokenizer_free", "lnb_tokenizer_vocab_size", "lnb_tokenizer_special", "lnb_tokenizer_token_id",
     "lnb_tokenizer_piece", "lnb_tokenizer_encode", "lnb_tokenizer_encode_chat",
-    "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens",
+    "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens",
 ]
 
 
@@ -105,6 +105,7 @@ def lib():
     L.lnb_ctx_zseq_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.lnb_pipeline_unique_id.argtypes = [vp]
     L.lnb_pipeline_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
+    L.lnb_pipeline_init_loopback.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
     L.lnb_pipeline_destroy.argtypes = [vp]
     L.lnb_pipeline_tick.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.lnb_pipeline_sync.argtypes = [vp]
@@ -373,9 +374,13 @@ class Pipeline:
     """One rank of the layer-sharded pipeline behind the C ABI (lnb_pipeline_*): RCCL send / recv straight from / into the stage's
     device buffers, stage steps as captured graphs, nothing synchronised per tick."""
 
-    def __init__(self, transformer, rank, world, unique_id=None):
+    def __init__(self, transformer, rank, world, unique_id=None, loopback_group=None):
+        """unique_id: rank 0's 128 RCCL id bytes (world > 1); loopback_group: a name -- the in-process transport instead of RCCL"""
         self.L, self.rank, self.world = transformer.L, rank, world
         self.h = C.c_void_p()
+        if loopback_group is not None:
+            _chk(self.L.lnb_pipeline_init_loopback(transformer.h, rank, world, loopback_group.encode(), C.byref(self.h)))
+            return
         idp = C.c_char_p(bytes(unique_id)) if unique_id is not None else None
         _chk(self.L.lnb_pipeline_init(transformer.h, rank, world, idp, C.byref(self.h)))
 

@@ -167,6 +167,45 @@ def test_one_stage_pipe_on_one_gpu_generates_the_oracle_tokens(lnb):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cuts", [(0, 3, 6), (0, 2, 6), (0, 1, 4, 6), (0, 1, 2, 3, 4, 5, 6)])
+def test_multi_stage_pipeline_ticks_through_the_in_process_transport(lnb, cuts):
+    """Several pipeline STAGES on one GPU, each with its own lnb_pipe, exchanging through the in-process transport (what RCCL send / recv
+    are replaced by is a mailbox + a device copy; the tick code -- events between the compute and exchange streams, captured stage graphs,
+    device-side token ring, pinned token log -- is the same).  Stages cut between and inside blocks (after an attention part: the hidden
+    state; after a gate/up part: hidden state + activations).  Every rank's schedule is stepped tick by tick, as N processes would, and
+    every token of the 2N sequences in flight must be the oracle's."""
+    import pipeline
+    from oracle import oracle as orc
+    cfg = dict(orc.TINY)
+    om = orc.Model(**cfg).fill_synthetic(1234).finalize()
+    world = len(cuts) - 1
+    P, n_seq, n_decode = 5, 2 * world, 7
+    stages = [lnb.LlamaTransformer(part_begin=a, part_end=b, **cfg).fill_synthetic(1234).finalize() for a, b in zip(cuts[:-1], cuts[1:])]
+    ctxs = [[lnb.InferenceContext(st, P + n_decode + 2) for _ in range(n_seq)] for st in stages]
+    pipes = [lnb.Pipeline(stages[r], r, world, loopback_group="t%s" % (cuts,)) for r in range(world)]
+    prompts = [orc.synth_tokens(70 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
+    n_ticks = (1 + n_decode) * n_seq + 2 * (world - 1)
+    state = [None] * world
+    for t in range(n_ticks):
+        for r in range(world):                                # the host order of one tick across the "ranks" is arbitrary: here 0..N-1
+            state[r] = pipeline.run_ticks_native(r, world, pipes[r], ctxs[r], prompts, n_decode, t, t + 1, state[r])
+    for p_ in pipes:
+        p_.sync()
+    for s in range(n_seq):
+        got = [int(pipes[-1].read_tokens(q, 1)[0]) for q in state[-1]["slots"][s]]
+        ref, _ = orc.Context(om, P + n_decode + 2).generate(prompts[s], n_decode + 1)
+        assert got == [int(t) for t in ref], (cuts, s)
+    for p_ in pipes:
+        p_.close()
+    for cs in ctxs:
+        for c in cs:
+            c.close()
+    for st in stages:
+        st.close()
+    om.close()
+
+
+@pytest.mark.gpu
 def test_bench_force_pipeline_on_one_gpu_runs_the_native_tick_path(lnb):
     import json
     import subprocess
