@@ -1633,10 +1633,11 @@ template <int HD> __global__ __launch_bounds__(ALS_NT) void attn_long_scores_ker
 }
 
 constexpr int ALP_DS = 16;                                   // output dims per workgroup
-constexpr int ALP_BATCH = 512;                               // cached positions per PV batch (one barrier per batch)
-constexpr int ALP_NT = 320;                                  // wave 0: adder; waves 1..4: producers
-constexpr int ALP_PITCH = ALP_BATCH + 20;                    // floats per dim row of a ring slot: 16 B reads of the 16 dims hit distinct banks; + read-ahead slack
-__host__ __device__ inline size_t alp_lds_bytes(int seq_len) { return (size_t)((seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4 + 2 * (size_t)ALP_DS * ALP_PITCH * 4 + 64; }
+constexpr int ALP_BATCH = 512;                               // cached positions per PV batch (one barrier per batch) = four 128-position chunks
+constexpr int ALP_NT = 512;                                  // waves 0..3: adders (4 dims each, one per DPP row); waves 4..7: producers
+constexpr int ALP_SLOT = ALP_DS * ALP_BATCH;                 // floats per ring slot: [dim][chunk][half][position % 16][4]
+constexpr int ALP_EU = 12;                                   // e_j per thread and round
+__host__ __device__ inline size_t alp_lds_bytes(int seq_len) { return (size_t)((seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4 + 2 * (size_t)ALP_SLOT * 4 + 64; }
 DEVINL float alp_p(double e, double z) { return bf_wide(bf_trunc((float)(e / z))); }     // impl:506 + ToBFloat16 :493
 template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1644,55 +1645,76 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = blockIdx.x, ds = blockIdx.y;
     const int T = p.st->pos + 1, nblk = (T + ALS_NT - 1) / ALS_NT, nbatch = (T + ALP_BATCH - 1) / ALP_BATCH;
-    const int Tpad = (nbatch + 1) * ALP_BATCH;               // the producers of the last iteration read one batch ahead: zeros
+    const int Tpad = (nbatch + 1) * ALP_BATCH;               // (+ one batch of zeros: the producers run ahead)
     float* pw = (float*)smem;                                // [Tpad] p_j (+0 beyond T)
-    float* ring = (float*)(smem + (size_t)((p.seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4);   // [2][ALP_DS][ALP_PITCH] products
-    double* zsh = (double*)(ring + 2 * ALP_DS * ALP_PITCH);
+    float* ring = (float*)(smem + (size_t)((p.seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4);   // [2][ALP_SLOT] products
+    double* zsh = (double*)(ring + 2 * ALP_SLOT);
     const double* E = p.e_buf + (size_t)h * p.seq_len;
     const int kvh = h / (p.H / p.KVH);
-#define ALP_STAMP(n) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && wave < 4) p.dbg[wave * 16 + (n)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+#define ALP_STAMP(n) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0) p.dbg[(wave >> 2) * 16 + (n)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
     ALP_STAMP(0);
-    // ---- Z estimate: the per-block tree sums, added in block order (same value in every thread).  One partial per lane, all loads
-    // in flight at once, then a register walk (a load-use loop paid one L2 round trip per block: 12 us at T = 4100)
+    // ---- everything that depends only on addresses goes in flight first, oldest-needed first (waits retire in issue order): the first
+    // round of e_j, the per-block partial sums, then the producers' first three batches of V rows (HBM: the slowest, needed last)
+    // (clamped to the ARRAY ends, not to T: the addresses must not wait for the position word to arrive; what lies past T is not used)
+    double ev[ALP_EU];
+#pragma unroll
+    for (int u = 0; u < ALP_EU; u++) { const int j = u * ALP_NT + tid; ev[u] = E[j < p.seq_len ? j : p.seq_len - 1]; }
+    const int nblk_max = (p.seq_len + ALS_NT - 1) / ALS_NT;
+    const double* zp = p.z_part + (size_t)h * nblk_max;
+    double zmine = zp[lane < nblk_max ? lane : nblk_max - 1];
+    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD + (size_t)ds * ALP_DS;
+    const size_t vrow = (size_t)p.KVH * HD;
+    const int pl = tid & 255, half8 = pl & 1, prow = pl >> 1;                // producers: 128 positions x two 8-dim halves per round, 4 rounds per batch
+    auto load = [&](uint4 (&v)[4], int b) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int j = b * ALP_BATCH + r * 128 + prow; j = j < T ? j : T - 1;
+            v[r] = *(const uint4*)(vbase + (size_t)j * vrow + half8 * 8);
+        }
+    };
+    uint4 v0[4], v1[4], v2[4], v3[4];
+    if (wave >= 4) { load(v0, 0); load(v1, 1); load(v2, 2); }
+    // ---- Z estimate: the per-block tree sums, added in block order (same value in every thread): one partial per lane, a register walk
     double zt = 0.0;
-    {
-        const double* zp = p.z_part + (size_t)h * ((p.seq_len + ALS_NT - 1) / ALS_NT);
-        for (int b0 = 0; b0 < nblk; b0 += 64) {
-            const double mine = zp[b0 + lane < nblk ? b0 + lane : nblk - 1];
-            const int nb = nblk - b0 < 64 ? nblk - b0 : 64;
-            for (int b = 0; b < nb; b++) zt += __shfl(mine, b);
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+        if (b0) zmine = zp[b0 + lane < nblk ? b0 + lane : nblk - 1];
+        const int nb = nblk - b0 < 64 ? nblk - b0 : 64;
+        const long long zbits = __double_as_longlong(zmine);
+        for (int b = 0; b < nb; b++) {                       // v_readlane (a shuffle is an LDS round trip per step: 4 k cycles for 17 blocks)
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)zbits, b), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(zbits >> 32), b);
+            zt += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
         }
     }
-    // ---- p_j with the estimate, certified (header comment); eight e_j per thread in flight at a time
-    const unsigned long long delta = 4ull * (unsigned long long)T + 4ull;
+    // ---- p_j with the estimate, certified (header comment).  The quotient is formed as e * (1 / Zt): within 2 ulps of the correctly
+    // rounded e / Zt, which the certification band absorbs (its half-width 4 T + 12 ulps instead of 4 T + 4)
+    const unsigned delta32 = 4u * (unsigned)T + 12u;         // (T < 2^20: far below the 2^28 between a cell's step point and its end)
     const double epsr = (double)(4 * T + 8) * 1.1102230246251565e-16;          // relative half-width of the interval that holds the reference's Z
-    const double zlo = zt * (1.0 - epsr), zhi = zt * (1.0 + epsr);
+    const double zlo = zt * (1.0 - epsr), zhi = zt * (1.0 + epsr), rzt = 1.0 / zt;
     int bad = p.force_zseq;
     int* const flag = (int*)(zsh + 1);                       // (own flag instead of __syncthreads_or: its library reduction takes static LDS)
     if (tid == 0) *flag = 0;
     __syncthreads();
-    for (int j0 = 0; j0 < Tpad; j0 += 8 * ALP_NT) {
-        double ev[8];
+    for (int j0 = 0; j0 < Tpad; j0 += ALP_EU * ALP_NT) {
+        if (j0 != 0) {
 #pragma unroll
-        for (int u = 0; u < 8; u++) { const int j = j0 + u * ALP_NT + tid; ev[u] = E[j < T ? j : T - 1]; }    // unconditional (clamped) loads
+            for (int u = 0; u < ALP_EU; u++) { const int j = j0 + u * ALP_NT + tid; ev[u] = E[j < T ? j : T - 1]; }
+        }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {
+        for (int u = 0; u < ALP_EU; u++) {
             const int j = j0 + u * ALP_NT + tid;
             if (j >= Tpad) continue;
             float pj = 0.0f;
             if (j < T) {
                 const double e = ev[u];
-                const double q = e / zt;
+                const double q = e * rzt;
                 pj = bf_wide(bf_trunc((float)q));
-                const unsigned long long b = (unsigned long long)__double_as_longlong(q);
-                const unsigned eq = (unsigned)(b >> 52) & 0x7FFu;
-                if (q != 0.0) {
-                    if (eq >= 1023u - 126u && eq <= 1023u) {     // f32-normal quotient (q <= 1): distance from the step point of its bf16 cell
-                        const unsigned long long lo45 = b & ((1ull << 45) - 1ull), thr = (1ull << 45) - (1ull << 28);
-                        const unsigned long long d = lo45 > thr ? lo45 - thr : thr - lo45;
-                        if (d <= delta) bad = 1;
-                    } else if (alp_p(e, zlo) != alp_p(e, zhi)) bad = 1;   // f32 denormals: both ends of the interval
-                }
+                // the band test on the two 32-bit halves of q (64-bit integer code made this loop the longest phase of the kernel): the low 45
+                // mantissa bits lie within delta of 2^45 - 2^28  <=>  bits 32..44 are all ones and the low word is within delta of 0xF0000000
+                const unsigned qh = (unsigned)__double2hiint(q), ql = (unsigned)__double2loint(q);
+                const unsigned eq = (qh >> 20) & 0x7FFu;
+                if (eq - 897u <= 126u) {                     // f32-normal quotient (2^-126 <= q < 2): distance from the step point of its bf16 cell
+                    if ((qh & 0x1FFFu) == 0x1FFFu && ql - (0xF0000000u - delta32) <= 2u * delta32) bad = 1;
+                } else if (q != 0.0 && (alp_p(e, zlo) != alp_p(e, zhi) || pj != alp_p(e, zlo))) bad = 1;   // f32 denormals: both ends of the interval
             }
             pw[j] = pj;
         }
@@ -1716,85 +1738,63 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
         }
         __syncthreads();
         const double z = zsh[0];
-        for (int j0 = 0; j0 < T; j0 += 8 * ALP_NT) {
-            double ev[8];
+        for (int j0 = 0; j0 < T; j0 += ALP_EU * ALP_NT) {
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int j = j0 + u * ALP_NT + tid; ev[u] = E[j < T ? j : T - 1]; }
+            for (int u = 0; u < ALP_EU; u++) { const int j = j0 + u * ALP_NT + tid; ev[u] = E[j < T ? j : T - 1]; }
 #pragma unroll
-            for (int u = 0; u < 8; u++) { const int j = j0 + u * ALP_NT + tid; if (j < T) pw[j] = alp_p(ev[u], z); }
+            for (int u = 0; u < ALP_EU; u++) { const int j = j0 + u * ALP_NT + tid; if (j < T) pw[j] = alp_p(ev[u], z); }
         }
         __syncthreads();
     }
-    // ---- PV: out[d] = trunc(sum_{j ascending} p_j * v[j][d]) for d = ds*16 .. +15 (llamatransformer.go:504-514)
-    // iteration it: producers turn batch it (rows already in registers, loaded three batches ahead) into exact products in ring[it & 1],
-    // laid out [dim][position] (pitch ALP_PITCH: conflict-free 16 B reads across the 16 dims); the adder walks batch it-1 with the
-    // chain wave's pipeline of the GEMV: 64 positions = 16 ds_read_b128 in flight behind the 64 dependent adds of the previous chunk.
-    // Positions past T carry p == +0 (products +-0, acc is never -0).
-    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD + (size_t)ds * ALP_DS;
-    const size_t vrow = (size_t)p.KVH * HD;
+    // ---- PV: out[d] = trunc(sum_{j ascending} p_j * v[j][d]) for d = ds*16 .. +15 (llamatransformer.go:504-514), the row-broadcast chain
+    // of rowcast_kernel: an adder wave owns 4 output dims, one per DPP row of 16 lanes; lane (q, jj) receives the exact products of dim q at
+    // the positions j = jj (mod 16) -- eight per 128-position chunk, two 16 B LDS reads -- and every lane of the row adds the 16 lanes'
+    // products in position order with v_add_f32_dpp row_newbcast (chain128): 6 cycles per position instead of 8.7 for an LDS-fed chain.
+    // Iteration it: the producers turn batch it (rows in registers, loaded three batches ahead) into products in ring[it & 1]
+    // ([dim][chunk][half][position % 16][4]: both the scattered 4 B writes and the 16 B reads are conflict-free); the adders walk batch
+    // it - 1.  Positions past T carry p == +0 (products +-0, acc is never -0).
     float acc = 0.0f;
-    if (wave == 0) {
-        const int d = lane & (ALP_DS - 1);
+    if (wave < 4) {
+        const int d = 4 * wave + (lane >> 4), jj = lane & 15;
         ALP_STAMP(3);
         for (int it = 0; it <= nbatch; it++) {
             if (it == 2) ALP_STAMP(4);
             if (it > 0) {
-                const float* src = ring + (size_t)((it - 1) & 1) * ALP_DS * ALP_PITCH + (size_t)d * ALP_PITCH;
-                float4 pa[4], pb[4];
+                const float* src = ring + (size_t)((it - 1) & 1) * ALP_SLOT + (size_t)d * ALP_BATCH + jj * 4;
+                float4 a0 = *(const float4*)(src), a1 = *(const float4*)(src + 64);
 #pragma unroll
-                for (int u = 0; u < 4; u++) pa[u] = *(const float4*)(src + 4 * u);
-                for (int c = 0; c < ALP_BATCH; c += 32) {    // 16 positions per half-step, the other half's reads in flight
-#pragma unroll
-                    for (int u = 0; u < 4; u++) pb[u] = *(const float4*)(src + c + 16 + 4 * u);
+                for (int c = 0; c < 4; c++) {
+                    float pr[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    if (c < 3) { a0 = *(const float4*)(src + (c + 1) * 128); a1 = *(const float4*)(src + (c + 1) * 128 + 64); }   // in flight behind the 128 adds
+                    asm volatile("" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]), "+v"(pr[4]), "+v"(pr[5]), "+v"(pr[6]), "+v"(pr[7]));
                     __builtin_amdgcn_sched_barrier(0);
-                    touch16(pa[0], pa[1], pa[2], pa[3]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc = add4(acc, pa[0]); acc = add4(acc, pa[1]); acc = add4(acc, pa[2]); acc = add4(acc, pa[3]);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int u = 0; u < 4; u++) pa[u] = *(const float4*)(src + c + 32 + 4 * u);       // (the pitch has room for the read past the batch)
-                    __builtin_amdgcn_sched_barrier(0);
-                    touch16(pb[0], pb[1], pb[2], pb[3]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    acc = add4(acc, pb[0]); acc = add4(acc, pb[1]); acc = add4(acc, pb[2]); acc = add4(acc, pb[3]);
-                    __builtin_amdgcn_sched_barrier(0);
+                    chain128(acc, pr);
                 }
             }
             __syncthreads();
         }
         ALP_STAMP(5);
-        if (lane < ALP_DS) p.out[(size_t)h * HD + ds * ALP_DS + lane] = bf_trunc(acc);
+        if (jj == 0) p.out[(size_t)h * HD + ds * ALP_DS + d] = bf_trunc(acc);
         ALP_STAMP(6);
     } else {
-        const int pl = tid - 64, half = pl & 1, prow = pl >> 1;            // 128 positions x two 8-dim halves per round, 4 rounds per batch
-        auto load = [&](uint4 (&v)[4], int b) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) {
-                int j = b * ALP_BATCH + r * 128 + prow; j = j < T ? j : T - 1;
-                v[r] = *(const uint4*)(vbase + (size_t)j * vrow + half * 8);
-            }
-        };
         auto produce = [&](const uint4 (&v)[4], int b) {
-            float* dst = ring + (size_t)(b & 1) * ALP_DS * ALP_PITCH + (size_t)(half * 8) * ALP_PITCH;
+            float* dst = ring + (size_t)(b & 1) * ALP_SLOT + (size_t)(half8 * 8) * ALP_BATCH + ((prow >> 6) & 1) * 64 + (prow & 15) * 4 + ((prow >> 4) & 3);
 #pragma unroll
-            for (int r = 0; r < 4; r++) {
-                const int jl = r * 128 + prow;
-                const float pj = pw[b * ALP_BATCH + jl];
+            for (int r = 0; r < 4; r++) {                    // round r = chunk r of the batch; position prow of it: e = prow >> 4, jj = prow & 15
+                const float pj = pw[b * ALP_BATCH + r * 128 + prow];
                 const uint4 w = v[r];                        // exact products: 8-bit x 8-bit significands
-                float* q = dst + jl;
-                q[0 * ALP_PITCH] = pj * bf_lo(w.x); q[1 * ALP_PITCH] = pj * bf_hi(w.x); q[2 * ALP_PITCH] = pj * bf_lo(w.y); q[3 * ALP_PITCH] = pj * bf_hi(w.y);
-                q[4 * ALP_PITCH] = pj * bf_lo(w.z); q[5 * ALP_PITCH] = pj * bf_hi(w.z); q[6 * ALP_PITCH] = pj * bf_lo(w.w); q[7 * ALP_PITCH] = pj * bf_hi(w.w);
+                float* q = dst + r * 128;
+                q[0 * ALP_BATCH] = pj * bf_lo(w.x); q[1 * ALP_BATCH] = pj * bf_hi(w.x); q[2 * ALP_BATCH] = pj * bf_lo(w.y); q[3 * ALP_BATCH] = pj * bf_hi(w.y);
+                q[4 * ALP_BATCH] = pj * bf_lo(w.z); q[5 * ALP_BATCH] = pj * bf_hi(w.z); q[6 * ALP_BATCH] = pj * bf_lo(w.w); q[7 * ALP_BATCH] = pj * bf_hi(w.w);
             }
         };
         auto step = [&](int it, const uint4 (&cur)[4], uint4 (&nxt)[4]) {
-            if (it <= nbatch) {                              // (uniform; one barrier per iteration, like the adder)
+            if (it <= nbatch) {                              // (uniform; one barrier per iteration, like the adders)
                 if (it < nbatch) { load(nxt, it + 3); produce(cur, it); }
                 __syncthreads();
             }
         };
-        uint4 v0[4], v1[4], v2[4], v3[4];
         ALP_STAMP(3);
-        load(v0, 0); load(v1, 1); load(v2, 2);
         for (int it = 0; it <= nbatch; it += 4) { step(it, v0, v3); if (it == 0) ALP_STAMP(4); step(it + 1, v1, v0); step(it + 2, v2, v1); step(it + 3, v3, v2); }
         ALP_STAMP(5); ALP_STAMP(6);
     }
