@@ -115,6 +115,12 @@ struct lnb_ctx {
     int dev_pos = -1;                      // position the device-side StepState will hold when the stream reaches this point (-1: unknown)
 };
 
+// every captured graph of a context bakes in its buffers, its arithmetic mode and its attention form: whatever changes one of those drops them all
+static void drop_graphs(lnb_ctx* c) {
+    if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
+    if (c->graph_long) { hipGraphExecDestroy(c->graph_long); c->graph_long = nullptr; }
+    for (int i = 0; i < 2; i++) if (c->stage_graph[i]) { hipGraphExecDestroy(c->stage_graph[i]); c->stage_graph[i] = nullptr; }
+}
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
 static int auto_rw(int lane_rows, const char* env, int K = 0, bool plain = false) {
     int v = env_int(env, 0);
@@ -458,9 +464,7 @@ extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     if (!c) return 0;
     hipSetDevice(c->m->device);
     if (c->stream) hipStreamSynchronize(c->stream);
-    if (c->graph) hipGraphExecDestroy(c->graph);
-    if (c->graph_long) hipGraphExecDestroy(c->graph_long);
-    for (int i = 0; i < 2; i++) if (c->stage_graph[i]) hipGraphExecDestroy(c->stage_graph[i]);
+    drop_graphs(c);
     if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
@@ -511,8 +515,7 @@ extern "C" int lnb_ctx_set_mode(lnb_ctx* c, int mode) {
     if (mode == c->mode) return 0;
     HIPCHK(hipSetDevice(c->m->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
-    if (c->graph_long) { hipGraphExecDestroy(c->graph_long); c->graph_long = nullptr; }
+    drop_graphs(c);
     c->mode = mode;
     return 0;
 }
@@ -524,8 +527,7 @@ extern "C" int lnb_ctx_set_attention(lnb_ctx* c, int long_threshold, int force_z
     if (!c) return fail("null argument");
     HIPCHK(hipSetDevice(c->m->device));
     HIPCHK(hipStreamSynchronize(c->stream));
-    if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
-    if (c->graph_long) { hipGraphExecDestroy(c->graph_long); c->graph_long = nullptr; }
+    drop_graphs(c);
     if (long_threshold >= 0) c->attn_long_T = long_threshold;
     c->force_zseq = force_zseq ? 1 : 0;
     return 0;
@@ -736,8 +738,7 @@ extern "C" int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int
         if (rows > c->logits_rows) {
             HIPCHK(hipStreamSynchronize(st));
             // the captured decode graph has the old buffer baked into its head GEMV / argmax nodes: drop it with the buffer
-            if (c->graph) { hipGraphExecDestroy(c->graph); c->graph = nullptr; }
-            if (c->graph_long) { hipGraphExecDestroy(c->graph_long); c->graph_long = nullptr; }
+            drop_graphs(c);
             hipFree(c->logits); c->logits = nullptr; c->logits_rows = 0;
             HIPCHK(hipMalloc((void**)&c->logits, (size_t)rows * V * 2)); c->logits_rows = rows;
         }
