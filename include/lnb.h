@@ -173,6 +173,9 @@ int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, cons
                       lnb_ctx* send, int send_rows, lnb_ctx* recv, int recv_rows, int* token_slot_out);
 int lnb_pipeline_sync(lnb_pipe* p);
 int lnb_pipeline_read_tokens(lnb_pipe* p, int first_slot, int n, int32_t* out);
+/* diagnostic: the same grouped ncclSend + ncclRecv as a tick, on a one-rank communicator (to itself), n_bytes device to device and
+ * compared -- checks the RCCL binding on a box with a single GPU, where a multi-rank communicator cannot be formed */
+int lnb_pipeline_selftest(int device, int n_bytes);
 
 /* ---- measurement aid (bench.py roofline leg): average HIP-event time of ONE kernel class of the decode step.
  * which: 0 attn_norm+QKV+RoPE GEMV, 1 attention, 2 wo GEMV, 3 ffn_norm+w1|w3 GEMV, 4 w2 GEMV, 5 norm+output GEMV,

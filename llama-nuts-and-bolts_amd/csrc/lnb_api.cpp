@@ -1117,6 +1117,46 @@ extern "C" int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int ru
     }
     return 0;
 }
+// The RCCL binding on real hardware without a second GPU: a one-rank communicator and the pipeline's own grouped exchange -- one
+// ncclSend + one ncclRecv, here both to rank 0 (itself) -- on a non-blocking stream, device buffer to device buffer, then a byte
+// compare.  Exercises dlopen, the by-value unique id, the group calls and a RCCL kernel launch from a process that never loaded torch.
+extern "C" int lnb_pipeline_selftest(int device, int n_bytes) {
+    if (n_bytes <= 0 || n_bytes > (1 << 26)) return fail("n_bytes out of range");
+    int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev == 0) return fail("no HIP device: liblnb_hip.so has no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    const lnb_rccl_api* api = lnb_rccl_load();
+    if (!api) return -1;
+    lnb_nccl_id id; memset(&id, 0, sizeof id);
+    int r = api->GetUniqueId(&id);
+    if (r != 0) return fail("ncclGetUniqueId failed: %s", api->GetErrorString(r));
+    void* comm = nullptr;
+    r = api->CommInitRank(&comm, 1, id, 0);
+    if (r != 0) return fail("ncclCommInitRank failed: %s", api->GetErrorString(r));
+    std::vector<unsigned char> h((size_t)n_bytes), back((size_t)n_bytes);
+    for (int i = 0; i < n_bytes; i++) h[i] = (unsigned char)((i * 131 + 7) >> 3);
+    unsigned char *src = nullptr, *dst = nullptr; hipStream_t xs = nullptr;
+    int rc = 0;
+    hipError_t e = hipMalloc((void**)&src, (size_t)n_bytes);
+    if (e == hipSuccess) e = hipMalloc((void**)&dst, (size_t)n_bytes);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&xs, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMemcpy(src, h.data(), (size_t)n_bytes, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemset(dst, 0, (size_t)n_bytes);
+    if (e != hipSuccess) rc = fail("selftest setup: %s", hipGetErrorString(e));
+    if (!rc) {
+        int r0 = api->GroupStart(), r1 = api->Send(src, (size_t)n_bytes, LNB_NCCL_INT8, 0, comm, xs), r2 = api->Recv(dst, (size_t)n_bytes, LNB_NCCL_INT8, 0, comm, xs), r3 = api->GroupEnd();
+        const int bad = r0 ? r0 : r1 ? r1 : r2 ? r2 : r3;
+        if (bad) rc = fail("RCCL self exchange failed: %s", api->GetErrorString(bad));
+    }
+    if (!rc && (e = hipStreamSynchronize(xs)) != hipSuccess) rc = fail("selftest sync: %s", hipGetErrorString(e));
+    if (!rc && (e = hipMemcpy(back.data(), dst, (size_t)n_bytes, hipMemcpyDeviceToHost)) != hipSuccess) rc = fail("selftest readback: %s", hipGetErrorString(e));
+    if (!rc && memcmp(back.data(), h.data(), (size_t)n_bytes) != 0) rc = fail("RCCL self exchange delivered different bytes");
+    api->CommDestroy(comm);
+    if (xs) hipStreamDestroy(xs);
+    if (src) hipFree(src);
+    if (dst) hipFree(dst);
+    return rc;
+}
 // block until everything enqueued so far (stage steps and exchanges) has finished
 extern "C" int lnb_pipeline_sync(lnb_pipe* p) {
     if (!p) return fail("null argument");

@@ -58,7 +58,7 @@ EXPORTS = [
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
     "lnb_tokenizer_load", "lnb_tokenizer_free", "lnb_tokenizer_vocab_size", "lnb_tokenizer_special", "lnb_tokenizer_token_id",
     "lnb_tokenizer_piece", "lnb_tokenizer_encode", "lnb_tokenizer_encode_chat",
-    "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens",
+    "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens", "lnb_pipeline_selftest",
 ]
 
 
@@ -108,6 +108,7 @@ def lib():
     L.lnb_pipeline_unique_id.argtypes = [vp]
     L.lnb_pipeline_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.lnb_pipeline_init_loopback.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
+    L.lnb_pipeline_selftest.argtypes = [C.c_int, C.c_int]
     L.lnb_pipeline_destroy.argtypes = [vp]
     L.lnb_pipeline_tick.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.lnb_pipeline_sync.argtypes = [vp]
@@ -151,6 +152,11 @@ def device_count():
     n = C.c_int(0)
     _chk(lib().lnb_device_count(C.byref(n)))
     return n.value
+
+
+def rccl_selftest(device=0, n_bytes=1 << 20):
+    """one-rank RCCL communicator, the pipeline's grouped send + recv to itself, bytes compared (lnb_pipeline_selftest)"""
+    _chk(lib().lnb_pipeline_selftest(device, n_bytes))
 
 
 DTYPES = {0: ("bf16", np.uint16), 1: ("f16", np.uint16), 2: ("f32", np.float32)}

@@ -7,6 +7,7 @@ GPU (-m gpu): a one-stage pipe on one GPU -- stage steps as captured graphs, dev
 the oracle's tokens for several sequences in flight.  (Ranks > 1 need one GPU each: the driver's multi-GPU run.)"""
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 import pytest
@@ -130,6 +131,19 @@ def test_native_schedule_posts_matching_sends_and_receives(world, n_decode):
                 assert peer.get("recv") is None
     for r in range(world):
         assert sorted(ran[r]) == sorted((s, k) for s in range(n_seq) for k in range(1 + n_decode))
+
+
+@pytest.mark.gpu
+def test_rccl_exchange_runs_on_hardware_in_a_one_rank_communicator():
+    """The exchange of a tick -- ncclGroupStart; ncclSend; ncclRecv; ncclGroupEnd on a non-blocking stream, device buffer to device
+    buffer -- against the real librccl on a one-GPU box: a one-rank communicator, both calls addressed to rank 0.  Run in a fresh
+    process that never imports torch (torch brings its own HIP runtime and RCCL), like a pipeline rank."""
+    import subprocess
+    code = ("import sys; sys.path.insert(0, %r); import lnb; lnb.rccl_selftest(0, 4); lnb.rccl_selftest(0, 8192); "
+            "lnb.rccl_selftest(0, (1 << 22) + 24); print('rccl selftest ok')" % os.path.join(ROOT, "llama-nuts-and-bolts_amd"))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "rccl selftest ok" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
 @pytest.mark.gpu

@@ -3,7 +3,11 @@
 The real tokenizer.model is not available offline, so the vocabulary is synthetic but well formed: all 256 single bytes plus
 byte-pair merges learned from a small corpus (ranked like a tiktoken file), written in the tiktoken format.  The oracle is the
 `regex` module running the reference's split pattern (src/model/vocabulary.go:32, with RE2's ASCII \\s spelled out) followed by
-a restatement of bytePairMerge (src/inference/tokenize.go:109-176).  Parity with the real Llama-3 vocabulary is UNPINNED."""
+a restatement of bytePairMerge (src/inference/tokenize.go:109-176).  Two further checkers do not come from this repo: the prompt the
+reference documents with its pieces and ids (docs/12-TOKENIZATION.md:40-62, replayed on a 128000-entry vocabulary that holds the
+documented pieces at the documented ranks) and HuggingFace `tokenizers` on the same synthetic vocabulary.  The merges of the real
+Llama-3 vocabulary themselves stay unpinned (no tokenizer.model offline; tests/test_real_weights.py replays the reference's token-id
+goldens when one is present)."""
 import base64
 import collections
 
@@ -151,3 +155,97 @@ def test_error_behaviour(tmp_path):
     bad.write_text("YQ== x\n")
     with pytest.raises(lnb.LnbError, match="invalid rank"):
         lnb.Tokenizer(str(bad))
+
+
+# ---- pinned to data the reference holds: docs/12-TOKENIZATION.md:40-62 ---------------------------------------------------------
+# The reference documents one prompt with its pieces and its ids under the real Llama-3.1 vocabulary.  The real tokenizer.model is not
+# available here, but the documented example fixes everything the test needs: a 128000-entry tiktoken file that holds the eleven
+# documented pieces at their documented ranks (byte tokens in tiktoken's byte order, '.' = 13), fillers elsewhere.  What is checked
+# against the reference's own numbers: the special-token layout behind the base vocabulary (128000 / 128006 / 128007 / 128009), the chat
+# template of Tokenize(promptParts), and the pattern split of the two sentences into the documented pieces.
+DOC_PIECES = {"system": 9125, "\n\n": 271, "You": 2675, " are": 527, " Einstein": 55152, "user": 882, "Describe": 75885, " your": 701,
+              " theory": 10334, ".": 13, "assistant": 78191}
+DOC_IDS = [128000, 128006, 9125, 128007, 271, 2675, 527, 55152, 128009, 128006, 882, 128007, 271, 75885, 701, 10334, 13, 128009, 128006,
+           78191, 128007, 271]
+
+
+def _tiktoken_byte_order():
+    bs = list(range(ord("!"), ord("~") + 1)) + list(range(0xA1, 0xAD)) + list(range(0xAE, 0x100))
+    return bs + [b for b in range(256) if b not in bs]
+
+
+def test_documented_prompt_gives_the_documented_ids(tmp_path):
+    table = [None] * 128000
+    for rank, b in enumerate(_tiktoken_byte_order()):
+        table[rank] = bytes([b])
+    for piece, rank in DOC_PIECES.items():
+        assert table[rank] is None or table[rank] == piece.encode()
+        table[rank] = piece.encode()
+    assert table[13] == b"."
+    for rank in range(128000):
+        if table[rank] is None:
+            table[rank] = b"\xf8\x88filler-%d" % rank              # never produced by the split of the test strings
+    path = tmp_path / "tokenizer.model"
+    with open(path, "w") as f:
+        for rank, piece in enumerate(table):
+            f.write("%s %d\n" % (base64.b64encode(piece).decode(), rank))
+    t = lnb.Tokenizer(str(path))
+    try:
+        assert (t.vocab_size, t.bos, t.eot) == (128256, 128000, 128009)
+        ids = t.encode_chat([("system", "You are Einstein"), ("user", "Describe your theory.")])
+        assert ids == DOC_IDS
+        pieces = [t.piece(i).decode() for i in ids]
+        assert pieces == ["<|begin_of_text|>", "<|start_header_id|>", "system", "<|end_header_id|>", "\n\n", "You", " are", " Einstein", "<|eot_id|>",
+                          "<|start_header_id|>", "user", "<|end_header_id|>", "\n\n", "Describe", " your", " theory", ".", "<|eot_id|>",
+                          "<|start_header_id|>", "assistant", "<|end_header_id|>", "\n\n"]                    # docs/12-TOKENIZATION.md:52-55
+    finally:
+        t.close()
+
+
+# ---- an independent third-party implementation: HuggingFace `tokenizers` (Oniguruma regex + its own BPE) -----------------------
+def test_encode_matches_huggingface_tokenizers(tok):
+    """The same vocabulary as a byte-level BPE in HuggingFace tokenizers (how the Llama-3 tokenizer is published there: Split on the
+    pattern, ByteLevel mapping, BPE with ignore_merges): a different regex engine and a different merge loop than ours or the test
+    oracle above.  The pattern keeps the reference's ASCII-only whitespace class (RE2's \\s, src/model/vocabulary.go:32)."""
+    hft = pytest.importorskip("tokenizers")
+    t, ranks = tok
+    bs = _tiktoken_byte_order()[:188]
+    cs, extra = list(bs), 0
+    for b in range(256):
+        if b not in bs:
+            bs.append(b); cs.append(256 + extra); extra += 1
+    b2u = {b: chr(c) for b, c in zip(bs, cs)}
+
+    def u(piece):
+        return "".join(b2u[b] for b in piece)
+
+    def parts_below(token, max_rank):                           # the tiktoken -> merges conversion: split a token with the lower ranks
+        parts = [bytes([b]) for b in token]
+        while True:
+            best, at = None, -1
+            for i in range(len(parts) - 1):
+                r = ranks.get(parts[i] + parts[i + 1])
+                if r is not None and r < max_rank and (best is None or r < best):
+                    best, at = r, i
+            if best is None:
+                return parts
+            parts[at:at + 2] = [parts[at] + parts[at + 1]]
+
+    merges = []
+    for token, r in sorted(ranks.items(), key=lambda kv: kv[1]):
+        if len(token) > 1:
+            a, b = parts_below(token, r)
+            merges.append((u(a), u(b)))
+    hf = hft.Tokenizer(hft.models.BPE(vocab={u(tk): r for tk, r in ranks.items()}, merges=merges, ignore_merges=True))
+    hf.pre_tokenizer = hft.pre_tokenizers.Sequence([hft.pre_tokenizers.Split(hft.Regex(PATTERN.pattern), behavior="isolated"),
+                                                    hft.pre_tokenizers.ByteLevel(add_prefix_space=False, use_regex=False)])
+    cases = ["", "a", "Hello world", "  two  spaces  ", "It's HERE'S we'RE can'T I'M she'LL he'D 'twas", "x\n\ny\r\n\r\n  \n z", "tabs\t\tand\fformfeed",
+             "12345678 3.14 1,000,000 ٣٤٥ ⅓", "naïve café Straße Ünïcödé", "東京タワー こんにちは 你好世界", "emoji 🙂👍🏽 done", "  \n", "\n\n\n", " \t \n \t ",
+             "a'sſ 'ſ", "snake_case CamelCase kebab-case ###!!!", "def f(x):\n    return x**2  # comment\n", CORPUS[:400],
+             "You are Einstein", "Describe your theory."]
+    rng = np.random.default_rng(11)
+    alphabet = list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789") + list(" \t\n\r\f'\".,;:!?-_()[]{}@#$%^&*+=/\\|<>~`") \
+        + list("äöüßéèêñçøåÆŁžščě") + list("αβγδεζηθ") + list("абвгдеж") + list("東京日本語中文") + list("٠١٢٣٤") + list("🙂👍🏽🚀") + ["'s", "'T", "'re", "'LL", " ", " ", "\n", "́"]
+    cases += ["".join(rng.choice(alphabet) for _ in range(int(rng.integers(0, 48)))) for _ in range(1500)]
+    for s in cases:
+        assert t.encode(s) == hf.encode(s, add_special_tokens=False).ids, repr(s)
