@@ -114,6 +114,42 @@ def check_golden(args, first_tok, warm_toks, timed_toks):
     return {"compared": n, "identical_prefix": agree, "golden": "tests/golden/configs1_tokens.json (CPU oracle)"}
 
 
+def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens):
+    """Not the headline (configs[1] is ONE prompt): the same resident model decoding `--concurrent` independent prompts at once, one
+    context and stream each, through the one-GPU form of the pipeline tick path (lnb_pipeline_tick: captured stage graphs, device-side
+    token ring).  Their kernels overlap -- one sequence's chain-bound launches under another's HBM-bound ones -- which is what every
+    pipeline rank gets per stage.  Sequence 0 has the headline run's prompt: its tokens are compared with that run's."""
+    import pipeline
+    n_seq, P, W, K = args.concurrent, args.prompt_len, min(args.warmup, 4), min(args.steps, 48)
+    seq_len = P + W + K + 8
+    ctxs = [lnb.InferenceContext(model, seq_len).set_mode(args.mode) for _ in range(n_seq)]
+    pipe = lnb.Pipeline(model, 0, 1, None)
+    prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
+    n_decode = W + K
+    t_split, t_end = n_seq * (1 + W), n_seq * (1 + W + K)
+    st = pipeline.run_ticks_native(0, 1, pipe, ctxs, prompts, n_decode, 0, t_split)
+    pipe.sync()
+    t0 = time.perf_counter()
+    pipeline.run_ticks_native(0, 1, pipe, ctxs, prompts, n_decode, t_split, t_end, st)
+    pipe.sync()
+    wall = time.perf_counter() - t0
+    toks0 = [int(pipe.read_tokens(q, 1)[0]) for q in st["slots"][0]]
+    n_cmp = min(len(toks0), len(single_run_tokens))
+    same = 0
+    while same < n_cmp and toks0[same] == single_run_tokens[same]:
+        same += 1
+    pipe.close()
+    for c in ctxs:
+        c.close()
+    tps = n_seq * K / wall
+    Tbar = P + W + (K - 1) / 2.0 + 1.0
+    B = algorithmic_bytes_per_token(a, model.ffn_hidden, Tbar)
+    return {"n": n_seq, "tokens_per_s": round(tps, 2), "steps_each": K, "ms_per_token": round(1e3 * wall / (n_seq * K), 4),
+            "frac_of_hbm_roofline": round(tps * B / 1e9 / PEAK_HBM_GBS, 4),
+            "sequence0_tokens_vs_single_run": {"compared": n_cmp, "identical_prefix": same},
+            "note": "aggregate of independent prompts on ONE GPU; weights are re-read per sequence (no batching: every token keeps its own exact chains)"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -122,6 +158,7 @@ def main():
     ap.add_argument("--prompt-len", type=int, default=128)
     ap.add_argument("--cpu-steps", type=int, default=24, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-iters", type=int, default=64)
+    ap.add_argument("--concurrent", type=int, default=8, help="also time this many independent prompts in flight on the one GPU (0/1 = skip)")
     ap.add_argument("--model", default="llama8b", choices=["llama8b", "tiny", "llama70b-like"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"],
                     help="exact (default, headline): the reference's k-ordered chains, token-identical to the CPU path; "
@@ -205,6 +242,8 @@ def main():
                        "frac_of_bf16_mfma_peak_2500": round(2.0 * P * 6979321856 / t_pf / 1e12 / 2500.0, 4) if name == "Llama-3.1-8B" else None,
                        "bound": "mfma (f32, exact order: v_mfma_f32_16x16x4_f32 is the k-ordered chain; the bf16 instructions are not)" if args.mode == "exact"
                                 else "mfma (bf16, tolerance mode) / HBM at small row counts"}}
+    if args.concurrent > 1:
+        res["sequences_in_flight"] = concurrent_sequences(lnb, model, cfg, args, a, [first_tok] + warm_toks + [int(t) for t in out])
     if args.cpu_steps > 0:
         res["cpu_baseline"] = cpu_baseline(cfg, prompt[:8], args.cpu_steps)        # 8 + 24 = configs[0]'s seq_len of 32
     ctx.close(); model.close()

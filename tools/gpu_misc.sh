@@ -1,11 +1,12 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-timeout 600 python -m pytest tests/test_pipeline_cabi.py -q -m gpu -x -k "rccl_exchange" > gpurun_out/u_rccl.log 2>&1; tail -15 gpurun_out/u_rccl.log
-timeout 900 python -m pytest tests/test_gpu_fast.py -q -m gpu -x > gpurun_out/u_fast.log 2>&1; tail -3 gpurun_out/u_fast.log
-for n in 2 3 4 8; do LNB_FORCE_PIPELINE=1 LNB_PIPELINE_SEQS=$n timeout 400 python bench.py --steps 32 --warmup 4 > gpurun_out/u_pipe_seq$n.json 2> gpurun_out/u_pipe_seq$n.err; python - <<PY
+( time python bench.py ) > gpurun_out/v_bench.json 2> gpurun_out/v_bench.err; tail -5 gpurun_out/v_bench.err
+python - <<'PY'
 import json
-try:
-    d=json.load(open("gpurun_out/u_pipe_seq$n.json")); print($n, d["value"], d["roofline"]["frac"], d["config"].get("host_enqueue_us_per_tick"))
-except Exception as e: print($n, "failed", e)
+d=json.load(open("gpurun_out/v_bench.json")); print(d["value"], d["roofline"]["frac"], d["roofline"]["whole_step"]["frac"], d.get("sequences_in_flight"), d["cpu_baseline"]["value"])
 PY
-done
+python bench.py --mode fast --cpu-steps 0 > gpurun_out/v_bench_fast.json 2>/dev/null
+python - <<'PY'
+import json
+d=json.load(open("gpurun_out/v_bench_fast.json")); print(d["value"], d["roofline"]["whole_step"]["frac"], d.get("sequences_in_flight"))
+PY
