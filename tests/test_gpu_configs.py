@@ -220,10 +220,10 @@ def test_argmax_kernel_edge_cases(lnb):
     cases = []
     a = bf(rng.standard_normal(128256).astype(np.float32)); a[[100000, 7, 60000]] = bf(np.float32(9.0)); cases.append(("ties at distant indices", a, 7))
     a = bf(rng.standard_normal(128256).astype(np.float32)); a[[128255, 128248]] = bf(np.float32(8.5)); cases.append(("tie inside the last 16 B unit", a, 128248))
-    a = bf(rng.standard_normal(4099).astype(np.float32)); a[4098] = bf(np.float32(50.0)); cases.append(("maximum in the scalar tail (V % 8 != 0)", a, 4098))
+    a = bf(rng.standard_normal(4099).astype(np.float32)); a[4098:] = bf(np.float32(50.0)); cases.append(("maximum in the scalar tail (V % 8 != 0)", a, 4098))
     a = bf(rng.standard_normal(13).astype(np.float32)); cases.append(("V smaller than one 16 B unit x threads", a, None))
     a = bf(rng.standard_normal(1001).astype(np.float32)); a[::3] = NAN; cases.append(("NaNs are skipped", a, None))
-    a = np.full(1024, NAN, dtype=np.uint16); a[777] = bf(np.float32(-3.0)); cases.append(("one number among NaNs", a, 777))
+    a = np.full(1024, NAN, dtype=np.uint16); a[777:778] = bf(np.float32(-3.0)); cases.append(("one number among NaNs", a, 777))
     cases.append(("all NaN", np.full(2048, NAN, dtype=np.uint16), -1))
     cases.append(("all -inf", np.full(128256, NINF, dtype=np.uint16), -1))
     a = np.full(5000, NINF, dtype=np.uint16); a[4321] = 0xFF7F; cases.append(("most negative finite bf16 beats -inf", a, 4321))

@@ -38,6 +38,11 @@ def test_llama8b_configs1_128_token_prompt_continuation_is_token_identical():
     assert got == GOLD["tokens"][:N_NEW], "first mismatch with the oracle's golden continuation at %d" % next(
         i for i, (a, b) in enumerate(zip(got, GOLD["tokens"])) if a != b)
 
+    # re-deriving the golden file costs ~1 minute of a 64+-thread host (the oracle's 128-row prefill of the 8B shape is 1e12 scalar MACs);
+    # on a small host it would take the better part of an hour, so there the committed oracle continuation above is the whole check
+    if (os.cpu_count() or 1) < 24 and os.environ.get("LNB_TEST_8B_FORCE_ORACLE") != "1":
+        gc.close(); gm.close()
+        return
     om = orc.Model(**orc.LLAMA_8B).fill_synthetic(GOLD["weights_seed"]).finalize()
     # spot-check the device copy of two big tensors against the oracle's generator (layout round trip at scale)
     for name in ("layers.31.feed_forward.w2.weight", "layers.0.attention.wk.weight"):
