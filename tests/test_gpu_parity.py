@@ -93,6 +93,62 @@ def test_prefill_rmsnorm_rows_then_gemm_is_bit_exact(lnb):
     assert (y == orc_linear(xn, w)).all()
 
 
+def _same_bits_or_both_nan(a, b):
+    """NaN-ness must agree; a NaN's sign and payload are left open (the reference does not define them either: Go's float32 arithmetic
+    returns whatever the host FPU propagates -- x86 SSE produces the negative default NaN for inf - inf, arm64 and gfx950 the positive one)"""
+    fa, fb = orc.bf16_to_f32(a), orc.bf16_to_f32(b)
+    return bool(((a == b) | (np.isnan(fa) & np.isnan(fb))).all())
+
+
+@pytest.mark.parametrize("rows,rw", [(1, 16), (1, 64), (1, 4), (3, 32), (20, 16), (20, 4), (130, 64)])
+def test_linear_special_values(lnb, rows, rw):
+    """Values outside the comfortable range, through every exact kernel family (chain GEMV, row-broadcast GEMV, f32 matrix-core GEMM):
+    signed zeros (the chain starts at +0, so a sum of -0 products is +0), +-inf and NaN in weights and activations (inf - inf, 0 * inf),
+    products that overflow f32, products and partial sums in the f32-subnormal range (bf16 shares f32's exponent range: two tiny
+    operands give a subnormal, inexactly rounded product -- operations_lineartransform.go:60 multiplies in float32), and sums that
+    cancel to exactly zero.  Bits must match the oracle; for NaN results only the NaN-ness.
+    The GEMVs multiply, then add, like the reference, and match everywhere.  The f32 matrix-core instruction of the prefill GEMM
+    (16 or more rows) FUSES the multiply: same bits whenever every single product is a normal f32 -- its rows
+    here keep sums that overflow and subnormal partial sums, but no single product outside [2^-126, 2^128)."""
+    k, n = 512, 96
+    rng = np.random.default_rng(rows * 131 + rw)
+    x = bf(rng.standard_normal((rows, k)))
+    w = bf(rng.standard_normal((n, k)) * 0.05)
+    xf, wf = orc.bf16_to_f32(x).copy(), orc.bf16_to_f32(w).copy()
+    wf[0, :] = -0.0                                              # all products -0 (or +0): result +0
+    wf[1, :] = 0.0; wf[1, 7] = np.inf                            # one inf product
+    wf[2, 3] = np.inf; wf[2, 200] = -np.inf                      # inf - inf -> NaN
+    wf[3, 11] = np.nan
+    gemm = rows >= 16
+    wf[4, :] = 3.0e38                                            # single products overflow (GEMV rows) ...
+    if gemm:
+        wf[4, :] = 0.0; wf[4, :64] = 1.0e37                      # ... or only the running SUM does (x[:, :64] = 2 below: 64 x 2e37)
+    wf[5, :] = 1e-30 * rng.standard_normal(k)                    # products ~1e-30 x 1: tiny but normal
+    wf[6, :] = 1e-38 * rng.standard_normal(k)                    # bf16 values at the edge of / inside the subnormal range
+    wf[7, :] = np.float32(2.0 ** -100) * rng.integers(1, 128, k)      # with the tiny activations below: subnormal products
+    wf[8, 0::2] = 1.0; wf[8, 1::2] = -1.0                        # exact cancellation on duplicated activations
+    wf[9, :] = 0.0; wf[9, 100] = np.inf                          # inf * 0 -> NaN (activation 100 is zeroed below)
+    wf[10, :] = -wf[5, :]
+    xf[:, 100] = 0.0
+    xf[:, 1::2] = xf[:, 0::2]
+    if gemm:
+        xf[:, :64] = 2.0
+    if rows > 1:
+        # tiny activations: with weight row 7 (2^-100 x small integers) the products are 2^-140 x integers -- exact subnormals in both
+        # arithmetics, partial sums subnormal; with weight row 6 (1e-38) single products underflow inexactly: GEMV rows only
+        xf[1, :] = np.float32(2.0 ** -40) * rng.integers(-127, 128, k)
+        if gemm:
+            wf[6, :] = 1e-20 * rng.standard_normal(k)
+    if rows > 2:
+        xf[2, 17] = np.nan; xf[2, 18] = -np.inf
+    x, w = bf(xf), bf(wf)
+    y = lnb.op_linear(x, w, rw=rw)
+    ref = orc_linear(x, w)
+    bad = np.argwhere(~((y == ref) | (np.isnan(orc.bf16_to_f32(y)) & np.isnan(orc.bf16_to_f32(ref)))))
+    assert bad.size == 0, "first differences (row, col): %s  got %s  oracle %s" % (bad[:6].tolist(), [hex(int(y[i, j])) for i, j in bad[:6]], [hex(int(ref[i, j])) for i, j in bad[:6]])
+    assert y[0, 0] == 0x0000                                     # +0, not -0
+
+
 def test_linear_lm_head_shape(lnb):
     rng = np.random.default_rng(7)
     x = bf(rng.standard_normal((1, 4096)))

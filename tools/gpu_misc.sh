@@ -1,12 +1,9 @@
 #!/bin/bash
 cd "${GRAFT_REPO_ROOT:-.}"; mkdir -p gpurun_out; export TMPDIR=/tmp
-( time python bench.py ) > gpurun_out/v_bench.json 2> gpurun_out/v_bench.err; tail -5 gpurun_out/v_bench.err
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/v_bench.json")); print(d["value"], d["roofline"]["frac"], d["roofline"]["whole_step"]["frac"], d.get("sequences_in_flight"), d["cpu_baseline"]["value"])
-PY
-python bench.py --mode fast --cpu-steps 0 > gpurun_out/v_bench_fast.json 2>/dev/null
-python - <<'PY'
-import json
-d=json.load(open("gpurun_out/v_bench_fast.json")); print(d["value"], d["roofline"]["whole_step"]["frac"], d.get("sequences_in_flight"))
-PY
+R=$PWD
+run() { tag=$1; shift; ( cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/rp_$tag -o t -- python $R/bench.py --steps 8 --warmup 2 --cpu-steps 0 --profile-iters 2 $EXTRA > /tmp/rp_$tag.json 2> /tmp/rp_$tag.err; echo "$tag rc=$? $(head -c 60 /tmp/rp_$tag.json)"; env | grep -c ROCP ); }
+
+
+
+
+python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "special_values" 2>&1 | tail -15
