@@ -208,6 +208,39 @@ def test_rmsnorm_exact_parallel_sum_adversarial(lnb, k, rw):
     assert (y == orc_linear(xn, w)).all()
 
 
+@pytest.mark.parametrize("k,rw,reps", [(4096, 32, 1), (512, 16, 1), (4096, 64, 1), (4096, 32, 2)])
+def test_rmsnorm_rows_with_non_finite_and_overflowing_squares(lnb, k, rw, reps):
+    """Rows the parity-map evaluation of the norm sum was not designed around: inf / NaN activations, squares that overflow f32
+    (|x| > 1.8e19), a running sum that overflows after a few terms, squares that underflow to zero.  The reference just keeps adding
+    (sum = inf -> mean = inf -> 1/sqrt = 0 -> x * 0, or NaN): the device must land on the same bits (NaN-ness for NaNs).
+    reps = 2: 20 rows, i.e. the prefill form (rmsnorm_rows_kernel + matrix-core GEMM)."""
+    rng = np.random.default_rng(k + rw + reps)
+    base = rng.standard_normal(k).astype(np.float32)
+    rows = []
+    for kind in range(10):
+        x = base.copy()
+        if kind == 0: x[k // 2] = np.inf
+        elif kind == 1: x[k // 3] = np.nan
+        elif kind == 2: x[5] = -np.inf
+        elif kind == 3: x[k // 2: k // 2 + 9] = 1e20                      # squares overflow
+        elif kind == 4: x[k - 1] = -3e38
+        elif kind == 5: x[:] = 3e38 * np.sign(base)
+        elif kind == 6: x[:] = 1e19                                       # squares 1e38: the running sum overflows at the fourth term
+        elif kind == 7: x[0] = np.nan
+        elif kind == 8: x[:] = 0.0; x[0] = np.inf
+        else: x[:] = 1e-30 * base                                         # squares underflow to zero: mean = 0, scale = 1/sqrt(eps)
+        rows.append(x)
+    x = bf(np.stack(rows * reps))
+    nw = bf(1 + 0.1 * rng.standard_normal(k))
+    w = bf(rng.standard_normal((48, k)) * 0.05)
+    y = lnb.op_rmsnorm_linear(x, nw, 1e-5, w, rw=rw)
+    xn = np.zeros_like(x)
+    orc.lib().orc_rmsnorm_bf16(orc._p(x), orc._p(nw), orc._p(xn), x.shape[0], k, np.float32(1e-5), None)
+    ref = orc_linear(xn, w)
+    bad = np.argwhere(~((y == ref) | (np.isnan(orc.bf16_to_f32(y)) & np.isnan(orc.bf16_to_f32(ref)))))
+    assert bad.size == 0, "rows that differ: %s; first: got %s oracle %s" % (sorted(set(int(i) for i, _ in bad)), [hex(int(y[i, j])) for i, j in bad[:6]], [hex(int(ref[i, j])) for i, j in bad[:6]])
+
+
 @pytest.fixture(scope="module")
 def tiny_pair(lnb):
     om = orc.Model(**TINY).fill_synthetic(1234).finalize()
@@ -276,6 +309,48 @@ def test_tiny_prefill_and_decode_bit_exact(lnb, tiny_pair):
         c.close()
     for c in (gc, gc2):
         c.close()
+
+
+def _eq_or_both_nan_f32(a, b):
+    return bool(((a.view(np.uint32) == b.view(np.uint32)) | (np.isnan(a) & np.isnan(b))).all())
+
+
+@pytest.mark.parametrize("rows,scale,expect_nan", [(12, 44.0, False), (12, 50.0, True), (20, 44.0, False), (20, 47.0, True)])
+def test_softmax_without_max_subtraction_overflows_like_the_reference(lnb, rows, scale, expect_nan):
+    """ml.Softmax (operations_impl.go:492-508) exponentiates the raw scores in f64 with NO max subtraction: scores beyond 709.78 give
+    exp = +inf, Z = +inf, p = inf / inf = NaN for those positions and e / inf = 0 for the others, and the NaN spreads through PV and wo
+    to the whole row.  A model whose layer-0 wq / wk are scaled up to the edge must give the same picture on the device: just below it
+    (scores of several hundred, e up to 1e300, one-hot probabilities) the same bits; just above it NaN where the oracle has NaN and the
+    same argmax (-1: ml.Argmax never selects a NaN).
+    rows = 12: one-workgroup-per-head kernel; 20: matrix-core prefill attention; then decode steps through both decode forms (the
+    certified softmax denominator of the long-context kernels sees Z = inf)."""
+    om = orc.Model(**TINY).fill_synthetic(1234)
+    gm = lnb.LlamaTransformer(**TINY).fill_synthetic(1234)
+    for name in ("layers.0.attention.wq.weight", "layers.0.attention.wk.weight"):
+        wt = orc.bf16_to_f32(om.get_tensor(name).copy()) * np.float32(scale)
+        om.set_tensor(name, bf(wt)); gm.set_tensor(name, bf(wt).reshape(-1, TINY["dim"]))
+    om.finalize(); gm.finalize()
+    toks = orc.synth_tokens(7, rows, TINY["vocab_size"])
+    oc = orc.Context(om, 64); gc = lnb.InferenceContext(gm, 64); gl = lnb.InferenceContext(gm, 64).set_attention(0, 0)
+    lo, ao = oc.forward(toks, 0)
+    lg, ag = gc.Forward(toks, 0)
+    ll, al = gl.Forward(toks, 0)
+    assert bool(np.isnan(lo).any()) == expect_nan, "the scale no longer sits on the intended side of exp's overflow"
+    assert _eq_or_both_nan_f32(lo, lg) and _eq_or_both_nan_f32(lo, ll) and ao == ag == al
+    for layer in range(TINY["n_layers"]):
+        for which in (0, 1):
+            ref, got = oc.cache(layer, which)[:rows], (gc.CacheK(layer) if which == 0 else gc.CacheV(layer))[:rows]
+            assert _same_bits_or_both_nan(got, ref), (layer, which)
+    tok, pos = (ao if ao >= 0 else 5), rows
+    for _ in range(5):
+        lo, ao = oc.forward([tok], pos)
+        lg, ag = gc.Forward([tok], pos)
+        ll, al = gl.Forward([tok], pos)
+        assert _eq_or_both_nan_f32(lo, lg) and _eq_or_both_nan_f32(lo, ll) and ao == ag == al
+        tok, pos = (ao if ao >= 0 else 5), pos + 1
+    for c in (oc, gc, gl):
+        c.close()
+    gm.close(); om.close()
 
 
 def test_tiny_device_greedy_loop_matches_oracle(lnb, tiny_pair):
