@@ -430,20 +430,25 @@ extern "C" int lnb_ctx_create(lnb_model* m, int seq_len, lnb_ctx** out) {
 }
 static int ctx_alloc(lnb_ctx* c) {
     lnb_model* m = c->m;
-    HIPCHK(hipStreamCreate(&c->stream));
+    // a NON-blocking stream: it never synchronises with the legacy (null) stream.  Contexts are driven from several host threads at
+    // once (one per generation); with a blocking stream, one thread's graph capture made any other thread's null-stream call
+    // (hipMemcpy, hipMemset) fail with "would make the legacy stream depend on a capturing blocking stream".  Everything a context
+    // does is therefore ordered on ITS stream: asynchronous copies and memsets + a stream synchronise, never the null stream.
+    HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&c->ev0)); HIPCHK(hipEventCreate(&c->ev1));
+    HIPCHK(hipHostMalloc((void**)&c->h_io, ((size_t)c->seq_len + 2) * 4, hipHostMallocDefault));
     const size_t kvn = (size_t)c->seq_len * m->kv_dim;
     for (size_t l = 0; l < m->layers.size(); l++) {
         uint16_t *k = nullptr, *v = nullptr;
         if (m->has_attn(m->layer_begin + (int)l)) {                         // a stage that holds only FFN parts of a block keeps no cache for it
             HIPCHK(hipMalloc((void**)&k, kvn * 2)); c->ck.push_back(k); c->cv.push_back(nullptr);
             HIPCHK(hipMalloc((void**)&v, kvn * 2)); c->cv.back() = v;
-            HIPCHK(hipMemset(k, 0, kvn * 2)); HIPCHK(hipMemset(v, 0, kvn * 2));     // ml.Zeros, inferencecontext.go:32-42
+            HIPCHK(hipMemsetAsync(k, 0, kvn * 2, c->stream)); HIPCHK(hipMemsetAsync(v, 0, kvn * 2, c->stream));     // ml.Zeros, inferencecontext.go:32-42
         } else { c->ck.push_back(nullptr); c->cv.push_back(nullptr); }
     }
-    HIPCHK(hipMalloc((void**)&c->st, sizeof(StepState))); HIPCHK(hipMemset(c->st, 0, sizeof(StepState)));
+    HIPCHK(hipMalloc((void**)&c->st, sizeof(StepState))); HIPCHK(hipMemsetAsync(c->st, 0, sizeof(StepState), c->stream));
     HIPCHK(hipMalloc((void**)&c->dtok, (size_t)c->seq_len * 4));
-    HIPCHK(hipMalloc((void**)&c->dnext, 16)); HIPCHK(hipMalloc((void**)&c->derr, 16)); HIPCHK(hipMemset(c->derr, 0, 16));
+    HIPCHK(hipMalloc((void**)&c->dnext, 16)); HIPCHK(hipMalloc((void**)&c->derr, 16)); HIPCHK(hipMemsetAsync(c->derr, 0, 16, c->stream));
     c->dout_cap = c->seq_len; HIPCHK(hipMalloc((void**)&c->dout, (size_t)c->dout_cap * 4));
     const size_t S = c->seq_len;
     HIPCHK(hipMalloc((void**)&c->x, S * m->a.dim * 2)); HIPCHK(hipMalloc((void**)&c->h, S * m->a.dim * 2));
@@ -453,7 +458,8 @@ static int ctx_alloc(lnb_ctx* c) {
     if (m->last()) { HIPCHK(hipMalloc((void**)&c->logits, (size_t)m->a.vocab_size * 2)); c->logits_rows = 1; }
     HIPCHK(hipMalloc((void**)&c->e_buf, (size_t)m->a.n_heads * S * 8));
     HIPCHK(hipMalloc((void**)&c->z_part, (size_t)m->a.n_heads * ((S + 255) / 256) * 8));
-    HIPCHK(hipMalloc((void**)&c->zseq_count, 16)); HIPCHK(hipMemset(c->zseq_count, 0, 16));
+    HIPCHK(hipMalloc((void**)&c->zseq_count, 16)); HIPCHK(hipMemsetAsync(c->zseq_count, 0, 16, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     // crossover measured on MI355X (tools/att_timing.py): the one-workgroup-per-head kernel wins below a few hundred positions
     c->attn_long_T = env_int("LNB_ATTN_LONG_T", 512);
     c->attn_short_cap = lnbk_attn_short_max_T(m->head_dim);
@@ -495,11 +501,11 @@ extern "C" int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which, uint16_t* host)
     HIPCHK(hipSetDevice(c->m->device));
     if (layer < c->m->layer_begin || layer >= c->m->layer_end || !c->m->has_attn(layer)) return fail("layer %d is not owned by this stage", layer);
     const size_t kvn = (size_t)c->seq_len * c->m->kv_dim;
-    HIPCHK(hipStreamSynchronize(c->stream));
-    if (which) { HIPCHK(hipMemcpy(host, c->cv[layer - c->m->layer_begin], kvn * 2, hipMemcpyDeviceToHost)); return 0; }
+    if (which) { HIPCHK(hipMemcpyAsync(host, c->cv[layer - c->m->layer_begin], kvn * 2, hipMemcpyDeviceToHost, c->stream)); HIPCHK(hipStreamSynchronize(c->stream)); return 0; }
     // K lives as [kv head][d/8][position][8] on the device; hand it back in the reference's [position][kv head][d] order
     std::vector<uint16_t> raw(kvn);
-    HIPCHK(hipMemcpy(raw.data(), c->ck[layer - c->m->layer_begin], kvn * 2, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpyAsync(raw.data(), c->ck[layer - c->m->layer_begin], kvn * 2, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
     const int hd = c->m->head_dim, nk = hd >> 3, KVH = c->m->kv_dim / hd;
     for (int j = 0; j < c->seq_len; j++)
         for (int kh = 0; kh < KVH; kh++)
@@ -536,8 +542,9 @@ extern "C" int lnb_ctx_set_attention(lnb_ctx* c, int long_threshold, int force_z
 extern "C" int lnb_ctx_zseq_count(lnb_ctx* c, int* out) {
     if (!c || !out) return fail("null argument");
     HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(hipMemcpyAsync(c->h_io, c->zseq_count, 4, hipMemcpyDeviceToHost, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
-    HIPCHK(hipMemcpy(out, c->zseq_count, 4, hipMemcpyDeviceToHost));
+    *out = c->h_io[0];
     return 0;
 }
 extern "C" int lnb_ctx_set_layer_callback(lnb_ctx* c, lnb_layer_cb cb, void* user) { if (!c) return fail("null argument"); c->cb = cb; c->cb_user = user; return 0; }
@@ -681,7 +688,6 @@ extern "C" int lnb_forward_stage_begin(lnb_ctx* c, const int32_t* tokens, int se
     if (tokens && !m->first()) return fail("tokens given to a stage that does not own tok_embeddings");
     if (!tokens && m->first()) return fail("first stage needs tokens");
     if (want_argmax && !m->last()) return fail("logits requested from a stage that does not own output.weight");
-    if (!c->h_io) HIPCHK(hipHostMalloc((void**)&c->h_io, ((size_t)c->seq_len + 2) * 4, hipHostMallocDefault));
     hipStream_t st = c->stream;
     c->attn_long = want_long_attention(c, seq, start_pos);
     HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
@@ -752,11 +758,9 @@ extern "C" int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int
         }
         if (argmax_last_out) HIPCHK(hipMemcpyAsync(argmax_last_out, c->dnext, 4, hipMemcpyDeviceToHost, st));
     }
+    if (tokens) HIPCHK(hipMemcpyAsync(c->h_io + 1, c->derr, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    if (tokens) {
-        int err = 0; HIPCHK(hipMemcpy(&err, c->derr, 4, hipMemcpyDeviceToHost));
-        if (err) return fail("token id at index %d is outside the vocabulary", err - 1);
-    }
+    if (tokens && c->h_io[1]) return fail("token id at index %d is outside the vocabulary", c->h_io[1] - 1);
     return 0;
 }
 
@@ -815,10 +819,10 @@ extern "C" int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n
     }
     HIPCHK(hipEventRecord(c->ev1, st));
     HIPCHK(hipMemcpyAsync(out_tokens, c->dout, (size_t)n_steps * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(c->h_io + 1, c->derr, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
-    int err = 0; HIPCHK(hipMemcpy(&err, c->derr, 4, hipMemcpyDeviceToHost));
-    if (err) return fail("generated token id is outside the vocabulary");
+    if (c->h_io[1]) return fail("generated token id is outside the vocabulary");
     return 0;
 }
 
@@ -850,7 +854,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     *avg_ms_out = ms / (float)iters;
     if (env_int("LNB_GEMV_TIMING", 0) && which == K_ATTN) {
         long long* dbuf = nullptr;
-        HIPCHK(hipMalloc((void**)&dbuf, 64 * 8)); HIPCHK(hipMemset(dbuf, 0, 64 * 8));
+        HIPCHK(hipMalloc((void**)&dbuf, 64 * 8)); HIPCHK(hipMemsetAsync(dbuf, 0, 64 * 8, st));
         g_dbg = dbuf;
         int rc = run(7);
         g_dbg = nullptr;
@@ -869,7 +873,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     if (env_int("LNB_GEMV_TIMING", 0) && which != K_ATTN && which != K_LAYER) {
         const size_t n = (size_t)4096 * 8 * 4;
         long long* dbuf = nullptr;
-        HIPCHK(hipMalloc((void**)&dbuf, n * 8)); HIPCHK(hipMemset(dbuf, 0, n * 8));
+        HIPCHK(hipMalloc((void**)&dbuf, n * 8)); HIPCHK(hipMemsetAsync(dbuf, 0, n * 8, st));
         g_dbg = dbuf;
         int rc = run(7);
         g_dbg = nullptr;
@@ -995,7 +999,6 @@ static int enqueue_stage_step(lnb_pipe* p, lnb_ctx* c, const int32_t* tokens, in
     auto body = [&](bool host_tokens) -> int {
         if (m->first()) {
             if (host_tokens) {
-                if (!c->h_io) HIPCHK(hipHostMalloc((void**)&c->h_io, ((size_t)c->seq_len + 2) * 4, hipHostMallocDefault));
                 memcpy(c->h_io + 2, tokens, (size_t)rows * 4);
                 HIPCHK(hipMemcpyAsync(c->dtok, c->h_io + 2, (size_t)rows * 4, hipMemcpyHostToDevice, st));
             }

@@ -353,6 +353,58 @@ def test_softmax_without_max_subtraction_overflows_like_the_reference(lnb, rows,
     gm.close(); om.close()
 
 
+def test_contexts_on_concurrent_host_threads_share_one_model(lnb, tiny_pair):
+    """a finalized lnb_model is immutable and shareable, one lnb_ctx per generation and per thread, calls may arrive on
+    any OS thread (cgo).  Four host threads, one context each on the same model, run prefill + the captured greedy loop + eager steps
+    at the same time (ctypes releases the GIL for the duration of a call); every thread must get the oracle's tokens for ITS prompt,
+    and a failing call's message must be the calling thread's own (lnb_last_error is thread-local)."""
+    import threading
+    om, gm = tiny_pair
+    n_threads, P, N = 4, 9, 24
+    prompts = [orc.synth_tokens(200 + t, P + t, TINY["vocab_size"]) for t in range(n_threads)]
+    refs = []
+    for pr in prompts:
+        ref, _ = orc.Context(om, 96).generate(pr, N + 1)
+        refs.append([int(v) for v in ref])
+    results, errors = [None] * n_threads, []
+    start = threading.Barrier(n_threads)
+
+    def work(t):
+        try:
+            pr = prompts[t]
+            for rep in range(3):
+                gc = lnb.InferenceContext(gm, 96)
+                start.wait()
+                _, first = gc.Forward(pr, 0, want_logits=(rep == 1))
+                got, _ = gc.decode_greedy(first, len(pr), N // 2)
+                toks = [first] + [int(v) for v in got]
+                tok, pos = toks[-1], len(pr) + N // 2
+                for _ in range(N - N // 2):                       # eager one-token steps on the same context
+                    _, tok = gc.Forward([tok], pos, want_logits=False)
+                    toks.append(int(tok)); pos += 1
+                with pytest.raises(lnb.LnbError, match="empty token array"):
+                    gc.Forward(np.zeros(0, dtype=np.int32), pos)
+                gc.close()
+                if results[t] is None:
+                    results[t] = toks
+                assert results[t] == toks
+        except BaseException as e:                                 # surfaces in the main thread below
+            errors.append((t, repr(e)))
+            try:
+                start.abort()
+            except Exception:
+                pass
+
+    threads = [threading.Thread(target=work, args=(t,)) for t in range(n_threads)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(300)
+    assert not errors, errors
+    for t in range(n_threads):
+        assert results[t] == refs[t], "thread %d" % t
+
+
 def test_tiny_device_greedy_loop_matches_oracle(lnb, tiny_pair):
     om, gm = tiny_pair
     prompt = orc.synth_tokens(5, 9, TINY["vocab_size"])

@@ -6,4 +6,4 @@ run() { tag=$1; shift; ( cd /tmp && env "$@" timeout 300 rocprofv3 --kernel-trac
 
 
 
-python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "softmax_without" 2>&1 | tail -15
+python -m pytest tests/test_gpu_parity.py -q -m gpu -x -k "concurrent_host_threads" 2>&1 | tail -15
