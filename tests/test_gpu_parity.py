@@ -405,6 +405,62 @@ def test_contexts_on_concurrent_host_threads_share_one_model(lnb, tiny_pair):
         assert results[t] == refs[t], "thread %d" % t
 
 
+def _device_free_bytes():
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    free, total = C.c_size_t(0), C.c_size_t(0)
+    assert hip.hipMemGetInfo(C.byref(free), C.byref(total)) == 0
+    return free.value
+
+
+def test_lifecycle_contexts_models_and_pipes_give_their_device_memory_back(lnb, tiny_pair):
+    """A host creates one context per generation (inference.go:174) for as long as it runs: everything a context, a pipe or a model
+    allocates -- KV caches, scratch, captured graphs of both attention forms and of the pipeline stage step, events, pinned words --
+    must go when it is destroyed.  Also: a context stays usable after a refused call, and reset() replays the same tokens."""
+    om, gm = tiny_pair
+    prompt = orc.synth_tokens(31, 10, TINY["vocab_size"])
+    ref, _ = orc.Context(om, 64).generate(prompt, 13)
+    ref = [int(v) for v in ref]
+
+    def one_generation(seq_len=64):
+        gc = lnb.InferenceContext(gm, seq_len)
+        _, first = gc.Forward(prompt, 0, want_logits=True)
+        got, _ = gc.decode_greedy(first, len(prompt), 6)                    # captures the short-attention graph
+        gc.set_attention(0, 0)
+        got2, _ = gc.decode_greedy(int(got[-1]), len(prompt) + 6, 6)        # and the long-attention one
+        toks = [first] + [int(v) for v in got] + [int(v) for v in got2]
+        with pytest.raises(lnb.LnbError):                                   # beyond the context: refused, nothing enqueued
+            gc.Forward(prompt, seq_len - 3)
+        gc.reset(); gc.set_attention(512, 0)
+        _, again = gc.Forward(prompt, 0, want_logits=False)
+        assert again == first
+        pipe = lnb.Pipeline(gm, 0, 1, None)
+        pc = lnb.InferenceContext(gm, seq_len)
+        slots = [pipe.tick(run=pc, run_rows=len(prompt), run_pos=0, run_tokens=np.ascontiguousarray(prompt, dtype=np.int32))]
+        for i in range(4):
+            slots.append(pipe.tick(run=pc, run_rows=1, run_pos=len(prompt) + i))
+        pipe.sync()
+        ptoks = [int(pipe.read_tokens(q, 1)[0]) for q in slots]
+        pipe.close(); pc.close(); gc.close()
+        return toks, ptoks
+
+    toks, ptoks = one_generation()                                         # warm-up: code objects, allocator pools, the library's one-time tables
+    assert toks == ref and ptoks == ref[:5]
+    one_generation()
+    before = _device_free_bytes()
+    for _ in range(25):
+        t2, p2 = one_generation()
+        assert t2 == ref and p2 == ref[:5]
+    mid = _device_free_bytes()
+    for _ in range(8):
+        m2 = lnb.LlamaTransformer(**TINY).fill_synthetic(7).finalize()
+        c2 = lnb.InferenceContext(m2, 32); c2.Forward(prompt, 0, want_logits=False); c2.close(); m2.close()
+    after = _device_free_bytes()
+    # (the runtime hands memory back in 2 MiB granules: anything below one granule per object kind is pool noise, a leak grows with the count)
+    assert before - mid <= 4 << 20 and mid - after <= 4 << 20, "device memory not returned: %.1f MB over 25 generations, %.1f MB over 8 models" % (
+        (before - mid) / 1048576.0, (mid - after) / 1048576.0)
+
+
 def test_tiny_device_greedy_loop_matches_oracle(lnb, tiny_pair):
     om, gm = tiny_pair
     prompt = orc.synth_tokens(5, 9, TINY["vocab_size"])
