@@ -147,9 +147,13 @@ def test_rccl_exchange_runs_on_hardware_in_a_one_rank_communicator():
 
 
 @pytest.mark.gpu
-def test_one_stage_pipe_on_one_gpu_generates_the_oracle_tokens(lnb):
+@pytest.mark.parametrize("long_threshold,mode", [(None, "exact"), (10, "exact"), (0, "exact"), (10, "fast")])
+def test_one_stage_pipe_on_one_gpu_generates_the_oracle_tokens(lnb, long_threshold, mode):
     """world == 1: no communicator, but everything else of lnb_pipeline_tick -- prefill with host tokens, one-token steps as replays of
-    the captured stage graph with the position on the device, the device-side token ring, the pinned token log."""
+    the captured stage graph with the position on the device, the device-side token ring, the pinned token log.
+    long_threshold 10: the sequences cross the attention crossover in mid-run (the stage step has one captured graph per attention
+    form); 0: the long-context kernels from the first decode step.  mode fast: the tick path runs the tolerance kernels -- compared
+    with the same context driven through lnb_forward (the tolerance mode is deterministic, not oracle-identical)."""
     import pipeline
     from oracle import oracle as orc
     cfg = dict(orc.TINY)
@@ -157,7 +161,10 @@ def test_one_stage_pipe_on_one_gpu_generates_the_oracle_tokens(lnb):
     gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1234).finalize()
     P, n_seq, n_decode = 6, 3, 9
     prompts = [orc.synth_tokens(50 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
-    ctxs = [lnb.InferenceContext(gm, P + n_decode + 2) for _ in range(n_seq)]
+    ctxs = [lnb.InferenceContext(gm, P + n_decode + 2).set_mode(mode) for _ in range(n_seq)]
+    if long_threshold is not None:
+        for c in ctxs:
+            c.set_attention(long_threshold, 0)
     pipe = lnb.Pipeline(gm, 0, 1)
     st = pipeline.run_ticks_native(0, 1, pipe, ctxs, prompts, n_decode, 0, n_seq * 4)      # two windows, like bench.py
     pipe.sync()
@@ -165,8 +172,18 @@ def test_one_stage_pipe_on_one_gpu_generates_the_oracle_tokens(lnb):
     pipe.sync()
     for s in range(n_seq):
         got = [int(pipe.read_tokens(q, 1)[0]) for q in st["slots"][s]]
-        ref, _ = orc.Context(om, P + n_decode + 2).generate(prompts[s], n_decode + 1)
-        assert got == [int(t) for t in ref], s
+        if mode == "exact":
+            ref, _ = orc.Context(om, P + n_decode + 2).generate(prompts[s], n_decode + 1)
+            ref = [int(t) for t in ref]
+        else:
+            fc = lnb.InferenceContext(gm, P + n_decode + 2).set_mode(mode)
+            _, tok = fc.Forward(prompts[s], 0, want_logits=False)
+            ref = [int(tok)]
+            for i in range(n_decode):
+                _, tok = fc.Forward([tok], P + i, want_logits=False)
+                ref.append(int(tok))
+            fc.close()
+        assert got == ref, s
     with pytest.raises(lnb.LnbError, match="out of range"):
         pipe.read_tokens(0, 10 ** 6)
     s1 = lnb.LlamaTransformer(layer_begin=0, layer_end=1, **cfg).fill_synthetic(1234).finalize()
