@@ -306,11 +306,12 @@ template <int EPI> DEVINL void fast_gemm_epilogue4(const GemmParams& p, const f3
     }
 }
 
-// the RoPE epilogue is long (f64 complex product): as an out-of-line call the 64-iteration epilogue loop still unrolls and the
-// accumulators stay in registers (inlined, the unroll was refused and the accumulator tiles went through scratch)
-__device__ __attribute__((noinline)) void fast_gemm_epilogue4_rope(const GemmParams& p, f32x4 g, int m, int n0) {
-    fast_gemm_epilogue4<EPI_QKV_ROPE>(p, g, g, m, n0);
-}
+// (The RoPE epilogue is long -- f64 complex product -- and hipcc refuses to unroll the 64-iteration epilogue loop around it: the
+// accumulator tiles of that instantiation are indexed through 576 B of scratch, once per output tile.  An out-of-line epilogue call
+// keeps them in registers but saves and restores them around each of the 64 calls: measured 609 against 469 us for the 4096-row
+// wq|wk|wv GEMM.  The refused unroll is therefore accepted, and its -Wpass-failed remark silenced.)
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Wpass-failed"
 // WB = weight register sets: 3 (two slabs of prefetch distance, one workgroup per CU, accumulators for 256 batch rows) or 2 (one slab, two
 // workgroups per CU within 256 registers per wave: a second wave per SIMD issues MFMAs while the first is parked on a wait)
 template <int EPI, int NCH, bool LAYB, int MT, int WB>
@@ -444,10 +445,10 @@ __global__ __launch_bounds__(256, WB == 2 ? 2 : 1) void fast_gemm_kernel(GemmPar
                 const f32x16& A0 = acc[0][a][t]; const f32x16& A1 = acc[NCH - 1][a][t];
                 const f32x4 gv = {A0[4 * g], A0[4 * g + 1], A0[4 * g + 2], A0[4 * g + 3]};
                 const f32x4 uv = {A1[4 * g], A1[4 * g + 1], A1[4 * g + 2], A1[4 * g + 3]};
-                if constexpr (EPI == EPI_QKV_ROPE) fast_gemm_epilogue4_rope(p, gv, m0 + 32 * t + ln, n0 + 32 * a + 8 * g + 4 * kg);
-                else fast_gemm_epilogue4<EPI>(p, gv, uv, m0 + 32 * t + ln, n0 + 32 * a + 8 * g + 4 * kg);
+                fast_gemm_epilogue4<EPI>(p, gv, uv, m0 + 32 * t + ln, n0 + 32 * a + 8 * g + 4 * kg);
             }
 }
+#pragma clang diagnostic pop
 
 template <int EPI, int NCH, bool LAYB, int MT, int WB = 3> hipError_t launch_gemm_fast_t(const GemmParams* p, hipStream_t st) {
     auto kfn = fast_gemm_kernel<EPI, NCH, LAYB, MT, WB>;
