@@ -172,6 +172,8 @@ int lnb_pipeline_destroy(lnb_pipe* p);
 int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,
                       lnb_ctx* send, int send_rows, lnb_ctx* recv, int recv_rows, int* token_slot_out);
 int lnb_pipeline_sync(lnb_pipe* p);
+/* tokens by log slot (token_slot_out of the tick that produced them); synchronises the device.  The log is a ring of the newest 65536
+ * tokens: slots count up for the life of the pipe, reading never has to "drain" anything, a slot older than that is refused */
 int lnb_pipeline_read_tokens(lnb_pipe* p, int first_slot, int n, int32_t* out);
 /* diagnostic: the same grouped ncclSend + ncclRecv as a tick, on a one-rank communicator (to itself), n_bytes device to device and
  * compared -- checks the RCCL binding on a box with a single GPU, where a multi-rank communicator cannot be formed */

@@ -916,9 +916,10 @@ struct lnb_pipe {
     LoopGroup* loop = nullptr; std::string loop_tag;
     void* comm = nullptr; const lnb_rccl_api* api = nullptr;
     hipStream_t xs = nullptr;              // exchange stream
-    int32_t* h_tok = nullptr; int tok_cap = 0, tok_n = 0;   // pinned log of the tokens the last stage produced, in tick order
+    int32_t* h_tok = nullptr; int tok_cap = 0, tok_n = 0;   // pinned RING of the tokens the last stage produced, in tick order: slot s lives at s % tok_cap
     bool use_graph = true;
 };
+static int pipe_log_cap() { const int v = env_int("LNB_PIPELINE_LOG_CAP", 1 << 16); return v < 4 ? 4 : v; }   // (the env knob is for the wrap-around test)
 #define NCCLCHK(p_, expr) do { int r_ = (expr); if (r_ != 0) return fail("%s failed: %s (%s:%d)", #expr, (p_)->api->GetErrorString(r_), __FILE__, __LINE__); } while (0)
 
 extern "C" int lnb_pipeline_unique_id(void* id128) {
@@ -950,7 +951,7 @@ extern "C" int lnb_pipeline_init(lnb_model* m, int rank, int world, const void* 
         if (r != 0) { fail("ncclCommInitRank failed: %s", p->api->GetErrorString(r)); delete p; return -1; }
     }
     hipError_t e = hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking);
-    if (e == hipSuccess) { p->tok_cap = 1 << 16; e = hipHostMalloc((void**)&p->h_tok, (size_t)p->tok_cap * 4, hipHostMallocDefault); }
+    if (e == hipSuccess) { p->tok_cap = pipe_log_cap(); e = hipHostMalloc((void**)&p->h_tok, (size_t)p->tok_cap * 4, hipHostMallocDefault); }
     if (e != hipSuccess) { fail("pipeline init: %s", hipGetErrorString(e)); if (p->comm) p->api->CommDestroy(p->comm); if (p->xs) hipStreamDestroy(p->xs); delete p; return -1; }
     *out = p;
     return 0;
@@ -966,7 +967,7 @@ extern "C" int lnb_pipeline_init_loopback(lnb_model* m, int rank, int world, con
     lnb_pipe* p = new lnb_pipe();
     p->m = m; p->rank = rank; p->world = world; p->use_graph = env_int("LNB_PIPELINE_GRAPH", 1) != 0;
     hipError_t e = hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking);
-    if (e == hipSuccess) { p->tok_cap = 1 << 16; e = hipHostMalloc((void**)&p->h_tok, (size_t)p->tok_cap * 4, hipHostMallocDefault); }
+    if (e == hipSuccess) { p->tok_cap = pipe_log_cap(); e = hipHostMalloc((void**)&p->h_tok, (size_t)p->tok_cap * 4, hipHostMallocDefault); }
     if (e != hipSuccess) { fail("pipeline init: %s", hipGetErrorString(e)); if (p->xs) hipStreamDestroy(p->xs); delete p; return -1; }
     if (world > 1) {
         std::lock_guard<std::mutex> lock(g_loops_mu);
@@ -1085,8 +1086,8 @@ extern "C" int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int ru
         if (run->sent_pending) { HIPCHK(hipStreamWaitEvent(run->stream, run->ev_sent, 0)); run->sent_pending = false; }  // its previous output has left
         if (enqueue_stage_step(p, run, run_tokens, run_rows, run_pos)) return -1;
         if (last) {
-            if (p->tok_n >= p->tok_cap) return fail("pipeline token log full (%d): call lnb_pipeline_read_tokens", p->tok_cap);
-            HIPCHK(hipMemcpyAsync(p->h_tok + p->tok_n, run->dnext, 4, hipMemcpyDeviceToHost, run->stream));
+            if (p->tok_n == 0x7FFFFFFF) return fail("pipeline token log: slot counter exhausted (2^31 tokens): create a new pipe");
+            HIPCHK(hipMemcpyAsync(p->h_tok + p->tok_n % p->tok_cap, run->dnext, 4, hipMemcpyDeviceToHost, run->stream));   // (the ring keeps the newest tok_cap tokens)
             if (token_slot_out) *token_slot_out = p->tok_n;
             p->tok_n++;
             if (p->world == 1) HIPCHK(hipMemcpyAsync(run->dtok, run->dnext, 4, hipMemcpyDeviceToDevice, run->stream));    // the ring of a one-stage pipe
@@ -1170,10 +1171,11 @@ extern "C" int lnb_pipeline_sync(lnb_pipe* p) {
 // tokens the last stage produced, by log slot (lnb_pipeline_tick's token_slot_out); valid after lnb_pipeline_sync
 extern "C" int lnb_pipeline_read_tokens(lnb_pipe* p, int first_slot, int n, int32_t* out) {
     if (!p || !out) return fail("null argument");
-    if (first_slot < 0 || n < 0 || first_slot + n > p->tok_n) return fail("token slots [%d, %d) out of range (%d logged)", first_slot, first_slot + n, p->tok_n);
+    if (first_slot < 0 || n < 0 || n > p->tok_n - first_slot) return fail("token slots [%d, %d) out of range (%d logged)", first_slot, first_slot + n, p->tok_n);
+    if (p->tok_n - first_slot > p->tok_cap) return fail("token slot %d has been overwritten: the log keeps the newest %d tokens (%d logged)", first_slot, p->tok_cap, p->tok_n);
     HIPCHK(hipSetDevice(p->m->device));
     HIPCHK(hipDeviceSynchronize());
-    memcpy(out, p->h_tok + first_slot, (size_t)n * 4);
+    for (int i = 0; i < n; i++) out[i] = p->h_tok[(first_slot + i) % p->tok_cap];
     return 0;
 }
 

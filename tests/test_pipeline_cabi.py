@@ -186,6 +186,24 @@ def test_one_stage_pipe_on_one_gpu_generates_the_oracle_tokens(lnb, long_thresho
         assert got == ref, s
     with pytest.raises(lnb.LnbError, match="out of range"):
         pipe.read_tokens(0, 10 ** 6)
+    if long_threshold is None:
+        # the token log is a ring (here shrunk to 8 slots): slots keep counting, old ones are refused, the newest ones read across the wrap
+        os.environ["LNB_PIPELINE_LOG_CAP"] = "8"
+        try:
+            small = lnb.Pipeline(gm, 0, 1)
+        finally:
+            del os.environ["LNB_PIPELINE_LOG_CAP"]
+        rc = lnb.InferenceContext(gm, P + 24)
+        slots = [small.tick(run=rc, run_rows=P, run_pos=0, run_tokens=np.ascontiguousarray(prompts[0], dtype=np.int32))]
+        slots += [small.tick(run=rc, run_rows=1, run_pos=P + i) for i in range(19)]
+        small.sync()
+        assert slots == list(range(20))
+        ref20, _ = orc.Context(om, P + 24).generate(prompts[0], 20)
+        assert [int(t) for t in small.read_tokens(12, 8)] == [int(t) for t in ref20[12:20]]
+        assert int(small.read_tokens(15, 1)[0]) == int(ref20[15])
+        with pytest.raises(lnb.LnbError, match="overwritten"):
+            small.read_tokens(11, 2)
+        small.close(); rc.close()
     s1 = lnb.LlamaTransformer(layer_begin=0, layer_end=1, **cfg).fill_synthetic(1234).finalize()
     with pytest.raises(lnb.LnbError, match="only the last stage owns"):
         lnb.Pipeline(s1, 0, 1)
