@@ -28,19 +28,34 @@ def _gpu_here():
 
 
 def test_rccl_is_resolved_on_first_use_and_errors_surface(lnb):
-    L = lnb.lib()
-    assert L.lnb_pipeline_unique_id(None) != 0 and b"null argument" in L.lnb_last_error()
-    buf = C.create_string_buffer(128)
-    rc = L.lnb_pipeline_unique_id(buf)
-    if rc == 0:                                 # a GPU box -- or an RCCL build that hands out ids without touching a device (PyTorch's
-        assert any(buf.raw)                     # bundled one does, and it is the one the process holds when torch was imported first)
+    """In a child process: on a box without a GPU librccl's own teardown can abort at exit ("double free or corruption") after it was
+    asked for an id -- that must not be this test process's exit.  The child reports what it saw before it exits."""
+    import json
+    import subprocess
+    code = r"""
+import ctypes as C, json, sys
+sys.path.insert(0, %r)
+import lnb
+L = lnb.lib()
+res = {"null_rc": L.lnb_pipeline_unique_id(None), "null_msg": L.lnb_last_error().decode()}
+buf = C.create_string_buffer(128)
+res["rc"] = L.lnb_pipeline_unique_id(buf)
+res["msg"] = L.lnb_last_error().decode()
+res["any"] = any(buf.raw)
+res["mapped"] = "librccl" in open("/proc/self/maps").read()
+print("RESULT " + json.dumps(res), flush=True)
+""" % os.path.join(ROOT, "llama-nuts-and-bolts_amd")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("RESULT ")]
+    assert line, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads(line[-1][7:])
+    assert res["null_rc"] != 0 and "null argument" in res["null_msg"]
+    if res["rc"] == 0:                          # a GPU box -- or an RCCL build that hands out ids without touching a device
+        assert res["any"]
     else:                                       # librccl was loaded and called: it is RCCL that reports the missing device, not the loader
         assert not _gpu_here()
-        msg = L.lnb_last_error().decode()
-        assert "ncclGetUniqueId failed" in msg, msg
-    # the loader mapped the library with every symbol the pipeline needs
-    maps = open("/proc/self/maps").read()
-    assert "librccl" in maps
+        assert "ncclGetUniqueId failed" in res["msg"], res["msg"]
+    assert res["mapped"]                        # the loader mapped the library with every symbol the pipeline needs
 
 
 def test_pipeline_init_validates_its_arguments(lnb):
