@@ -505,7 +505,11 @@ template <int HD> __global__ __launch_bounds__(256, 2) void fast_attn_prefill_ke
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int ln = lane & 31, kg = lane >> 5;
-    const int h = blockIdx.x, qb = (int)gridDim.y - 1 - (int)blockIdx.y;
+    // XCD-aware (like xcd_head_block of lnb_kernels.hip): XCD x runs heads x*H/8 .. -- the heads of a GQA group read their K / V tiles
+    // through one L2 --, and inside the XCD the longest query blocks of all its heads come first
+    const unsigned H_ = gridDim.x, nb_ = gridDim.y, lin_ = blockIdx.y * H_ + blockIdx.x;
+    int h = (int)blockIdx.x, qb = (int)nb_ - 1 - (int)blockIdx.y;
+    if ((H_ & 7u) == 0) { const unsigned hg_ = H_ >> 3, w_ = lin_ >> 3; h = (int)((lin_ & 7u) * hg_ + w_ % hg_); qb = (int)nb_ - 1 - (int)(w_ / hg_); }
     const int S = p.S, H = p.H, KVH = p.KVH;
     const int pos0 = p.st->pos, T = pos0 + S;
     const int kvh = h / (H / KVH);

@@ -1195,13 +1195,37 @@ extern "C" hipError_t lnbk_exp_table(double* tab, float divisor, hipStream_t st)
 // (k-groups 2c, 2c+1) with one v_perm_b32 each; the four kk-lanes of a position load the same unit (L1 traffic, not HBM).
 // grid (H, ceil(S/64)), block 256 = 4 independent waves (no workgroup barrier anywhere).
 // ------------------------------------------------------------------------------------------------
+// workgroup -> (head, sub-block) for the attention grids (gridDim = (heads, sub-blocks)).  The hardware hands workgroup w to XCD w % 8,
+// each XCD has its own L2, and the query heads of one GQA group read the SAME K / V rows: with the plain (blockIdx.x, blockIdx.y)
+// mapping the four heads of a group sit on four XCDs and the rows are fetched from HBM four times (rocprofv3 FETCH_SIZE of the
+// long-context kernels at T = 4101: 33.3 MB per launch against 8.4 MB of V).  Here consecutive VIRTUAL ids stay on one XCD and virtual
+// ids are head-major, so a group's heads share an L2 (8B shape: XCD x runs heads 4x .. 4x+3 = KV head x).
+// xcd_head_block: inside an XCD head-major (a head's sub-blocks follow each other: the decode kernels, equal-cost sub-blocks; measured
+// 191.0 against 189.5 tokens/s at configs[2] for the other order).  xcd_head_block_bmajor: sub-block-major (all of the XCD's heads for
+// sub-block 0, then sub-block 1, ...), so a caller whose sub-blocks differ in cost can hand out the longest ones first (prefill).
+DEVINL void xcd_head_block(int& h, int& b) {
+    const unsigned H = gridDim.x, nb = gridDim.y, lin = blockIdx.y * H + blockIdx.x;
+    if ((H & 7u) == 0) {
+        const unsigned v = (lin & 7u) * ((H >> 3) * nb) + (lin >> 3);     // consecutive virtual ids stay on one XCD
+        h = (int)(v / nb); b = (int)(v % nb);
+    } else { h = (int)blockIdx.x; b = (int)blockIdx.y; }
+}
+DEVINL void xcd_head_block_bmajor(int& h, int& b) {
+    const unsigned H = gridDim.x, lin = blockIdx.y * H + blockIdx.x;
+    if ((H & 7u) == 0) {
+        const unsigned hg = H >> 3, w = lin >> 3;            // heads per XCD; index inside the XCD's share
+        h = (int)((lin & 7u) * hg + w % hg); b = (int)(w / hg);
+    } else { h = (int)blockIdx.x; b = (int)blockIdx.y; }
+}
 constexpr int ATM_ET = 144, ATM_PT = 80, ATM_WLDS = 16 * ATM_ET + 16 * ATM_PT + 128;     // per-wave LDS patch: e tile | p tile | Z row
 template <int HD> __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(AttnParams p) {
     __shared__ __attribute__((aligned(16))) char sm[4 * ATM_WLDS];
     constexpr int NK = HD / 8, DPL = HD / 16;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = blockIdx.x, i0 = (blockIdx.y * 4 + wave) * 16;
+    int h, by_; xcd_head_block_bmajor(h, by_);
+    by_ = (int)gridDim.y - 1 - by_;                          // the last query rows see the longest context: handed out first
+    const int i0 = (by_ * 4 + wave) * 16;
     const int S = p.S, H = p.H, KVH = p.KVH;
     if (i0 >= S) return;                                     // (waves are independent)
     const int pos0 = p.st->pos, T = pos0 + S;
@@ -1452,7 +1476,7 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     constexpr int NK = HD / 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = blockIdx.x, i = blockIdx.y;
+    int h, i; xcd_head_block(h, i);
     const int S = p.S, KVH = p.KVH;
     const int pos0 = p.st->pos, T = pos0 + S;
     const int kvh = h / (p.H / KVH);
@@ -1610,7 +1634,8 @@ template <int HD> __global__ __launch_bounds__(ALS_NT) void attn_long_scores_ker
     constexpr int NK = HD / 8;
     __shared__ __attribute__((aligned(16))) float qf[HD];
     __shared__ double wsum[ALS_NT / 64];
-    const int tid = threadIdx.x, h = blockIdx.x, blk = blockIdx.y;
+    const int tid = threadIdx.x;
+    int h, blk; xcd_head_block(h, blk);
     const int T = p.st->pos + 1, j0 = blk * ALS_NT;
     if (j0 >= T) return;                                     // (uniform: the grid is sized for seq_len, the captured graph serves every T)
     const int kvh = h / (p.H / p.KVH);
@@ -1643,7 +1668,7 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int h = blockIdx.x, ds = blockIdx.y;
+    int h, ds; xcd_head_block(h, ds);
     const int T = p.st->pos + 1, nblk = (T + ALS_NT - 1) / ALS_NT, nbatch = (T + ALP_BATCH - 1) / ALP_BATCH;
     const int Tpad = (nbatch + 1) * ALP_BATCH;               // (+ one batch of zeros: the producers run ahead)
     float* pw = (float*)smem;                                // [Tpad] p_j (+0 beyond T)

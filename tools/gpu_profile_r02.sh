@@ -14,6 +14,10 @@ O=$PWD/gpurun_out/prof_r02
 ( time timeout 900 python bench.py ) > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -4 $O/bench_default.err
 timeout 600 python bench.py --mode fast --cpu-steps 0 > gpurun_out/prof_r02_fast/bench_default.json 2>/dev/null
 timeout 600 python bench.py --prompt-len 4096 --steps 64 --warmup 8 --cpu-steps 0 > $O/bench_cfg2.json 2>/dev/null; head -c 600 $O/bench_cfg2.json; echo
+# configs[2] decode under rocprofv3: the long-context attention kernels per launch, + a FETCH_SIZE pass
+O2=$PWD/gpurun_out/prof_r02_cfg2; mkdir -p $O2
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d $O2/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --prompt-len 4096 --steps 32 --warmup 4 --cpu-steps 0 --profile-iters 8 > $O2/trace_bench.json 2> $O2/trace.err; echo "cfg2 trace rc=$?" )
+( cd /tmp && timeout 900 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O2/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/bench.py --prompt-len 4096 --steps 8 --warmup 2 --cpu-steps 0 --profile-iters 4 > $O2/pmc_fetch_bench.json 2> $O2/pmc_fetch.err; echo "cfg2 pmc rc=$?" )
 # prefill: per-kernel times and the matrix-core counters, S = 4096, both modes
 cat > /tmp/pf.py <<'PY'
 import lnb, sys

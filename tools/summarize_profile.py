@@ -70,7 +70,8 @@ def one(label):
         for r in csv.DictReader(open(fp)):
             if r["Counter_Name"] == "FETCH_SIZE":
                 fetch[(r["Kernel_Name"], r["Grid_Size"], r.get("LDS_Block_Size", ""))].append(float(r["Counter_Value"]))
-    lines = ["# %s: rocprofv3 summary of `python bench.py%s --steps 32 --warmup 4` (Llama-3.1-8B shape, 1 x MI355X)" % (label, " --mode fast" if "fast" in label else ""), "",
+    lines = ["# %s: rocprofv3 summary of `python bench.py%s%s --steps 32 --warmup 4` (Llama-3.1-8B shape, 1 x MI355X)" % (
+                 label, " --mode fast" if "fast" in label else "", " --prompt-len 4096 (configs[2] decode: long-context attention kernels)" if "cfg2" in label else ""), "",
              "Per-dispatch averages by (kernel, grid, LDS).  `HBM read` = FETCH_SIZE (KB) x 2 / 1024 -- the gfx950 correction of",
              "/opt/skills/guides/MI355X_MICROARCH.md section HBM (wide coalesced reads are tallied at half their bytes); its own --pmc pass.", "",
              "| kernel | class | grid (threads) | LDS B | launches | avg us | HBM read MB (PMC, corrected) | GB/s |", "|---|---|---|---|---|---|---|---|"]
