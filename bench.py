@@ -25,7 +25,6 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "llama-nuts-and-bolts_amd"))
 
-import numpy as np  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 KERNEL_NAMES = ["attn_norm+wqkv+rope GEMV", "attention", "wo+residual GEMV", "ffn_norm+w1|w3+silu GEMV",
