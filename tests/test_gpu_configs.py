@@ -161,6 +161,39 @@ def test_context_beyond_the_reach_of_the_one_workgroup_per_head_kernel(lnb):
     gc.close(); oc.close(); gm.close(); om.close()
 
 
+def test_the_longest_context_the_library_accepts(lnb):
+    """22 000 positions, head_dim 128: close to the limit lnb_ctx_create enforces (the long-context PV kernel keeps p_j for the whole
+    context in the LDS).  The CPU oracle would need minutes for the 22 000-row prefill, so this is a device-side consistency check at
+    full length: the prefill (chunks on the matrix cores; RoPE rows and bf16 positions far beyond the reference's table) feeds decode
+    steps whose attention runs with the CERTIFIED softmax denominator and, on a second context with identical history, with the
+    reference's serial f64 sum -- logits and tokens must agree bit for bit, no certification fallback may have been needed, and the
+    captured loop must continue the eager steps."""
+    cfg = dict(LONG_CFGS["hd128"], max_seq_len=11008)
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(5).finalize()
+    P, chunk = 21984, 2748                                        # 8 chunks: every call keeps T % S == 0 (the reference's mask rule)
+    toks = orc.synth_tokens(11, P, cfg["vocab_size"])
+    ctxs = [lnb.InferenceContext(gm, P + 24).set_attention(512, z) for z in (0, 1)]
+    firsts = []
+    for gc in ctxs:
+        for c0 in range(0, P, chunk):
+            _, tok = gc.Forward(toks[c0:c0 + chunk], c0, want_logits=False)
+        firsts.append(tok)
+    assert firsts[0] == firsts[1]
+    tok = firsts[0]
+    for i in range(4):
+        la, ta = ctxs[0].Forward(np.array([tok], dtype=np.int32), P + i)
+        lb, tb = ctxs[1].Forward(np.array([tok], dtype=np.int32), P + i)
+        assert (_bits(la) == _bits(lb)).all() and ta == tb, i
+        tok = ta
+    assert ctxs[0].zseq_count() == 0 and ctxs[1].zseq_count() > 0
+    ga, _ = ctxs[0].decode_greedy(tok, P + 4, 6)
+    gb, _ = ctxs[1].decode_greedy(tok, P + 4, 6)
+    assert [int(t) for t in ga] == [int(t) for t in gb]
+    for gc in ctxs:
+        gc.close()
+    gm.close()
+
+
 def test_greedy_loop_switches_graphs_at_the_attention_crossover(lnb, long_pair):
     """lnb_decode_greedy replays the short-attention graph up to the crossover context and the long-attention graph beyond it: a run
     that starts below and ends above (default crossover 512, and a crossover in the middle of a short run) equals the oracle's tokens."""
