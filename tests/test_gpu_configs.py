@@ -9,6 +9,8 @@
 * decode -> multi-row Forward -> decode on ONE context (the captured decode graph must not outlive the logits buffer it was
   captured with).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -186,6 +188,23 @@ def test_the_longest_context_the_library_accepts(lnb):
         assert (_bits(la) == _bits(lb)).all() and ta == tb, i
         tok = ta
     assert ctxs[0].zseq_count() == 0 and ctxs[1].zseq_count() > 0
+    if (os.cpu_count() or 1) >= 32 or os.environ.get("LNB_TEST_FORCE_ORACLE") == "1":
+        # with enough host cores (about a minute of them) the oracle walks the same 22 000 positions: same chunks, then two decode steps
+        om = orc.Model(**cfg).fill_synthetic(5).finalize()
+        oc = orc.Context(om, P + 24)
+        for c0 in range(0, P, chunk):
+            _, otok = oc.forward(toks[c0:c0 + chunk], c0, want_logits=False)
+        assert otok == firsts[0]
+        t2 = otok
+        gc2 = lnb.InferenceContext(gm, P + 24)
+        for c0 in range(0, P, chunk):
+            gc2.Forward(toks[c0:c0 + chunk], c0, want_logits=False)
+        for i in range(2):
+            lo, ao = oc.forward([t2], P + i)
+            lg, ag = gc2.Forward(np.array([t2], dtype=np.int32), P + i)
+            assert (_bits(lo) == _bits(lg)).all() and ao == ag, i
+            t2 = ao
+        gc2.close(); oc.close(); om.close()
     ga, _ = ctxs[0].decode_greedy(tok, P + 4, 6)
     gb, _ = ctxs[1].decode_greedy(tok, P + 4, 6)
     assert [int(t) for t in ga] == [int(t) for t in gb]
