@@ -327,3 +327,59 @@ def test_create_rejects_degenerate_arguments_without_crashing(lnb):
     for bad in (dict(n_kv_heads=0), dict(vocab_size=-1), dict(vocab_size=0), dict(n_layers=0), dict(multiple_of=0), dict(dim=0), dict(n_heads=0)):
         with pytest.raises(lnb.LnbError):
             lnb.LlamaTransformer(**dict(orc.TINY, **bad))
+
+
+def test_calls_with_bad_arguments_fail_with_a_message_and_leave_the_handles_usable(lnb):
+    """Every refusal goes through status < 0 + lnb_last_error() (the Go side turns it into an error value): none may crash, hang or
+    poison the context.  Raw ctypes calls, so that nothing is filtered by the Python wrapper."""
+    import ctypes as C
+    L = lnb.lib()
+    cfg = dict(orc.TINY)
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(3).finalize()
+    om = orc.Model(**cfg).fill_synthetic(3).finalize()
+    out = C.c_void_p()
+    assert L.lnb_ctx_create(gm.h, 10 ** 9, C.byref(out)) != 0 and b"too long" in L.lnb_last_error()
+    for seq_len in (0, -5):                                                  # SequenceLength <= 0 means the model's MaxSequenceLength (inferencecontext.go:22-26)
+        assert L.lnb_ctx_create(gm.h, seq_len, C.byref(out)) == 0 and out.value
+        kv = np.zeros((cfg["max_seq_len"], cfg["n_kv_heads"] * (cfg["dim"] // cfg["n_heads"])), dtype=np.uint16)
+        assert L.lnb_ctx_read_kv(out, 0, 1, kv.ctypes.data_as(C.c_void_p)) == 0 and not kv.any()      # max_seq_len rows of zeros (ml.Zeros)
+        L.lnb_ctx_destroy(out)
+    assert L.lnb_ctx_create(None, 16, C.byref(out)) != 0
+    gc = lnb.InferenceContext(gm, 24)
+    toks = np.ascontiguousarray(orc.synth_tokens(1, 8, cfg["vocab_size"]), dtype=np.int32)
+    tp = toks.ctypes.data_as(C.c_void_p)
+    am = C.c_int32(0)
+    bad_calls = [
+        lambda: L.lnb_forward(gc.h, tp, 0, 0, None, C.byref(am)),            # empty token array
+        lambda: L.lnb_forward(gc.h, tp, -3, 0, None, C.byref(am)),
+        lambda: L.lnb_forward(gc.h, None, 8, 0, None, C.byref(am)),          # null tokens
+        lambda: L.lnb_forward(gc.h, tp, 8, -1, None, C.byref(am)),           # negative start
+        lambda: L.lnb_forward(gc.h, tp, 8, 20, None, C.byref(am)),           # beyond the context
+        lambda: L.lnb_forward(gc.h, tp, 8, 2 ** 31 - 4, None, C.byref(am)),  # start_pos + seq overflows int
+        lambda: L.lnb_forward(None, tp, 8, 0, None, C.byref(am)),
+        lambda: L.lnb_decode_greedy(gc.h, 5, 0, 0, tp, None),                # zero steps
+        lambda: L.lnb_decode_greedy(gc.h, 5, 0, -2, tp, None),
+        lambda: L.lnb_decode_greedy(gc.h, 5, 20, 8, tp, None),               # runs past the context
+        lambda: L.lnb_decode_greedy(gc.h, -1, 0, 2, tp, None),               # token outside the vocabulary
+        lambda: L.lnb_decode_greedy(gc.h, cfg["vocab_size"], 0, 2, tp, None),
+        lambda: L.lnb_decode_greedy(gc.h, 5, 0, 2, None, None),              # no output buffer
+        lambda: L.lnb_ctx_read_kv(gc.h, 99, 0, tp),
+        lambda: L.lnb_ctx_read_kv(gc.h, -1, 0, tp),
+        lambda: L.lnb_ctx_read_kv(gc.h, 0, 0, None),
+        lambda: L.lnb_ctx_set_mode(gc.h, 7),
+        lambda: L.lnb_profile_kernel(gc.h, 99, 0, 4, C.byref(C.c_float(0))),
+        lambda: L.lnb_profile_kernel(gc.h, 1, 0, 0, C.byref(C.c_float(0))),
+        lambda: L.lnb_forward_stage_end(gc.h, None),                         # end without begin
+    ]
+    for i, call in enumerate(bad_calls):
+        assert call() != 0, i
+        assert len(L.lnb_last_error()) > 0, i
+    bad_tok = toks.copy(); bad_tok[3] = cfg["vocab_size"] + 7                 # a token id outside the vocabulary: reported with its index
+    assert L.lnb_forward(gc.h, bad_tok.ctypes.data_as(C.c_void_p), 8, 0, None, C.byref(am)) != 0 and b"index 3" in L.lnb_last_error()
+    # ... and the context still generates the oracle's tokens
+    gc.reset()
+    _, first = gc.Forward(toks, 0, want_logits=False)
+    got, _ = gc.decode_greedy(first, 8, 6)
+    ref, _ = orc.Context(om, 24).generate(toks, 7)
+    assert [first] + [int(t) for t in got] == [int(t) for t in ref]
+    gc.close(); gm.close(); om.close()
