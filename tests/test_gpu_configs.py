@@ -383,3 +383,44 @@ def test_calls_with_bad_arguments_fail_with_a_message_and_leave_the_handles_usab
     ref, _ = orc.Context(om, 24).generate(toks, 7)
     assert [first] + [int(t) for t in got] == [int(t) for t in ref]
     gc.close(); gm.close(); om.close()
+
+
+def test_model_and_pipe_api_misuse_is_refused(lnb):
+    import ctypes as C
+    L = lnb.lib()
+    cfg = dict(orc.TINY)
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(3)
+    out = C.c_void_p()
+    assert L.lnb_ctx_create(gm.h, 16, C.byref(out)) != 0 and b"not finalized" in L.lnb_last_error()
+    pipe = C.c_void_p()
+    assert L.lnb_pipeline_init(gm.h, 0, 1, None, C.byref(pipe)) != 0 and b"not finalized" in L.lnb_last_error()
+    gm.finalize()
+    w = np.zeros((cfg["vocab_size"], cfg["dim"]), dtype=np.uint16)
+    shape = (C.c_int64 * 2)(cfg["vocab_size"], cfg["dim"])
+    assert L.lnb_model_set_tensor(gm.h, b"output.weight", None, shape, 2) != 0                                  # null data
+    assert L.lnb_model_set_tensor(gm.h, b"output.weight", w.ctypes.data_as(C.c_void_p), shape, 7) != 0         # absurd rank
+    assert L.lnb_model_get_tensor(gm.h, b"output.weight", w.ctypes.data_as(C.c_void_p), 5) != 0               # buffer too small
+    assert L.lnb_model_get_tensor(gm.h, b"no.such", w.ctypes.data_as(C.c_void_p), w.size) != 0
+    nm, shp, rk = C.c_char_p(), (C.c_int64 * 2)(), C.c_int(0)
+    assert L.lnb_model_tensor_info(gm.h, -1, C.byref(nm), shp, C.byref(rk)) != 0
+    assert L.lnb_model_tensor_info(gm.h, 10 ** 6, C.byref(nm), shp, C.byref(rk)) != 0
+    # pipe: ranks, foreign contexts, tokens on the wrong stage, a multi-row step without tokens
+    assert L.lnb_pipeline_init(gm.h, 1, 1, None, C.byref(pipe)) != 0 and L.lnb_pipeline_init(gm.h, 0, 0, None, C.byref(pipe)) != 0
+    assert L.lnb_pipeline_init(gm.h, 0, 2, None, C.byref(pipe)) != 0                                            # world 2 on a whole model
+    p1 = lnb.Pipeline(gm, 0, 1)
+    other = lnb.LlamaTransformer(**cfg).fill_synthetic(4).finalize()
+    oc, gc = lnb.InferenceContext(other, 16), lnb.InferenceContext(gm, 16)
+    slot = C.c_int(0)
+    toks = np.ascontiguousarray(orc.synth_tokens(1, 4, cfg["vocab_size"]), dtype=np.int32)
+    tp = toks.ctypes.data_as(C.c_void_p)
+    assert L.lnb_pipeline_tick(p1.h, oc.h, 4, 0, tp, None, 0, None, 0, C.byref(slot)) != 0 and b"another model" in L.lnb_last_error()
+    assert L.lnb_pipeline_tick(p1.h, gc.h, 4, 0, None, None, 0, None, 0, C.byref(slot)) != 0                    # multi-row step without tokens
+    assert L.lnb_pipeline_tick(p1.h, gc.h, 4, 14, tp, None, 0, None, 0, C.byref(slot)) != 0                     # beyond the context
+    assert L.lnb_pipeline_tick(p1.h, gc.h, 0, 0, tp, None, 0, None, 0, C.byref(slot)) != 0                      # no rows
+    assert L.lnb_pipeline_read_tokens(p1.h, 0, 1, tp) != 0                                                      # nothing logged yet
+    assert L.lnb_pipeline_tick(p1.h, gc.h, 4, 0, tp, None, 0, None, 0, C.byref(slot)) == 0 and slot.value == 0  # ... and a good tick still works
+    assert L.lnb_pipeline_sync(p1.h) == 0
+    om = orc.Model(**cfg).fill_synthetic(3).finalize()
+    _, ref = orc.Context(om, 16).forward(toks, 0, want_logits=False)
+    assert int(p1.read_tokens(0, 1)[0]) == ref
+    p1.close(); oc.close(); gc.close(); other.close(); gm.close(); om.close()
