@@ -1380,7 +1380,7 @@ constexpr int ATT_JC = 64;                                  // cached positions 
 __host__ __device__ inline size_t attn_off_pw(int seq_len) { return (((size_t)seq_len + 32) * 8 + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t attn_off_q(int seq_len) { return attn_off_pw(seq_len) + ((((size_t)seq_len + ATT_JC) * 4 + 15) & ~(size_t)15); }
 __host__ __device__ inline size_t attn_off_z(int seq_len, int hd) { return attn_off_q(seq_len) + (((size_t)hd * 4 + 15) & ~(size_t)15); }
-__host__ __device__ inline size_t attn_off_ring(int seq_len, int hd) { return attn_off_z(seq_len, hd) + 16; }
+__host__ __device__ inline size_t attn_off_ring(int seq_len, int hd) { return attn_off_z(seq_len, hd) + 128; }   // zb: Z | - | flag | - | 8 wave partials
 
 constexpr int ATT_NT = 512;                                 // 8 waves: two per SIMD (one wave alone issues ~1 instruction / 4.4 cycles)
 constexpr int ATT_NPROD = 4;                                // PV: waves 0,1 add; waves 2,3,6,7 produce; waves 4,5 share the adders' SIMDs and
@@ -1471,6 +1471,31 @@ template <int HD> DEVINL void attn_pv_add(int c, int nchunks, int d, const char*
     __syncthreads();
 }
 
+// p_j = trunc_bf16(f32(e / Z)) evaluated with an ESTIMATE Zt of the reference's serial f64 sum Z, and certified: any order of adding T
+// non-negative doubles is within (T-1) 2^-53 of the exact sum, so Z lies in Zt (1 +- eps), eps = (4T + 8) 2^-53 -- and p is a step
+// function of Z.  The quotient is formed as e * (1 / Zt) (within 2 ulps of e / Zt); it must not lie within delta32 = 4T + 12 ulps of the
+// one point per bf16 cell where the result changes (low 45 mantissa bits = 2^45 - 2^28); f32-denormal quotients are certified by
+// evaluating both ends of the interval.  Returns p; sets bad when the element cannot be certified (the caller then walks the serial sum).
+// (Header of attn_long_pv_kernel / DESIGN.md 5.9.)
+struct CertZ { double rzt, zlo, zhi; unsigned delta32; };
+DEVINL CertZ cert_z(double zt, int T) {
+    const double epsr = (double)(4 * T + 8) * 1.1102230246251565e-16;
+    CertZ c; c.rzt = 1.0 / zt; c.zlo = zt * (1.0 - epsr); c.zhi = zt * (1.0 + epsr); c.delta32 = 4u * (unsigned)T + 12u;
+    return c;
+}
+DEVINL float cert_p(double e, const CertZ& c, int& bad) {
+    const double q = e * c.rzt;
+    const float pj = bf_wide(bf_trunc((float)q));
+    const unsigned qh = (unsigned)__double2hiint(q), ql = (unsigned)__double2loint(q);
+    const unsigned eq = (qh >> 20) & 0x7FFu;
+    if (eq - 897u <= 126u) {                                 // f32-normal quotient (2^-126 <= q < 2): distance from the step point of its bf16 cell
+        if ((qh & 0x1FFFu) == 0x1FFFu && ql - (0xF0000000u - c.delta32) <= 2u * c.delta32) bad = 1;
+    } else if (q != 0.0) {                                   // f32 denormals, and anything that is not a finite in-range quotient (inf, NaN)
+        const float plo = bf_wide(bf_trunc((float)(e / c.zlo))), phi = bf_wide(bf_trunc((float)(e / c.zhi)));
+        if (__float_as_uint(plo) != __float_as_uint(phi) || __float_as_uint(pj) != __float_as_uint(plo)) bad = 1;
+    }
+    return pj;
+}
 template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NK = HD / 8;
@@ -1532,43 +1557,65 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     ATT_STAMP(2);
     __syncthreads();
     ATT_STAMP(3);
-    if (wave == 0) {                                         // rowExpSum += exp(...), j ascending, f64 (impl:492-499)
-        typedef double d2 __attribute__((ext_vector_type(2)));
-        const d2* e2 = (const d2*)e;
-        double z = 0.0;
-        d2 a[8], b[8];
-#define ATT_TOUCH8(r) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]))
+    // ---- softmax denominator.  The reference adds the T exponentials one by one in f64 (impl:492-499): ~9 cycles per position on one
+    // wave (1.1 us at T = 272, 2 us at 512).  As in the long-context kernels it is replaced by a tree estimate + CERTIFIED p_j
+    // (cert_p); only a row that cannot be certified (or force_zseq) walks the serial sum.
+    int* const zflag = (int*)(zb + 2);
+    {
+        double part = 0.0;
+        for (int j = tid; j < T; j += ATT_NT) part += e[j];
 #pragma unroll
-        for (int u = 0; u < 8; u++) a[u] = e2[u];
-        ATT_TOUCH8(a);
-        for (int j = 0; j < T; j += 32) {                    // 16 values per half, the other half's reads in flight, one wait per half;
-                                                             // branch-free (e is zero-padded to 32): a conditional second half made
-                                                             // hipcc sink the adds below the wait and expose the LDS latency
-#pragma unroll
-            for (int u = 0; u < 8; u++) b[u] = e2[((j + 16) >> 1) + u];
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 8; u++) { z += a[u].x; z += a[u].y; }
-            __builtin_amdgcn_sched_barrier(0);
-            ATT_TOUCH8(b);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = e2[((j + 32) >> 1) + u];      // may run into the p / ring region: unused then
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int u = 0; u < 8; u++) { z += b[u].x; z += b[u].y; }
-            __builtin_amdgcn_sched_barrier(0);
-            ATT_TOUCH8(a);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (lane == 0) zb[0] = z;
+        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        if (lane == 0) zb[4 + wave] = part;
+        if (tid == 0) *zflag = 0;
+    }
+    __syncthreads();
+    const int Tp = (T + ATT_JC - 1) / ATT_JC * ATT_JC;
+    {
+        const double zt = ((zb[4] + zb[5]) + (zb[6] + zb[7])) + ((zb[8] + zb[9]) + (zb[10] + zb[11]));
+        const CertZ cz = cert_z(zt, T);
+        int bad = p.force_zseq;
+        for (int j = tid; j < Tp; j += ATT_NT)               // impl:506 + ToBFloat16 :493 ; +0 padding up to the chunk
+            pw[j] = j < T ? cert_p(e[j], cz, bad) : 0.0f;
+        if (bad) *zflag = 1;
     }
     ATT_STAMP(4);
     __syncthreads();
-    const double z = zb[0];
-    const int Tp = (T + ATT_JC - 1) / ATT_JC * ATT_JC;
-    for (int j = tid; j < Tp; j += ATT_NT)                   // impl:506 + ToBFloat16 :493 ; +0 padding up to the chunk
-        pw[j] = j < T ? bf_wide(bf_trunc((float)(e[j] / z))) : 0.0f;
+    if (*zflag) {
+        if (wave == 0) {                                     // rowExpSum += exp(...), j ascending, f64 (impl:492-499)
+            typedef double d2 __attribute__((ext_vector_type(2)));
+            const d2* e2 = (const d2*)e;
+            double z = 0.0;
+            d2 a[8], b[8];
+#define ATT_TOUCH8(r) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]))
+#pragma unroll
+            for (int u = 0; u < 8; u++) a[u] = e2[u];
+            ATT_TOUCH8(a);
+            for (int j = 0; j < T; j += 32) {                // 16 values per half, the other half's reads in flight, one wait per half;
+                                                             // branch-free (e is zero-padded to 32)
+#pragma unroll
+                for (int u = 0; u < 8; u++) b[u] = e2[((j + 16) >> 1) + u];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++) { z += a[u].x; z += a[u].y; }
+                __builtin_amdgcn_sched_barrier(0);
+                ATT_TOUCH8(b);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++) a[u] = e2[((j + 32) >> 1) + u];      // may run into the p / ring region: unused then
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int u = 0; u < 8; u++) { z += b[u].x; z += b[u].y; }
+                __builtin_amdgcn_sched_barrier(0);
+                ATT_TOUCH8(a);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (lane == 0) { zb[0] = z; if (p.zseq_count && tid == 0) atomicAdd(p.zseq_count, 1); }
+        }
+        __syncthreads();
+        const double z = zb[0];
+        for (int j = tid; j < T; j += ATT_NT) pw[j] = bf_wide(bf_trunc((float)(e[j] / z)));
+    }
     __syncthreads();
     ATT_STAMP(5);
 

@@ -103,9 +103,9 @@ def test_long_context_prefill_and_decode_bit_exact(lnb, long_pair, chunks, steps
 
 @pytest.mark.parametrize("P", [3, 70, 300, 700])
 def test_long_context_attention_kernels_equal_the_oracle_at_every_context(lnb, long_pair, P):
-    """attn_long_scores_kernel + attn_long_pv_kernel forced on at every T (threshold 0), with the certified tree estimate of the
-    softmax denominator and with the serial f64 sum forced (force_zseq), against the one-workgroup-per-head kernel (threshold off)
-    and the oracle: identical logits bits, identical KV."""
+    """attn_long_scores_kernel + attn_long_pv_kernel forced on at every T (threshold 0) and the one-workgroup-per-head kernel (threshold
+    off), each with the certified tree estimate of the softmax denominator and with the serial f64 sum forced (force_zseq), against
+    the oracle: identical logits bits, identical KV; no certification fallback unless forced."""
     cfg, om, gm = long_pair
     toks = orc.synth_tokens(5000 + P, P, cfg["vocab_size"])
     oc = orc.Context(om, P + 8)
@@ -114,7 +114,7 @@ def test_long_context_attention_kernels_equal_the_oracle_at_every_context(lnb, l
     for i in range(4):
         lo, tok_n = oc.forward([tok], P + i)
         ref.append((lo, tok_n)); tok = tok_n
-    for thr, zseq in ((10 ** 9, 0), (0, 0), (0, 1)):
+    for thr, zseq in ((10 ** 9, 0), (10 ** 9, 1), (0, 0), (0, 1)):
         gc = lnb.InferenceContext(gm, P + 8).set_attention(thr, zseq)
         _, t0 = gc.Forward(toks, 0, want_logits=False)
         assert t0 == tok0
@@ -124,8 +124,10 @@ def test_long_context_attention_kernels_equal_the_oracle_at_every_context(lnb, l
             assert (_bits(ref[i][0]) == _bits(lg)).all() and tg == ref[i][1], (thr, zseq, i)
             tok = tg
         n = gc.zseq_count()
-        if thr == 0:                                                          # 4 steps x layers x heads rows went through the long kernels
-            assert (n == 4 * cfg["n_layers"] * cfg["n_heads"]) if zseq else (n == 0), n
+        # rows that took the serial walk: none unless forced; forced: the 4 decode steps (either kernel form) plus the prompt's rows when
+        # the prompt is short enough to run on the one-workgroup kernel (fewer than 16 rows), x layers x heads
+        rows = 4 + (P if P < 16 else 0)
+        assert n == (rows * cfg["n_layers"] * cfg["n_heads"] if zseq else 0), (thr, zseq, n)
         for layer in range(cfg["n_layers"]):
             assert (oc.cache(layer, 0)[:P + 4] == gc.CacheK(layer)[:P + 4]).all() and (oc.cache(layer, 1)[:P + 4] == gc.CacheV(layer)[:P + 4]).all()
         gc.close()
