@@ -154,6 +154,60 @@ def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens):
             "note": "aggregate of independent prompts on ONE GPU; weights are re-read per sequence (no batching: every token keeps its own exact chains)"}
 
 
+def traffic_child(lnb, cfg, args):
+    """Runs under `rocprofv3 --pmc FETCH_SIZE` (probe_traffic): the same shape cut to two layers, a short prompt, then the dominant decode
+    kernel class launched 24 times, alternating between the layers so that every launch streams its weights from HBM."""
+    cfg = dict(cfg, n_layers=min(cfg["n_layers"], 2))
+    pos = args.traffic_pos
+    model = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize(rope_rows=max(pos + 16, 2 * cfg["max_seq_len"]))
+    ctx = lnb.InferenceContext(model, pos + 8).set_mode(args.mode)
+    ctx.Forward(lnb.synth_tokens(99, 16, cfg["vocab_size"]), 0, want_logits=False)
+    ctx.profile_kernel(args.traffic_child, pos, 24)
+    ctx.close(); model.close()
+    return 0
+
+
+def probe_traffic(args, dom, pos):
+    """HBM bytes per launch of the dominant kernel, measured in THIS run: PMC counters cannot be read from inside a process, so a child
+    (traffic_child) is run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (a counter pass of its own, no other trace domains) and its
+    counter file is read back.  FETCH_SIZE is in KiB and tallies wide coalesced reads at half their bytes on gfx950 (MI355X_MICROARCH.md,
+    section HBM): bytes = KiB x 1024 x 2.  None when rocprofv3 is missing, when this process already runs under it, or on any failure
+    (the committed profile's number is reported then, flagged as not measured in the run)."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    rp = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if os.environ.get("ROCP_TOOL_LIBRARIES") or not os.path.exists(rp):
+        return None
+    tmp = tempfile.mkdtemp(prefix="lnb_traffic_", dir="/tmp")
+    try:
+        cmd = [rp, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
+               os.path.abspath(__file__), "--traffic-child", str(dom), "--traffic-pos", str(pos), "--model", args.model, "--mode", args.mode]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
+        if r.returncode != 0:
+            return None
+        per = {}
+        for root, _, files in os.walk(tmp):
+            for fn in files:
+                if fn.endswith("counter_collection.csv"):
+                    for row in csv.DictReader(open(os.path.join(root, fn))):
+                        if row.get("Counter_Name") == "FETCH_SIZE":
+                            per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+        per = {k: v for k, v in per.items() if len(v) >= 20}          # the looped class (24 + 3 warm-up launches); the prompt's kernels ran twice
+        if not per:
+            return None
+        kname, vals = max(per.items(), key=lambda kv: sum(kv[1]))     # (the long-context attention is two kernels: the heavier one)
+        total = sum(sum(v) / len(v) for v in per.values())
+        return {"bytes_per_launch": int(total * 1024 * 2), "launches": len(vals),
+                "source": "this run: rocprofv3 --pmc FETCH_SIZE over %d launches of %s (child process, two layers of the shape), KiB x 1024 x 2 (gfx950 correction)"
+                          % (len(vals), kname.split("(")[0][:80])}
+    except Exception:                                                  # the probe must never take the bench line down
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -163,6 +217,9 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=24, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-iters", type=int, default=64)
     ap.add_argument("--concurrent", type=int, default=8, help="also time this many independent prompts in flight on the one GPU (0/1 = skip)")
+    ap.add_argument("--no-traffic-probe", action="store_true", help="do not run the rocprofv3 FETCH_SIZE pass of the dominant kernel")
+    ap.add_argument("--traffic-child", type=int, default=-1, help=argparse.SUPPRESS)      # internal: kernel class to loop under rocprofv3
+    ap.add_argument("--traffic-pos", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--model", default="llama8b", choices=["llama8b", "tiny", "llama70b-like"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"],
                     help="exact (default, headline): the reference's k-ordered chains, token-identical to the CPU path; "
@@ -180,6 +237,8 @@ def main():
         cfg.update(dim=8192, n_layers=80, n_heads=64, n_kv_heads=8, multiple_of=4096)
         name = "random-init Llama-shape dim=8192 n_layers=80"
 
+    if args.traffic_child >= 0:
+        return traffic_child(lnb, cfg, args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("LNB_FORCE_PIPELINE") == "1":     # (the env switch runs the N-GPU code path on one GPU)
         import pipeline
@@ -221,9 +280,12 @@ def main():
     dom = max(range(6), key=lambda i: (1 if i == 5 else cfg["n_layers"]) * kernels[KERNEL_NAMES[i]]["ms"])
     dom_ms = kernels[KERNEL_NAMES[dom]]["ms"]
     traffic, traffic_src, traffic_head = pmc_traffic(KERNEL_NAMES[dom], name, args.mode)
+    traffic_live = None if args.no_traffic_probe else probe_traffic(args, dom, int(Tbar) - 1)
+    if traffic_live:
+        traffic, traffic_src, traffic_head = traffic_live["bytes_per_launch"], traffic_live["source"], None
     roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "achieved": round(kb[dom] / dom_ms / 1e6, 1), "peak": PEAK_HBM_GBS,
                 "unit": "GB/s", "frac": round(kb[dom] / dom_ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_measured_in_run": False, "traffic_profile_git_head": traffic_head,
+                "traffic_measured_in_run": bool(traffic_live), "traffic_profile_git_head": traffic_head,
                 "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": dom_ms,
                 "whole_step": {"achieved": round(tps * B / 1e9, 1), "frac": round(tps * B / 1e9 / PEAK_HBM_GBS, 4),
                                "algorithmic_bytes_per_token": int(B), "mean_context": Tbar,
