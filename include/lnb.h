@@ -12,7 +12,8 @@
  * (the reference's weight tensors are sub-slices of an mmap, src/torch/types.go:51-55).
  * Handles: lnb_model is immutable after lnb_model_finalize and may be shared by several lnb_ctx
  * (reference: the transformer is read-only after construction, one InferenceContext per GenerateString
- * call, src/inference/inference.go:174); an lnb_ctx must be used by one thread at a time.
+ * call, src/inference/inference.go:174); an lnb_ctx must be used by one thread at a time.  The entry points
+ * may be mixed on one context (ticks, lnb_forward, lnb_decode_greedy, lnb_profile_kernel): each one re-establishes the device-side position.
  */
 #ifndef LNB_H
 #define LNB_H
@@ -92,8 +93,10 @@ int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which /*0=K 1=V*/, uint16_t* host
 /* Arithmetic mode of a context.  LNB_MODE_EXACT (default): every matmul output is the reference's single k-ordered f32 chain
  * (src/ml/operations_lineartransform.go:46-65), every intermediate bit-identical to the Go CPU path.  LNB_MODE_FAST: the same
  * operators and bf16 truncation points with split-K f32 sums (decode) and bf16 matrix-core GEMMs (prefill): HBM / MFMA bound instead
- * of add-latency bound, logits within the 1e-2 tolerance of the north star but NOT bit-identical, token ids may diverge (measured:
- * DESIGN.md 6.2).  Opt-in, per context, switchable between calls; the KV cache is shared by both modes. */
+ * of add-latency bound.  NOT a parity mode: per operator it stays within one bf16 ulp of the chain, but after 32 blocks the logits are
+ * NOT within the north star's 1e-2 of the reference's (measured on the 8B shape: max |dlogit| 0.578, argmax differs in 13.9 % of
+ * teacher-forced steps -- DESIGN.md 6.2) and token ids diverge.  Opt-in, per context, switchable between calls; the KV cache is
+ * shared by both modes. */
 enum { LNB_MODE_EXACT = 0, LNB_MODE_FAST = 1 };
 int lnb_ctx_set_mode(lnb_ctx* c, int mode);
 int lnb_ctx_get_mode(const lnb_ctx* c);
@@ -166,7 +169,9 @@ int lnb_pipeline_unique_id(void* id128);                       /* rank 0: ncclGe
 int lnb_pipeline_init(lnb_model* stage, int rank, int world, const void* id128, lnb_pipe** out);   /* world == 1: no communicator, the token ring is a device copy */
 /* the same pipe with an IN-PROCESS transport instead of RCCL: every stage lives in this process (pipes that name the same `group`), a send
  * meets its receive in a mailbox and becomes a device-to-device copy.  Same ticks, events and graphs; for single-process hosts and for
- * testing a schedule where RCCL cannot run (it wants one GPU per rank) */
+ * testing a schedule where RCCL cannot run (it wants one GPU per rank).  All stages of a group must live on ONE device and be ticked from
+ * ONE host thread in lock-step order (a stage on another device is refused; running a sequence whose input has been requested but not
+ * yet posted by its sender is an error, not a read of stale data) */
 int lnb_pipeline_init_loopback(lnb_model* stage, int rank, int world, const char* group, lnb_pipe** out);
 int lnb_pipeline_destroy(lnb_pipe* p);
 int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,

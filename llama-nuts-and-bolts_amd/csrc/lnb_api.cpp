@@ -113,7 +113,28 @@ struct lnb_ctx {
     hipEvent_t ev_done = nullptr, ev_in = nullptr, ev_sent = nullptr;
     bool in_pending = false, sent_pending = false;
     int dev_pos = -1;                      // position the device-side StepState will hold when the stream reaches this point (-1: unknown)
+    int call_T = 0;                        // start_pos + rows of the call being enqueued (0: not known to the host, e.g. inside a replayed graph)
+    hipEvent_t ev_h2d = nullptr; bool h2d_pending = false;   // the last copy out of the pinned staging words h_io[2..] (enqueue-only paths)
+    bool recv_unmatched = false;           // in-process transport: a receive into this context is posted and its sender has not arrived yet
 };
+// Every path that rewrites the device-side StepState goes through here, so that the pipeline tick's "the graph left pos+1 behind, skip
+// the set_state launch" shortcut (dev_pos) can never act on a position some OTHER entry point has since overwritten (lnb_forward,
+// lnb_decode_greedy and lnb_profile_kernel may be mixed with ticks on one context).  known = false: the caller is about to advance
+// the state on the device by itself (greedy loop) and the host stops tracking it.
+static hipError_t ctx_set_state(lnb_ctx* c, int pos, int n_out, bool known) {
+    c->dev_pos = known ? pos : -1;
+    return lnbk_set_state(c->st, pos, n_out, c->stream);
+}
+// the pinned staging words h_io[2..] are reused by every enqueue-only call that takes host tokens: wait for the copy that still reads them
+static int staging_acquire(lnb_ctx* c) {
+    if (c->h2d_pending) { HIPCHK(hipEventSynchronize(c->ev_h2d)); c->h2d_pending = false; }
+    return 0;
+}
+static int staging_release(lnb_ctx* c) {
+    if (!c->ev_h2d) HIPCHK(hipEventCreateWithFlags(&c->ev_h2d, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(c->ev_h2d, c->stream)); c->h2d_pending = true;
+    return 0;
+}
 
 // every captured graph of a context bakes in its buffers, its arithmetic mode and its attention form: whatever changes one of those drops them all
 static void drop_graphs(lnb_ctx* c) {
@@ -474,6 +495,7 @@ extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     if (c->ev_done) hipEventDestroy(c->ev_done);
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
+    if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
     hipFree(c->e_buf); hipFree(c->z_part); hipFree(c->zseq_count);
     for (auto p : c->ck) if (p) hipFree(p);
     for (auto p : c->cv) if (p) hipFree(p);
@@ -606,6 +628,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
         AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st; ap.dbg = g_dbg;
         ap.S = S; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = c->seq_len;
         ap.lds_T = c->seq_len < c->attn_short_cap ? c->seq_len : c->attn_short_cap;
+        ap.host_T = c->call_T;
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
         ap.mfma = use_mfma(S) ? 1 : 0; ap.exp_tab = m->exp_tab;
         ap.longctx = (S == 1 && c->attn_long) ? 1 : 0; ap.force_zseq = c->force_zseq; ap.e_buf = c->e_buf; ap.z_part = c->z_part; ap.zseq_count = c->zseq_count;
@@ -670,9 +693,13 @@ static int check_call(lnb_ctx* c, int seq, int start_pos) {
     if (T > c->m->cis_rows) return fail("incompatible locStart, locEnd values and tensor (position %d beyond the %d-row RoPE table)", T, c->m->cis_rows);
     if (T > c->seq_len) return fail("incompatible locStart, locEnd values and tensor (position %d beyond the KV cache of %d)", T, c->seq_len);
     if (seq > 1 && T % seq != 0) return fail("two tensor shapes cannot be broadcasted: [%d %d %d] and [%d %d]", c->m->a.n_heads, seq, T, seq, seq);
-    if (seq > 1 && !use_mfma(seq) && T > c->attn_short_cap)
-        return fail("a call of %d rows (2..15) at context %d: the row-per-workgroup attention kernel stages at most %d positions in the LDS; "
-                    "use one-token calls or 16 or more rows there", seq, T, c->attn_short_cap);
+    // calls of 2.. rows that do NOT run on the matrix-core attention (fewer than 16 rows, or head_dim 32, which attn_mfma_kernel does not
+    // take) go through the row-per-workgroup kernel, whose LDS arrays are sized for attn_short_cap positions
+    const bool mfma_attn = use_mfma(seq) && (c->m->head_dim == 64 || c->m->head_dim == 128);
+    c->call_T = T;
+    if (seq > 1 && !mfma_attn && T > c->attn_short_cap)
+        return fail("a call of %d rows (2..15, or any multi-row call at head_dim 32) at context %d: the row-per-workgroup attention kernel stages "
+                    "at most %d positions in the LDS; use one-token calls or 16 or more rows there", seq, T, c->attn_short_cap);
     return 0;
 }
 
@@ -690,10 +717,12 @@ extern "C" int lnb_forward_stage_begin(lnb_ctx* c, const int32_t* tokens, int se
     if (want_argmax && !m->last()) return fail("logits requested from a stage that does not own output.weight");
     hipStream_t st = c->stream;
     c->attn_long = want_long_attention(c, seq, start_pos);
-    HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
+    HIPCHK(ctx_set_state(c, start_pos, 0, true));
     if (tokens) {
+        if (staging_acquire(c)) return -1;
         memcpy(c->h_io + 2, tokens, (size_t)seq * 4);        // the caller's array need not outlive this call
         HIPCHK(hipMemcpyAsync(c->dtok, c->h_io + 2, (size_t)seq * 4, hipMemcpyHostToDevice, st));
+        if (staging_release(c)) return -1;
         HIPCHK(hipMemsetAsync(c->derr, 0, 4, st));
         HIPCHK(lnbk_embed(m->tok_embd, c->dtok, c->x, seq, m->a.dim, V, c->derr, st));       // Fwd_Get_Rows :118
         HIPCHK(hipMemcpyAsync(c->h_io + 1, c->derr, 4, hipMemcpyDeviceToHost, st));
@@ -732,7 +761,7 @@ extern "C" int lnb_forward_stage(lnb_ctx* c, const int32_t* tokens, int seq, int
     if ((logits_out || argmax_last_out) && !m->last()) return fail("logits requested from a stage that does not own output.weight");
     hipStream_t st = c->stream;
     c->attn_long = want_long_attention(c, seq, start_pos);
-    HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
+    HIPCHK(ctx_set_state(c, start_pos, 0, true));
     if (tokens) {
         HIPCHK(hipMemcpyAsync(c->dtok, tokens, (size_t)seq * 4, hipMemcpyHostToDevice, st));
         HIPCHK(hipMemsetAsync(c->derr, 0, 4, st));
@@ -810,7 +839,8 @@ extern "C" int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n
     if (use_graph && any_long && capture(&c->graph_long, true)) return -1;
     HIPCHK(hipMemcpyAsync(c->dtok, &token, 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(c->derr, 0, 4, st));
-    HIPCHK(lnbk_set_state(c->st, start_pos, 0, st));
+    HIPCHK(ctx_set_state(c, start_pos, 0, false));          // the argmax kernel advances the position on the device from here on
+    c->call_T = 0;                                           // (the captured graphs serve every position: nothing host-side to validate)
     HIPCHK(hipEventRecord(c->ev0, st));
     for (int i = 0; i < n_steps; i++) {
         const bool longctx = want_long_attention(c, 1, start_pos + i);
@@ -835,7 +865,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     if (which == K_HEAD && !m->last()) return fail("this stage does not own output.weight");
     hipStream_t st = c->stream;
     c->attn_long = want_long_attention(c, 1, pos);
-    HIPCHK(lnbk_set_state(c->st, pos, 0, st));
+    HIPCHK(ctx_set_state(c, pos, 0, true));
     const int nl = m->layer_end - m->layer_begin;
     // consecutive launches walk through the layers so that every launch streams its weights from HBM
     // (one layer's 235 MB gate/up matrix would otherwise sit in the 256 MiB Infinity Cache)
@@ -907,7 +937,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
 // graphs as the RCCL transport -- what it replaces is only ncclSend / ncclRecv.  Used to test host schedules where RCCL cannot run
 // (two ranks need two GPUs) and by single-process multi-GPU hosts.
 struct LoopMsg { lnb_ctx* ctx; int rows; };
-struct LoopGroup { std::map<std::pair<int, int>, std::deque<LoopMsg>> sends, recvs; int users = 0; };
+struct LoopGroup { std::map<std::pair<int, int>, std::deque<LoopMsg>> sends, recvs; int users = 0; int device = -1; };
 static std::map<std::string, LoopGroup> g_loops;
 static std::mutex g_loops_mu;
 
@@ -970,8 +1000,18 @@ extern "C" int lnb_pipeline_init_loopback(lnb_model* m, int rank, int world, con
     if (e == hipSuccess) { p->tok_cap = pipe_log_cap(); e = hipHostMalloc((void**)&p->h_tok, (size_t)p->tok_cap * 4, hipHostMallocDefault); }
     if (e != hipSuccess) { fail("pipeline init: %s", hipGetErrorString(e)); if (p->xs) hipStreamDestroy(p->xs); delete p; return -1; }
     if (world > 1) {
+        // The mailbox transport records a context's events on whichever pipe's exchange stream posts second, and a context's flags are
+        // plain fields: every stage of a group must live on ONE device and be ticked from ONE host thread in lock-step order (what the
+        // tests and single-process hosts do).  One stage per GPU is the RCCL transport's job (lnb_pipeline_init).
         std::lock_guard<std::mutex> lock(g_loops_mu);
-        p->loop_tag = group; p->loop = &g_loops[p->loop_tag]; p->loop->users++;
+        LoopGroup& g = g_loops[group];
+        if (g.users > 0 && g.device != m->device) {
+            const int have = g.device;
+            hipStreamDestroy(p->xs); hipHostFree(p->h_tok); delete p;
+            return fail("in-process pipeline group \"%s\" lives on device %d: a stage on device %d cannot join it (use lnb_pipeline_init for one stage per GPU)", group, have, m->device);
+        }
+        g.device = m->device;
+        p->loop_tag = group; p->loop = &g; p->loop->users++;
     }
     *out = p;
     return 0;
@@ -999,9 +1039,11 @@ static int enqueue_stage_step(lnb_pipe* p, lnb_ctx* c, const int32_t* tokens, in
     const bool longctx = want_long_attention(c, rows, pos);
     auto body = [&](bool host_tokens) -> int {
         if (m->first()) {
-            if (host_tokens) {
+            if (host_tokens) {                               // a second multi-row tick (chunked prefill) must not overwrite words a queued copy still reads
+                if (staging_acquire(c)) return -1;
                 memcpy(c->h_io + 2, tokens, (size_t)rows * 4);
                 HIPCHK(hipMemcpyAsync(c->dtok, c->h_io + 2, (size_t)rows * 4, hipMemcpyHostToDevice, st));
+                if (staging_release(c)) return -1;
             }
             HIPCHK(lnbk_embed(m->tok_embd, c->dtok, c->x, rows, m->a.dim, V, c->derr, st));   // Fwd_Get_Rows :118
         }
@@ -1026,13 +1068,13 @@ static int enqueue_stage_step(lnb_pipe* p, lnb_ctx* c, const int32_t* tokens, in
             HIPCHK(hipGraphInstantiate(slot, g, nullptr, nullptr, 0));
             HIPCHK(hipGraphDestroy(g));
         }
-        if (c->dev_pos != pos) HIPCHK(lnbk_set_state(c->st, pos, 0, st));
+        if (c->dev_pos != pos) HIPCHK(ctx_set_state(c, pos, 0, true));
+        c->call_T = 0;
         HIPCHK(hipGraphLaunch(*slot, st));
-        c->dev_pos = pos + 1;
+        c->dev_pos = pos + 1;                                // (the graph ends with advance_state)
         return 0;
     }
-    HIPCHK(lnbk_set_state(c->st, pos, 0, st));
-    c->dev_pos = pos;
+    HIPCHK(ctx_set_state(c, pos, 0, true));
     return body(tokens != nullptr);
 }
 // What crosses the boundary behind this stage (towards rank+1) / in front of it: the [rows, dim] hidden state, plus the [rows, ffn_hidden]
@@ -1066,8 +1108,9 @@ static int loop_post(lnb_pipe* p, bool sending, lnb_ctx* c, int rows, int peer, 
     auto& mine = sending ? p->loop->sends[key] : p->loop->recvs[key];
     auto& theirs = sending ? p->loop->recvs[key] : p->loop->sends[key];
     const LoopMsg msg{c, rows};
-    if (theirs.empty()) { mine.push_back(msg); return 0; }
+    if (theirs.empty()) { mine.push_back(msg); if (!sending) c->recv_unmatched = true; return 0; }
     const LoopMsg other = theirs.front(); theirs.pop_front();
+    (sending ? other.ctx : c)->recv_unmatched = false;
     return sending ? loop_copy(p, msg, other, token) : loop_copy(p, other, msg, token);
 }
 extern "C" int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,
@@ -1082,6 +1125,8 @@ extern "C" int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int ru
         if (check_call(run, run_rows, run_pos)) return -1;
         if (run_tokens && !first) return fail("tokens given to a stage that does not own tok_embeddings");
         if (!run_tokens && first && run_rows != 1) return fail("the first stage needs host tokens for a multi-row step");
+        if (run->recv_unmatched) return fail("in-process pipeline: this sequence's input has been requested but the sending stage has not posted it yet "
+                                             "(the mailbox transport needs the stages ticked in lock-step order from one thread)");
         if (run->in_pending) { HIPCHK(hipStreamWaitEvent(run->stream, run->ev_in, 0)); run->in_pending = false; }      // its input has arrived
         if (run->sent_pending) { HIPCHK(hipStreamWaitEvent(run->stream, run->ev_sent, 0)); run->sent_pending = false; }  // its previous output has left
         if (enqueue_stage_step(p, run, run_tokens, run_rows, run_pos)) return -1;

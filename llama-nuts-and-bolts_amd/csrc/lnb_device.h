@@ -111,6 +111,7 @@ struct AttnParams {
     const StepState* st;
     int S, H, KVH, hd, seq_len;
     int lds_T;                  // positions the LDS arrays of attn_exact_kernel are sized for (min(seq_len, what fits 160 KB)); the call's T must not exceed it
+    int host_T;                 // start_pos + S of this call as the HOST knows it (0: unknown -- a replayed graph); lets the launcher refuse a call beyond lds_T
     float divisor;              // wide(trunc(f32(sqrt(hd))))  (llamatransformer.go:464)
     long long* dbg;             // LNB_GEMV_TIMING: phase stamps of workgroup (0,0)
     int mfma;                   // S >= 16: 16-row tiles on the f32 matrix cores (attn_mfma_kernel), same bits

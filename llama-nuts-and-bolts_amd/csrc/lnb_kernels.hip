@@ -2155,6 +2155,7 @@ extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     }
     size_t lds = attn_lds_bytes(p->lds_T, p->hd);
     if (lds > 160 * 1024 || p->lds_T <= 0 || p->lds_T > p->seq_len) return hipErrorInvalidValue;
+    if (p->host_T > p->lds_T) return hipErrorInvalidValue;      // e[] / pw[] are sized for lds_T positions: never launch past them (lnb_api.cpp check_call refuses first)
     switch (p->hd) {
     case 128: hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
     case 64: hipLaunchKernelGGL(attn_exact_kernel<64>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;

@@ -41,8 +41,12 @@ type InferenceContext struct {
 
 	handle *C.lnb_ctx
 	lt     *LlamaTransformer // keeps the transformer alive (and finalized after this context)
-	self   cgo.Handle
 }
+
+// LayerProgress switches the per-layer "Transformer block layer %d / %d was run" message (llamatransformer.go:163) on or off for
+// contexts that were given a logFn.  The hook makes the library synchronise its stream after every block (that is what it times), which
+// costs a few percent of a decode step: a host that only wants the text can set this to false.
+var LayerProgress = true
 
 // NewInferenceContext: same signature and defaults as src/model/inferencecontext.go:17-46.  The device side is created on the first
 // Forward (the reference's constructor has no error return, and the context does not know its transformer until then).
@@ -91,16 +95,30 @@ func (ic *InferenceContext) attach(lt *LlamaTransformer) error {
 	lt.ctxs++
 	lt.mu.Unlock()
 	ic.lt = lt
-	if ic.logFn != nil { // the hook forces a per-layer stream sync: only when somebody listens
-		ic.self = cgo.NewHandle(ic)
-		if err := lnbCall(func() C.int {
-			return C.lnb_ctx_set_layer_callback(ic.handle, C.lnb_layer_cb(C.lnbGoLayerCallback), unsafe.Pointer(uintptr(ic.self)))
-		}); err != nil {
-			return err
-		}
-	}
+	// Nothing pins the Go object: the reference creates one context per generation and never closes it (inference.go:174), so the
+	// finalizer is what returns the device KV cache.  (A cgo.Handle held for the life of the context would keep it reachable for ever.)
 	runtime.SetFinalizer(ic, func(c *InferenceContext) { c.Close() })
 	return nil
+}
+
+// installLayerHook points the library's per-layer callback at this context for the duration of ONE Forward call: the cgo.Handle that
+// lets the C side find the Go object exists only while the call runs (the callback fires synchronously inside lnb_forward, on the
+// calling thread), so it never keeps the context alive.  The returned function removes the hook and deletes the handle.
+func (ic *InferenceContext) installLayerHook() (release func(), err error) {
+	if ic.logFn == nil || !LayerProgress {
+		return func() {}, nil
+	}
+	h := cgo.NewHandle(ic)
+	if err := lnbCall(func() C.int {
+		return C.lnb_ctx_set_layer_callback(ic.handle, C.lnb_layer_cb(C.lnbGoLayerCallback), unsafe.Pointer(uintptr(h)))
+	}); err != nil {
+		h.Delete()
+		return nil, err
+	}
+	return func() {
+		C.lnb_ctx_set_layer_callback(ic.handle, nil, nil)
+		h.Delete()
+	}, nil
 }
 
 // SyncCachesFromDevice copies every layer's K and V cache into the host mirrors, in the reference's [position, kv head, dim] order
@@ -128,10 +146,6 @@ func (ic *InferenceContext) Close() error {
 	}
 	C.lnb_ctx_destroy(ic.handle)
 	ic.handle = nil
-	if ic.self != 0 {
-		ic.self.Delete()
-		ic.self = 0
-	}
 	ic.lt.mu.Lock()
 	ic.lt.ctxs--
 	ic.lt.mu.Unlock()

@@ -3,7 +3,9 @@
 // llamatransformer_hip.go -- package model's LlamaTransformer on the MI355X library (liblnb_hip.so), selected with `-tags hip`.
 //
 // This file and inferencecontext_hip.go define THE SAME exported names as the reference's src/model/llamatransformer.go and
-// src/model/inferencecontext.go, so that everything that uses them compiles unchanged:
+// src/model/inferencecontext.go that the rest of the reference uses (tests/test_go_binding.py scans every non-test .go file of
+// src/model, src/inference and cmd for what it reads from these types and checks that each name is declared here; the files have
+// never been through a Go compiler -- there is none in the build image):
 //     Model.Transformer *LlamaTransformer                                   src/model/model.go:48
 //     NewLlamaTransformer(model *Model) (*LlamaTransformer, error)          src/model/llamatransformer.go:64   (called by the loader)
 //     (*LlamaTransformer).Forward(infContext, inputTokens, startPos)        src/model/llamatransformer.go:145  (called at src/inference/inference.go:202)
@@ -60,9 +62,29 @@ type LlamaTransformer struct {
 	ctxs   int // live InferenceContexts (Close refuses while > 0)
 }
 
-// LlamaTransformerBlock: the reference's blocks hold weight tensors; here a block is its index (the weights are on the device).
+// LlamaTransformerBlock: the reference's blocks hold weight tensors; here the weights are on the device and a block keeps what the
+// rest of package model reads from it: its index and the two derived dimensions printModelInfo prints through the private
+// attention / feedForward fields (src/model/loader.go:156-163; field names as in src/model/llamatransformer.go:27-57).
 type LlamaTransformerBlock struct {
 	LayerIndex int
+
+	attention   *LlamaAttention
+	feedForward *LlamaFeedForward
+}
+
+// LlamaAttention: the head geometry of src/model/llamatransformer.go:37-43 (no weight tensors on the host).
+type LlamaAttention struct {
+	LayerIndex int
+
+	N_Heads   int
+	N_KVHeads int
+	N_Rep     int
+	HeadDim   int
+}
+
+// LlamaFeedForward: FFNHiddenDim as derived by src/model/llamatransformer.go:569-577 (here: lnb_model_ffn_hidden_dim).
+type LlamaFeedForward struct {
+	FFNHiddenDim int
 }
 
 func boolToC(b bool) C.int32_t {
@@ -131,9 +153,18 @@ func NewLlamaTransformer(model *Model) (*LlamaTransformer, error) {
 		lt.Close()
 		return nil, err
 	}
+	nKVHeads := a.N_KVHeads
+	if nKVHeads < 0 { // llamatransformer.go:73-75
+		nKVHeads = a.N_Heads
+	}
+	ffnHiddenDim := int(C.lnb_model_ffn_hidden_dim(&cargs))
 	lt.Layers = make([]*LlamaTransformerBlock, a.N_Layers)
 	for i := range lt.Layers {
-		lt.Layers[i] = &LlamaTransformerBlock{LayerIndex: i}
+		lt.Layers[i] = &LlamaTransformerBlock{
+			LayerIndex:  i,
+			attention:   &LlamaAttention{LayerIndex: i, N_Heads: a.N_Heads, N_KVHeads: nKVHeads, N_Rep: a.N_Heads / nKVHeads, HeadDim: a.Dim / a.N_Heads},
+			feedForward: &LlamaFeedForward{FFNHiddenDim: ffnHiddenDim},
+		}
 	}
 	runtime.SetFinalizer(lt, func(t *LlamaTransformer) { t.Close() })
 	return lt, nil
@@ -166,6 +197,11 @@ func (lt *LlamaTransformer) Forward(infContext *InferenceContext, inputTokens *m
 	}
 	seq := inputTokens.Size[0]
 	output := ml.NewEmptyTensor([]int{seq, lt.args.VocabSize}, ml.DT_F32)
+	release, err := infContext.installLayerHook() // per-layer Logf (llamatransformer.go:163), only while this call runs
+	if err != nil {
+		return nil, err
+	}
+	defer release()
 	if err := lnbCall(func() C.int {
 		return C.lnb_forward(infContext.handle, (*C.int32_t)(unsafe.Pointer(&inputTokens.RawData[0])), C.int(seq), C.int(startPos),
 			(*C.float)(unsafe.Pointer(&output.RawData[0])), nil)

@@ -1,0 +1,189 @@
+"""The Go binding (llama-nuts-and-bolts_amd/go/*_hip.go) against the reference's own sources, without a Go toolchain.
+
+`go build -tags hip ./...` cannot run here (no Go in the image), so this test does the part of the compiler's work that a binding
+usually gets wrong: NAME RESOLUTION.  The two hip files replace src/model/llamatransformer.go and src/model/inferencecontext.go
+(`//go:build !hip` on those); every other non-test .go file of the reference keeps compiling only if each name it takes from the
+replaced files is declared by the replacement:
+
+  1. package-level identifiers of the two replaced files (types, functions, methods) that any OTHER non-test file of package model
+     mentions, or that src/inference / cmd mention as `model.X`;
+  2. selector chains rooted at values of the replaced types -- `model.Transformer.Layers[0].attention.HeadDim` (loader.go:156-163),
+     `ie.model.Transformer.Forward(...)`, `infContext.SequenceLength` (inference.go:174-242) -- walked field by field / method by
+     method through the struct declarations of the hip files.
+
+It is a scan, not a type checker: it cannot see a wrong argument type.  It prints what it checked (pytest -s).  Skipped where the
+reference checkout is absent (the GPU box)."""
+import os
+import re
+
+import pytest
+
+REF = "/root/reference"
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HIP_DIR = os.path.join(ROOT, "llama-nuts-and-bolts_amd", "go")
+REPLACED = ["src/model/llamatransformer.go", "src/model/inferencecontext.go"]
+
+pytestmark = pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "src", "model")), reason="reference checkout not present")
+
+
+def strip_go(src):
+    """comments and string / rune literals blanked out (line structure kept)"""
+    out, i, n = [], 0, len(src)
+    while i < n:
+        c = src[i]
+        if src.startswith("//", i):
+            while i < n and src[i] != "\n":
+                i += 1
+        elif src.startswith("/*", i):
+            j = src.find("*/", i + 2)
+            j = n if j < 0 else j + 2
+            out.append("".join(ch if ch == "\n" else " " for ch in src[i:j]))
+            i = j
+        elif c in "\"`'":
+            q, j = c, i + 1
+            while j < n and src[j] != q:
+                j += 2 if (src[j] == "\\" and q != "`") else 1
+            out.append(q + " " * max(0, j - i - 1) + q)
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def parse_decls(src):
+    """package-level declarations: {'types': {name: {field: type}}, 'funcs': set, 'methods': {recv type: set}, 'vars': set}"""
+    s = strip_go(src)
+    d = {"types": {}, "funcs": set(), "methods": {}, "vars": set()}
+    for m in re.finditer(r"^type\s+(\w+)\s+struct\s*\{(.*?)^\}", s, re.S | re.M):
+        fields = {}
+        for line in m.group(2).splitlines():
+            line = line.strip()
+            fm = re.match(r"^([A-Za-z_]\w*(?:\s*,\s*[A-Za-z_]\w*)*)\s+(\S.*)$", line)
+            if fm:
+                for nm in fm.group(1).split(","):
+                    fields[nm.strip()] = fm.group(2).strip()
+        d["types"][m.group(1)] = fields
+    for m in re.finditer(r"^type\s+(\w+)\s+(?!struct)", s, re.M):
+        d["types"].setdefault(m.group(1), {})
+    for m in re.finditer(r"^func\s+(\w+)\s*\(", s, re.M):
+        d["funcs"].add(m.group(1))
+    for m in re.finditer(r"^func\s*\(\s*\w+\s+\*?(\w+)\s*\)\s*(\w+)\s*\(", s, re.M):
+        d["methods"].setdefault(m.group(1), set()).add(m.group(2))
+    for m in re.finditer(r"^(?:var|const)\s+(\w+)", s, re.M):
+        d["vars"].add(m.group(1))
+    return d
+
+
+def merged(paths):
+    tot = {"types": {}, "funcs": set(), "methods": {}, "vars": set()}
+    for p in paths:
+        d = parse_decls(open(p).read())
+        tot["types"].update(d["types"]); tot["funcs"] |= d["funcs"]; tot["vars"] |= d["vars"]
+        for k, v in d["methods"].items():
+            tot["methods"].setdefault(k, set()).update(v)
+    return tot
+
+
+def base_type(t):
+    """'[]*LlamaTransformerBlock' -> ('LlamaTransformerBlock', True)   '*ml.Tensor' -> ('ml.Tensor', False)"""
+    t = t.split("//")[0].strip()
+    is_slice = t.startswith("[]")
+    t = t.lstrip("[]*")
+    return t, is_slice
+
+
+def other_files():
+    fs = []
+    for sub in ("src/model", "src/inference", "cmd"):
+        for fn in sorted(os.listdir(os.path.join(REF, sub))):
+            rel = sub + "/" + fn
+            if fn.endswith(".go") and not fn.endswith("_test.go") and rel not in REPLACED:
+                fs.append(rel)
+    return fs
+
+
+CHAIN = re.compile(r"((?:\.\w+(?:\[[^\]]*\])?)+)")
+
+
+def walk_chain(hip, type_name, chain, where, checked, problems):
+    """chain = '.Layers[0].attention.HeadDim' starting at a value of struct type `type_name`"""
+    cur = type_name
+    for part in re.findall(r"\.(\w+)(\[[^\]]*\])?", chain):
+        name, idx = part
+        if cur is None or cur not in hip["types"]:
+            return                                            # left the replaced types (ml.Tensor, int ...): not ours to check
+        fields, methods = hip["types"][cur], hip["methods"].get(cur, set())
+        if name in fields:
+            t, is_slice = base_type(fields[name])
+            checked.append("%s: %s.%s (field, %s)" % (where, cur, name, fields[name]))
+            if idx and not is_slice:
+                problems.append("%s: %s.%s is indexed but declared as %s" % (where, cur, name, fields[name]))
+            cur = t if t in hip["types"] else None
+        elif name in methods:
+            checked.append("%s: %s.%s (method)" % (where, cur, name))
+            cur = None
+        else:
+            problems.append("%s: %s has no field or method %s in go/*_hip.go" % (where, cur, name))
+            return
+
+
+def test_every_name_the_reference_takes_from_the_replaced_files_is_declared_by_the_binding():
+    ref = merged([os.path.join(REF, p) for p in REPLACED])
+    hip = merged([os.path.join(HIP_DIR, f) for f in sorted(os.listdir(HIP_DIR)) if f.endswith("_hip.go")])
+    checked, problems = [], []
+    ref_idents = set(ref["types"]) | ref["funcs"] | ref["vars"]
+    hip_idents = set(hip["types"]) | hip["funcs"] | hip["vars"]
+    # names of OTHER declarations in package model that merely look the same (a local variable called `model` etc.) are not in ref_idents
+    for rel in other_files():
+        src = strip_go(open(os.path.join(REF, rel)).read())
+        same_pkg = rel.startswith("src/model/")
+        for lineno, line in enumerate(src.splitlines(), 1):
+            where = "%s:%d" % (rel, lineno)
+            # 1. package-level identifiers
+            names = set(re.findall(r"(?<![\w.])(\w+)\b", line)) if same_pkg else set(re.findall(r"\bmodel\.(\w+)", line))
+            for nm in sorted(names & ref_idents):
+                checked.append("%s: identifier %s" % (where, nm))
+                if nm not in hip_idents:
+                    problems.append("%s: %s is defined in a replaced file and not declared in go/*_hip.go" % (where, nm))
+            # 2. selector chains rooted at the replaced types
+            for m in re.finditer(r"\bTransformer" + CHAIN.pattern, line):               # Model.Transformer *LlamaTransformer (model.go:48)
+                walk_chain(hip, "LlamaTransformer", m.group(1), where, checked, problems)
+            for m in re.finditer(r"\b(?:infContext|inferenceContext)" + CHAIN.pattern, line):   # values of *InferenceContext (inference.go:174)
+                walk_chain(hip, "InferenceContext", m.group(1), where, checked, problems)
+    # the seam itself: constructors and methods with the reference's names, on the reference's receiver types
+    for fn in ("NewLlamaTransformer", "NewInferenceContext"):
+        assert fn in hip["funcs"], fn
+    assert "Forward" in hip["methods"].get("LlamaTransformer", set())
+    assert "Logf" in hip["methods"].get("InferenceContext", set())
+    # exported fields of the replaced structs that the reference's own tests read (llamatransformer_simulated_test.go:527-538)
+    for t, f in (("LlamaTransformer", "Layers"), ("LlamaTransformer", "PrecomputedFreqsCis"), ("InferenceContext", "SequenceLength"),
+                 ("InferenceContext", "CacheK"), ("InferenceContext", "CacheV"), ("LlamaTransformerBlock", "LayerIndex")):
+        assert f in hip["types"][t], (t, f)
+        assert base_type(hip["types"][t][f])[0] == base_type(ref["types"][t][f])[0], "type of %s.%s differs from the reference's" % (t, f)
+    print("\n".join(["go binding scan: %d uses checked" % len(checked)] + sorted(set(checked))))
+    assert not problems, "\n".join(problems)
+    # the scan must actually have seen the lines VERDICT r02 named (loader.go:156-163) and the call at inference.go:202
+    joined = "\n".join(checked)
+    assert "LlamaTransformerBlock.attention" in joined and "LlamaAttention.HeadDim" in joined and "LlamaFeedForward.FFNHiddenDim" in joined
+    assert "LlamaTransformer.Forward (method)" in joined and "InferenceContext.SequenceLength" in joined
+
+
+def test_the_scan_catches_a_missing_field():
+    """the round-2 binding (a block with only LayerIndex) must fail the walk"""
+    hip = {"types": {"LlamaTransformer": {"Layers": "[]*LlamaTransformerBlock"}, "LlamaTransformerBlock": {"LayerIndex": "int"}}, "methods": {}}
+    checked, problems = [], []
+    walk_chain(hip, "LlamaTransformer", ".Layers[0].attention.HeadDim", "loader.go:157", checked, problems)
+    assert problems and "attention" in problems[0]
+
+
+def test_cgo_calls_name_functions_that_the_header_declares():
+    """every C.lnb_* the Go files call is declared in include/lnb.h"""
+    hdr = open(os.path.join(ROOT, "include", "lnb.h")).read()
+    declared = set(re.findall(r"\b(lnb_\w+)\s*\(", hdr)) | set(re.findall(r"typedef\s+struct\s+\w+\s+(\w+);", hdr)) | {"lnb_model_args", "lnb_layer_cb"}
+    used = set()
+    for f in sorted(os.listdir(HIP_DIR)):
+        if f.endswith(".go"):
+            used |= set(re.findall(r"\bC\.(lnb_\w+)", strip_go(open(os.path.join(HIP_DIR, f)).read())))
+    missing = sorted(used - declared)
+    assert used and not missing, missing
