@@ -21,6 +21,8 @@ import os
 import sys
 import time
 
+import numpy as np
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "llama-nuts-and-bolts_amd"))
@@ -99,23 +101,52 @@ def pmc_traffic(kernel_name, model_name, mode):
     return None, None, None
 
 
+GOLDENS = {("llama8b", 128): "configs1_tokens.json", ("llama8b-2l", 4096): "configs2_2layer_tokens.json"}
+
+
 def check_golden(args, first_tok, warm_toks, timed_toks):
-    """configs[1] exactly (8B shape, seed-1234 weights, the 128-token synthetic prompt): the tokens this run produced against the
-    CPU ORACLE's continuation committed in tests/golden/configs1_tokens.json (generated by tests/golden/make_configs1_tokens.py;
-    the device run is re-checked against it by tests/test_gpu_full_8b.py).  exact mode: a mismatch is a parity failure and the
-    bench refuses to print a number; fast mode: reports how many leading tokens agree.  None when the workload is another one."""
-    path = os.path.join(ROOT, "tests", "golden", "configs1_tokens.json")
-    if args.model != "llama8b" or args.prompt_len != 128 or not os.path.exists(path):
+    """The tokens this run produced against the CPU ORACLE's continuation committed under tests/golden/: configs[1] exactly (8B shape,
+    seed-1234 weights, the 128-token synthetic prompt; make_configs1_tokens.py) or the configs[2] workload on the two-layer cut of the
+    shape (`--model llama8b-2l --prompt-len 4096`; make_configs2_2layer_tokens.py).  exact mode: a mismatch is a parity failure and the
+    bench refuses to print a number; fast mode: reports how many leading tokens agree.  None when no golden covers the workload (then
+    device_self_check below is what stands behind the number, and the line says so)."""
+    fn = GOLDENS.get((args.model, args.prompt_len))
+    path = os.path.join(ROOT, "tests", "golden", fn) if fn else None
+    if not path or not os.path.exists(path):
         return None
     gold = json.load(open(path))["tokens"]
     got = [int(first_tok)] + [int(t) for t in warm_toks] + [int(t) for t in timed_toks]
     n = min(len(got), len(gold))
     agree = next((i for i in range(n) if got[i] != gold[i]), n)
     if args.mode == "exact" and agree < n:
-        sys.stderr.write("PARITY FAILURE: token %d of the configs[1] run is %d, the CPU oracle's is %d (tests/golden/configs1_tokens.json)\n"
-                         % (agree, got[agree], gold[agree]))
+        sys.stderr.write("PARITY FAILURE: token %d of the run is %d, the CPU oracle's is %d (tests/golden/%s)\n" % (agree, got[agree], gold[agree], fn))
         sys.exit(3)
-    return {"compared": n, "identical_prefix": agree, "golden": "tests/golden/configs1_tokens.json (CPU oracle)"}
+    return {"compared": n, "identical_prefix": agree, "golden": "tests/golden/%s (CPU oracle)" % fn}
+
+
+def device_self_check(lnb, model, args, prompt, seq_len, run_tokens):
+    """No oracle golden exists for this workload (the CPU oracle cannot walk a 32-layer model over thousands of positions in a test's
+    time): the number is backed by a DEVICE-side consistency check instead, and says so.  The same continuation is replayed on fresh
+    contexts through the OTHER forms of the decode attention -- the reference's serial f64 softmax denominator forced (no certified
+    estimate), and, where the context fits its LDS staging, the one-workgroup-per-head kernel instead of the chip-wide pair -- all of
+    which are oracle-checked at smaller sizes (tests/test_gpu_round3.py: the same head geometry on two layers).  Tokens must be identical;
+    a mismatch is a parity failure and the bench refuses to print a number."""
+    n = min(len(run_tokens) - 1, 24)
+    forms = [("serial f64 softmax denominator forced", (-1, 1))]
+    forms.append(("one-workgroup-per-head attention kernel", (10 ** 9, 0)) if args.prompt_len + n + 1 < 7000 else ("long-context kernels at every context", (0, 0)))
+    agree = {}
+    for label, (thr, zseq) in forms:
+        c = lnb.InferenceContext(model, seq_len).set_mode(args.mode).set_attention(thr, zseq)
+        _, f = c.Forward(prompt, 0, want_logits=False)
+        got, _ = c.decode_greedy(f, len(prompt), n)
+        c.close()
+        mine = [f] + [int(t) for t in got]
+        same = next((i for i in range(n + 1) if mine[i] != run_tokens[i]), n + 1)
+        agree[label] = {"compared": n + 1, "identical_prefix": same}
+        if args.mode == "exact" and same < n + 1:
+            sys.stderr.write("PARITY FAILURE (device self-check, %s): token %d is %d, the run's is %d\n" % (label, same, mine[same], run_tokens[same]))
+            sys.exit(3)
+    return {"oracle": "none at this size (no CPU-oracle golden for %s at prompt length %d)" % (args.model, args.prompt_len), "forms": agree}
 
 
 def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens):
@@ -152,6 +183,77 @@ def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens):
             "frac_of_hbm_roofline": round(tps * B / 1e9 / PEAK_HBM_GBS, 4),
             "sequence0_tokens_vs_single_run": {"compared": n_cmp, "identical_prefix": same},
             "note": "aggregate of independent prompts on ONE GPU; weights are re-read per sequence (no batching: every token keeps its own exact chains)"}
+
+
+def batched_sequences(lnb, model, cfg, args, a, single_run_tokens):
+    """Sequences in flight, BATCHED (lnb_batch_*): n independent prompts decoded together, one pass over the weights per step for all of them
+    -- each sequence is a column of the f32 matrix-core product, whose k-ordered chain is the reference's (bit-identical per sequence;
+    tests/test_gpu_batch.py).  Not the headline (configs[1] is one prompt); it is what a server, and every pipeline rank, runs.
+    Sequence 0 has the headline's prompt: its tokens are compared with the single run's."""
+    P, W, K = args.prompt_len, min(args.warmup, 4), min(args.steps, 48)
+    seq_len = P + W + K + 8
+    t0 = time.perf_counter()
+    model.enable_batch()
+    t_enable = time.perf_counter() - t0
+    out = {"weights_second_copy_bytes": model.batch_bytes(), "enable_batch_s": round(t_enable, 2), "runs": []}
+    n_max = max(args.batch_sizes)
+    ctxs = [lnb.InferenceContext(model, seq_len) for _ in range(n_max)]
+    prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_max)]
+    for n in args.batch_sizes:
+        firsts = []
+        for s in range(n):
+            ctxs[s].reset()
+            firsts.append(ctxs[s].Forward(prompts[s], 0, want_logits=False)[1])
+        b = lnb.Batch(ctxs[:n])
+        warm, _ = b.decode(firsts, [P] * n, W) if W > 0 else (np.zeros((n, 0), dtype=np.int32), 0.0)
+        toks = [int(warm[s][-1]) if W > 0 else firsts[s] for s in range(n)]
+        lnb._chk(lnb.lib().lnb_ctx_synchronize(ctxs[0].h))
+        t1 = time.perf_counter()
+        got, ev_ms = b.decode(toks, [P + W] * n, K)
+        wall = time.perf_counter() - t1
+        seq0 = [firsts[0]] + [int(t) for t in warm[0]] + [int(t) for t in got[0]]
+        n_cmp = min(len(seq0), len(single_run_tokens))
+        same = next((i for i in range(n_cmp) if seq0[i] != single_run_tokens[i]), n_cmp)
+        Tbar = P + W + (K - 1) / 2.0 + 1.0
+        per_seq = algorithmic_bytes_per_token(a, model.ffn_hidden, Tbar)
+        kv = a["n_layers"] * 2 * (a["n_kv_heads"] * (a["dim"] // a["n_heads"])) * 2
+        own = a["dim"] * 2 + kv * Tbar + kv                  # a sequence's own traffic: its embedding row, its KV read and write
+        step_bytes = (per_seq - own) + n * own               # the weights ONCE per step + every sequence's own bytes
+        tps = n * K / wall
+        run = {"n": n, "tokens_per_s": round(tps, 1), "ms_per_step": round(1e3 * wall / K, 4), "hip_event_ms_per_step": round(ev_ms / K, 4), "steps": K,
+               "hbm_frac_of_bytes_actually_needed": round(step_bytes * (K / wall) / 1e9 / PEAK_HBM_GBS, 4),
+               "equivalent_frac_if_each_sequence_read_the_weights": round(tps * per_seq / 1e9 / PEAK_HBM_GBS, 4),
+               "sequence0_tokens_vs_single_run": {"compared": n_cmp, "identical_prefix": same}}
+        if n == n_max:
+            names = ["norm+wqkv+rope", "attention", "wo+residual", "norm+w1|w3+silu", "w2+residual", "norm+output", "whole block"]
+            run["kernels_us"] = {names[w]: round(1e3 * b.profile_kernel(w, int(Tbar) - 1, 16), 2) for w in range(7)}
+        out["runs"].append(run)
+        b.close()
+    for c in ctxs:
+        c.close()
+    out["note"] = ("aggregate tokens/s of n independent prompts decoded together on ONE GPU: one pass over the weights per step, each sequence a "
+                   "column of v_mfma_f32_16x16x4_f32 (exact k-ordered chains; token-identical per sequence)")
+    return out
+
+
+def chain_floor(a, ffn_hidden, Tbar, tps):
+    """The bound the EXACT arithmetic allows: every output is one k-ordered chain of K dependent f32 adds (operations_lineartransform.go:
+    46-65) and a dependent v_add_f32 issues every 4.33 cycles on this chip (tools/microbench.hip), so a GEMV launch cannot finish before
+    K x 4.33 cycles however many CUs share its rows; per launch max(that, its bytes at 8 TB/s), summed over the token's launches."""
+    d, hd = a["dim"], a["dim"] // a["n_heads"]
+    kvd = a["n_kv_heads"] * hd
+    CYC, GHZ = 4.33, 2.4
+    kb = kernel_bytes(a, ffn_hidden, Tbar)
+    ks = [d, None, a["n_heads"] * hd, d, ffn_hidden, d]          # chain length of each launch class (attention: its own short chains, bytes only)
+    per = []
+    for i in range(6):
+        t_hbm = kb[i] / (PEAK_HBM_GBS * 1e9)
+        t_chain = (ks[i] * CYC / (GHZ * 1e9)) if ks[i] else 0.0
+        per.append(max(t_hbm, t_chain))
+    t_tok = a["n_layers"] * sum(per[:5]) + per[5]
+    return {"cycles_per_dependent_add": CYC, "clock_GHz": GHZ, "ms_per_token": round(1e3 * t_tok, 4), "tokens_per_s": round(1.0 / t_tok, 1),
+            "achieved_frac_of_attainable": round(tps * t_tok, 4),
+            "note": "sum over the token's launches of max(K x 4.33 cycles at 2.4 GHz, algorithmic bytes / 8 TB/s): what exact k-ordered chains allow with operands arriving for free"}
 
 
 def traffic_child(lnb, cfg, args):
@@ -208,6 +310,36 @@ def probe_traffic(args, dom, pos):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N copies of this command, one rank per GPU (RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_* in the environment, exactly what torch.distributed.run would set -- which keeps working: under it WORLD_SIZE is already set and
+    no one spawns).  Rank 0's stdout is this process's stdout (the ONE JSON line); the other ranks' stdout goes to stderr.  The exit code is
+    the first non-zero one; if a rank dies the others are terminated (their peers would wait for it for minutes)."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    env0 = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = []
+    for r in range(n):
+        env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env, stdout=None if r == 0 else sys.stderr))
+    rc, live = 0, set(range(n))
+    while live:
+        for r in sorted(live):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            live.discard(r)
+            if code != 0 and rc == 0:
+                rc = code
+                sys.stderr.write("bench.py: rank %d exited with code %d; stopping the other ranks\n" % (r, code))
+                for q in live:
+                    procs[q].terminate()
+        time.sleep(0.05)
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -217,14 +349,27 @@ def main():
     ap.add_argument("--cpu-steps", type=int, default=24, help="decode steps of the CPU baseline sample (0 = skip)")
     ap.add_argument("--profile-iters", type=int, default=64)
     ap.add_argument("--concurrent", type=int, default=8, help="also time this many independent prompts in flight on the one GPU (0/1 = skip)")
+    ap.add_argument("--batch-sizes", type=lambda v: [int(x) for x in v.split(",") if x], default=[2, 4, 8, 16],
+                    help="also time BATCHED exact decode of this many prompts (comma list, each 1..16; empty = skip)")
     ap.add_argument("--no-traffic-probe", action="store_true", help="do not run the rocprofv3 FETCH_SIZE pass of the dominant kernel")
     ap.add_argument("--traffic-child", type=int, default=-1, help=argparse.SUPPRESS)      # internal: kernel class to loop under rocprofv3
     ap.add_argument("--traffic-pos", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--model", default="llama8b", choices=["llama8b", "tiny", "llama70b-like"])
+    ap.add_argument("--model", default="llama8b", choices=["llama8b", "llama8b-2l", "tiny", "llama70b-like"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"],
                     help="exact (default, headline): the reference's k-ordered chains, token-identical to the CPU path; "
                          "fast: split-K / bf16-MFMA tolerance mode (opt-in, measured distance in DESIGN.md 6.2)")
+    ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # launcher check without a GPU: every rank reports its environment and exits
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        return spawn_ranks(args.gpus)                        # `python bench.py --gpus N` as ONE plain command: this process becomes the launcher
+    if args.dry_run:
+        info = {k: os.environ.get(k) for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+        if int(info["RANK"] or 0) == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": args.gpus, "env": info}))
+        else:
+            print("rank %s of %s up" % (info["RANK"], info["WORLD_SIZE"]))
+        return 7 if os.environ.get("LNB_DRY_RUN_FAIL_RANK") == (info["RANK"] or "0") else 0
 
     import lnb
     lnb.build()
@@ -233,6 +378,9 @@ def main():
     if args.model == "tiny":
         cfg.update(dim=256, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=1024, multiple_of=64)
         name = "tiny-256x2"
+    elif args.model == "llama8b-2l":
+        cfg.update(n_layers=2)                               # the 8B shape's geometry on two layers: the size the CPU oracle reaches at a 4096-token prompt
+        name = "Llama-3.1-8B shape cut to 2 layers"
     elif args.model == "llama70b-like":
         cfg.update(dim=8192, n_layers=80, n_heads=64, n_kv_heads=8, multiple_of=4096)
         name = "random-init Llama-shape dim=8192 n_layers=80"
@@ -245,7 +393,8 @@ def main():
         return pipeline.bench_main(args, cfg, name)
 
     P, W, K = args.prompt_len, args.warmup, args.steps
-    seq_len = P + W + K + 8
+    K_LONG = 256 if (K < 64 and args.model in ("llama8b", "llama8b-2l")) else 0    # a short timed region (the driver passes --steps 20) is followed by a 256-step one, reported next to it
+    seq_len = P + W + K + K_LONG + 8
     t_load = time.time()
     model = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"]))
     ctx = lnb.InferenceContext(model, seq_len).set_mode(args.mode)
@@ -264,7 +413,21 @@ def main():
     t0 = time.perf_counter()
     out, ev_ms = ctx.decode_greedy(tok, pos, K)                   # EXACTLY K steps; returns after stream sync
     t1 = time.perf_counter()
+    long_run = None
+    if K_LONG:
+        lnb._chk(lnb.lib().lnb_ctx_synchronize(ctx.h))
+        tl = time.perf_counter()
+        out_long, _ = ctx.decode_greedy(int(out[-1]), pos + K, K_LONG)
+        tl = time.perf_counter() - tl
+        long_run = {"steps": K_LONG, "tokens_per_s": round(K_LONG / tl, 2), "ms_per_step": round(1e3 * tl / K_LONG, 4),
+                    "note": "the same context continued for %d more steps after the %d timed ones (mean context %.1f)" % (K_LONG, K, pos + K + (K_LONG - 1) / 2.0 + 1.0)}
+        golden_long = check_golden(args, first_tok, warm_toks, list(out) + list(out_long))
+        if golden_long:
+            long_run["tokens_vs_oracle_golden"] = golden_long
     golden_ok = check_golden(args, first_tok, warm_toks, out)
+    self_check = None
+    if golden_ok is None and args.model != "tiny":
+        self_check = device_self_check(lnb, model, args, prompt, seq_len, [first_tok] + warm_toks + [int(t) for t in out])
     wall = t1 - t0
     tps = K / wall
     Tbar = pos + (K - 1) / 2.0 + 1.0
@@ -294,13 +457,14 @@ def main():
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "%s bf16, 1xMI355X, single-prompt greedy decode, seq_len=%d -> +%d tokens (%s)"
-                                  % (name, P, K, ("configs[2] decode" if P >= 4096 else "configs[1]") if args.model == "llama8b" else "shape of configs[4] on one GPU" if args.model == "llama70b-like" else "test shape"),
+                                  % (name, P, K, ("configs[2] decode" if P >= 4096 else "configs[1]") if args.model == "llama8b" else "shape of configs[4] on one GPU" if args.model == "llama70b-like" else
+                                     "configs[2] workload on the two-layer cut the CPU oracle reaches" if args.model == "llama8b-2l" else "test shape"),
                       "prompt_len": P, "sequences_in_flight": 1, "parallelism": "single GPU",
                       "mode": "exact-order (token-id identical to the CPU reference path)" if args.mode == "exact" else
                               "fast (opt-in tolerance mode: split-K f32 sums, same bf16 truncation points; NOT token-identical, see DESIGN.md 6.2)",
-                      "tokens_vs_oracle_golden": golden_ok,
+                      "tokens_vs_oracle_golden": golden_ok, "device_self_check": self_check,
                       "hip_event_ms_per_step": round(ev_ms / K, 4), "weight_bytes_resident": model.weight_bytes(), "model_build_s": round(t_load, 1)},
-           "roofline": roofline, "kernels": kernels, "last_tokens": [int(t) for t in out[-4:]],
+           "roofline": roofline, "kernels": kernels, "last_tokens": [int(t) for t in out[-4:]], "long_run": long_run,
            # prefill of the prompt: the same exact f32 chains on the matrix cores (v_mfma_f32_16x16x4_f32, bit-identical to the
            # k-ordered loop); FLOPs = 2 x rows x layer-matmul elements; peak = f32 MFMA (MI355X_MICROARCH.md: 157.3 TFLOP/s)
            "prefill": {"rows": P, "ms": round(1e3 * t_pf, 2), "TFLOP/s": round(2.0 * P * 6979321856 / t_pf / 1e12, 2) if name == "Llama-3.1-8B" else None,
@@ -314,6 +478,12 @@ def main():
         res["sequences_in_flight"] = {"skipped": "running under rocprofv3 (set LNB_BENCH_CONCURRENT_UNDER_PROFILER=1 to force)"}
     elif args.concurrent > 1:
         res["sequences_in_flight"] = concurrent_sequences(lnb, model, cfg, args, a, [first_tok] + warm_toks + [int(t) for t in out])
+    roofline["chain_floor"] = chain_floor(a, model.ffn_hidden, Tbar, tps)
+    if args.batch_sizes and args.mode == "exact" and not os.environ.get("ROCP_TOOL_LIBRARIES"):
+        try:
+            res["sequences_in_flight_batched"] = batched_sequences(lnb, model, cfg, args, a, [first_tok] + warm_toks + [int(t) for t in out])
+        except lnb.LnbError as e:                                # (e.g. the second weight copy does not fit next to a 141 GB model)
+            res["sequences_in_flight_batched"] = {"skipped": str(e)}
     if args.cpu_steps > 0:
         res["cpu_baseline"] = cpu_baseline(cfg, prompt[:8], args.cpu_steps)        # 8 + 24 = configs[0]'s seq_len of 32
     ctx.close(); model.close()

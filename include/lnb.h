@@ -130,6 +130,29 @@ int lnb_forward(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, float
  * the n_steps measured with HIP events on the library's stream. */
 int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int32_t* out_tokens, float* ms_out);
 
+/* ---- batched exact decode: several generations per pass over the weights ----------------------------------
+ * The reference runs one generation per InferenceContext (src/inference/inference.go:174) and shares the weight matrix across the rows of a
+ * call (src/ml/operations_lineartransform.go:173-193).  A batch groups 1..16 contexts of ONE whole-model handle; per step, every
+ * sequence's one-token Forward + Argmax (inference.go:194-252) is evaluated in a single pass over the weights: the sequences are the 16
+ * columns of the f32 matrix-core instruction, which computes each column's k-ordered chain exactly.  Per-sequence position, RoPE row, KV
+ * append and attention; every sequence's tokens, logits and caches are bit-identical to its single-sequence run (and the CPU reference).
+ * lnb_model_enable_batch: builds the weights' second, matrix-core friendly copy on the device (once, after lnb_model_finalize; it costs the
+ *   model's matrix bytes again -- 15 GB for the 8B shape; fails cleanly when that does not fit, the other entry points stay usable).
+ * lnb_batch_create: the contexts keep their own KV caches and positions (prefill each with lnb_forward first); seq_len of each context at
+ *   most ~7.8 K positions (head_dim 128).  A context must not be used by another call while a batch call that contains it runs.
+ * lnb_batch_decode: sequence s continues from tokens[s] at position start_pos[s] (different positions are fine); n_steps greedy steps for
+ *   all of them as replays of one captured hipGraph; out_tokens[s * n_steps + i] = token i of sequence s.  Afterwards every context's
+ *   cache holds its new rows: lnb_forward / lnb_decode_greedy / another batch may continue it. */
+typedef struct lnb_batch lnb_batch;
+int lnb_model_enable_batch(lnb_model* m);
+int64_t lnb_model_batch_bytes(lnb_model* m);
+int lnb_batch_create(lnb_ctx* const* ctxs, int n, lnb_batch** out);
+int lnb_batch_destroy(lnb_batch* b);
+int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, float* ms_out);
+/* measurement aid: average HIP-event time of one kernel class of the batched step (which as lnb_profile_kernel; a norm launch counts
+ * with the product it feeds), every sequence placed at `pos`; overwrites the caches' row `pos` */
+int lnb_batch_profile_kernel(lnb_batch* b, int which, int pos, int iters, float* avg_ms_out);
+
 /* ---- pipeline-stage form (layer-sharded multi-GPU) -------------------------------
  * hidden state buffers live on the device and are owned by the ctx: [seq_len, dim] bf16.
  * which: 0 = stage input, 1 = stage output, 2 = the [seq_len, ffn_hidden] gate*up activations, part of the hand-off when the
@@ -177,6 +200,9 @@ int lnb_pipeline_destroy(lnb_pipe* p);
 int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,
                       lnb_ctx* send, int send_rows, lnb_ctx* recv, int recv_rows, int* token_slot_out);
 int lnb_pipeline_sync(lnb_pipe* p);
+/* the number of ranks the exchange spans as the TRANSPORT reports it (ncclCommCount of the communicator; pipes joined to an in-process
+ * group; 1 for a one-stage pipe): lets a host check that N processes really formed ONE N-rank communicator */
+int lnb_pipeline_comm_count(lnb_pipe* p, int* out);
 /* tokens by log slot (token_slot_out of the tick that produced them); synchronises the device.  The log is a ring of the newest 65536
  * tokens: slots count up for the life of the pipe, reading never has to "drain" anything, a slot older than that is refused */
 int lnb_pipeline_read_tokens(lnb_pipe* p, int first_slot, int n, int32_t* out);

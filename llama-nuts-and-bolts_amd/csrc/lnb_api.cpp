@@ -3,6 +3,7 @@
 // device-resident weights (re-tiled once), device-resident KV cache, 5 launches per transformer block,
 // and a hipGraph-replayed greedy decode loop whose position/token state lives on the device.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -37,6 +38,12 @@ hipError_t lnbk_fast_gemv(const GemvParams* p, int rw, int nch, int epi, int nor
 hipError_t lnbk_fast_gemm(const GemmParams* p, int epi, hipStream_t st);
 hipError_t lnbk_fast_attn(const AttnParams* p, hipStream_t st);
 hipError_t lnbk_fast_init(void);
+hipError_t lnbk_m16_from_tiled(const uint16_t* src, uint16_t* dst, int rows, int K, int RW, int NCH, hipStream_t st);
+hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int num_cus, hipStream_t st);
+hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K, int nseq, hipStream_t st);
+hipError_t lnbk_batch_embed(const uint16_t* emb, const BatchTab* tab, uint16_t* x, int nseq, int dim, int vocab, int* err, hipStream_t st);
+hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const BatchTab* tab, int nseq, hipStream_t st);
+hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, hipStream_t st);
 }
 
 static thread_local char g_err[1024] = "";
@@ -65,6 +72,8 @@ struct TensorRef {
 struct LayerW {
     uint16_t* attn_norm = nullptr; uint16_t* ffn_norm = nullptr;
     TiledDesc wqkv{}, wo{}, w13{}, w2{};
+    // batched decode (lnb_model_enable_batch): the same matrices in the 16-row matrix-core layout (M16, lnb_device.h)
+    uint16_t *m_wqkv = nullptr, *m_wo = nullptr, *m_w13 = nullptr, *m_w2 = nullptr;
 };
 struct lnb_model {
     lnb_model_args a{};
@@ -79,6 +88,7 @@ struct lnb_model {
     hipStream_t stream = nullptr;
     bool finalized = false;
     int64_t weight_bytes = 0;
+    bool batch_enabled = false; uint16_t* m_output = nullptr; int64_t batch_bytes = 0;
     bool first() const { return part_begin == 0; }
     bool last() const { return part_end == 3 * a.n_layers; }
     bool has_part(int l, int q) const { return 3 * l + q >= part_begin && 3 * l + q < part_end; }
@@ -285,7 +295,9 @@ extern "C" int lnb_model_destroy(lnb_model* m) {
     if (m->output.w) hipFree(m->output.w);
     for (auto& L : m->layers) {
         hipFree(L.attn_norm); hipFree(L.ffn_norm); hipFree(L.wqkv.w); hipFree(L.wo.w); hipFree(L.w13.w); hipFree(L.w2.w);
+        hipFree(L.m_wqkv); hipFree(L.m_wo); hipFree(L.m_w13); hipFree(L.m_w2);
     }
+    hipFree(m->m_output);
     if (m->cis) hipFree(m->cis);
     if (m->silu) hipFree(m->silu);
     if (m->exp_tab) hipFree(m->exp_tab);
@@ -301,6 +313,7 @@ extern "C" int lnb_model_set_tensor(lnb_model* m, const char* name, const uint16
     HIPCHK(hipSetDevice(m->device));
     auto it = m->tensors.find(name);
     if (it == m->tensors.end()) return fail("tensor \"%s\" does not belong to this model stage", name);
+    if (m->batch_enabled) return fail("tensor \"%s\": the model's batched-decode copy has been built; bind tensors before lnb_model_enable_batch", name);
     TensorRef& r = it->second;
     // shape check as loader.go:183-192
     if (rank != r.rank || (rank == 1 && shape[0] != r.cols) || (rank == 2 && (shape[0] != r.rows || shape[1] != r.cols)))
@@ -350,6 +363,7 @@ extern "C" int lnb_model_get_tensor(lnb_model* m, const char* name, uint16_t* ho
 
 extern "C" int lnb_model_fill_synthetic(lnb_model* m, uint64_t seed) {
     if (!m) return fail("null argument");
+    if (m->batch_enabled) return fail("the model's batched-decode copy has been built; fill the weights before lnb_model_enable_batch");
     HIPCHK(hipSetDevice(m->device));
     for (auto& kv : m->tensors) {
         TensorRef& r = kv.second;
@@ -922,6 +936,245 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     return 0;
 }
 
+
+// ---- batched exact decode: several independent sequences per pass over the weights --------------------------------------------------
+// The reference runs one generation per InferenceContext (src/inference/inference.go:174) and shares the weight matrix across the rows of
+// a call (src/ml/operations_lineartransform.go:173-193).  A batch groups up to 16 contexts of ONE whole-model handle: per step every
+// sequence's one-token Forward + Argmax happens in a single pass over the weights -- the sequences are the 16 columns of
+// v_mfma_f32_16x16x4_f32, which evaluates each column's k-ordered chain exactly (lnb_batch_kernels.h) -- with per-sequence position, RoPE
+// row, KV append and attention.  Every sequence's tokens and caches are bit-identical to its single-sequence run.
+struct lnb_batch {
+    lnb_model* m = nullptr; int n = 0; std::vector<lnb_ctx*> ctxs;
+    hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    BatchTab* tab = nullptr; BatchKV* kv = nullptr;
+    uint16_t *x = nullptr, *h = nullptr, *xt = nullptr, *q = nullptr, *att_xt = nullptr, *ffn_xt = nullptr, *logits = nullptr;
+    int* derr = nullptr; int32_t *d_tokens = nullptr, *d_pos = nullptr; int32_t* h_io = nullptr;   // pinned: [0..15] tokens, [16..31] positions, [32] error word
+    hipGraphExec_t graph = nullptr; int lds_T = 0;
+};
+static int m16_copy(lnb_model* m, const TiledDesc& t, int rows, uint16_t** out) {
+    const size_t bytes = m16_elems(rows, t.k, t.nch) * 2;
+    HIPCHK(hipMalloc((void**)out, bytes));
+    HIPCHK(hipMemsetAsync(*out, 0, bytes, m->stream));
+    HIPCHK(lnbk_m16_from_tiled(t.w, *out, rows, t.k, t.rw, t.nch, m->stream));
+    m->batch_bytes += (int64_t)bytes;
+    return 0;
+}
+extern "C" int lnb_model_enable_batch(lnb_model* m) {
+    if (!m) return fail("null argument");
+    if (!m->finalized) return fail("model not finalized");
+    if (m->batch_enabled) return 0;
+    if (!m->first() || !m->last()) return fail("batched decode needs a whole-model handle");
+    if (m->a.dim % 128 || m->q_dim % 128 || m->ffn_hidden % 128)
+        return fail("batched decode streams the weights in 128-step chunks: dim (%d), n_heads*head_dim (%d) and the FFN hidden size (%d) must be multiples of 128", m->a.dim, m->q_dim, m->ffn_hidden);
+    HIPCHK(hipSetDevice(m->device));
+    int rc = 0;
+    for (auto& L : m->layers) {
+        rc |= m16_copy(m, L.wqkv, L.wqkv.n_rows, &L.m_wqkv) | m16_copy(m, L.wo, m->a.dim, &L.m_wo) | m16_copy(m, L.w13, m->ffn_hidden, &L.m_w13) | m16_copy(m, L.w2, m->a.dim, &L.m_w2);
+        if (rc) break;
+    }
+    if (!rc) rc = m16_copy(m, m->output, m->a.vocab_size, &m->m_output);
+    hipError_t e = hipStreamSynchronize(m->stream);
+    if (rc || e != hipSuccess) {                             // (out of memory on a model that fills the HBM: the single-sequence paths stay usable)
+        for (auto& L : m->layers) { hipFree(L.m_wqkv); hipFree(L.m_wo); hipFree(L.m_w13); hipFree(L.m_w2); L.m_wqkv = L.m_wo = L.m_w13 = L.m_w2 = nullptr; }
+        hipFree(m->m_output); m->m_output = nullptr; m->batch_bytes = 0;
+        if (!rc) return fail("lnb_model_enable_batch: %s", hipGetErrorString(e));
+        return -1;
+    }
+    m->batch_enabled = true;
+    return 0;
+}
+extern "C" int64_t lnb_model_batch_bytes(lnb_model* m) { return m ? m->batch_bytes : 0; }
+
+extern "C" int lnb_batch_destroy(lnb_batch* b) {
+    if (!b) return 0;
+    hipSetDevice(b->m->device);
+    if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->graph) hipGraphExecDestroy(b->graph);
+    hipFree(b->tab); hipFree(b->kv); hipFree(b->x); hipFree(b->h); hipFree(b->xt); hipFree(b->q); hipFree(b->att_xt); hipFree(b->ffn_xt); hipFree(b->logits);
+    hipFree(b->derr); hipFree(b->d_tokens); hipFree(b->d_pos);
+    if (b->h_io) hipHostFree(b->h_io);
+    if (b->ev0) hipEventDestroy(b->ev0);
+    if (b->ev1) hipEventDestroy(b->ev1);
+    if (b->stream) hipStreamDestroy(b->stream);
+    delete b;
+    return 0;
+}
+static int batch_alloc(lnb_batch* b) {
+    lnb_model* m = b->m; const int n = b->n;
+    HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
+    HIPCHK(hipHostMalloc((void**)&b->h_io, 64 * 4, hipHostMallocDefault));
+    BatchTab t{}; t.n = n;
+    std::vector<BatchKV> kv(m->layers.size());
+    for (int s = 0; s < LNB_BATCH_MAX; s++) {
+        lnb_ctx* c = b->ctxs[s < n ? s : 0];                // (unused columns point at sequence 0's words: never dereferenced, never null)
+        t.st[s] = c->st; t.dtok[s] = c->dtok; t.dout[s] = c->dout; t.dout_cap[s] = c->dout_cap; t.seq_len[s] = c->seq_len;
+        for (size_t l = 0; l < m->layers.size(); l++) { kv[l].ck[s] = c->ck[l]; kv[l].cv[s] = c->cv[l]; }
+    }
+    HIPCHK(hipMalloc((void**)&b->tab, sizeof t)); HIPCHK(hipMemcpyAsync(b->tab, &t, sizeof t, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMalloc((void**)&b->kv, kv.size() * sizeof(BatchKV)));
+    HIPCHK(hipMemcpyAsync(b->kv, kv.data(), kv.size() * sizeof(BatchKV), hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));                 // (the host copies above are stack / vector memory)
+    const size_t N = LNB_BATCH_MAX, dim = m->a.dim;
+    auto zalloc = [&](uint16_t** p, size_t elems) -> int { HIPCHK(hipMalloc((void**)p, elems * 2)); HIPCHK(hipMemsetAsync(*p, 0, elems * 2, b->stream)); return 0; };
+    // activations in the B-operand layout are [K][16 sequences]: the columns past n stay zero for ever
+    if (zalloc(&b->x, N * dim) || zalloc(&b->h, N * dim) || zalloc(&b->xt, N * dim) || zalloc(&b->q, N * m->q_dim) || zalloc(&b->att_xt, N * m->q_dim) ||
+        zalloc(&b->ffn_xt, N * m->ffn_hidden) || zalloc(&b->logits, N * (size_t)m->a.vocab_size)) return -1;
+    HIPCHK(hipMalloc((void**)&b->derr, 16)); HIPCHK(hipMemsetAsync(b->derr, 0, 16, b->stream));
+    HIPCHK(hipMalloc((void**)&b->d_tokens, 64)); HIPCHK(hipMalloc((void**)&b->d_pos, 64));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
+extern "C" int lnb_batch_create(lnb_ctx* const* ctxs, int n, lnb_batch** out) {
+    if (!ctxs || !out) return fail("null argument");
+    *out = nullptr;
+    if (n < 1 || n > LNB_BATCH_MAX) return fail("a batch holds 1..%d sequences (got %d)", LNB_BATCH_MAX, n);
+    for (int s = 0; s < n; s++) {
+        if (!ctxs[s]) return fail("null context at index %d", s);
+        if (ctxs[s]->m != ctxs[0]->m) return fail("context %d belongs to another model handle", s);
+        for (int r = 0; r < s; r++) if (ctxs[r] == ctxs[s]) return fail("context %d appears twice in the batch", s);
+        if (ctxs[s]->mode != LNB_MODE_EXACT) return fail("context %d is in the tolerance mode: batched decode is exact-order only", s);
+    }
+    lnb_model* m = ctxs[0]->m;
+    if (!m->batch_enabled) return fail("lnb_model_enable_batch has not been called on this model");
+    HIPCHK(hipSetDevice(m->device));
+    lnb_batch* b = new lnb_batch();
+    b->m = m; b->n = n; b->ctxs.assign(ctxs, ctxs + n);
+    for (int s = 0; s < n; s++) {
+        if (ctxs[s]->seq_len > ctxs[s]->attn_short_cap) {
+            const int sl = ctxs[s]->seq_len, cap = ctxs[s]->attn_short_cap; delete b;
+            return fail("context %d: seq_len %d is beyond the %d positions the batched attention stages in the LDS", s, sl, cap);
+        }
+        b->lds_T = std::max(b->lds_T, ctxs[s]->seq_len);
+    }
+    if (batch_alloc(b)) { lnb_batch_destroy(b); return -1; }
+    *out = b;
+    return 0;
+}
+static StreamParams stream_of(const lnb_batch* b, const uint16_t* w, const uint16_t* xt, int K, int n_rows, int nch) {
+    StreamParams p{}; p.w = w; p.xt = xt; p.K = K; p.n_rows = n_rows; p.nch = nch; p.n_chains = ((n_rows + 15) / 16) * nch; p.nseq = b->n; p.dbg = g_dbg;
+    return p;
+}
+static bool stream_acc2(const StreamParams& p) { return p.nch == 2 || p.n_chains > 4 * g_num_cus; }   // thin matrices: one tile per wave, every tile on its own SIMD
+// which: K_QKV (attention norm + wq|wk|wv + RoPE + KV append), K_ATTN, K_WO, K_W13 (ffn norm + w1|w3 + SiLU*up), K_W2, K_HEAD (norm + output)
+static int enqueue_batch_kernel(lnb_batch* b, int l, int which) {
+    lnb_model* m = b->m; const lnb_model_args& a = m->a; hipStream_t st = b->stream;
+    const int n = b->n, dim = a.dim, F = m->ffn_hidden;
+    if (which == K_HEAD) {
+        HIPCHK(lnbk_batch_rmsnorm(b->x, m->norm, a.norm_eps, b->xt, dim, n, st));
+        StreamParams p = stream_of(b, m->m_output, b->xt, dim, a.vocab_size, 1); p.out = b->logits;
+        HIPCHK(lnbk_stream(&p, EPI_STORE, stream_acc2(p), g_num_cus, st));
+        return 0;
+    }
+    LayerW& L = m->layers[l - m->layer_begin];
+    switch (which) {
+    case K_QKV: {
+        HIPCHK(lnbk_batch_rmsnorm(b->x, L.attn_norm, a.norm_eps, b->xt, dim, n, st));
+        StreamParams p = stream_of(b, L.m_wqkv, b->xt, dim, L.wqkv.n_rows, 1);
+        p.cis = m->cis; p.q_out = b->q; p.tab = b->tab; p.kv = b->kv + (l - m->layer_begin); p.q_dim = m->q_dim; p.kv_dim = m->kv_dim; p.head_dim = m->head_dim;
+        HIPCHK(lnbk_stream(&p, EPI_QKV_ROPE, stream_acc2(p), g_num_cus, st)); return 0; }
+    case K_ATTN: {
+        AttnParams ap{}; ap.q = b->q; ap.out_xt = b->att_xt; ap.btab = b->tab; ap.bkv = b->kv + (l - m->layer_begin); ap.dbg = nullptr;
+        ap.S = n; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = b->lds_T; ap.lds_T = b->lds_T; ap.host_T = 0;
+        ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));
+        ap.force_zseq = 0; ap.zseq_count = b->ctxs[0]->zseq_count;
+        HIPCHK(lnbk_attn(&ap, st)); return 0; }
+    case K_WO: {
+        StreamParams p = stream_of(b, L.m_wo, b->att_xt, m->q_dim, dim, 1); p.out = b->h; p.res = b->x;
+        HIPCHK(lnbk_stream(&p, EPI_RESID, stream_acc2(p), g_num_cus, st)); return 0; }
+    case K_W13: {
+        HIPCHK(lnbk_batch_rmsnorm(b->h, L.ffn_norm, a.norm_eps, b->xt, dim, n, st));
+        StreamParams p = stream_of(b, L.m_w13, b->xt, dim, F, 2); p.out_xt = b->ffn_xt; p.silu = m->silu;
+        HIPCHK(lnbk_stream(&p, EPI_SILU_MUL, 1, g_num_cus, st)); return 0; }
+    case K_W2: {
+        StreamParams p = stream_of(b, L.m_w2, b->ffn_xt, F, dim, 1); p.out = b->x; p.res = b->h;
+        HIPCHK(lnbk_stream(&p, EPI_RESID, stream_acc2(p), g_num_cus, st)); return 0; }
+    }
+    return fail("bad kernel id");
+}
+static int enqueue_batch_step(lnb_batch* b) {
+    lnb_model* m = b->m;
+    HIPCHK(lnbk_batch_embed(m->tok_embd, b->tab, b->x, b->n, m->a.dim, m->a.vocab_size, b->derr, b->stream));
+    for (int l = m->layer_begin; l < m->layer_end; l++)
+        for (int k = K_QKV; k <= K_W2; k++) if (enqueue_batch_kernel(b, l, k)) return -1;
+    if (enqueue_batch_kernel(b, 0, K_HEAD)) return -1;
+    HIPCHK(lnbk_batch_argmax(b->logits, m->a.vocab_size, b->tab, b->n, b->stream));
+    return 0;
+}
+extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, float* ms_out) {
+    if (!b || !tokens || !start_pos || !out_tokens) return fail("null argument");
+    lnb_model* m = b->m;
+    HIPCHK(hipSetDevice(m->device));
+    if (n_steps <= 0) return fail("n_steps must be positive");
+    for (int s = 0; s < b->n; s++) {
+        lnb_ctx* c = b->ctxs[s];
+        if (n_steps > c->dout_cap) return fail("sequence %d: n_steps %d exceeds the context length %d", s, n_steps, c->dout_cap);
+        if (check_call(c, 1, start_pos[s]) || check_call(c, 1, start_pos[s] + n_steps - 1)) return -1;
+        if (tokens[s] < 0 || tokens[s] >= m->a.vocab_size) return fail("sequence %d: token id at index 0 is outside the vocabulary", s);
+        if (c->pending) return fail("sequence %d: a lnb_forward_stage_begin has not been ended", s);
+        HIPCHK(hipStreamSynchronize(c->stream));             // whatever the context's own stream still does to its caches comes first
+        c->dev_pos = -1; c->call_T = 0;                      // the batch advances the context's device-side position by itself
+    }
+    hipStream_t st = b->stream;
+    const bool use_graph = env_int("LNB_NO_GRAPH", 0) == 0;
+    if (use_graph && !b->graph) {
+        hipGraph_t g = nullptr;
+        HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+        int rc = enqueue_batch_step(b);
+        hipError_t e = hipStreamEndCapture(st, &g);
+        if (rc) { if (g) hipGraphDestroy(g); return -1; }
+        HIPCHK(e);
+        HIPCHK(hipGraphInstantiate(&b->graph, g, nullptr, nullptr, 0));
+        HIPCHK(hipGraphDestroy(g));
+    }
+    memcpy(b->h_io, tokens, (size_t)b->n * 4); memcpy(b->h_io + 16, start_pos, (size_t)b->n * 4);
+    HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + 16, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(b->derr, 0, 4, st));
+    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, st));
+    HIPCHK(hipEventRecord(b->ev0, st));
+    for (int i = 0; i < n_steps; i++) {
+        if (use_graph) HIPCHK(hipGraphLaunch(b->graph, st));
+        else if (enqueue_batch_step(b)) return -1;
+    }
+    HIPCHK(hipEventRecord(b->ev1, st));
+    for (int s = 0; s < b->n; s++)
+        HIPCHK(hipMemcpyAsync(out_tokens + (size_t)s * n_steps, b->ctxs[s]->dout, (size_t)n_steps * 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(b->h_io + 32, b->derr, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, b->ev0, b->ev1));
+    if (b->h_io[32]) return fail("sequence %d: generated token id is outside the vocabulary", b->h_io[32] - 1);
+    return 0;
+}
+// measurement aid (bench.py): average HIP-event time of ONE kernel class of the batched step (which as in lnb_profile_kernel; the norm
+// launches count with the product they feed), consecutive launches cycling through the layers; every sequence is placed at `pos`
+extern "C" int lnb_batch_profile_kernel(lnb_batch* b, int which, int pos, int iters, float* avg_ms_out) {
+    if (!b || !avg_ms_out) return fail("null argument");
+    lnb_model* m = b->m;
+    HIPCHK(hipSetDevice(m->device));
+    if (iters <= 0 || which < 0 || which > K_LAYER) return fail("bad arguments");
+    for (int s = 0; s < b->n; s++) { if (check_call(b->ctxs[s], 1, pos)) return -1; b->h_io[s] = 0; b->h_io[16 + s] = pos; b->ctxs[s]->dev_pos = -1; }
+    hipStream_t st = b->stream;
+    HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + 16, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, st));
+    const int nl = m->layer_end - m->layer_begin;
+    auto run = [&](int i) -> int {
+        const int l = m->layer_begin + i % nl;
+        if (which == K_HEAD) return enqueue_batch_kernel(b, 0, K_HEAD);
+        if (which == K_LAYER) { for (int k = K_QKV; k <= K_W2; k++) if (enqueue_batch_kernel(b, l, k)) return -1; return 0; }
+        return enqueue_batch_kernel(b, l, which);
+    };
+    for (int i = 0; i < 3; i++) if (run(i)) return -1;
+    HIPCHK(hipEventRecord(b->ev0, st));
+    for (int i = 0; i < iters; i++) if (run(i + 3)) return -1;
+    HIPCHK(hipEventRecord(b->ev1, st));
+    HIPCHK(hipStreamSynchronize(st));
+    float ms = 0; HIPCHK(hipEventElapsedTime(&ms, b->ev0, b->ev1));
+    *avg_ms_out = ms / (float)iters;
+    return 0;
+}
+
 // ---- layer-sharded pipeline: the exchange behind the C ABI ---------------------------------------------------------------------
 // The reference runs its 32 blocks in one loop (llamatransformer.go:156-164); a pipeline cuts that loop over the GPUs of a node.  Rank r
 // holds a stage (lnb_model_create_parts) and one lnb_ctx per sequence in flight; a TICK enqueues, without ever blocking the host:
@@ -1205,6 +1458,18 @@ extern "C" int lnb_pipeline_selftest(int device, int n_bytes) {
     if (src) hipFree(src);
     if (dst) hipFree(dst);
     return rc;
+}
+// how many ranks the exchange spans, asked of the transport itself: ncclCommCount of the RCCL communicator (world > 1), the number of pipes
+// that joined the in-process group (loopback), 1 for a one-stage pipe (no communicator exists)
+extern "C" int lnb_pipeline_comm_count(lnb_pipe* p, int* out) {
+    if (!p || !out) return fail("null argument");
+    *out = 1;
+    if (p->world == 1) return 0;
+    if (p->loop) { std::lock_guard<std::mutex> lock(g_loops_mu); *out = p->loop->users; return 0; }
+    int n = 0;
+    NCCLCHK(p, p->api->CommCount(p->comm, &n));
+    *out = n;
+    return 0;
 }
 // block until everything enqueued so far (stage steps and exchanges) has finished
 extern "C" int lnb_pipeline_sync(lnb_pipe* p) {

@@ -1,0 +1,255 @@
+// lnb_batch_kernels.h -- batched EXACT decode: up to 16 independent sequences per pass over the weights.  Included at the end of
+// lnb_kernels.hip (one translation unit: it reuses the RMSNorm prologue, the epilogue arithmetic and the ring-load idiom defined there).
+//
+// Reference: the reference shares W across the rows of a call (src/ml/operations_lineartransform.go:173-193) and creates one context per
+// generation (src/inference/inference.go:174); N generations in flight are N independent one-token Forward calls per step.  Here their
+// tokens are the COLUMNS of one matrix product: v_mfma_f32_16x16x4_f32 is bit for bit the reference's k-ordered chain
+// acc = fma(x_k, w_k, acc) for each of its 16 x 16 outputs (tools/mfma_exact.hip), so column s carries sequence s's chains
+// unchanged -- same bits as its single-sequence run -- while the weights are streamed from HBM ONCE for all of them.
+//
+//   mfma_stream_kernel   weights (M16 layout, lnb_device.h) HBM -> VGPR -> matrix-core A operand, activations of the batch (B-operand
+//                        layout "xt") L2 -> VGPR -> B operand; no LDS, no barrier, every wave independent and persistent over its jobs;
+//                        epilogues of the decode kernels per column (RoPE + KV append with the column's own position and cache,
+//                        SiLU*up, residual) -- the next product's activations are written straight in the B-operand layout;
+//   batch_rmsnorm_xt_kernel   one workgroup per sequence: the exact parallel norm sum of the GEMV prologue (lnb_seqsum.h), output in xt;
+//   attn_exact_kernel    (lnb_kernels.hip) takes the per-sequence position / caches from the batch tables;
+//   batch_embed_kernel, batch_argmax_kernel   per-sequence token feedback: each context keeps its own position, token word and log.
+#pragma once
+
+// ---- one-time re-tile of a resident matrix into the M16 layout (lnb_model_enable_batch) -------------------------------------------
+__global__ void m16_from_tiled_kernel(const uint16_t* src, uint16_t* dst, int rows, int K, int RW, int NCH) {
+    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x, total = (size_t)rows * NCH * K;
+    if (idx >= total) return;
+    const int k = (int)(idx % K); const size_t rc = idx / K; const int c = (int)(rc % NCH), n = (int)(rc / NCH);
+    dst[m16_index(n, k, c, K, NCH)] = src[tiled_index(n, k, c, K, RW, NCH)];
+}
+
+// ---- ring loads (asm: hipcc's waitcnt pass drains vmcnt(0) around loop-carried register prefetch; retired by hand-counted waits) -----
+// the immediate offset selects the unit m of the chunk: it must be a literal in the asm text
+template <int M> DEVINL void ld_unit_nt(u32x4& d, unsigned voff, const char* sb) {
+    static_assert(M >= 0 && M < 4, "unit");
+    if constexpr (M == 0) asm volatile("global_load_dwordx4 %0, %1, %2 nt ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 nt ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072 nt ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+}
+template <int M> DEVINL void ld_unit(u32x4& d, unsigned voff, const char* sb) {       // activations: every CU reads them, keep them cached
+    static_assert(M >= 0 && M < 4, "unit");
+    if constexpr (M == 0) asm volatile("global_load_dwordx4 %0, %1, %2 ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072 ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+}
+template <int N, int L> DEVINL void wait_chunk(u32x4 (&b)[L]) {
+    static_assert(L == 8 || L == 12, "loads per chunk");
+    if constexpr (L == 8) asm volatile("s_waitcnt vmcnt(%8) ; RING_RETIRE %0 %1 %2 %3 %4 %5 %6 %7" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "n"(N) : "memory");
+    if constexpr (L == 12) asm volatile("s_waitcnt vmcnt(%12) ; RING_RETIRE %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]), "+v"(b[9]), "+v"(b[10]), "+v"(b[11]) : "n"(N) : "memory");
+}
+DEVINL float unit_elem(const u32x4& v, int e) { const uint32_t d = v[e >> 1]; return __uint_as_float((e & 1) ? (d & 0xFFFF0000u) : (d << 16)); }
+
+// epilogue of one 16-row tile-chain: this lane holds column s (a sequence), output rows n0 .. n0+3 (n0 % 4 == 0)
+template <int EPI> DEVINL void stream_epilogue(const StreamParams& p, const f32x4& g, const f32x4& u, int s, int n0) {
+    if (s >= p.nseq) return;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int n = n0 + r;
+        if (n >= p.n_rows) continue;
+        const size_t o = (size_t)s * p.n_rows + n;
+        if (EPI == EPI_STORE) p.out[o] = bf_trunc(g[r]);
+        else if (EPI == EPI_RESID) p.out[o] = bf_trunc(bf_wide(p.res[o]) + bf_wide(bf_trunc(g[r])));                    // ml.Add, impl:320-332
+        else if (EPI == EPI_SILU_MUL) {                                                                                   // activations.go:36-39, :614
+            const uint16_t gs = bf_trunc(p.silu[bf_trunc(g[r])]);
+            p.out_xt[xt_index(s, n)] = bf_trunc(bf_wide(gs) * bf_wide(bf_trunc(u[r])));
+        } else if (EPI == EPI_QKV_ROPE) {                                                                                 // llamatransformer.go:297-403
+            const int pos = p.tab->st[s]->pos;                                                                            // this sequence's own position
+            const uint16_t mine = bf_trunc(g[r]), other = bf_trunc(g[r ^ 1]);                                             // RoPE partner 2i <-> 2i+1: same lane
+            if (n < p.q_dim + p.kv_dim) {
+                const int d = n % p.head_dim, i = d >> 1;
+                const float2 cs = *(const float2*)(p.cis + ((size_t)pos * (p.head_dim >> 1) + i) * 2);
+                const double cr = (double)cs.x, ci = (double)cs.y;
+                uint16_t r16;
+                if ((n & 1) == 0) { const double a = (double)bf_wide(mine), bb = (double)bf_wide(other); r16 = bf_trunc((float)(a * cr - bb * ci)); }
+                else              { const double a = (double)bf_wide(other), bb = (double)bf_wide(mine); r16 = bf_trunc((float)(a * ci + bb * cr)); }
+                if (n < p.q_dim) p.q_out[(size_t)s * p.q_dim + n] = r16;
+                else {                                                                                                    // :402, K cache [kv head][d/8][position][8]
+                    const int kc = n - p.q_dim, kh = kc / p.head_dim;
+                    p.kv->ck[s][(((size_t)kh * (p.head_dim >> 3) + (d >> 3)) * p.tab->seq_len[s] + pos) * 8 + (d & 7)] = r16;
+                }
+            } else p.kv->cv[s][(size_t)pos * p.kv_dim + (n - p.q_dim - p.kv_dim)] = mine;                                 // :403
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// mfma_stream_kernel<ACC, EPI>: a wave owns ACC tile-chains at a time (job j = tile-chains j*ACC .. j*ACC + ACC-1: the gate and up chains of
+// one tile of w1|w3, two tiles of a fat matrix, or one tile of a thin one) and walks K in 128-step chunks: 4 x 16 B weight loads per chain
+// and 4 x 16 B activation loads per lane and chunk, R chunks in flight (hand-counted ring), then per chunk 32 k-groups in order g = 4e + m:
+// unpack (one VALU op per operand: bf16 -> f32 is a shift or a mask) in batches of 4*EB groups AHEAD of runs of back-to-back MFMAs.
+// Measured (tools/mfma_stream_bench.hip, MI355X): a dependent v_mfma_f32_16x16x4_f32 chain issues every 32.4 cycles back to back, 52
+// with ONE VALU op between two of them (the accumulator forwarding is lost), 36.6-39 with the VALU in batches; so the unpacks never sit
+// between two MFMAs of a run.  One wave per SIMD; persistent over its jobs (the load ring runs across job boundaries).
+// grid.x = min(ceil(n_jobs / 4), CUs), block 256, no LDS.
+// ------------------------------------------------------------------------------------------------
+template <int ACC, int EPI>
+__global__ __launch_bounds__(256) void mfma_stream_kernel(StreamParams p) {
+    constexpr int R = 4, L = ACC * 4 + 4, EB = ACC == 1 ? 8 : 4;
+    static_assert(R * L <= 60, "vmcnt is a 6-bit counter");
+    static_assert(EPI != EPI_SILU_MUL || ACC == 2, "gate and up chains of a tile travel together");
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int gw = blockIdx.x * 4 + wave, TW = gridDim.x * 4;
+    const int nchunks = p.K >> 7;
+    if (gw >= p.n_jobs) return;
+    const long long t_begin = p.dbg ? (long long)__builtin_amdgcn_s_memtime() : 0;
+    const int njobs_mine = (p.n_jobs - gw + TW - 1) / TW;
+    const int T = njobs_mine * nchunks;
+    const size_t chain_bytes = (size_t)nchunks * 4096;
+    const unsigned aoff = (unsigned)(((lane & 15) * 4 + (lane >> 4)) * 16), boff = (unsigned)lane * 16u;
+    const int last_chain = p.n_chains - 1;
+    u32x4 buf[R][L];
+    // issue cursor: next chunk to load = (job ij, chunk ic); past the end it stays put and re-reads
+    int ij = gw, ic = 0, issued = 0;
+    auto issue_next = [&](u32x4 (&dst)[L]) {
+        const char* xb = (const char*)p.xt + (size_t)ic * 4096;
+#pragma unroll
+        for (int a = 0; a < ACC; a++) {
+            int tc = ij * ACC + a; tc = tc < last_chain ? tc : last_chain;          // (a ragged last job loads a valid chain and drops the result)
+            const char* wb = (const char*)p.w + (size_t)tc * chain_bytes + (size_t)ic * 4096;
+            ld_unit_nt<0>(dst[a * 4 + 0], aoff, wb); ld_unit_nt<1>(dst[a * 4 + 1], aoff, wb);
+            ld_unit_nt<2>(dst[a * 4 + 2], aoff, wb); ld_unit_nt<3>(dst[a * 4 + 3], aoff, wb);
+        }
+        ld_unit<0>(dst[ACC * 4 + 0], boff, xb); ld_unit<1>(dst[ACC * 4 + 1], boff, xb);
+        ld_unit<2>(dst[ACC * 4 + 2], boff, xb); ld_unit<3>(dst[ACC * 4 + 3], boff, xb);
+        if (issued + 1 < T) { issued++; if (++ic == nchunks) { ic = 0; ij += TW; } }
+    };
+#pragma unroll
+    for (int j = 0; j < R; j++) issue_next(buf[j]);
+    f32x4 acc[ACC];
+#pragma unroll
+    for (int a = 0; a < ACC; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int c = 0, job = gw;
+    for (int t0 = 0; t0 < T; t0 += R) {
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (t0 + j < T) {
+                wait_chunk<(R - 1) * L, L>(buf[j]);          // chunk t0+j landed; R-1 younger ones stay in flight
+#pragma unroll
+                for (int e0 = 0; e0 < 8; e0 += EB) {
+                    float av[ACC][4 * EB], bv[4 * EB];
+#pragma unroll
+                    for (int ee = 0; ee < EB; ee++)
+#pragma unroll
+                        for (int m = 0; m < 4; m++) {
+#pragma unroll
+                            for (int a = 0; a < ACC; a++) av[a][ee * 4 + m] = unit_elem(buf[j][a * 4 + m], e0 + ee);
+                            bv[ee * 4 + m] = unit_elem(buf[j][ACC * 4 + m], e0 + ee);
+                        }
+                    if (e0 + EB == 8) {
+                        // every register of the slot has been read: refill it.  The unpacked operands are pinned in front of the refill --
+                        // otherwise hipcc sinks unpack ops below the asm that reloads the slot and keeps the old value alive through a
+                        // register copy made BEFORE the wait (seen in the ISA of the first version: v_mov of in-flight registers)
+#pragma unroll
+                        for (int q = 0; q < 4 * EB; q++) {
+#pragma unroll
+                            for (int a = 0; a < ACC; a++) asm volatile("" : "+v"(av[a][q]));
+                            asm volatile("" : "+v"(bv[q]));
+                        }
+                        issue_next(buf[j]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int q = 0; q < 4 * EB; q++)         // k-groups g = 4 (e0 + ee) + m ascending: the reference's k order (operations_lineartransform.go:46-65)
+#pragma unroll
+                        for (int a = 0; a < ACC; a++) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][q], bv[q], acc[a], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if (++c == nchunks) {                        // end of this job's chains: D layout = column lane & 15, rows (lane >> 4) * 4 + r
+                    const int s = lane & 15, tc0 = job * ACC;
+                    if (EPI == EPI_SILU_MUL) {
+                        if (tc0 + 1 <= last_chain) stream_epilogue<EPI>(p, acc[0], acc[ACC - 1], s, (tc0 / 2) * 16 + (lane >> 4) * 4);
+                    } else {
+#pragma unroll
+                        for (int a = 0; a < ACC; a++)
+                            if (tc0 + a <= last_chain) stream_epilogue<EPI>(p, acc[a], acc[a], s, (tc0 + a) * 16 + (lane >> 4) * 4);
+                    }
+#pragma unroll
+                    for (int a = 0; a < ACC; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    c = 0; job += TW;
+                }
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
+    if (p.dbg && lane == 0) p.dbg[gw] = (long long)__builtin_amdgcn_s_memtime() - t_begin;
+}
+
+// ------------------------------------------------------------------------------------------------
+// batch_rmsnorm_xt_kernel: RMSNorm (llamatransformer.go:633-660) of the batch's rows, one workgroup per sequence, with the EXACT parallel
+// evaluation of the reference's serial sum of squares -- the prologue of the norm-fused GEMVs (rms_fold / rms_scale_wide, lnb_seqsum.h) --
+// written out in the B-operand layout of the following product.  grid = nseq, block = (1 + NH) * 64, dynamic LDS = scratch + (kpad + 8) f32.
+// ------------------------------------------------------------------------------------------------
+constexpr int BN_NH = 6;
+__host__ __device__ inline int bn_kpad(int K) { return ((K + 7) & ~7) + 320; }
+__host__ __device__ inline size_t bn_scratch() { return (rms_scratch_bytes(BN_NH) + 255) & ~(size_t)255; }
+__global__ __launch_bounds__((1 + BN_NH) * 64) void batch_rmsnorm_xt_kernel(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NH = BN_NH, NS = 1 + NH, CW = 3;
+    char* scratch = smem;
+    float* xs = (float*)(smem + bn_scratch());
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int s = blockIdx.x, kpad = bn_kpad(K);
+    GemvParams p{}; p.K = K; p.norm_w = norm_w; p.eps = eps; p.dbg = nullptr;
+    const uint16_t* xrow = x + (size_t)s * K;
+    long long t_aux = 0;
+    uint4 xv[XCh<true>::value], nv[XCh<true>::value];
+    if (wave != CW) {
+        const int hw = wave < CW ? wave : wave - 1;
+        x_issue<true, NS>(p, xrow, 1 + hw, lane, xv, nv);
+        x_store<true, NS>(p, xs, kpad, 1 + hw, lane, xv);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();                        // B1: the squares are in LDS
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        rms_fold<NH>(p, xs, scratch, hw, lane, t_aux);       // X1, X2 inside
+        __builtin_amdgcn_s_barrier();                        // B2: r published
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        x_normalize<NS>(p, xs, kpad, xs[kpad], 1 + hw, lane, xv, nv);
+    } else {
+        x_issue<true, NS>(p, xrow, 0, lane, xv, nv);
+        x_store<true, NS>(p, xs, kpad, 0, lane, xv);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();                        // B1
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const float r = rms_scale_wide<NH>(p, xs, scratch, lane, t_aux);     // X1, X2 inside
+        if (lane == 0) xs[kpad] = r;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_s_barrier();                        // B2
+        x_normalize<NS>(p, xs, kpad, r, 0, lane, xv, nv);
+    }
+    __syncthreads();                                         // B3: xs holds trunc(trunc(x*r)*w) as f32 (bf16-exact)
+    // 16 B units of the B-operand layout: unit (C, m, kk) of sequence s = the eight k = 128C + 16e + 4m + kk, e = 0..7
+    for (int u = threadIdx.x; u < (K >> 3); u += (1 + NH) * 64) {
+        const int C = u >> 4, m = (u >> 2) & 3, kk = u & 3, kb = 128 * C + 4 * m + kk;
+        uint32_t w4[4];
+#pragma unroll
+        for (int e = 0; e < 8; e += 2) w4[e >> 1] = (uint32_t)bf_trunc(xs[kb + 16 * e]) | ((uint32_t)bf_trunc(xs[kb + 16 * (e + 1)]) << 16);
+        *(uint4*)(xt + xt_index(s, kb)) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+    }
+}
+
+// Fwd_Get_Rows (operations_impl.go:142-173) for the batch: row s = embedding of sequence s's current token (its context's device word)
+__global__ void batch_embed_kernel(const uint16_t* emb, const BatchTab* tab, uint16_t* x, int dim, int vocab, int* err) {
+    const int s = blockIdx.x;
+    const int t = *tab->dtok[s];
+    if (t < 0 || t >= vocab) { if (threadIdx.x == 0) atomicExch(err, 1 + s); return; }
+    const uint4* src = (const uint4*)(emb + (size_t)t * dim);
+    uint4* dst = (uint4*)(x + (size_t)s * dim);
+    for (int i = threadIdx.x; i < dim / 8; i += blockDim.x) dst[i] = src[i];
+}
+// start of a batched run: every sequence's token word and position (its own context's StepState)
+__global__ void batch_set_state_kernel(const BatchTab* tab, const int32_t* tokens, const int32_t* pos) {
+    const int s = threadIdx.x;
+    if (s >= tab->n) return;
+    *tab->dtok[s] = tokens[s];
+    tab->st[s]->pos = pos[s]; tab->st[s]->n_out = 0;
+}

@@ -122,4 +122,49 @@ struct AttnParams {
     double* e_buf;              // [H][seq_len] f64: exp of every score of the current token
     double* z_part;             // [H][ceil(seq_len / 256)] f64: per-block tree sums of e (only an ESTIMATE of Z, see the kernel)
     int* zseq_count;            // counts workgroups that had to fall back to the sequential Z chain (diagnostics)
+    // batched decode (attn_exact_kernel, S = 1 per sequence): query row i belongs to sequence i of the batch -- its own position, caches and
+    // cache length come from the tables; the output goes to out_xt in the B-operand layout of the wo product (lnb_batch_kernels.h)
+    const struct BatchTab* btab; const struct BatchKV* bkv; uint16_t* out_xt;
+};
+
+// ---- batched exact decode: up to 16 independent sequences per pass over the weights (lnb_batch_kernels.h) --------------------------
+// v_mfma_f32_16x16x4_f32 IS the reference's k-ordered chain; its 16 batch columns carry 16 SEQUENCES' decode tokens,
+// so one pass over the weights serves all of them, each with its own bit-exact chains.  The matrix cores are fed straight from HBM:
+// M16 weight layout of a logical [N, K] matrix (K % 128 == 0), NCH chains per 16-row tile:
+//   [tile t = n / 16][chain c][chunk C = k / 128][m = (k % 16) / 4][i = n % 16][kk = k % 4][e = (k % 128) / 16]      (bf16)
+// -- the element mapping of the row-broadcast layout above (a 16 B unit = the eight k of one row with the same k % 16), in 16-row
+// tiles: a wave-wide 16 B-per-lane load of unit (C, m) is 1 KiB contiguous and matrix-core lane (i, kk) finds in it, as elements
+// e = 0..7, its A operands of the k-groups g = 4e + m of the chunk (k = 128C + 4g + kk).  Activations of the batch ("xt"):
+//   [C][m][kk][s = sequence 0..15][e]   -- lane (s, kk) loads its B operands of the same k-groups with the same instruction shape.
+constexpr int LNB_BATCH_MAX = 16;
+LNB_HD size_t m16_index(int n, int k, int c, int K, int NCH) {
+    const int t = n >> 4, i = n & 15, C = k >> 7, e = (k >> 4) & 7, m = (k >> 2) & 3, kk = k & 3;
+    return ((((((size_t)t * NCH + c) * (size_t)(K >> 7) + C) * 4 + m) * 16 + i) * 4 + kk) * 8 + e;
+}
+LNB_HD size_t m16_elems(int n_rows, int K, int NCH) { return (size_t)((n_rows + 15) / 16) * 16 * (size_t)NCH * (size_t)K; }
+LNB_HD size_t xt_index(int s, int k) {
+    const int C = k >> 7, e = (k >> 4) & 7, m = (k >> 2) & 3, kk = k & 3;
+    return ((((size_t)C * 4 + m) * 4 + kk) * 16 + s) * 8 + e;
+}
+struct BatchTab {                  // device-resident: the sequences of a batch = the contexts they belong to (column s of every product)
+    StepState* st[LNB_BATCH_MAX];  // each context's own position / token counter
+    int32_t* dtok[LNB_BATCH_MAX];  // ... next-token word (read by the embedding gather, written by the argmax)
+    int32_t* dout[LNB_BATCH_MAX];  // ... generated-token log
+    int32_t dout_cap[LNB_BATCH_MAX];
+    int32_t seq_len[LNB_BATCH_MAX];   // ... KV-cache length (the K cache layout depends on it)
+    int32_t n, pad[3];
+};
+struct BatchKV { uint16_t* ck[LNB_BATCH_MAX]; uint16_t* cv[LNB_BATCH_MAX]; };   // one per layer: every sequence's caches of that layer
+
+struct StreamParams {              // mfma_stream_kernel: Y[s][n] = trunc(sum_k x_s[k] W[n][k]) for the nseq sequences of a batch
+    const uint16_t* w;             // M16 weights
+    const uint16_t* xt;            // activations in the B-operand layout (already normalised where the GEMV would fuse the norm)
+    int K, n_rows, nch;            // n_rows: logical rows per chain
+    int n_chains;                  // tile-chains = ceil(n_rows / 16) * nch
+    int n_jobs;                    // jobs of ACC tile-chains each
+    int nseq;
+    uint16_t* out; const uint16_t* res;            // EPI_STORE / EPI_RESID: [nseq][n_rows] bf16
+    uint16_t* out_xt; const float* silu;           // EPI_SILU_MUL: gate*up activations in the B-operand layout of the next product (K' = n_rows)
+    const float* cis; uint16_t* q_out; const BatchTab* tab; const BatchKV* kv; int q_dim, kv_dim, head_dim;   // EPI_QKV_ROPE
+    long long* dbg;
 };

@@ -1502,8 +1502,11 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     int h, i; xcd_head_block(h, i);
-    const int S = p.S, KVH = p.KVH;
-    const int pos0 = p.st->pos, T = pos0 + S;
+    // batched decode: query row i is the one new token of SEQUENCE i of the batch -- its own position, caches and cache length
+    const BatchTab* const bt = p.btab;
+    const int S = bt ? 1 : p.S, KVH = p.KVH;
+    const int seq_len = bt ? bt->seq_len[i] : p.seq_len;
+    const int pos0 = bt ? bt->st[i]->pos : p.st->pos, T = pos0 + S;
     const int kvh = h / (p.H / KVH);
     double* e = (double*)smem;
     float* pw = (float*)(smem + attn_off_pw(p.lds_T));
@@ -1512,8 +1515,8 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     char* ring = smem + attn_off_ring(p.lds_T, HD);
     const uint32_t row_bytes = (uint32_t)KVH * HD * 2;
     // K cache is stored [kv head][d/8][position][8] so that "one position per lane" reads are contiguous across the wave
-    const uint4* kbase = (const uint4*)p.cache_k + (size_t)kvh * NK * p.seq_len;
-    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD;
+    const uint4* kbase = (const uint4*)(bt ? p.bkv->ck[i] : p.cache_k) + (size_t)kvh * NK * seq_len;
+    const uint16_t* vbase = (bt ? p.bkv->cv[i] : p.cache_v) + (size_t)kvh * HD;
     const int Tend = (S > 1 && pos0 == 0) ? (i + 1) : T;    // see PV below
     const int nchunks = (Tend + ATT_JC - 1) / ATT_JC;
 #define ATT_STAMP(n) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0) p.dbg[wave * 16 + (n)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
@@ -1523,7 +1526,7 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     const uint16_t* q = p.q + ((size_t)i * p.H + h) * HD;
     const uint16_t q16 = q[tid < HD ? tid : 0];             // unconditional: a predicated load would be waited on at once
     uint4 ka[NK], kb[NK];
-    attn_load_k<NK>(ka, kbase, p.seq_len, tid < T ? tid : T - 1);
+    attn_load_k<NK>(ka, kbase, seq_len, tid < T ? tid : T - 1);
     if (tid < HD) qf[tid] = bf_wide(q16);
     __syncthreads();
     ATT_STAMP(1);
@@ -1532,10 +1535,10 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     for (int j0 = 0; j0 < T; j0 += 2 * ATT_NT) {
         const int j = j0 + tid;
         const bool more = j0 + ATT_NT < T, more2 = j0 + 2 * ATT_NT < T;       // block-uniform
-        if (more) attn_load_k<NK>(kb, kbase, p.seq_len, j + ATT_NT < T ? j + ATT_NT : T - 1);
+        if (more) attn_load_k<NK>(kb, kbase, seq_len, j + ATT_NT < T ? j + ATT_NT : T - 1);
         attn_score<NK>(ka, qf, j, T, S, i, p.divisor, e);
         if (more) {
-            if (more2) attn_load_k<NK>(ka, kbase, p.seq_len, j + 2 * ATT_NT < T ? j + 2 * ATT_NT : T - 1);
+            if (more2) attn_load_k<NK>(ka, kbase, seq_len, j + 2 * ATT_NT < T ? j + 2 * ATT_NT : T - 1);
             attn_score<NK>(kb, qf, j + ATT_NT, T, S, i, p.divisor, e);
         }
     }
@@ -1642,7 +1645,10 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     ATT_STAMP(6);
     if (wave < 2) {
         const int d = wave * 64 + lane;
-        if (d < HD) p.out[((size_t)i * p.H + h) * HD + d] = bf_trunc(acc);   // [S, H*hd] (:508-514)
+        if (d < HD) {
+            if (bt) p.out_xt[xt_index(i, h * HD + d)] = bf_trunc(acc);         // batch: straight into the B-operand layout of the wo product
+            else p.out[((size_t)i * p.H + h) * HD + d] = bf_trunc(acc);        // [S, H*hd] (:508-514)
+        }
     }
 }
 
@@ -1888,10 +1894,7 @@ __global__ void embed_kernel(const uint16_t* emb, const int32_t* tokens, uint16_
 // ml.Argmax (operations_impl.go:513-548): strict '<' scan from -MaxFloat32 => first maximum wins, NaN and
 // -inf are never selected (index -1 if nothing qualifies).  Parallel form: max value, lowest index.
 // Also advances the device-resident greedy loop (inference.go:211-226): next token -> tokens[0], pos += 1.
-__global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, int V, int32_t* next_token, StepState* st,
-                                                      int32_t* out_tokens, int out_cap, int advance) {
-    __shared__ float sv[1024];
-    __shared__ int si[1024];
+DEVINL int argmax_block(const uint16_t* logits, int V, float* sv, int* si) {      // result valid in thread 0
     const int tid = threadIdx.x;
     float best = -3.40282346638528859811704183484516925440e+38f; int bi = -1;
     // 16 B loads, four in flight per thread (the scalar one-load-per-iteration form was pure latency: 42 us for V=128256);
@@ -1928,8 +1931,14 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, in
         }
         __syncthreads();
     }
-    if (tid == 0) {
-        const int tok = si[0];
+    return si[0];
+}
+__global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, int V, int32_t* next_token, StepState* st,
+                                                      int32_t* out_tokens, int out_cap, int advance) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    const int tok = argmax_block(logits, V, sv, si);
+    if (threadIdx.x == 0) {
         next_token[0] = tok;
         if (advance) {
             int n = st->n_out;
@@ -1937,6 +1946,21 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, in
             st->n_out = n + 1;
             st->pos = st->pos + 1;
         }
+    }
+}
+// the same for the batch: block s = sequence s's logits row; its context's token word, token log and position advance (inference.go:211-226)
+__global__ __launch_bounds__(1024) void batch_argmax_kernel(const uint16_t* logits, int V, const BatchTab* tab) {
+    __shared__ float sv[1024];
+    __shared__ int si[1024];
+    const int s = blockIdx.x;
+    const int tok = argmax_block(logits + (size_t)s * V, V, sv, si);
+    if (threadIdx.x == 0) {
+        *tab->dtok[s] = tok;
+        StepState* st = tab->st[s];
+        const int n = st->n_out;
+        if (n < tab->dout_cap[s]) tab->dout[s][n] = tok;
+        st->n_out = n + 1;
+        st->pos = st->pos + 1;
     }
 }
 
@@ -1981,6 +2005,8 @@ __global__ void synth_fill_kernel(uint16_t* dst, int rows, int K, int row_off, i
     size_t o = RW ? tiled_index(row_off + r, k, chain, K, RW, NCH) : idx;
     dst[o] = bf_trunc(v);
 }
+
+#include "lnb_batch_kernels.h"
 
 // ------------------------------------------------------------------------------------------------
 // host-side launchers (called from lnb_api.cpp)
@@ -2195,5 +2221,50 @@ extern "C" hipError_t lnbk_synth_fill(uint16_t* dst, int rows, int K, int row_of
     size_t total = (size_t)rows * K;
     unsigned blocks = (unsigned)((total + 255) / 256);
     hipLaunchKernelGGL(synth_fill_kernel, dim3(blocks), dim3(256), 0, st, dst, rows, K, row_off, chain, RW, NCH, base, kind, sigma);
+    return hipGetLastError();
+}
+
+// ---- batched decode launchers -----------------------------------------------------------------------
+extern "C" hipError_t lnbk_m16_from_tiled(const uint16_t* src, uint16_t* dst, int rows, int K, int RW, int NCH, hipStream_t st) {
+    const size_t total = (size_t)rows * NCH * K;
+    hipLaunchKernelGGL(m16_from_tiled_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, src, dst, rows, K, RW, NCH);
+    return hipGetLastError();
+}
+// acc2: two tile-chains per wave (fat matrices and the gate|up pairs); else one (thin matrices: every tile on its own SIMD)
+extern "C" hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int num_cus, hipStream_t st) {
+    if ((p->K & 127) || p->nseq < 1 || p->nseq > LNB_BATCH_MAX || p->n_chains < 1) return hipErrorInvalidValue;
+    StreamParams q = *p;
+    const int ACC = acc2 ? 2 : 1;
+    q.n_jobs = (p->n_chains + ACC - 1) / ACC;
+    unsigned grid = (unsigned)((q.n_jobs + 3) / 4); if (grid > (unsigned)num_cus) grid = (unsigned)num_cus;
+#define LNB_STREAM(A, E) hipLaunchKernelGGL((mfma_stream_kernel<A, E>), dim3(grid), dim3(256), 0, st, q)
+    switch (epi) {
+    case EPI_STORE: if (acc2) LNB_STREAM(2, EPI_STORE); else LNB_STREAM(1, EPI_STORE); break;
+    case EPI_RESID: if (acc2) LNB_STREAM(2, EPI_RESID); else LNB_STREAM(1, EPI_RESID); break;
+    case EPI_QKV_ROPE: if (acc2) LNB_STREAM(2, EPI_QKV_ROPE); else LNB_STREAM(1, EPI_QKV_ROPE); break;
+    case EPI_SILU_MUL: if (!acc2 || p->nch != 2) return hipErrorInvalidValue; LNB_STREAM(2, EPI_SILU_MUL); break;
+    default: return hipErrorInvalidValue;
+    }
+#undef LNB_STREAM
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K, int nseq, hipStream_t st) {
+    static bool prepared = false;
+    const size_t lds = bn_scratch() + ((size_t)bn_kpad(K) + 8) * 4;
+    if ((K & 127) || lds > 160 * 1024 || (size_t)bn_kpad(K) > (size_t)XCh<true>::value * (1 + BN_NH) * 512 || seq_leaf_size(K, BN_NH * 64) > 256) return hipErrorInvalidValue;
+    if (!prepared) { hipError_t e = hipFuncSetAttribute((const void*)batch_rmsnorm_xt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e; prepared = true; }
+    hipLaunchKernelGGL(batch_rmsnorm_xt_kernel, dim3((unsigned)nseq), dim3((1 + BN_NH) * 64), lds, st, x, norm_w, eps, xt, K);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_batch_embed(const uint16_t* emb, const BatchTab* tab, uint16_t* x, int nseq, int dim, int vocab, int* err, hipStream_t st) {
+    hipLaunchKernelGGL(batch_embed_kernel, dim3((unsigned)nseq), dim3(256), 0, st, emb, tab, x, dim, vocab, err);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const BatchTab* tab, int nseq, hipStream_t st) {
+    hipLaunchKernelGGL(batch_argmax_kernel, dim3((unsigned)nseq), dim3(1024), 0, st, logits, V, tab);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, hipStream_t st) {
+    hipLaunchKernelGGL(batch_set_state_kernel, dim3(1), dim3(64), 0, st, tab, tokens, pos);
     return hipGetLastError();
 }

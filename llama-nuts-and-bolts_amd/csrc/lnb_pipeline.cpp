@@ -29,6 +29,7 @@ extern "C" __attribute__((visibility("hidden"))) const lnb_rccl_api* lnb_rccl_lo
         {"ncclCommDestroy", (void**)&g_api.CommDestroy}, {"ncclGroupStart", (void**)&g_api.GroupStart},
         {"ncclGroupEnd", (void**)&g_api.GroupEnd}, {"ncclSend", (void**)&g_api.Send}, {"ncclRecv", (void**)&g_api.Recv},
         {"ncclGetErrorString", (void**)&g_api.GetErrorString}, {"ncclGetVersion", (void**)&g_api.GetVersion},
+        {"ncclCommCount", (void**)&g_api.CommCount},
     };
     for (auto& s : syms) {
         *s.slot = dlsym(h, s.name);

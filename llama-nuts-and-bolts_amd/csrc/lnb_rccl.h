@@ -14,5 +14,6 @@ struct lnb_rccl_api {
     int (*Recv)(void* buf, size_t count, int dtype, int peer, void* comm, void* stream);
     const char* (*GetErrorString)(int);
     int (*GetVersion)(int*);
+    int (*CommCount)(const void* comm, int* count);         // ncclCommCount: the communicator's own idea of how many ranks it spans
 };
 extern "C" const lnb_rccl_api* lnb_rccl_load(void);         // nullptr + lnb_last_error() when the library cannot be loaded

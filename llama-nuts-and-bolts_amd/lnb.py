@@ -58,7 +58,8 @@ EXPORTS = [
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
     "lnb_tokenizer_load", "lnb_tokenizer_free", "lnb_tokenizer_vocab_size", "lnb_tokenizer_special", "lnb_tokenizer_token_id",
     "lnb_tokenizer_piece", "lnb_tokenizer_encode", "lnb_tokenizer_encode_chat",
-    "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens", "lnb_pipeline_selftest",
+    "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens", "lnb_pipeline_selftest", "lnb_pipeline_comm_count",
+    "lnb_model_enable_batch", "lnb_model_batch_bytes", "lnb_batch_create", "lnb_batch_destroy", "lnb_batch_decode", "lnb_batch_profile_kernel",
 ]
 
 
@@ -112,6 +113,14 @@ def lib():
     L.lnb_pipeline_destroy.argtypes = [vp]
     L.lnb_pipeline_tick.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
     L.lnb_pipeline_sync.argtypes = [vp]
+    L.lnb_pipeline_comm_count.argtypes = [vp, C.POINTER(C.c_int)]
+    L.lnb_model_enable_batch.argtypes = [vp]
+    L.lnb_model_batch_bytes.argtypes = [vp]
+    L.lnb_model_batch_bytes.restype = C.c_int64
+    L.lnb_batch_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
+    L.lnb_batch_destroy.argtypes = [vp]
+    L.lnb_batch_decode.argtypes = [vp, i32p, i32p, C.c_int, vp, f32p]
+    L.lnb_batch_profile_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p]
     L.lnb_pipeline_read_tokens.argtypes = [vp, C.c_int, C.c_int, vp]
     L.lnb_op_linear_mode.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_op_argmax.argtypes = [C.c_int, vp, C.c_int, i32p]
@@ -307,6 +316,14 @@ class LlamaTransformer:
     def weight_bytes(self):
         return int(self.L.lnb_model_weight_bytes(self.h))
 
+    def enable_batch(self):
+        """build the matrix-core friendly copy of the weights that batched decode streams (lnb_model_enable_batch); after finalize()"""
+        _chk(self.L.lnb_model_enable_batch(self.h))
+        return self
+
+    def batch_bytes(self):
+        return int(self.L.lnb_model_batch_bytes(self.h))
+
     def close(self):
         if self.h:
             self.L.lnb_model_destroy(self.h)
@@ -378,6 +395,38 @@ class InferenceContext:
             self.h = C.c_void_p()
 
 
+class Batch:
+    """1..16 InferenceContexts of one transformer decoded together: one pass over the weights per step for all of them, every sequence
+    bit-identical to its single-sequence run (lnb_batch_*).  The contexts keep their own caches and positions."""
+
+    def __init__(self, contexts):
+        self.ctxs = list(contexts)
+        self.L = self.ctxs[0].L
+        arr = (C.c_void_p * len(self.ctxs))(*[c.h for c in self.ctxs])
+        self.h = C.c_void_p()
+        _chk(self.L.lnb_batch_create(arr, len(self.ctxs), C.byref(self.h)))
+
+    def decode(self, tokens, start_pos, n_steps):
+        """sequence s continues from tokens[s] at position start_pos[s]; -> (int32 [n, n_steps], device ms of the n_steps)"""
+        n = len(self.ctxs)
+        tok = np.ascontiguousarray(tokens, dtype=np.int32); pos = np.ascontiguousarray(start_pos, dtype=np.int32)
+        assert tok.size == n and pos.size == n
+        out = np.empty((n, n_steps), dtype=np.int32)
+        ms = C.c_float(0)
+        _chk(self.L.lnb_batch_decode(self.h, tok.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_int32)), n_steps, _p(out), C.byref(ms)))
+        return out, ms.value
+
+    def profile_kernel(self, which, pos, iters):
+        ms = C.c_float(0)
+        _chk(self.L.lnb_batch_profile_kernel(self.h, which, pos, iters, C.byref(ms)))
+        return ms.value
+
+    def close(self):
+        if self.h:
+            self.L.lnb_batch_destroy(self.h)
+            self.h = C.c_void_p()
+
+
 class Pipeline:
     """One rank of the layer-sharded pipeline behind the C ABI (lnb_pipeline_*): RCCL send / recv straight from / into the stage's
     device buffers, stage steps as captured graphs, nothing synchronised per tick."""
@@ -407,6 +456,12 @@ class Pipeline:
 
     def sync(self):
         _chk(self.L.lnb_pipeline_sync(self.h))
+
+    def comm_count(self):
+        """ranks the exchange spans, as the transport itself reports it (ncclCommCount)"""
+        n = C.c_int(0)
+        _chk(self.L.lnb_pipeline_comm_count(self.h, C.byref(n)))
+        return n.value
 
     def read_tokens(self, first_slot, n):
         out = np.empty(n, dtype=np.int32)

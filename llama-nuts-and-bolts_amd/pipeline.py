@@ -462,6 +462,46 @@ class LnbStage(Stage):
         self.model.close()
 
 
+def run_single_stream_native(rank, world, pipe, ctx, prompt, n_decode, lo=0, hi=None, state=None):
+    """ONE greedy sequence through the pipeline (configs[3]'s "single-stream" figure): inherently serial across the stages -- token t + 1
+    needs token t from the last rank -- so every rank simply enqueues, per step, the receive of its input, its stage step and the send
+    of its result; the events inside lnb_pipeline_tick order them on the device and nothing is synchronised here.  Steps [lo, hi) of
+    1 + n_decode (step 0 = the prompt).  state["slots"] on the last rank = token-log slots in order."""
+    P = len(prompt)
+    first, last = rank == 0, rank == world - 1
+    if state is None:
+        state = {"slots": []}
+    if hi is None:
+        hi = 1 + n_decode
+    for k in range(lo, hi):
+        rows, pos = (P, 0) if k == 0 else (1, P + k - 1)
+        if world > 1 and (not first or k > 0):
+            pipe.tick(recv=ctx, recv_rows=rows)               # hidden state from rank - 1; on rank 0 the token of step k - 1 from the last rank
+        slot = pipe.tick(run=ctx, run_rows=rows, run_pos=pos, run_tokens=(np.ascontiguousarray(prompt, dtype=np.int32) if (first and k == 0) else None))
+        if last:
+            state["slots"].append(slot)
+        if world > 1 and (not last or k + 1 < 1 + n_decode):  # (the token of the final step is not needed by rank 0)
+            pipe.tick(send=ctx, send_rows=rows)
+    return state
+
+
+def blocks_split(rank, world, n_layers):
+    """configs[3] literally: n_layers / world whole blocks per GPU (the head on top of the last stage's share)"""
+    return 3 * (rank * n_layers // world), 3 * ((rank + 1) * n_layers // world)
+
+
+def _golden_check(tokens, prompt_len, model_name):
+    """sequence 0 of the pipeline run has the headline's prompt (synth_tokens(99, P)): its tokens against the CPU oracle's golden
+    continuation of configs[1] (tests/golden/configs1_tokens.json), as bench.py's one-GPU line does"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "configs1_tokens.json")
+    if model_name != "Llama-3.1-8B" or prompt_len != 128 or not os.path.exists(path):
+        return None
+    gold = json.load(open(path))["tokens"]
+    n = min(len(tokens), len(gold))
+    agree = next((i for i in range(n) if int(tokens[i]) != gold[i]), n)
+    return {"compared": n, "identical_prefix": agree, "golden": "tests/golden/configs1_tokens.json (CPU oracle)"}
+
+
 def bench_main(args, cfg, name):
     """bench.py --gpus N under torchrun: weak scaling, 2N sequences in flight, one rank per GPU.
 
@@ -479,8 +519,8 @@ def bench_main(args, cfg, name):
     os.dup2(2, 1)
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", str(rank)))
-    if world != args.gpus:
-        raise SystemExit("launch with torch.distributed.run --nproc-per-node %d (WORLD_SIZE=%d)" % (args.gpus, world))
+    if world != args.gpus:                                   # (bench.py spawns the ranks itself when WORLD_SIZE is not set: this is a mismatched manual launch)
+        raise SystemExit("WORLD_SIZE=%d but --gpus %d: launch `python bench.py --gpus N` plainly, or under torch.distributed.run with --nproc-per-node N" % (world, args.gpus))
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")           # (only used by the single-process LNB_FORCE_PIPELINE=1 run)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -520,23 +560,59 @@ def bench_main(args, cfg, name):
         prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
         n_decode = W + K
         t_split, t_end = n_seq * (1 + W), n_seq * (1 + W + K)
-        st = run_ticks_native(rank, world, pipe, stage.ctx, prompts, n_decode, 0, t_split)
-        pipe.sync()
-        grp.barrier()
-        t0 = time.perf_counter()
-        t_host = time.perf_counter()
-        run_ticks_native(rank, world, pipe, stage.ctx, prompts, n_decode, t_split, t_end, st)
-        t_host = time.perf_counter() - t_host                # host time of ENQUEUEING the K*n_seq ticks of the timed window
-        pipe.sync()
-        grp.barrier()
-        wall = grp.all_reduce(time.perf_counter() - t0, max)
+
+        def slots_tokens(sl):
+            return [int(t) for t in pipe.read_tokens(sl[0], len(sl))] if sl and sl == list(range(sl[0], sl[0] + len(sl))) else [int(pipe.read_tokens(q, 1)[0]) for q in sl]
+
+        def measure():
+            """untimed prefill + W warm-up rounds, then EXACTLY K timed decode rounds of the n_seq sequences in flight, bracketed by a device
+            sync + barrier on both sides, max over ranks; then the same model with ONE sequence (single-stream) on a fresh context"""
+            st = run_ticks_native(rank, world, pipe, stage.ctx, prompts, n_decode, 0, t_split)
+            pipe.sync(); grp.barrier()
+            t0 = time.perf_counter()
+            run_ticks_native(rank, world, pipe, stage.ctx, prompts, n_decode, t_split, t_end, st)
+            t_host = time.perf_counter() - t0                # host time of ENQUEUEING the K*n_seq ticks of the timed window
+            pipe.sync(); grp.barrier()
+            wall = grp.all_reduce(time.perf_counter() - t0, max)
+            toks0 = slots_tokens(st["slots"][0]) if rank == world - 1 else None
+            # single stream: sequence 0 again on its (reset) context, W_s warm-up + K_s timed steps
+            Ks, Ws = min(K, int(os.environ.get("LNB_SINGLE_STREAM_STEPS", "32"))), min(W, 4)
+            c0 = stage.ctx[0]; c0.reset()
+            ss = run_single_stream_native(rank, world, pipe, c0, prompts[0], Ws + Ks, 0, 1 + Ws)
+            pipe.sync(); grp.barrier()
+            t1 = time.perf_counter()
+            run_single_stream_native(rank, world, pipe, c0, prompts[0], Ws + Ks, 1 + Ws, 1 + Ws + Ks, ss)
+            pipe.sync(); grp.barrier()
+            wall_s = grp.all_reduce(time.perf_counter() - t1, max)
+            toks_s = slots_tokens(ss["slots"]) if rank == world - 1 else None
+            info = grp.all_reduce([(rank, pipe.comm_count(), toks0, toks_s)], lambda vs: sorted(sum(vs, [])))
+            toks0 = info[-1][2]; toks_s = info[-1][3]
+            return {"wall": wall, "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * n_seq), 1),
+                    "rccl_comm_count_per_rank": [c for _, c, _, _ in info], "tokens_seq0": toks0,
+                    "single_stream": {"tokens_per_s": round(Ks / wall_s, 2), "steps": Ks, "ms_per_token": round(1e3 * wall_s / Ks, 4),
+                                      "tokens_equal_sequence0_of_the_batch": bool(toks_s is not None and toks0 is not None and toks_s[:len(toks0)] == toks0[:len(toks_s)])}}
+
+        m_bal = measure()
+        wall = m_bal["wall"]
+        toks0 = m_bal.pop("tokens_seq0")
         extra = {"exchange": "RCCL point-to-point inside the library (lnb_pipeline_tick), stage steps as captured graphs",
-                 "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * n_seq), 1)}
+                 "host_enqueue_us_per_tick": m_bal["host_enqueue_us_per_tick"], "rccl_comm_count_per_rank": m_bal["rccl_comm_count_per_rank"],
+                 "single_stream": m_bal["single_stream"], "tokens_vs_oracle_golden": _golden_check(toks0, P, name) if toks0 else None}
         if rank == world - 1 and os.environ.get("LNB_PIPELINE_DUMP_TOKENS"):
-            toks = {s: [int(t) for t in pipe.read_tokens(sl[0], len(sl))] if sl and sl == list(range(sl[0], sl[0] + len(sl))) else
-                    [int(pipe.read_tokens(q, 1)[0]) for q in sl] for s, sl in enumerate(st["slots"])}
-            json.dump(toks, open(os.environ["LNB_PIPELINE_DUMP_TOKENS"], "w"))
+            json.dump({"0": toks0}, open(os.environ["LNB_PIPELINE_DUMP_TOKENS"], "w"))
         pipe.close()
+        # configs[3] literally -- n_layers / N whole blocks per GPU -- next to the cost-balanced cut above (the headline): same run again
+        if world > 1 and cfg["n_layers"] % world == 0 and os.environ.get("LNB_PIPELINE_LITERAL_SPLIT", "1") != "0":
+            stage.close()
+            stage = LnbStage(lnb, None, cfg, rank, world, n_seq, seq_len, local, parts=blocks_split(rank, world, cfg["n_layers"]), costs=costs)
+            for c in stage.ctx:
+                c.set_mode(mode)
+            uid = grp.broadcast(lnb.Pipeline.unique_id() if rank == 0 else None)
+            pipe = lnb.Pipeline(stage.model, rank, world, uid)
+            m_lit = measure()
+            m_lit.pop("tokens_seq0")
+            extra["literal_blocks_split"] = dict(m_lit, blocks_per_gpu=cfg["n_layers"] // world, tokens_per_s=round(K * n_seq / m_lit.pop("wall"), 2))
+            pipe.close()
         grp.close()
     else:
         import datetime
@@ -603,6 +679,8 @@ def bench_main(args, cfg, name):
                "roofline": {"bound": "hbm", "achieved": round(tps * B / 1e9, 1), "peak": _b.PEAK_HBM_GBS * world, "unit": "GB/s",
                             "frac": round(tps * B / 1e9 / (_b.PEAK_HBM_GBS * world), 4), "traffic": None,
                             "note": "whole job: tokens/s x algorithmic bytes per token over N x 8 TB/s"}}
+        if getattr(args, "cpu_steps", 0) > 0:                # the same bounded CPU sample as the one-GPU line (after the timed regions; the other ranks are done)
+            res["cpu_baseline"] = _b.cpu_baseline(cfg, lnb.synth_tokens(99, P, cfg["vocab_size"])[:8], args.cpu_steps)
         os.write(json_fd, (json.dumps(res) + "\n").encode())
     os.close(json_fd)
     stage.close()

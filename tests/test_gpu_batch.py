@@ -1,0 +1,136 @@
+"""Batched EXACT decode (lnb_batch_*, -m gpu): 1..16 independent sequences per pass over the weights, each the column of an f32 matrix-core
+product.  Parity: every sequence's tokens and KV-cache bits equal the CPU oracle's single-sequence run (tiny shapes) and the device's own
+oracle-verified single-sequence path (8B shape; sequence 0 also against the committed configs[1] golden).
+Reference: one context per generation (src/inference/inference.go:174), W shared across rows (src/ml/operations_lineartransform.go:173-193)."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lnb():
+    import lnb as _lnb
+    _lnb.build()
+    assert _lnb.device_count() >= 1
+    return _lnb
+
+
+CFGS = {
+    "tiny_hd64": dict(orc.TINY),                                                  # dim 256, 4/2 heads, FFN 896 (7 chunks of 128: not a multiple of the ring depth)
+    "tiny_hd128": dict(orc.TINY, n_heads=2, n_kv_heads=1),
+    "h8kv2_hd128": dict(orc.TINY, dim=1024, n_heads=8, n_kv_heads=2),             # (n_heads & 7) == 0: the XCD-aware attention grid
+    "odd_tiles": dict(orc.TINY, dim=384, n_heads=3, n_kv_heads=1, vocab_size=1000, multiple_of=128),   # 24 / 40 / 63 tiles: ragged jobs, ragged vocabulary
+}
+
+
+@pytest.mark.parametrize("name", sorted(CFGS))
+def test_every_sequence_of_a_batch_equals_its_own_oracle_run(lnb, name):
+    cfg = CFGS[name]
+    om = orc.Model(**cfg).fill_synthetic(606).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(606).finalize().enable_batch()
+    assert gm.batch_bytes() > 0
+    steps = 11
+    for n in (1, 2, 5, 16):
+        plens = [4 + 3 * s + (17 if s % 4 == 1 else 0) for s in range(n)]           # different prompt lengths: different positions per column
+        prompts = [orc.synth_tokens(100 * n + s, plens[s], cfg["vocab_size"]) for s in range(n)]
+        refs, ocs = [], []
+        for s in range(n):
+            oc = orc.Context(om, plens[s] + steps + 6)
+            r, _ = oc.generate(prompts[s], steps + 4)
+            refs.append([int(t) for t in r]); ocs.append(oc)
+        ctxs = [lnb.InferenceContext(gm, plens[s] + steps + 6) for s in range(n)]
+        firsts = []
+        for s in range(n):
+            _, t = ctxs[s].Forward(prompts[s], 0, want_logits=False)
+            firsts.append(t)
+        assert firsts == [r[0] for r in refs]
+        b = lnb.Batch(ctxs)
+        got, ms = b.decode(firsts, plens, steps)
+        assert ms > 0
+        for s in range(n):
+            assert [int(t) for t in got[s]] == refs[s][1:1 + steps], (name, n, s)
+            T = plens[s] + steps
+            for layer in range(cfg["n_layers"]):
+                assert (ocs[s].cache(layer, 0)[:T] == ctxs[s].CacheK(layer)[:T]).all(), (name, n, s, layer)
+                assert (ocs[s].cache(layer, 1)[:T] == ctxs[s].CacheV(layer)[:T]).all(), (name, n, s, layer)
+        # a second call on the same batch continues where the first stopped; then one context goes on alone
+        more, _ = b.decode([refs[s][steps] for s in range(n)], [plens[s] + steps for s in range(n)], 2)
+        for s in range(n):
+            assert [int(t) for t in more[s]] == refs[s][steps + 1:steps + 3], (name, n, s)
+        solo, _ = ctxs[n - 1].decode_greedy(refs[n - 1][steps + 2], plens[n - 1] + steps + 2, 1)
+        assert int(solo[0]) == refs[n - 1][steps + 3]
+        b.close()
+        for c in ctxs:
+            c.close()
+        for oc in ocs:
+            oc.close()
+    gm.close(); om.close()
+
+
+def test_batch_decode_at_the_8b_shape_equals_single_sequence_runs_and_the_golden(lnb):
+    """Llama-3.1-8B shape, 16 prompts of 128 tokens in flight: each sequence's tokens equal its own run through lnb_decode_greedy (the
+    path tests/test_gpu_full_8b.py checks against the oracle); sequence 0 is the configs[1] prompt: equal to the oracle's golden tokens"""
+    cfg = dict(lnb.LLAMA_8B)
+    P, steps, n = 128, 24, 16
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1234).finalize().enable_batch()
+    prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n)]
+    ctxs = [lnb.InferenceContext(gm, P + steps + 8) for _ in range(n)]
+    firsts = [ctxs[s].Forward(prompts[s], 0, want_logits=False)[1] for s in range(n)]
+    b = lnb.Batch(ctxs)
+    got, ms = b.decode(firsts, [P] * n, steps)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "configs1_tokens.json")))["tokens"]
+    assert [firsts[0]] + [int(t) for t in got[0]] == gold[:steps + 1]
+    solo = lnb.InferenceContext(gm, P + steps + 8)
+    for s in (1, 7, 15):
+        solo.reset()
+        _, f = solo.Forward(prompts[s], 0, want_logits=False)
+        assert f == firsts[s]
+        ref, _ = solo.decode_greedy(f, P, steps)
+        assert [int(t) for t in got[s]] == [int(t) for t in ref], s
+        for layer in (0, 31):
+            assert (solo.CacheK(layer)[:P + steps] == ctxs[s].CacheK(layer)[:P + steps]).all() and (solo.CacheV(layer)[:P + steps] == ctxs[s].CacheV(layer)[:P + steps]).all()
+    print("8B shape, 16 sequences: %.3f ms per step = %.0f tokens/s aggregate" % (ms / steps, 1e3 * n * steps / ms))
+    b.close(); solo.close()
+    for c in ctxs:
+        c.close()
+    gm.close()
+
+
+def test_batch_argument_checks(lnb):
+    cfg = dict(orc.TINY)
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1).finalize()
+    c0, c1 = lnb.InferenceContext(gm, 32), lnb.InferenceContext(gm, 32)
+    with pytest.raises(lnb.LnbError, match="enable_batch"):
+        lnb.Batch([c0, c1])
+    gm.enable_batch()
+    with pytest.raises(lnb.LnbError, match="twice"):
+        lnb.Batch([c0, c0])
+    with pytest.raises(lnb.LnbError, match="1..16"):
+        lnb.Batch([lnb.InferenceContext(gm, 16) for _ in range(17)])
+    with pytest.raises(lnb.LnbError, match="enable_batch"):
+        gm.fill_synthetic(2)                                 # the second copy would go stale
+    c1.set_mode("fast")
+    with pytest.raises(lnb.LnbError, match="exact-order only"):
+        lnb.Batch([c0, c1])
+    c1.set_mode("exact")
+    b = lnb.Batch([c0, c1])
+    with pytest.raises(lnb.LnbError, match="beyond the KV cache"):
+        b.decode([1, 2], [30, 3], 4)
+    with pytest.raises(lnb.LnbError, match="outside the vocabulary"):
+        b.decode([1, cfg["vocab_size"]], [0, 0], 2)
+    other = lnb.LlamaTransformer(**cfg).fill_synthetic(1).finalize().enable_batch()
+    co = lnb.InferenceContext(other, 32)
+    with pytest.raises(lnb.LnbError, match="another model"):
+        lnb.Batch([c0, co])
+    odd = lnb.LlamaTransformer(**dict(cfg, dim=192, n_heads=3, n_kv_heads=3)).fill_synthetic(1).finalize()
+    with pytest.raises(lnb.LnbError, match="multiples of 128"):
+        odd.enable_batch()
+    for x in (b, c0, c1, co, other, odd, gm):
+        x.close()

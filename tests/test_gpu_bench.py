@@ -35,3 +35,37 @@ def test_single_gpu_bench_prints_one_json_line_with_the_contract_keys(mode):
     sf = d["sequences_in_flight"]
     assert sf["n"] == 3 and sf["tokens_per_s"] > 0
     assert sf["sequence0_tokens_vs_single_run"]["identical_prefix"] == sf["sequence0_tokens_vs_single_run"]["compared"] > 0
+    cf = rf["chain_floor"]
+    assert cf["tokens_per_s"] > 0 and 0 < cf["achieved_frac_of_attainable"] <= 1.0
+    if mode == "exact":                                    # batched exact decode: n prompts per pass over the weights, sequence 0 = the single run's prompt
+        sb = d["sequences_in_flight_batched"]
+        assert [r["n"] for r in sb["runs"]] == [2, 4, 8, 16] and sb["weights_second_copy_bytes"] > 0
+        for r in sb["runs"]:
+            assert r["tokens_per_s"] > 0 and r["sequence0_tokens_vs_single_run"]["identical_prefix"] == r["sequence0_tokens_vs_single_run"]["compared"] > 0
+        assert set(sb["runs"][-1]["kernels_us"]) >= {"norm+wqkv+rope", "attention", "w2+residual", "norm+output"}
+    else:
+        assert "sequences_in_flight_batched" not in d
+
+
+def test_bench_gpus_2_as_a_plain_command_on_one_gpu_with_gloo():
+    """the driver's N-GPU command line -- `python bench.py --gpus N --steps K --warmup W`, no launcher -- on a one-GPU box: the two ranks
+    bench.py spawns share GPU 0 and exchange through gloo (LNB_PIPELINE_BACKEND=gloo; RCCL wants one GPU per rank)"""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--model", "tiny", "--steps", "6", "--warmup", "2", "--prompt-len", "20", "--cpu-steps", "0"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(env, LNB_PIPELINE_BACKEND="gloo", LNB_PIPELINE_PROBE="0"))
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["value"] > 0 and d["config"]["parallelism"] == "pp2" and d["config"]["sequences_in_flight"] == 4
+
+
+def test_forced_pipeline_line_carries_the_single_stream_figure_and_the_transport_rank_count():
+    """LNB_FORCE_PIPELINE=1: the N-GPU code path (native ticks) on one GPU -- the JSON line of an N > 1 run has the same extra fields"""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--model", "tiny", "--steps", "8", "--warmup", "2", "--prompt-len", "20", "--cpu-steps", "2"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, LNB_FORCE_PIPELINE="1", MASTER_PORT="29581"))
+    assert r.returncode == 0, r.stdout[-1000:] + r.stderr[-4000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][0])
+    c = d["config"]
+    assert c["rccl_comm_count_per_rank"] == [1] and c["single_stream"]["tokens_per_s"] > 0 and c["single_stream"]["tokens_equal_sequence0_of_the_batch"] is True
+    assert d["cpu_baseline"]["value"] > 0

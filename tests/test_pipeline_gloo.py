@@ -183,3 +183,29 @@ def test_stage_parts_reaches_the_min_max_optimum():
         assert cuts[0][0] == 0 and cuts[-1][1] == n and all(b > a for a, b in cuts) and all(x[1] == y[0] for x, y in zip(cuts, cuts[1:]))
         got = max(pre[b] - pre[a] for a, b in cuts)
         assert got <= best(0, world) * (1 + 1e-9) + 1e-12, (L, world, c, cuts)
+
+
+def test_bench_gpus_n_is_one_plain_command():
+    """`python bench.py --gpus N` spawns its own ranks (no torchrun): rank 0's stdout is the one JSON line, the other ranks' output goes to
+    stderr, every rank sees RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*, and a failing rank fails the command.  --dry-run: no GPU is touched."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 4 and d["env"]["WORLD_SIZE"] == "4" and d["env"]["RANK"] == "0" and d["env"]["MASTER_ADDR"] == "127.0.0.1"
+    for k in (1, 2, 3):
+        assert "rank %d of 4 up" % k in r.stderr
+    # under a launcher (WORLD_SIZE already set) nobody spawns: the process IS a rank
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "4", "--dry-run"], capture_output=True, text=True, timeout=120,
+                        env=dict(env, RANK="2", LOCAL_RANK="2", WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT="29999"))
+    assert r2.returncode == 0 and r2.stdout.strip() == "rank 2 of 4 up"
+    # a rank that fails takes the command down with its exit code
+    r3 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "3", "--dry-run"], capture_output=True, text=True, timeout=120,
+                        env=dict(env, LNB_DRY_RUN_FAIL_RANK="1"))
+    assert r3.returncode == 7 and "rank 1 exited with code 7" in r3.stderr

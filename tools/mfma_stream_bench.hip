@@ -177,7 +177,7 @@ DEVINL float unpack(const u32x4& v, int e) { const uint32_t d = v[e >> 1]; retur
 
 // ACC accumulator chains per wave (the two chains of a gate|up tile, or two tiles, or one tile), R chunks in flight, EB e-values (4 k-groups each)
 // unpacked ahead of each run of MFMAs.  out[s][chain_row] = trunc_bf16(acc); chain a of job j is tile-chain j*ACC + a, rows 16*(j*ACC+a) ..
-template <int ACC, int R, int EB>
+template <int ACC, int R, int EB, int MODE = 0>
 __global__ __launch_bounds__(256) void k_stream(const uint16_t* __restrict__ Wm, const uint16_t* __restrict__ xt, uint16_t* __restrict__ out,
                                                 float* __restrict__ outf, int n_jobs, int K, int rows_total, int nseq, long long* dbg) {
     constexpr int L = ACC * 4 + 4;
@@ -215,7 +215,7 @@ __global__ __launch_bounds__(256) void k_stream(const uint16_t* __restrict__ Wm,
 #pragma unroll
         for (int j = 0; j < R; j++) {
             if (t0 + j < T) {
-                wait_slot<(R - 1) * L, L>(buf[j]);
+                if (MODE != 1) wait_slot<(R - 1) * L, L>(buf[j]);
 #pragma unroll
                 for (int e0 = 0; e0 < 8; e0 += EB) {
                     float av[ACC][4 * EB], bv[4 * EB];
@@ -237,13 +237,16 @@ __global__ __launch_bounds__(256) void k_stream(const uint16_t* __restrict__ Wm,
                             for (int a = 0; a < ACC; a++) asm volatile("" : "+v"(av[a][q]));
                             asm volatile("" : "+v"(bv[q]));
                         }
-                        issue_next(buf[j]);
+                        if (MODE != 1) issue_next(buf[j]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int q = 0; q < 4 * EB; q++)         // k-groups g = 4 (e0 + ee) + m ascending: the reference's k order
 #pragma unroll
-                        for (int a = 0; a < ACC; a++) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][q], bv[q], acc[a], 0, 0, 0);
+                        for (int a = 0; a < ACC; a++) {
+                            if (MODE == 2) { if ((q & 3) == 0) asm volatile("v_add_f32 %0, %1, %0" : "+v"(acc[a][0]) : "v"(av[a][q] * bv[q])); }
+                            else acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][q], bv[q], acc[a], 0, 0, 0);
+                        }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (++c == nchunks) {
@@ -273,7 +276,7 @@ __global__ __launch_bounds__(256) void k_stream(const uint16_t* __restrict__ Wm,
 
 static double max_of(const long long* h, int n) { double m = 0; for (int i = 0; i < n; i++) if ((double)h[i] > m) m = (double)h[i]; return m; }
 
-template <int ACC, int R, int EB>
+template <int ACC, int R, int EB, int MODE = 0>
 static void run_shape(const char* name, int N, int K, int NCH, int nseq, int copies, int iters, bool check) {
     // rows of the logical matrix = N * NCH tile-chain rows; jobs = (N / 16) * NCH / ACC
     const int tiles = N / 16, n_jobs = tiles * NCH / ACC, rows_total = N * NCH;
@@ -291,7 +294,7 @@ static void run_shape(const char* name, int N, int K, int NCH, int nseq, int cop
     int grid = (n_jobs + 3) / 4; if (grid > cus) grid = cus;
     if (check) {
         // NCH = 2: Wlin is [n][c][k] = tile-chain rows in (n, c) order; the kernel's chain order is [t][c][i]: row id = (t*NCH + c)*16 + i
-        hipLaunchKernelGGL((k_stream<ACC, R, EB>), dim3(grid), dim3(256), 0, 0, Wm, xt, out, outf, n_jobs, K, rows_total, nseq, nullptr);
+        hipLaunchKernelGGL((k_stream<ACC, R, EB, MODE>), dim3(grid), dim3(256), 0, 0, Wm, xt, out, outf, n_jobs, K, rows_total, nseq, nullptr);
         hipLaunchKernelGGL(k_naive, dim3((unsigned)(((size_t)rows_total * nseq + 255) / 256)), dim3(256), 0, 0, Wlin, xlin, ref, rows_total, K, nseq);
         CHK(hipDeviceSynchronize());
         std::vector<float> ho((size_t)16 * rows_total), hr((size_t)16 * rows_total);
@@ -301,18 +304,21 @@ static void run_shape(const char* name, int N, int K, int NCH, int nseq, int cop
             for (int n = 0; n < N; n++)
                 for (int c = 0; c < NCH; c++) {
                     const int krow = ((n >> 4) * NCH + c) * 16 + (n & 15), lrow = n * NCH + c;
-                    if (memcmp(&ho[(size_t)s * rows_total + krow], &hr[(size_t)s * rows_total + lrow], 4)) bad++;
+                    if (memcmp(&ho[(size_t)s * rows_total + krow], &hr[(size_t)s * rows_total + lrow], 4)) {
+                        if (bad < 6) printf("    differs: seq %d row %d chain %d: kernel %a reference %a\n", s, n, c, ho[(size_t)s * rows_total + krow], hr[(size_t)s * rows_total + lrow]);
+                        bad++;
+                    }
                 }
         printf("  [check] %-22s N=%d K=%d NCH=%d nseq=%d ACC=%d R=%d EB=%d: %ld / %ld outputs differ from the k-ordered fmaf chain\n", name, N, K, NCH, nseq, ACC, R, EB, bad, (long)nseq * N * NCH);
     }
     hipEvent_t e0, e1; CHK(hipEventCreate(&e0)); CHK(hipEventCreate(&e1));
     long long* dbg; CHK(hipMalloc(&dbg, (size_t)cus * 4 * 8)); CHK(hipMemset(dbg, 0, (size_t)cus * 4 * 8));
-    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_stream<ACC, R, EB>), dim3(grid), dim3(256), 0, 0, Wm + welems * (i % copies), xt, out, (float*)nullptr, n_jobs, K, rows_total, nseq, (long long*)nullptr);
+    for (int i = 0; i < 3; i++) hipLaunchKernelGGL((k_stream<ACC, R, EB, MODE>), dim3(grid), dim3(256), 0, 0, Wm + welems * (i % copies), xt, out, (float*)nullptr, n_jobs, K, rows_total, nseq, (long long*)nullptr);
     CHK(hipEventRecord(e0));
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((k_stream<ACC, R, EB>), dim3(grid), dim3(256), 0, 0, Wm + welems * (i % copies), xt, out, (float*)nullptr, n_jobs, K, rows_total, nseq, (long long*)nullptr);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL((k_stream<ACC, R, EB, MODE>), dim3(grid), dim3(256), 0, 0, Wm + welems * (i % copies), xt, out, (float*)nullptr, n_jobs, K, rows_total, nseq, (long long*)nullptr);
     CHK(hipEventRecord(e1)); CHK(hipDeviceSynchronize());
     float ms; CHK(hipEventElapsedTime(&ms, e0, e1));
-    hipLaunchKernelGGL((k_stream<ACC, R, EB>), dim3(grid), dim3(256), 0, 0, Wm, xt, out, (float*)nullptr, n_jobs, K, rows_total, nseq, dbg);
+    hipLaunchKernelGGL((k_stream<ACC, R, EB, MODE>), dim3(grid), dim3(256), 0, 0, Wm, xt, out, (float*)nullptr, n_jobs, K, rows_total, nseq, dbg);
     CHK(hipDeviceSynchronize());
     std::vector<long long> hd((size_t)cus * 4); CHK(hipMemcpy(hd.data(), dbg, hd.size() * 8, hipMemcpyDeviceToHost));
     const double us = 1e3 * ms / iters, cyc = max_of(hd.data(), (int)hd.size());
@@ -370,6 +376,9 @@ int main(int argc, char** argv) {
     run_shape<1, 4, 2>("check one chain", 1024, 512, 1, 16, 1, 2, true);
     run_shape<2, 3, 2>("check gate|up pairs", 2048, 1024, 2, 5, 1, 2, true);
     run_shape<2, 3, 2>("check two tiles", 4096 + 32, 256, 1, 16, 1, 2, true);
+    run_shape<2, 3, 2>("check two tiles K=512", 4096 + 32, 512, 1, 16, 1, 2, true);
+    run_shape<2, 3, 2>("check two tiles N=4096", 4096, 256, 1, 16, 1, 2, true);
+    run_shape<1, 4, 2>("check one chain K=256", 1024, 256, 1, 16, 1, 2, true);
     run_shape<1, 4, 8>("check EB 8", 512, 4096, 1, 3, 1, 2, true);
     if (quick) return 0;
     for (int nseq = 16; nseq >= 1; nseq -= 15) {
@@ -382,6 +391,13 @@ int main(int argc, char** argv) {
         run_shape<1, 4, 8>("wq|wk|wv EB=8", 6144, 4096, 1, nseq, 8, 40, false);
         run_shape<1, 4, 2>("wo one tile/wave", 4096, 4096, 1, nseq, 8, 40, false);
         run_shape<1, 4, 2>("w2 one tile/wave", 4096, 14336, 1, nseq, 4, 40, false);
+        if (nseq == 16) {
+            run_shape<1, 4, 2, 1>("w2 NO refill loads", 4096, 14336, 1, nseq, 4, 40, false);
+            run_shape<1, 4, 2, 2>("w2 NO mfma", 4096, 14336, 1, nseq, 4, 40, false);
+            run_shape<1, 4, 8, 1>("w2 EB=8 NO refill loads", 4096, 14336, 1, nseq, 4, 40, false);
+            run_shape<2, 3, 4, 1>("w1|w3 EB=4 NO refill loads", 14336, 4096, 2, nseq, 4, 40, false);
+            run_shape<2, 3, 4, 2>("w1|w3 EB=4 NO mfma", 14336, 4096, 2, nseq, 4, 40, false);
+        }
         run_shape<1, 4, 4>("w2 EB=4", 4096, 14336, 1, nseq, 4, 40, false);
         run_shape<1, 4, 8>("w2 EB=8", 4096, 14336, 1, nseq, 4, 40, false);
     }
