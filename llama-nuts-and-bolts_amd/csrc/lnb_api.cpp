@@ -44,6 +44,7 @@ hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float e
 hipError_t lnbk_batch_embed(const uint16_t* emb, const BatchTab* tab, uint16_t* x, int nseq, int dim, int vocab, int* err, hipStream_t st);
 hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const BatchTab* tab, int nseq, hipStream_t st);
 hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, hipStream_t st);
+hipError_t lnbk_batch_prepare(void);
 }
 
 static thread_local char g_err[1024] = "";
@@ -967,6 +968,7 @@ extern "C" int lnb_model_enable_batch(lnb_model* m) {
     if (m->a.dim % 128 || m->q_dim % 128 || m->ffn_hidden % 128)
         return fail("batched decode streams the weights in 128-step chunks: dim (%d), n_heads*head_dim (%d) and the FFN hidden size (%d) must be multiples of 128", m->a.dim, m->q_dim, m->ffn_hidden);
     HIPCHK(hipSetDevice(m->device));
+    HIPCHK(lnbk_batch_prepare());
     int rc = 0;
     for (auto& L : m->layers) {
         rc |= m16_copy(m, L.wqkv, L.wqkv.n_rows, &L.m_wqkv) | m16_copy(m, L.wo, m->a.dim, &L.m_wo) | m16_copy(m, L.w13, m->ffn_hidden, &L.m_w13) | m16_copy(m, L.w2, m->a.dim, &L.m_w2);

@@ -92,7 +92,7 @@ template <int EPI> DEVINL void stream_epilogue(const StreamParams& p, const f32x
 // ------------------------------------------------------------------------------------------------
 template <int ACC, int EPI>
 __global__ __launch_bounds__(256) void mfma_stream_kernel(StreamParams p) {
-    constexpr int R = 4, L = ACC * 4 + 4, EB = ACC == 1 ? 8 : 4;
+    constexpr int R = ACC == 1 ? 4 : 3, L = ACC * 4 + 4, EB = ACC == 1 ? 8 : 4;     // (two chains with R = 4 need 260+ registers: values start living in AGPRs)
     static_assert(R * L <= 60, "vmcnt is a 6-bit counter");
     static_assert(EPI != EPI_SILU_MUL || ACC == 2, "gate and up chains of a tile travel together");
     const int lane = threadIdx.x & 63;

@@ -2248,11 +2248,12 @@ extern "C" hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int 
 #undef LNB_STREAM
     return hipGetLastError();
 }
+extern "C" hipError_t lnbk_batch_prepare(void) {             // raise the dynamic-LDS limit once, outside any stream capture
+    return hipFuncSetAttribute((const void*)batch_rmsnorm_xt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
 extern "C" hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K, int nseq, hipStream_t st) {
-    static bool prepared = false;
     const size_t lds = bn_scratch() + ((size_t)bn_kpad(K) + 8) * 4;
     if ((K & 127) || lds > 160 * 1024 || (size_t)bn_kpad(K) > (size_t)XCh<true>::value * (1 + BN_NH) * 512 || seq_leaf_size(K, BN_NH * 64) > 256) return hipErrorInvalidValue;
-    if (!prepared) { hipError_t e = hipFuncSetAttribute((const void*)batch_rmsnorm_xt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); if (e != hipSuccess) return e; prepared = true; }
     hipLaunchKernelGGL(batch_rmsnorm_xt_kernel, dim3((unsigned)nseq), dim3((1 + BN_NH) * 64), lds, st, x, norm_w, eps, xt, K);
     return hipGetLastError();
 }

@@ -448,6 +448,8 @@ static int attention_forward(orc_ctx* c, int layer, const uint16_t* x, int S, in
     float divisor = wide(trunc16((float)sqrt((double)hd)));
     uint16_t neg_inf = trunc16(-INFINITY);
     uint16_t* scores_dump = c->dump ? (uint16_t*)malloc((size_t)H * S * T * 2) : NULL;
+    uint16_t* raw_dump = c->dump ? (uint16_t*)malloc((size_t)H * S * T * 2) : NULL;       /* scores after the division (:464), before the mask */
+    uint16_t* masked_dump = c->dump ? (uint16_t*)malloc((size_t)H * S * T * 2) : NULL;    /* ... after Add(scores, mask) (:469-473) */
     uint16_t* att = (uint16_t*)malloc((size_t)S * qd * 2);                    /* [S, H*hd] after transpose+reshape :508-514 */
 #pragma omp parallel for collapse(2) schedule(dynamic, 1) num_threads(c->nthreads)
     for (int h = 0; h < H; h++) for (int i = 0; i < S; i++) {
@@ -460,12 +462,14 @@ static int attention_forward(orc_ctx* c, int layer, const uint16_t* x, int S, in
             for (int d = 0; d < hd; d++) { float p = wide(q[d]) * wide(kr[d]); acc += p; }
             uint16_t s = trunc16(acc);
             s = trunc16(wide(s) / divisor);                                    /* DivToScalar :464 */
+            if (raw_dump) raw_dump[((size_t)h * S + i) * T + j] = s;
             if (S > 1) {                                                       /* Add(scores, mask) :469-473, modulo broadcast */
                 int jj = j % S;
                 uint16_t mk = (jj - i >= 1) ? neg_inf : 0;
                 s = trunc16(wide(s) + wide(mk));
             }
             s16[j] = s;
+            if (masked_dump) masked_dump[((size_t)h * S + i) * T + j] = s;
         }
         /* :484-495 ToFloat32 -> Softmax (f64) -> ToBFloat16 */
         double z = 0.0;
@@ -480,6 +484,8 @@ static int attention_forward(orc_ctx* c, int layer, const uint16_t* x, int S, in
         }
         free(s16);
     }
+    if (raw_dump) { DUMP(c, "scores", layer, 0, raw_dump, H, S, T); free(raw_dump); }
+    if (masked_dump) { DUMP(c, "scores_masked", layer, 0, masked_dump, H, S, T); free(masked_dump); }
     if (scores_dump) { DUMP(c, "softmax", layer, 0, scores_dump, H, S, T); free(scores_dump); }
     DUMP(c, "attn_pre_wo", layer, 0, att, S, qd);
     linear_core(att, layer_tensor(m, layer, "attention.wo.weight"), out, S, dim, qd, c->nthreads);   /* :522 */
@@ -520,7 +526,11 @@ int orc_forward(orc_ctx* c, const int32_t* tokens, int S, int start_pos, float* 
     }
     DUMP(c, "embedding", -1, 0, x, S, dim);
     for (int l = 0; l < a->n_layers; l++) {                                      /* LlamaTransformerBlock.Forward :215-254 */
-        orc_rmsnorm_bf16(x, layer_tensor(m, l, "attention_norm.weight"), n, S, dim, a->norm_eps, NULL);
+        {   /* doNormalization's own output (trunc(x * rsqrt), llamatransformer.go:641-660) is a stage the reference's test pins too */
+            uint16_t* pre = c->dump ? (uint16_t*)malloc((size_t)S * dim * 2) : NULL;
+            orc_rmsnorm_bf16(x, layer_tensor(m, l, "attention_norm.weight"), n, S, dim, a->norm_eps, pre);
+            if (pre) { DUMP(c, "attn_norm_part", l, 0, pre, S, dim); free(pre); }
+        }
         DUMP(c, "attn_norm", l, 0, n, S, dim);
         attention_forward(c, l, n, S, start_pos, t);
         DUMP(c, "attn_out", l, 0, t, S, dim);
