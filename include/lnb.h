@@ -137,7 +137,8 @@ int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int
  * columns of the f32 matrix-core instruction, which computes each column's k-ordered chain exactly.  Per-sequence position, RoPE row, KV
  * append and attention; every sequence's tokens, logits and caches are bit-identical to its single-sequence run (and the CPU reference).
  * lnb_model_enable_batch: builds the weights' second, matrix-core friendly copy on the device (once, after lnb_model_finalize; it costs the
- *   model's matrix bytes again -- 15 GB for the 8B shape; fails cleanly when that does not fit, the other entry points stay usable).
+ *   model's matrix bytes again -- 15 GB for the 8B shape; fails cleanly when that does not fit, the other entry points stay usable).  Works
+ *   on a whole model and on a pipeline stage of whole blocks.
  * lnb_batch_create: the contexts keep their own KV caches and positions (prefill each with lnb_forward first); seq_len of each context at
  *   most ~7.8 K positions (head_dim 128).  A context must not be used by another call while a batch call that contains it runs.
  * lnb_batch_decode: sequence s continues from tokens[s] at position start_pos[s] (different positions are fine); n_steps greedy steps for
@@ -199,6 +200,14 @@ int lnb_pipeline_init_loopback(lnb_model* stage, int rank, int world, const char
 int lnb_pipeline_destroy(lnb_pipe* p);
 int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,
                       lnb_ctx* send, int send_rows, lnb_ctx* recv, int recv_rows, int* token_slot_out);
+/* The same with a BATCH of sequences as the unit that moves through the stages (lnb_batch over this rank's stage model and its contexts of
+ * those sequences; lnb_model_enable_batch works on stages of whole blocks).  Prefill each sequence with single-sequence ticks, call
+ * lnb_batch_set_state on every rank (tokens: rank 0 only, or NULL to keep what the prefill's token ring left in the contexts), then per step:
+ * run = ONE pass over the stage's weights for all the batch's sequences (captured graph; positions advance on the device; on the last rank
+ * the n tokens go to the pinned log, *token_slot_out = the first of n consecutive slots), send = hidden states [n, dim] to rank + 1 (last
+ * rank: the n token words to rank 0), recv = the mirror image.  Same grouping, events and transports as lnb_pipeline_tick. */
+int lnb_batch_set_state(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos);
+int lnb_pipeline_tick_batch(lnb_pipe* p, lnb_batch* run, lnb_batch* send, lnb_batch* recv, int* token_slot_out);
 int lnb_pipeline_sync(lnb_pipe* p);
 /* the number of ranks the exchange spans as the TRANSPORT reports it (ncclCommCount of the communicator; pipes joined to an in-process
  * group; 1 for a one-stage pipe): lets a host check that N processes really formed ONE N-rank communicator */

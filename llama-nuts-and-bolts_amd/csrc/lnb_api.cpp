@@ -42,8 +42,10 @@ hipError_t lnbk_m16_from_tiled(const uint16_t* src, uint16_t* dst, int rows, int
 hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int num_cus, hipStream_t st);
 hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K, int nseq, hipStream_t st);
 hipError_t lnbk_batch_embed(const uint16_t* emb, const BatchTab* tab, uint16_t* x, int nseq, int dim, int vocab, int* err, hipStream_t st);
-hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const BatchTab* tab, int nseq, hipStream_t st);
-hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, hipStream_t st);
+hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const BatchTab* tab, int nseq, int32_t* ring, hipStream_t st);
+hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring, hipStream_t st);
+hipError_t lnbk_batch_scatter_ring(const BatchTab* tab, const int32_t* ring, hipStream_t st);
+hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st);
 hipError_t lnbk_batch_prepare(void);
 }
 
@@ -951,6 +953,10 @@ struct lnb_batch {
     uint16_t *x = nullptr, *h = nullptr, *xt = nullptr, *q = nullptr, *att_xt = nullptr, *ffn_xt = nullptr, *logits = nullptr;
     int* derr = nullptr; int32_t *d_tokens = nullptr, *d_pos = nullptr; int32_t* h_io = nullptr;   // pinned: [0..15] tokens, [16..31] positions, [32] error word
     hipGraphExec_t graph = nullptr; int lds_T = 0;
+    // pipeline stage (lnb_pipeline_tick_batch): the contiguous token words exchanged between the last and the first stage, the stage step
+    // as a captured graph, events towards / from the exchange stream (as lnb_ctx has them for single-sequence ticks)
+    int32_t* ring = nullptr; hipGraphExec_t stage_graph = nullptr;
+    hipEvent_t ev_done = nullptr, ev_in = nullptr, ev_sent = nullptr; bool in_pending = false, sent_pending = false, recv_unmatched = false;
 };
 static int m16_copy(lnb_model* m, const TiledDesc& t, int rows, uint16_t** out) {
     const size_t bytes = m16_elems(rows, t.k, t.nch) * 2;
@@ -964,7 +970,7 @@ extern "C" int lnb_model_enable_batch(lnb_model* m) {
     if (!m) return fail("null argument");
     if (!m->finalized) return fail("model not finalized");
     if (m->batch_enabled) return 0;
-    if (!m->first() || !m->last()) return fail("batched decode needs a whole-model handle");
+    if (m->part_begin % 3 || m->part_end % 3) return fail("batched decode needs a stage of whole blocks (this one is cut inside a block: parts [%d, %d))", m->part_begin, m->part_end);
     if (m->a.dim % 128 || m->q_dim % 128 || m->ffn_hidden % 128)
         return fail("batched decode streams the weights in 128-step chunks: dim (%d), n_heads*head_dim (%d) and the FFN hidden size (%d) must be multiples of 128", m->a.dim, m->q_dim, m->ffn_hidden);
     HIPCHK(hipSetDevice(m->device));
@@ -974,7 +980,7 @@ extern "C" int lnb_model_enable_batch(lnb_model* m) {
         rc |= m16_copy(m, L.wqkv, L.wqkv.n_rows, &L.m_wqkv) | m16_copy(m, L.wo, m->a.dim, &L.m_wo) | m16_copy(m, L.w13, m->ffn_hidden, &L.m_w13) | m16_copy(m, L.w2, m->a.dim, &L.m_w2);
         if (rc) break;
     }
-    if (!rc) rc = m16_copy(m, m->output, m->a.vocab_size, &m->m_output);
+    if (!rc && m->last()) rc = m16_copy(m, m->output, m->a.vocab_size, &m->m_output);
     hipError_t e = hipStreamSynchronize(m->stream);
     if (rc || e != hipSuccess) {                             // (out of memory on a model that fills the HBM: the single-sequence paths stay usable)
         for (auto& L : m->layers) { hipFree(L.m_wqkv); hipFree(L.m_wo); hipFree(L.m_w13); hipFree(L.m_w2); L.m_wqkv = L.m_wo = L.m_w13 = L.m_w2 = nullptr; }
@@ -993,7 +999,11 @@ extern "C" int lnb_batch_destroy(lnb_batch* b) {
     if (b->stream) hipStreamSynchronize(b->stream);
     if (b->graph) hipGraphExecDestroy(b->graph);
     hipFree(b->tab); hipFree(b->kv); hipFree(b->x); hipFree(b->h); hipFree(b->xt); hipFree(b->q); hipFree(b->att_xt); hipFree(b->ffn_xt); hipFree(b->logits);
-    hipFree(b->derr); hipFree(b->d_tokens); hipFree(b->d_pos);
+    hipFree(b->derr); hipFree(b->d_tokens); hipFree(b->d_pos); hipFree(b->ring);
+    if (b->stage_graph) hipGraphExecDestroy(b->stage_graph);
+    if (b->ev_done) hipEventDestroy(b->ev_done);
+    if (b->ev_in) hipEventDestroy(b->ev_in);
+    if (b->ev_sent) hipEventDestroy(b->ev_sent);
     if (b->h_io) hipHostFree(b->h_io);
     if (b->ev0) hipEventDestroy(b->ev0);
     if (b->ev1) hipEventDestroy(b->ev1);
@@ -1021,9 +1031,10 @@ static int batch_alloc(lnb_batch* b) {
     auto zalloc = [&](uint16_t** p, size_t elems) -> int { HIPCHK(hipMalloc((void**)p, elems * 2)); HIPCHK(hipMemsetAsync(*p, 0, elems * 2, b->stream)); return 0; };
     // activations in the B-operand layout are [K][16 sequences]: the columns past n stay zero for ever
     if (zalloc(&b->x, N * dim) || zalloc(&b->h, N * dim) || zalloc(&b->xt, N * dim) || zalloc(&b->q, N * m->q_dim) || zalloc(&b->att_xt, N * m->q_dim) ||
-        zalloc(&b->ffn_xt, N * m->ffn_hidden) || zalloc(&b->logits, N * (size_t)m->a.vocab_size)) return -1;
+        zalloc(&b->ffn_xt, N * m->ffn_hidden) || (m->last() && zalloc(&b->logits, N * (size_t)m->a.vocab_size))) return -1;
     HIPCHK(hipMalloc((void**)&b->derr, 16)); HIPCHK(hipMemsetAsync(b->derr, 0, 16, b->stream));
     HIPCHK(hipMalloc((void**)&b->d_tokens, 64)); HIPCHK(hipMalloc((void**)&b->d_pos, 64));
+    HIPCHK(hipMalloc((void**)&b->ring, 64)); HIPCHK(hipMemsetAsync(b->ring, 0, 64, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
@@ -1094,18 +1105,28 @@ static int enqueue_batch_kernel(lnb_batch* b, int l, int which) {
     }
     return fail("bad kernel id");
 }
-static int enqueue_batch_step(lnb_batch* b) {
+// One batched step of this model STAGE: the embedding gather on the first stage (otherwise the hidden states [n, dim] are already in b->x:
+// received from the stage before), the owned blocks, and on the last stage norm + output + argmax (which advances every sequence's
+// position); a stage without the head advances the positions itself.  ring_in: the first stage of a multi-stage pipeline takes the tokens
+// from the contiguous words the last stage sent (lnb_pipeline_tick_batch).
+static int enqueue_batch_step(lnb_batch* b, bool ring_in = false) {
     lnb_model* m = b->m;
-    HIPCHK(lnbk_batch_embed(m->tok_embd, b->tab, b->x, b->n, m->a.dim, m->a.vocab_size, b->derr, b->stream));
+    if (m->first()) {
+        if (ring_in) HIPCHK(lnbk_batch_scatter_ring(b->tab, b->ring, b->stream));
+        HIPCHK(lnbk_batch_embed(m->tok_embd, b->tab, b->x, b->n, m->a.dim, m->a.vocab_size, b->derr, b->stream));
+    }
     for (int l = m->layer_begin; l < m->layer_end; l++)
         for (int k = K_QKV; k <= K_W2; k++) if (enqueue_batch_kernel(b, l, k)) return -1;
-    if (enqueue_batch_kernel(b, 0, K_HEAD)) return -1;
-    HIPCHK(lnbk_batch_argmax(b->logits, m->a.vocab_size, b->tab, b->n, b->stream));
+    if (m->last()) {
+        if (enqueue_batch_kernel(b, 0, K_HEAD)) return -1;
+        HIPCHK(lnbk_batch_argmax(b->logits, m->a.vocab_size, b->tab, b->n, b->ring, b->stream));
+    } else HIPCHK(lnbk_batch_advance(b->tab, b->stream));
     return 0;
 }
 extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, float* ms_out) {
     if (!b || !tokens || !start_pos || !out_tokens) return fail("null argument");
     lnb_model* m = b->m;
+    if (!m->first() || !m->last()) return fail("lnb_batch_decode needs a whole-model handle; pipeline stages run their batches through lnb_pipeline_tick_batch");
     HIPCHK(hipSetDevice(m->device));
     if (n_steps <= 0) return fail("n_steps must be positive");
     for (int s = 0; s < b->n; s++) {
@@ -1133,7 +1154,7 @@ extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32
     HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + 16, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(b->derr, 0, 4, st));
-    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, st));
+    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, b->ring, st));
     HIPCHK(hipEventRecord(b->ev0, st));
     for (int i = 0; i < n_steps; i++) {
         if (use_graph) HIPCHK(hipGraphLaunch(b->graph, st));
@@ -1148,6 +1169,28 @@ extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32
     if (b->h_io[32]) return fail("sequence %d: generated token id is outside the vocabulary", b->h_io[32] - 1);
     return 0;
 }
+// Every sequence's position (and, on the first stage, optionally its next input token) before a run of lnb_pipeline_tick_batch steps: the
+// positions then advance on the device with every step.  tokens == NULL keeps what each context's token word holds (what the
+// single-sequence prefill ticks left there).
+extern "C" int lnb_batch_set_state(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos) {
+    if (!b || !start_pos) return fail("null argument");
+    HIPCHK(hipSetDevice(b->m->device));
+    for (int s = 0; s < b->n; s++) {
+        lnb_ctx* c = b->ctxs[s];
+        if (check_call(c, 1, start_pos[s])) return -1;
+        if (tokens && (tokens[s] < 0 || tokens[s] >= b->m->a.vocab_size)) return fail("sequence %d: token id at index 0 is outside the vocabulary", s);
+        c->dev_pos = -1; c->call_T = 0;
+    }
+    HIPCHK(hipDeviceSynchronize());                          // a setup call: whatever the contexts' streams and the pipe's exchange stream still do
+                                                             // (the prefill's token hand-off into the contexts' token words) comes first
+    if (tokens) memcpy(b->h_io, tokens, (size_t)b->n * 4);
+    memcpy(b->h_io + 16, start_pos, (size_t)b->n * 4);
+    if (tokens) HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + 16, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(lnbk_batch_set_state(b->tab, tokens ? b->d_tokens : nullptr, b->d_pos, b->ring, b->stream));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    return 0;
+}
 // measurement aid (bench.py): average HIP-event time of ONE kernel class of the batched step (which as in lnb_profile_kernel; the norm
 // launches count with the product they feed), consecutive launches cycling through the layers; every sequence is placed at `pos`
 extern "C" int lnb_batch_profile_kernel(lnb_batch* b, int which, int pos, int iters, float* avg_ms_out) {
@@ -1155,11 +1198,12 @@ extern "C" int lnb_batch_profile_kernel(lnb_batch* b, int which, int pos, int it
     lnb_model* m = b->m;
     HIPCHK(hipSetDevice(m->device));
     if (iters <= 0 || which < 0 || which > K_LAYER) return fail("bad arguments");
+    if (which == K_HEAD && !m->last()) return fail("this stage does not own output.weight");
     for (int s = 0; s < b->n; s++) { if (check_call(b->ctxs[s], 1, pos)) return -1; b->h_io[s] = 0; b->h_io[16 + s] = pos; b->ctxs[s]->dev_pos = -1; }
     hipStream_t st = b->stream;
     HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + 16, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, st));
+    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, b->ring, st));
     const int nl = m->layer_end - m->layer_begin;
     auto run = [&](int i) -> int {
         const int l = m->layer_begin + i % nl;
@@ -1191,7 +1235,7 @@ extern "C" int lnb_batch_profile_kernel(lnb_batch* b, int which, int pos, int it
 // "send" meets its "receive" in a mailbox; whichever side is posted second enqueues the device copy.  Same tick code, same events, same
 // graphs as the RCCL transport -- what it replaces is only ncclSend / ncclRecv.  Used to test host schedules where RCCL cannot run
 // (two ranks need two GPUs) and by single-process multi-GPU hosts.
-struct LoopMsg { lnb_ctx* ctx; int rows; };
+struct LoopMsg { lnb_ctx* ctx; int rows; lnb_batch* bat = nullptr; };   // a single-sequence hand-off (ctx) or a batch's (bat)
 struct LoopGroup { std::map<std::pair<int, int>, std::deque<LoopMsg>> sends, recvs; int users = 0; int device = -1; };
 static std::map<std::string, LoopGroup> g_loops;
 static std::mutex g_loops_mu;
@@ -1365,6 +1409,7 @@ static int loop_post(lnb_pipe* p, bool sending, lnb_ctx* c, int rows, int peer, 
     const LoopMsg msg{c, rows};
     if (theirs.empty()) { mine.push_back(msg); if (!sending) c->recv_unmatched = true; return 0; }
     const LoopMsg other = theirs.front(); theirs.pop_front();
+    if (other.bat) return fail("in-process pipeline: a single-sequence hand-off met a batch hand-off (the stages must post the same ticks in the same order)");
     (sending ? other.ctx : c)->recv_unmatched = false;
     return sending ? loop_copy(p, msg, other, token) : loop_copy(p, other, msg, token);
 }
@@ -1416,6 +1461,99 @@ extern "C" int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int ru
         int re = p->api->GroupEnd();
         if (rc) return -1;
         if (re != 0) return fail("ncclGroupEnd failed: %s", p->api->GetErrorString(re));
+        if (send) { HIPCHK(hipEventRecord(send->ev_sent, p->xs)); send->sent_pending = true; }
+        if (recv) { HIPCHK(hipEventRecord(recv->ev_in, p->xs)); recv->in_pending = true; }
+    }
+    return 0;
+}
+
+// ---- the pipeline with BATCHES as the unit that moves through the stages ---------------------------------------------------------------
+// Every rank holds, per group of sequences in flight, one lnb_batch over its stage's contexts of those sequences (prefill them one by one
+// with the single-sequence ticks above, then lnb_batch_set_state on every rank).  A batched tick enqueues, like lnb_pipeline_tick:
+//   run : one decode step of the group on this stage -- ONE pass over the stage's weights for all its sequences (captured graph); the
+//         positions advance on the device; on the last rank the n tokens are appended to the pinned log (*token_slot_out = first slot);
+//   send: the group's hidden states [n, dim] to rank + 1 (the last rank: its n token words to rank 0);   recv: the mirror image.
+static int batch_events(lnb_batch* b) {
+    if (!b->ev_done) { HIPCHK(hipEventCreateWithFlags(&b->ev_done, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&b->ev_in, hipEventDisableTiming));
+                       HIPCHK(hipEventCreateWithFlags(&b->ev_sent, hipEventDisableTiming)); }
+    return 0;
+}
+static int loop_copy_batch(lnb_pipe* p, lnb_batch* sb, lnb_batch* rb, bool token) {
+    if (sb->n != rb->n) return fail("loopback exchange: a batch of %d sequences sent, %d expected", sb->n, rb->n);
+    HIPCHK(hipStreamWaitEvent(p->xs, sb->ev_done, 0));
+    HIPCHK(hipStreamWaitEvent(p->xs, rb->ev_done, 0));
+    if (token) HIPCHK(hipMemcpyAsync(rb->ring, sb->ring, (size_t)sb->n * 4, hipMemcpyDeviceToDevice, p->xs));
+    else HIPCHK(hipMemcpyAsync(rb->x, sb->x, (size_t)sb->n * sb->m->a.dim * 2, hipMemcpyDeviceToDevice, p->xs));
+    HIPCHK(hipEventRecord(sb->ev_sent, p->xs)); sb->sent_pending = true;
+    HIPCHK(hipEventRecord(rb->ev_in, p->xs)); rb->in_pending = true;
+    return 0;
+}
+static int loop_post_batch(lnb_pipe* p, bool sending, lnb_batch* b, int peer, bool token) {
+    std::lock_guard<std::mutex> lock(g_loops_mu);
+    const std::pair<int, int> key = sending ? std::make_pair(p->rank, peer) : std::make_pair(peer, p->rank);
+    auto& mine = sending ? p->loop->sends[key] : p->loop->recvs[key];
+    auto& theirs = sending ? p->loop->recvs[key] : p->loop->sends[key];
+    LoopMsg msg{nullptr, b->n}; msg.bat = b;
+    if (theirs.empty()) { mine.push_back(msg); if (!sending) b->recv_unmatched = true; return 0; }
+    const LoopMsg other = theirs.front(); theirs.pop_front();
+    if (!other.bat) return fail("in-process pipeline: a batch hand-off met a single-sequence hand-off (the stages must post the same ticks in the same order)");
+    (sending ? other.bat : b)->recv_unmatched = false;
+    return sending ? loop_copy_batch(p, b, other.bat, token) : loop_copy_batch(p, other.bat, b, token);
+}
+extern "C" int lnb_pipeline_tick_batch(lnb_pipe* p, lnb_batch* run, lnb_batch* send, lnb_batch* recv, int* token_slot_out) {
+    if (!p) return fail("null argument");
+    lnb_model* m = p->m;
+    HIPCHK(hipSetDevice(m->device));
+    const bool first = p->rank == 0, last = p->rank == p->world - 1;
+    for (lnb_batch* b : {run, send, recv}) if (b) { if (b->m != m) return fail("batch of another model stage"); if (batch_events(b)) return -1; }
+    if (token_slot_out) *token_slot_out = -1;
+    if (run) {
+        hipStream_t st = run->stream;
+        if (run->recv_unmatched) return fail("in-process pipeline: this batch's input has been requested but the sending stage has not posted it yet "
+                                             "(the mailbox transport needs the stages ticked in lock-step order from one thread)");
+        if (run->in_pending) { HIPCHK(hipStreamWaitEvent(st, run->ev_in, 0)); run->in_pending = false; }
+        if (run->sent_pending) { HIPCHK(hipStreamWaitEvent(st, run->ev_sent, 0)); run->sent_pending = false; }
+        const bool ring_in = first && p->world > 1;
+        if (p->use_graph) {
+            if (!run->stage_graph) {
+                hipGraph_t g = nullptr;
+                HIPCHK(hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal));
+                int rc = enqueue_batch_step(run, ring_in);
+                hipError_t e = hipStreamEndCapture(st, &g);
+                if (rc) { if (g) hipGraphDestroy(g); return -1; }
+                HIPCHK(e);
+                HIPCHK(hipGraphInstantiate(&run->stage_graph, g, nullptr, nullptr, 0));
+                HIPCHK(hipGraphDestroy(g));
+            }
+            HIPCHK(hipGraphLaunch(run->stage_graph, st));
+        } else if (enqueue_batch_step(run, ring_in)) return -1;
+        if (last) {
+            if (p->tok_n > 0x7FFFFFFF - LNB_BATCH_MAX) return fail("pipeline token log: slot counter exhausted (2^31 tokens): create a new pipe");
+            const int slot = p->tok_n, at = slot % p->tok_cap, fit = std::min(run->n, p->tok_cap - at);   // (the ring keeps the newest tok_cap tokens)
+            HIPCHK(hipMemcpyAsync(p->h_tok + at, run->ring, (size_t)fit * 4, hipMemcpyDeviceToHost, st));
+            if (fit < run->n) HIPCHK(hipMemcpyAsync(p->h_tok, run->ring + fit, (size_t)(run->n - fit) * 4, hipMemcpyDeviceToHost, st));
+            if (token_slot_out) *token_slot_out = slot;
+            p->tok_n += run->n;
+        }
+        HIPCHK(hipEventRecord(run->ev_done, st));
+    }
+    if (p->world > 1 && p->loop && (send || recv)) {         // in-process transport
+        if (recv) HIPCHK(hipEventRecord(recv->ev_done, recv->stream));
+        if (send && loop_post_batch(p, true, send, last ? 0 : p->rank + 1, last)) return -1;
+        if (recv && loop_post_batch(p, false, recv, first ? p->world - 1 : p->rank - 1, first)) return -1;
+        return 0;
+    }
+    if (p->world > 1 && (send || recv)) {
+        if (send) HIPCHK(hipStreamWaitEvent(p->xs, send->ev_done, 0));
+        if (recv) { HIPCHK(hipEventRecord(recv->ev_done, recv->stream)); HIPCHK(hipStreamWaitEvent(p->xs, recv->ev_done, 0)); }
+        NCCLCHK(p, p->api->GroupStart());
+        int r1 = 0, r2 = 0;
+        if (send) r1 = last ? p->api->Send(send->ring, (size_t)send->n * 4, LNB_NCCL_INT8, 0, p->comm, p->xs)
+                            : p->api->Send(send->x, (size_t)send->n * m->a.dim * 2, LNB_NCCL_INT8, p->rank + 1, p->comm, p->xs);
+        if (recv) r2 = first ? p->api->Recv(recv->ring, (size_t)recv->n * 4, LNB_NCCL_INT8, p->world - 1, p->comm, p->xs)
+                             : p->api->Recv(recv->x, (size_t)recv->n * m->a.dim * 2, LNB_NCCL_INT8, p->rank - 1, p->comm, p->xs);
+        const int re = p->api->GroupEnd();
+        if (r1 || r2 || re) return fail("RCCL batch exchange failed: %s", p->api->GetErrorString(r1 ? r1 : r2 ? r2 : re));
         if (send) { HIPCHK(hipEventRecord(send->ev_sent, p->xs)); send->sent_pending = true; }
         if (recv) { HIPCHK(hipEventRecord(recv->ev_in, p->xs)); recv->in_pending = true; }
     }

@@ -160,7 +160,13 @@ __global__ __launch_bounds__(256) void mfma_stream_kernel(StreamParams p) {
 #pragma unroll
                     for (int q = 0; q < 4 * EB; q++)         // k-groups g = 4 (e0 + ee) + m ascending: the reference's k order (operations_lineartransform.go:46-65)
 #pragma unroll
-                        for (int a = 0; a < ACC; a++) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][q], bv[q], acc[a], 0, 0, 0);
+                        for (int a = 0; a < ACC; a++) {
+                            // the first k-group of a job starts from C = 0 IN the instruction (an inline constant): zeroing the accumulator
+                            // registers after the epilogue instead made them a loop-carried phi of {matrix-core result, 0} and hipcc moved all
+                            // of them AGPR -> VGPR -> AGPR at every chunk boundary
+                            if (e0 == 0 && q == 0 && c == 0) acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][q], bv[q], f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
+                            else acc[a] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[a][q], bv[q], acc[a], 0, 0, 0);
+                        }
                     __builtin_amdgcn_sched_barrier(0);
                 }
                 if (++c == nchunks) {                        // end of this job's chains: D layout = column lane & 15, rows (lane >> 4) * 4 + r
@@ -172,8 +178,6 @@ __global__ __launch_bounds__(256) void mfma_stream_kernel(StreamParams p) {
                         for (int a = 0; a < ACC; a++)
                             if (tc0 + a <= last_chain) stream_epilogue<EPI>(p, acc[a], acc[a], s, (tc0 + a) * 16 + (lane >> 4) * 4);
                     }
-#pragma unroll
-                    for (int a = 0; a < ACC; a++) acc[a] = f32x4{0.f, 0.f, 0.f, 0.f};
                     c = 0; job += TW;
                 }
             }
@@ -246,10 +250,22 @@ __global__ void batch_embed_kernel(const uint16_t* emb, const BatchTab* tab, uin
     uint4* dst = (uint4*)(x + (size_t)s * dim);
     for (int i = threadIdx.x; i < dim / 8; i += blockDim.x) dst[i] = src[i];
 }
-// start of a batched run: every sequence's token word and position (its own context's StepState)
-__global__ void batch_set_state_kernel(const BatchTab* tab, const int32_t* tokens, const int32_t* pos) {
+// start of a batched run: every sequence's token word (tokens == nullptr: keep what its context holds) and position (its own context's
+// StepState); ring = the batch's contiguous token words (the pipeline's token exchange), kept equal to the contexts' words
+__global__ void batch_set_state_kernel(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring) {
     const int s = threadIdx.x;
     if (s >= tab->n) return;
-    *tab->dtok[s] = tokens[s];
+    if (tokens) *tab->dtok[s] = tokens[s];
+    if (ring) ring[s] = *tab->dtok[s];
     tab->st[s]->pos = pos[s]; tab->st[s]->n_out = 0;
+}
+// pipeline, first stage: the tokens the last stage sent (contiguous) -> every sequence's own token word
+__global__ void batch_scatter_ring_kernel(const BatchTab* tab, const int32_t* ring) {
+    const int s = threadIdx.x;
+    if (s < tab->n) *tab->dtok[s] = ring[s];
+}
+// pipeline, a stage without the head: the step is done, every sequence moves on by one position (the last stage's argmax does it there)
+__global__ void batch_advance_kernel(const BatchTab* tab) {
+    const int s = threadIdx.x;
+    if (s < tab->n) tab->st[s]->pos = tab->st[s]->pos + 1;
 }

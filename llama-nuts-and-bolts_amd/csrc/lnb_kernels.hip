@@ -1949,13 +1949,14 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, in
     }
 }
 // the same for the batch: block s = sequence s's logits row; its context's token word, token log and position advance (inference.go:211-226)
-__global__ __launch_bounds__(1024) void batch_argmax_kernel(const uint16_t* logits, int V, const BatchTab* tab) {
+__global__ __launch_bounds__(1024) void batch_argmax_kernel(const uint16_t* logits, int V, const BatchTab* tab, int32_t* ring) {
     __shared__ float sv[1024];
     __shared__ int si[1024];
     const int s = blockIdx.x;
     const int tok = argmax_block(logits + (size_t)s * V, V, sv, si);
     if (threadIdx.x == 0) {
         *tab->dtok[s] = tok;
+        if (ring) ring[s] = tok;                             // (pipeline: the contiguous words the last stage sends to the first)
         StepState* st = tab->st[s];
         const int n = st->n_out;
         if (n < tab->dout_cap[s]) tab->dout[s][n] = tok;
@@ -2261,11 +2262,19 @@ extern "C" hipError_t lnbk_batch_embed(const uint16_t* emb, const BatchTab* tab,
     hipLaunchKernelGGL(batch_embed_kernel, dim3((unsigned)nseq), dim3(256), 0, st, emb, tab, x, dim, vocab, err);
     return hipGetLastError();
 }
-extern "C" hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const BatchTab* tab, int nseq, hipStream_t st) {
-    hipLaunchKernelGGL(batch_argmax_kernel, dim3((unsigned)nseq), dim3(1024), 0, st, logits, V, tab);
+extern "C" hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const BatchTab* tab, int nseq, int32_t* ring, hipStream_t st) {
+    hipLaunchKernelGGL(batch_argmax_kernel, dim3((unsigned)nseq), dim3(1024), 0, st, logits, V, tab, ring);
     return hipGetLastError();
 }
-extern "C" hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, hipStream_t st) {
-    hipLaunchKernelGGL(batch_set_state_kernel, dim3(1), dim3(64), 0, st, tab, tokens, pos);
+extern "C" hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring, hipStream_t st) {
+    hipLaunchKernelGGL(batch_set_state_kernel, dim3(1), dim3(64), 0, st, tab, tokens, pos, ring);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_batch_scatter_ring(const BatchTab* tab, const int32_t* ring, hipStream_t st) {
+    hipLaunchKernelGGL(batch_scatter_ring_kernel, dim3(1), dim3(64), 0, st, tab, ring);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st) {
+    hipLaunchKernelGGL(batch_advance_kernel, dim3(1), dim3(64), 0, st, tab);
     return hipGetLastError();
 }

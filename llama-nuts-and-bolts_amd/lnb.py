@@ -59,7 +59,7 @@ EXPORTS = [
     "lnb_tokenizer_load", "lnb_tokenizer_free", "lnb_tokenizer_vocab_size", "lnb_tokenizer_special", "lnb_tokenizer_token_id",
     "lnb_tokenizer_piece", "lnb_tokenizer_encode", "lnb_tokenizer_encode_chat",
     "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens", "lnb_pipeline_selftest", "lnb_pipeline_comm_count",
-    "lnb_model_enable_batch", "lnb_model_batch_bytes", "lnb_batch_create", "lnb_batch_destroy", "lnb_batch_decode", "lnb_batch_profile_kernel",
+    "lnb_model_enable_batch", "lnb_model_batch_bytes", "lnb_batch_create", "lnb_batch_destroy", "lnb_batch_decode", "lnb_batch_profile_kernel", "lnb_batch_set_state", "lnb_pipeline_tick_batch",
 ]
 
 
@@ -121,6 +121,8 @@ def lib():
     L.lnb_batch_destroy.argtypes = [vp]
     L.lnb_batch_decode.argtypes = [vp, i32p, i32p, C.c_int, vp, f32p]
     L.lnb_batch_profile_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p]
+    L.lnb_batch_set_state.argtypes = [vp, i32p, i32p]
+    L.lnb_pipeline_tick_batch.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int)]
     L.lnb_pipeline_read_tokens.argtypes = [vp, C.c_int, C.c_int, vp]
     L.lnb_op_linear_mode.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_op_argmax.argtypes = [C.c_int, vp, C.c_int, i32p]
@@ -421,6 +423,13 @@ class Batch:
         _chk(self.L.lnb_batch_profile_kernel(self.h, which, pos, iters, C.byref(ms)))
         return ms.value
 
+    def set_state(self, tokens, start_pos):
+        """positions (and optionally next input tokens) of the sequences before a run of Pipeline.tick_batch steps"""
+        pos = np.ascontiguousarray(start_pos, dtype=np.int32)
+        tok = None if tokens is None else np.ascontiguousarray(tokens, dtype=np.int32)
+        _chk(self.L.lnb_batch_set_state(self.h, None if tok is None else tok.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_int32))))
+        return self
+
     def close(self):
         if self.h:
             self.L.lnb_batch_destroy(self.h)
@@ -452,6 +461,12 @@ class Pipeline:
         tok = None if run_tokens is None else np.ascontiguousarray(run_tokens, dtype=np.int32)
         _chk(self.L.lnb_pipeline_tick(self.h, run.h if run else None, run_rows, run_pos, _p(tok) if tok is not None else None,
                                       send.h if send else None, send_rows, recv.h if recv else None, recv_rows, C.byref(slot)))
+        return slot.value
+
+    def tick_batch(self, run=None, send=None, recv=None):
+        """the tick with a Batch as the unit: one pass over the stage's weights for all its sequences; -> first token-log slot (last rank)"""
+        slot = C.c_int(-1)
+        _chk(self.L.lnb_pipeline_tick_batch(self.h, run.h if run else None, send.h if send else None, recv.h if recv else None, C.byref(slot)))
         return slot.value
 
     def sync(self):

@@ -485,6 +485,60 @@ def run_single_stream_native(rank, world, pipe, ctx, prompt, n_decode, lo=0, hi=
     return state
 
 
+def prefill_through_pipeline(rank, world, pipe, ctx, prompt):
+    """one sequence's prompt through all stages with the single-sequence ticks; afterwards rank 0's context holds the first generated token
+    in its device token word (received from the last rank) -- the state lnb_batch_set_state(tokens = NULL) picks up"""
+    P = len(prompt)
+    first, last = rank == 0, rank == world - 1
+    if world > 1 and not first:
+        pipe.tick(recv=ctx, recv_rows=P)
+    slot = pipe.tick(run=ctx, run_rows=P, run_pos=0, run_tokens=(np.ascontiguousarray(prompt, dtype=np.int32) if first else None))
+    if world > 1:
+        pipe.tick(send=ctx, send_rows=P)                      # (the last rank: its token word to rank 0)
+        if first:
+            pipe.tick(recv=ctx, recv_rows=1)
+    return slot
+
+
+def run_ticks_native_batched(rank, world, pipe, batches, n_decode, lo=0, hi=None, state=None):
+    """The overlapped schedule with BATCHES as items (lnb_pipeline_tick_batch): group g = batches[g] (every rank's batch over its stage's
+    contexts of the same sequences); item i = (decode step i // G, group i % G); rank r runs item t - gap*r at tick t, sends the result of
+    the item it ran in the previous tick and receives the input of the item of the next tick.  2*world groups in flight (world == 1: any
+    number; the token ring stays inside the batch).  state["slots"][g] on the last rank = first token-log slot of each of the group's steps."""
+    G = len(batches)
+    n_items = n_decode * G
+    gap = 2 if world > 1 else 1
+    assert world == 1 or G == 2 * world, "the overlapped schedule keeps 2*world groups in flight"
+    first, last = rank == 0, rank == world - 1
+    if state is None:
+        state = {"prev": None, "slots": [[] for _ in range(G)]}
+    if hi is None:
+        hi = n_items + gap * (world - 1)
+    for t, item in schedule(rank, world, n_decode, G, gap):
+        if t < lo:
+            continue
+        if t >= hi:
+            break
+        kw = {}
+        if item is not None:
+            kw["run"] = batches[item % G]
+        prev = state["prev"]
+        if prev is not None and world > 1:
+            k, g = divmod(prev, G)
+            if not last or k + 1 < n_decode:                  # the tokens of the final step are not needed by rank 0
+                kw["send"] = batches[g]
+        nxt = t + 1 - gap * rank
+        if 0 <= nxt < n_items and world > 1:
+            k, g = divmod(nxt, G)
+            if not first or k > 0:                            # (step 0's tokens are already in the contexts: the prefill's ring)
+                kw["recv"] = batches[g]
+        slot = pipe.tick_batch(**kw)
+        if item is not None and last:
+            state["slots"][item % G].append(slot)
+        state["prev"] = item
+    return state
+
+
 def blocks_split(rank, world, n_layers):
     """configs[3] literally: n_layers / world whole blocks per GPU (the head on top of the last stage's share)"""
     return 3 * (rank * n_layers // world), 3 * ((rank + 1) * n_layers // world)
@@ -592,6 +646,43 @@ def bench_main(args, cfg, name):
                     "single_stream": {"tokens_per_s": round(Ks / wall_s, 2), "steps": Ks, "ms_per_token": round(1e3 * wall_s / Ks, 4),
                                       "tokens_equal_sequence0_of_the_batch": bool(toks_s is not None and toks0 is not None and toks_s[:len(toks0)] == toks0[:len(toks_s)])}}
 
+        def measure_batched(nb):
+            """the same pipeline with BATCHES of nb sequences as the unit that moves through the stages (lnb_pipeline_tick_batch): 2*world groups in
+            flight, each decode step of a group = ONE pass over a stage's weights for its nb sequences (exact per sequence).  Whole-block stages."""
+            lb, le = stage_layers(rank, world, cfg["n_layers"], head_cost=(costs[3] / max(1e-9, sum(costs[:3])) if costs else 1.2))
+            G = 2 * world if world > 1 else int(os.environ.get("LNB_PIPELINE_SEQS", "2"))
+            st = LnbStage(lnb, None, cfg, rank, world, G * nb, seq_len, local, parts=(3 * lb, 3 * le), costs=costs)
+            st.model.enable_batch()
+            uid2 = grp.broadcast(lnb.Pipeline.unique_id() if (rank == 0 and world > 1) else None)
+            pp = lnb.Pipeline(st.model, rank, world, uid2)
+            prm = [lnb.synth_tokens(99 + q, P, cfg["vocab_size"]) for q in range(G * nb)]          # sequence 0 = the headline's prompt
+            first_slot0 = None
+            for q in range(G * nb):
+                sl = prefill_through_pipeline(rank, world, pp, st.ctx[q], prm[q])
+                if q == 0:
+                    first_slot0 = sl
+            pp.sync(); grp.barrier()
+            bats = [lnb.Batch(st.ctx[g * nb:(g + 1) * nb]).set_state(None, [P] * nb) for g in range(G)]
+            n_dec = W + K
+            sb = run_ticks_native_batched(rank, world, pp, bats, n_dec, 0, G * W)
+            pp.sync(); grp.barrier()
+            t0 = time.perf_counter()
+            run_ticks_native_batched(rank, world, pp, bats, n_dec, G * W, G * (W + K), sb)
+            t_host = time.perf_counter() - t0
+            pp.sync(); grp.barrier()
+            wall_b = grp.all_reduce(time.perf_counter() - t0, max)
+            toks0 = None
+            if rank == world - 1:
+                toks0 = [int(pp.read_tokens(first_slot0, 1)[0])] + [int(pp.read_tokens(q, 1)[0]) for q in sb["slots"][0]]
+            info = grp.all_reduce([(rank, pp.comm_count(), toks0)], lambda vs: sorted(sum(vs, [])))
+            res_b = {"wall": wall_b, "sequences_in_flight": G * nb, "groups": G, "batch": nb, "blocks_per_gpu": le - lb,
+                     "tokens_per_s": round(K * G * nb / wall_b, 2), "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * G), 1),
+                     "rccl_comm_count_per_rank": [c for _, c, _ in info], "tokens_vs_oracle_golden": _golden_check(info[-1][2], P, name) if info[-1][2] else None}
+            for b_ in bats:
+                b_.close()
+            pp.close(); st.close()
+            return res_b
+
         m_bal = measure()
         wall = m_bal["wall"]
         toks0 = m_bal.pop("tokens_seq0")
@@ -613,6 +704,17 @@ def bench_main(args, cfg, name):
             m_lit.pop("tokens_seq0")
             extra["literal_blocks_split"] = dict(m_lit, blocks_per_gpu=cfg["n_layers"] // world, tokens_per_s=round(K * n_seq / m_lit.pop("wall"), 2))
             pipe.close()
+        nb = int(os.environ.get("LNB_PIPELINE_BATCH", "8" if mode == "exact" else "0"))
+        if nb > 0:
+            try:
+                mb = measure_batched(min(nb, 16))
+            except lnb.LnbError as e:                         # (setup errors are the same on every rank: e.g. dims that are no multiples of 128)
+                mb = {"skipped": str(e)}
+            extra["batched"] = dict(mb)
+            if "wall" in mb:
+                extra["unbatched_ticks"] = {"tokens_per_s": round(K * n_seq / wall, 2), "sequences_in_flight": n_seq}
+                wall, n_seq = mb["wall"], mb["sequences_in_flight"]     # the line's value: the batched pipeline
+                extra["batched"].pop("wall")
         grp.close()
     else:
         import datetime

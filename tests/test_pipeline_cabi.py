@@ -281,3 +281,98 @@ def test_bench_force_pipeline_on_one_gpu_runs_the_native_tick_path(lnb):
     assert len(lines) == 1, r.stdout
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and "lnb_pipeline_tick" in d["config"]["exchange"] and d["config"]["host_enqueue_us_per_tick"] > 0
+
+
+class _FakeBatchPipe:
+    def __init__(self, rank):
+        self.rank, self.ticks = rank, []
+
+    def tick_batch(self, **kw):
+        self.ticks.append(kw)
+        return len(self.ticks) - 1
+
+
+@pytest.mark.parametrize("world,n_decode", [(2, 3), (3, 2), (4, 5), (8, 2)])
+def test_batched_schedule_posts_matching_sends_and_receives(world, n_decode):
+    """run_ticks_native_batched (groups of sequences as items): every send meets its receive in the same tick, no group runs a step before
+    its input arrived (hidden states on ranks > 0; the previous step's tokens on rank 0), every rank runs every (group, step) once"""
+    import pipeline
+    G = 2 * world
+    pipes = [_FakeBatchPipe(r) for r in range(world)]
+    batches = [["b%d_%d" % (r, g) for g in range(G)] for r in range(world)]
+    for r in range(world):
+        pipeline.run_ticks_native_batched(r, world, pipes[r], batches[r], n_decode)
+    n_ticks = len(pipes[0].ticks)
+    assert all(len(p.ticks) == n_ticks for p in pipes)
+    grp = lambda name: int(name.split("_")[1])
+    got_input = [set() for _ in range(world)]
+    step = [[0] * G for _ in range(world)]
+    ran = [[] for _ in range(world)]
+    for t in range(n_ticks):
+        for r in range(world):
+            kw = pipes[r].ticks[t]
+            if kw.get("run") is not None:
+                g = grp(kw["run"]); k = step[r][g]
+                if r > 0 or k > 0:
+                    assert (g, k) in got_input[r], "rank %d ran step %d of group %d before its input arrived" % (r, k, g)
+                ran[r].append((g, k)); step[r][g] += 1
+        for r in range(world):
+            kw, peer = pipes[r].ticks[t], pipes[(r + 1) % world].ticks[t]
+            if kw.get("send") is not None:
+                assert peer.get("recv") is not None and grp(peer["recv"]) == grp(kw["send"])
+                g = grp(kw["send"])
+                assert (g, step[r][g] - 1) in ran[r]
+                got_input[(r + 1) % world].add((g, step[r][g] - 1 + (1 if r == world - 1 else 0)))
+            else:
+                assert peer.get("recv") is None
+    for r in range(world):
+        assert sorted(ran[r]) == sorted((g, k) for g in range(G) for k in range(n_decode))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("cuts,n", [((0, 6), 3), ((0, 3, 6), 3), ((0, 3, 6), 16), ((0, 3, 6, 9), 2)])
+def test_batched_pipeline_ticks_through_the_in_process_transport(lnb, cuts, n):
+    """Pipeline stages of whole blocks on one GPU, BATCHES of n sequences as the unit that moves through them (lnb_pipeline_tick_batch):
+    prompts prefilled with single-sequence ticks, then every decode step of a group is one pass over each stage's weights for all its
+    sequences.  2 x stages groups in flight (one stage: 2 groups), every rank's schedule stepped tick by tick; every token of every
+    sequence must be the oracle's."""
+    import pipeline
+    from oracle import oracle as orc
+    cfg = dict(orc.TINY, n_layers=cuts[-1] // 3)
+    om = orc.Model(**cfg).fill_synthetic(1234).finalize()
+    world = len(cuts) - 1
+    P, n_decode = 6, 7
+    G = 2 * world if world > 1 else 2
+    stages = [lnb.LlamaTransformer(part_begin=a, part_end=b, **cfg).fill_synthetic(1234).finalize().enable_batch() for a, b in zip(cuts[:-1], cuts[1:])]
+    ctxs = [[[lnb.InferenceContext(st, P + n_decode + 2) for _ in range(n)] for _ in range(G)] for st in stages]            # [rank][group][seq]
+    pipes = [lnb.Pipeline(stages[r], r, world, loopback_group="b%s%d" % (cuts, n)) if world > 1 else lnb.Pipeline(stages[r], 0, 1) for r in range(world)]
+    prompts = [[orc.synth_tokens(900 + 16 * g + s, P, cfg["vocab_size"]) for s in range(n)] for g in range(G)]
+    first_slots = {}
+    for g in range(G):
+        for s in range(n):
+            for r in range(world):                            # (lock step: rank order inside each sequence's prefill)
+                slot = pipeline.prefill_through_pipeline(r, world, pipes[r], ctxs[r][g][s], prompts[g][s])
+            first_slots[(g, s)] = slot
+    batches = [[lnb.Batch(ctxs[r][g]).set_state(None, [P] * n) for g in range(G)] for r in range(world)]
+    n_ticks = n_decode * G + 2 * (world - 1)
+    state = [None] * world
+    for t in range(n_ticks):
+        for r in range(world):
+            state[r] = pipeline.run_ticks_native_batched(r, world, pipes[r], batches[r], n_decode, t, t + 1, state[r])
+    for p_ in pipes:
+        p_.sync()
+    for g in range(G):
+        steps = [pipes[-1].read_tokens(q, n) for q in state[-1]["slots"][g]]          # [step][seq]
+        for s in range(n):
+            ref, _ = orc.Context(om, P + n_decode + 2).generate(prompts[g][s], n_decode + 1)
+            got = [int(pipes[-1].read_tokens(first_slots[(g, s)], 1)[0])] + [int(st_[s]) for st_ in steps]
+            assert got == [int(t) for t in ref], (cuts, n, g, s)
+    for r in range(world):
+        for b in batches[r]:
+            b.close()
+        pipes[r].close()
+        for grp_ in ctxs[r]:
+            for c in grp_:
+                c.close()
+        stages[r].close()
+    om.close()

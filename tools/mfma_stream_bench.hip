@@ -95,6 +95,16 @@ __global__ __launch_bounds__(512) void k_roles(float* out, long long* cyc, int i
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+    } else if (role == 4) {
+        float p0 = __uint_as_float(v & 0x3fff0000u), a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+        for (int it = 0; it < iters; it++) {
+#pragma unroll
+            for (int i = 0; i < 32; i++) {               // 4 independent VALU ops per step, 128 per iteration (an issue-hungry wave)
+                const uint32_t w = v + i + it;
+                a0 = a0 * 0.5f + __uint_as_float(w << 16); a1 = a1 * 0.5f + __uint_as_float(w & 0xffff0000u);
+            }
+        }
+        acc = a0 + a1 + a2 + a3 + p0;
     } else if (role == 3) {
         const float p = __uint_as_float(v & 0x3fff0000u);
         for (int it = 0; it < iters; it++) {
@@ -342,15 +352,18 @@ static void bench_roles(const char* what, unsigned roles, float* out, long long*
         const int role = (roles >> (4 * w)) & 15;
         if (!role) continue;
         double mx = 0; for (int b = 0; b < 256; b++) if ((double)h[b * 8 + w] > mx) mx = (double)h[b * 8 + w];
-        printf(" w%d:%s %.2f", w, role == 1 ? "dpp/step" : role == 2 ? "mfma/instr" : "add/step", mx / (iters * (role == 2 ? 32.0 : 128.0)));
+        printf(" w%d:%s %.2f", w, role == 1 ? "dpp/step" : role == 2 ? "mfma/instr" : role == 4 ? "valu/op" : "add/step", mx / (iters * (role == 2 ? 32.0 : 128.0)));
     }
     printf("\n");
 }
 
 int main(int argc, char** argv) {
     const bool quick = argc > 1 && !strcmp(argv[1], "quick");
+    const bool skip1 = argc > 1 && !strcmp(argv[1], "part2");
+    setvbuf(stdout, nullptr, _IONBF, 0);                     // (a GPU fault must not take buffered lines with it)
     float* out; long long* cyc;
     CHK(hipMalloc(&out, 256 * 512 * 4)); CHK(hipMalloc(&cyc, 256 * 8 * 8));
+    if (!skip1) {
     printf("part 1a: dependent MFMA chains (s_memtime cycles; 32 issue / 40 dependent expected)\n");
     bench_chain<1, 32, 0>("bare, back to back", out, cyc);
     bench_chain<1, 1, 1>("1 VALU between", out, cyc);
@@ -370,6 +383,9 @@ int main(int argc, char** argv) {
     bench_roles("DPP chain (0-3) + dependent MFMA chain (4-7) per SIMD", 0x22221111u, out, cyc);
     bench_roles("dependent MFMA chain alone (4-7)", 0x22220000u, out, cyc);
     bench_roles("two dependent MFMA chains per SIMD", 0x22222222u, out, cyc);
+    bench_roles("DPP chain (0-3) + VALU-heavy helper wave (4-7) per SIMD", 0x44441111u, out, cyc);
+    bench_roles("DPP chain (4-7, younger) + VALU-heavy helper (0-3)", 0x11114444u, out, cyc);
+    }
 
     printf("part 2: the streaming kernel (weights in the 16-row matrix-core layout, up to 16 sequences)\n");
     // exactness on small shapes (ragged job counts, both chain modes), then the 8B shapes
