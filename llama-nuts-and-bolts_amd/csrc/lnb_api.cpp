@@ -158,7 +158,7 @@ static void drop_graphs(lnb_ctx* c) {
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
 static int auto_rw(int lane_rows, const char* env, int K = 0, bool plain = false) {
     int v = env_int(env, 0);
-    if (v == 16 || v == 32 || v == 64 || (v == 4 && plain && K % 128 == 0 && K <= 16384) || (v == 56 && lane_rows % 56 == 0)) return v;
+    if (v == 16 || v == 32 || v == 64 || (v == 4 && plain && K % 128 == 0 && K <= 16384) || ((v == 56 || v == 28) && lane_rows % v == 0)) return v;
     // thin matrices without a fused norm / rope epilogue: the row-broadcast kernel (products stay in registers)
     if (plain && lane_rows <= 16 * 256 && K > 0 && K % 128 == 0 && K <= 16384) return 4;
     // thin matrices: one workgroup (16 or 32 rows) per CU, all resident at once on the 256 CUs -- a second round of
@@ -613,8 +613,8 @@ static hipError_t gemm_dispatch(int mode, const GemmParams* g, int epi, hipStrea
     if (mode == LNB_MODE_FAST && g->S >= min_rows) { hipError_t e = lnbk_fast_gemm(g, epi, st); if (e != hipErrorNotSupported) return e; }
     return lnbk_gemm(g, epi, st);
 }
-static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
-    lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = c->stream;
+static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t st_other = nullptr, int lds_pad = 0) {
+    lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = st_other ? st_other : c->stream;
     LayerW& L = m->layers[l - m->layer_begin];
     uint16_t* ck = c->ck[l - m->layer_begin]; uint16_t* cv = c->cv[l - m->layer_begin];
     // h = x + attention (llamatransformer.go:232) normally has its own buffer; in a block this stage holds only a part of, it lives
@@ -662,7 +662,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which) {
         f.out = c->ffn; f.silu = m->silu;
         set_grid(f, L.w13); HIPCHK(gemv_dispatch(c, &f, L.w13.rw, 2, EPI_SILU_MUL, 1, st)); return 0; }
     case K_W2: {    // w2 + residual  (:619, :248)
-        GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = hbuf;
+        GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = hbuf; d.lds_pad = lds_pad;
         set_grid(d, L.w2); HIPCHK(gemv_dispatch(c, &d, L.w2.rw, 1, EPI_RESID, 0, st)); return 0; }
     }
     return fail("bad kernel id");
@@ -877,10 +877,39 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     if (!c || !avg_ms_out) return fail("null argument");
     lnb_model* m = c->m;
     HIPCHK(hipSetDevice(m->device));
-    if (iters <= 0 || which < 0 || which > K_LAYER) return fail("bad arguments");
+    // which 7 / 8 (measurement only): the gate|up kernel and the down kernel of a block launched CONCURRENTLY on two streams (7: w2 first, i.e.
+    // its waves are the older ones on every SIMD; 8: w1|w3 first), w2's LDS request padded so that exactly one workgroup of each kernel sits on
+    // every CU -- what co-residency would cost a w1|w3 -> w2 row-band pipeline; results are NOT meaningful (w2 reads stale input)
+    if (iters <= 0 || which < 0 || which > K_LAYER + 2) return fail("bad arguments");
     if (check_call(c, 1, pos)) return -1;
     if (which == K_HEAD && !m->last()) return fail("this stage does not own output.weight");
     hipStream_t st = c->stream;
+    if (which > K_LAYER) {
+        hipStream_t st2 = nullptr; hipEvent_t ef = nullptr, ej = nullptr;
+        HIPCHK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+        c->attn_long = false;
+        HIPCHK(ctx_set_state(c, pos, 0, true));
+        const int nl2 = m->layer_end - m->layer_begin, pad = env_int("LNB_W2_LDS_PAD", 28 * 1024);
+        auto pair = [&](int i) -> int {
+            const int l = m->layer_begin + i % nl2;
+            HIPCHK(hipEventRecord(ef, st)); HIPCHK(hipStreamWaitEvent(st2, ef, 0));
+            if (which == K_LAYER + 1) { if (enqueue_layer_kernel(c, l, 1, K_W2, st2, pad)) return -1; if (enqueue_layer_kernel(c, l, 1, K_W13)) return -1; }
+            else { if (enqueue_layer_kernel(c, l, 1, K_W13)) return -1; if (enqueue_layer_kernel(c, l, 1, K_W2, st2, pad)) return -1; }
+            HIPCHK(hipEventRecord(ej, st2)); HIPCHK(hipStreamWaitEvent(st, ej, 0));
+            return 0;
+        };
+        int rc = 0;
+        for (int i = 0; i < 3 && !rc; i++) rc = pair(i);
+        if (!rc) { HIPCHK(hipEventRecord(c->ev0, st)); for (int i = 0; i < iters && !rc; i++) rc = pair(i + 3); HIPCHK(hipEventRecord(c->ev1, st)); }
+        hipError_t e = hipDeviceSynchronize();
+        float ms2 = 0; if (!rc && e == hipSuccess) e = hipEventElapsedTime(&ms2, c->ev0, c->ev1);
+        hipEventDestroy(ef); hipEventDestroy(ej); hipStreamDestroy(st2);
+        if (rc) return -1;
+        HIPCHK(e);
+        *avg_ms_out = ms2 / (float)iters;
+        return 0;
+    }
     c->attn_long = want_long_attention(c, 1, pos);
     HIPCHK(ctx_set_state(c, pos, 0, true));
     const int nl = m->layer_end - m->layer_begin;

@@ -90,6 +90,7 @@ struct GemvParams {
     int seq_len;
     int q_dim, kv_dim, head_dim;
     long long* dbg;             // optional per-wave timing dump (nullptr in production)
+    int lds_pad;                // host side only: extra dynamic LDS requested for the launch (co-residency experiments: forces one workgroup per CU)
 };
 
 // exact-order prefill GEMM on the f32 matrix cores (gemm_mfma_kernel): Y[m][n] for S >= 16 rows per call

@@ -527,7 +527,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
     float acc[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
-    const int row = (RW & (RW - 1)) == 0 ? (lane & (RW - 1)) : (lane < RW ? lane : lane - RW);   // RW 56: lanes 56..63 shadow rows 0..7
+    const int row = (RW & (RW - 1)) == 0 ? (lane & (RW - 1)) : (lane % RW);   // RW 56 / 28: the lanes past RW shadow rows 0.. (every lane stays active: a partially masked wave issues slower)
     int st = 0, blk = wg;
     // every stage is walked in full: beyond K the x values (hence the products) are +0, and acc + 0 == acc
     // because acc is never -0
@@ -2046,6 +2046,9 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     // RW 56 (two chains only): 28672 gate/up rows = 256 blocks of 56 x 2 -- one block per CU on ALL 256 CUs instead of 224 of them;
     // seven helpers (448 lanes = one (k-chunk, row) pair each), 64-step stages
     if constexpr (NCH == 2) if (rw == 56) return launch_chain_t<56, 2, 14336, 7, 8, EPI, NORM>(p, st);
+    // RW 28 (two chains, LNB_RW_W13=28): the same stream cut into 512 half-height blocks, two per workgroup -- rows [0, F/2) are complete
+    // after the first block of every workgroup: the row-band order a w1|w3 -> w2 pipeline needs (measurement)
+    if constexpr (NCH == 2) if (rw == 28) return launch_chain_t<28, 2, 14336, 7, 8, EPI, NORM>(p, st);
     return hipErrorInvalidValue;
 }
 
@@ -2053,7 +2056,7 @@ template <int EPI> static hipError_t launch_rowcast(const GemvParams* p, hipStre
     auto kfn = rowcast_kernel<EPI>;
     if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if ((p->K & 127) || p->K > 16384) return hipErrorInvalidValue;              // x staging: 8 x 16 B per thread, K*4 bytes of LDS
-    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3(256), (size_t)p->K * 4, st, *p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3(256), (size_t)p->K * 4 + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0), st, *p);
     return hipGetLastError();
 }
 
@@ -2132,7 +2135,8 @@ extern "C" hipError_t lnbk_init(void) {
     { hipError_t eg; for (int ep = EPI_STORE; ep <= EPI_SILU_MUL; ep++) if ((eg = lnbk_gemm(nullptr, ep, nullptr)) != hipSuccess) return eg;
       if ((eg = hipFuncSetAttribute((const void*)rmsnorm_rows_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return eg; }
     { hipError_t e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_STORE, 0, nullptr)) != hipSuccess) return e4; if ((e4 = lnbk_gemv(nullptr, 4, 1, EPI_RESID, 0, nullptr)) != hipSuccess) return e4; }
-    { hipError_t e56; if ((e56 = lnbk_gemv(nullptr, 56, 2, EPI_SILU_MUL, 1, nullptr)) != hipSuccess) return e56; }
+    { hipError_t e56; if ((e56 = lnbk_gemv(nullptr, 56, 2, EPI_SILU_MUL, 1, nullptr)) != hipSuccess) return e56;
+      if ((e56 = lnbk_gemv(nullptr, 28, 2, EPI_SILU_MUL, 1, nullptr)) != hipSuccess) return e56; }
     { hipError_t el;
       if ((el = launch_chain_t<16, 1, 8192, 4, 7, EPI_STORE, false>(nullptr, nullptr)) != hipSuccess) return el;
       if ((el = launch_chain_t<32, 1, 8192, 4, 7, EPI_STORE, false>(nullptr, nullptr)) != hipSuccess) return el;
