@@ -768,6 +768,13 @@ def bench_main(args, cfg, name):
         a = {k: cfg[k] for k in ("dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size")}
         Tbar = P + W + (K - 1) / 2.0 + 1.0
         B = _b.algorithmic_bytes_per_token(a, stage.model.ffn_hidden, Tbar)
+        if isinstance(extra.get("batched"), dict) and "batch" in extra["batched"]:
+            # a batched step reads the weights ONCE for the group's sequences: the bytes really needed per token = weights / batch + the
+            # sequence's own KV / embedding traffic
+            hd = a["dim"] // a["n_heads"]
+            kvb = a["n_layers"] * 2 * (a["n_kv_heads"] * hd) * 2
+            own = a["dim"] * 2 + kvb * Tbar + kvb
+            B = (B - own) / extra["batched"]["batch"] + own
         res = {"metric": "decode tokens/s Llama-3.1-8B bf16 @1/2/4/8 MI355X; % HBM roofline", "value": round(tps, 2), "unit": "tokens/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

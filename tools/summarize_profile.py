@@ -26,12 +26,16 @@ CLASSES = [
     ("gemv_chain_kernel<56, 2,", None, "ffn_norm+w1|w3+silu GEMV"), ("gemv_chain_kernel<64, 1,", None, "norm+output GEMV"),
     ("fast_gemv_a<1, 1,", None, "attn_norm+wqkv+rope GEMV"), 
     ("fast_gemv_a<2, 3,", None, "ffn_norm+w1|w3+silu GEMV"), ("fast_gemv_a<1, 0,", None, "norm+output GEMV"),
+    # batched decode (lnb_batch_kernels.h): mfma_stream_kernel<ACC, EPI>, EPI 0 store / 1 qkv+rope / 2 residual / 3 silu*up
+    ("mfma_stream_kernel<1, 1>", None, "batch: wq|wk|wv+rope stream"), ("mfma_stream_kernel<2, 3>", None, "batch: w1|w3+silu stream"),
+    ("mfma_stream_kernel<2, 0>", None, "batch: output stream"), ("batch_rmsnorm_xt_kernel", None, "batch: rmsnorm -> B-operand layout"),
 ]
 
 
 # wo and w2 run through ONE kernel symbol with the same grid (rocprofv3 reports only static LDS, which is 0 for both): their launches are
 # told apart by size -- durations in the trace pass, bytes in the PMC pass -- at the geometric mean of the extremes (K = 4096 against 14336)
-SPLIT = {"rowcast_kernel<2>": ("wo+residual GEMV", "w2+residual GEMV"), "fast_gemv_b<2>": ("wo+residual GEMV", "w2+residual GEMV")}
+SPLIT = {"rowcast_kernel<2>": ("wo+residual GEMV", "w2+residual GEMV"), "fast_gemv_b<2>": ("wo+residual GEMV", "w2+residual GEMV"),
+         "mfma_stream_kernel<1, 2>": ("batch: wo+residual stream", "batch: w2+residual stream")}
 
 
 def split_two(vals):
@@ -70,8 +74,9 @@ def one(label):
         for r in csv.DictReader(open(fp)):
             if r["Counter_Name"] == "FETCH_SIZE":
                 fetch[(r["Kernel_Name"], r["Grid_Size"], r.get("LDS_Block_Size", ""))].append(float(r["Counter_Value"]))
-    lines = ["# %s: rocprofv3 summary of `python bench.py%s%s --steps 32 --warmup 4` (Llama-3.1-8B shape, 1 x MI355X)" % (
-                 label, " --mode fast" if "fast" in label else "", " --prompt-len 4096 (configs[2] decode: long-context attention kernels)" if "cfg2" in label else ""), "",
+    cmdline = ("python tools/batch_bench.py --n 16 --steps 16` (batched exact decode, 16 sequences; prefill of the 16 prompts included" if "batch" in label else
+               "python bench.py%s%s --steps 32 --warmup 4`" % (" --mode fast" if "fast" in label else "", " --prompt-len 4096 (configs[2] decode: long-context attention kernels)" if "cfg2" in label else ""))
+    lines = ["# %s: rocprofv3 summary of `%s (Llama-3.1-8B shape, 1 x MI355X)" % (label, cmdline), "",
              "Per-dispatch averages by (kernel, grid, LDS).  `HBM read` = FETCH_SIZE (KB) x 2 / 1024 -- the gfx950 correction of",
              "/opt/skills/guides/MI355X_MICROARCH.md section HBM (wide coalesced reads are tallied at half their bytes); its own --pmc pass.", "",
              "| kernel | class | grid (threads) | LDS B | launches | avg us | HBM read MB (PMC, corrected) | GB/s |", "|---|---|---|---|---|---|---|---|"]
@@ -106,7 +111,7 @@ def one(label):
                             classes[cls]["hbm_read_bytes_per_launch"] = int(2 * sum(ff) / len(ff) * 1024)
                         lines.append("| %s | %s | %s | - | %d | %.1f | %s | %s |" % (key[0][:60], cls.replace("|", "/"), key[1], len(dd), sum(dd) / len(dd),
                                      ("%.1f" % (2 * sum(ff) / len(ff) / 1024.0)) if ff else "-", ("%.0f" % (2 * sum(ff) / len(ff) * 1024 / (sum(dd) / len(dd)) / 1e3)) if ff else "-"))
-    for fn in ("trace_bench.json", "bench_default.json"):
+    for fn in ("trace_bench.json", "bench_default.json", "batch_bench.json"):
         pth = os.path.join(src, fn)
         if os.path.exists(pth) and os.path.getsize(pth):
             lines += ["", "## %s" % fn, "```json", open(pth).read().strip(), "```"]
