@@ -47,6 +47,7 @@ hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, cons
 hipError_t lnbk_batch_scatter_ring(const BatchTab* tab, const int32_t* ring, hipStream_t st);
 hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st);
 hipError_t lnbk_batch_prepare(void);
+hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream_t st);
 }
 
 static thread_local char g_err[1024] = "";
@@ -597,7 +598,7 @@ enum { K_QKV = 0, K_ATTN = 1, K_WO = 2, K_W13 = 3, K_W2 = 4, K_HEAD = 5, K_LAYER
 // keeps them on the S = 1 kernels (one launch row per token row), which is what the parity tests compare the two with.
 static bool use_mfma(int S) { static const int on = env_int("LNB_PREFILL_MFMA", 1); return on && S >= 16; }
 static GemmParams gemm_of(const TiledDesc& t, const uint16_t* x, int K, int n_rows, int S, const StepState* st) {
-    GemmParams g{}; g.w = t.w; g.rw = t.rw; g.nch = t.nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = S; g.st = st; return g;
+    GemmParams g{}; g.w = t.w; g.rw = t.rw; g.nch = t.nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = S; g.st = st; g.w16 = t.w16; return g;
 }
 // S < 16 rows: the exact-order chain kernels, or (LNB_MODE_FAST) the split-K kernels over the same resident weights
 static hipError_t gemv_dispatch(const lnb_ctx* c, const GemvParams* g, int rw, int nch, int epi, int norm, hipStream_t st) {
@@ -611,6 +612,10 @@ static hipError_t gemm_dispatch(int mode, const GemmParams* g, int epi, hipStrea
     // use an exact kernel
     static const int min_rows = env_int("LNB_FAST_GEMM_MIN_ROWS", 192);
     if (mode == LNB_MODE_FAST && g->S >= min_rows) { hipError_t e = lnbk_fast_gemm(g, epi, st); if (e != hipErrorNotSupported) return e; }
+    // exact order with the matrix-core copy of the weights present (lnb_model_enable_batch): the streaming feed -- the same chains, the
+    // same bits (tests/test_gpu_batch.py), the weights never staged through the LDS; LNB_PREFILL_STREAM=0 keeps the LDS-tiled kernel
+    static const int stream_on = env_int("LNB_PREFILL_STREAM", 1);
+    if (stream_on && g->w16 && (g->K & 127) == 0) return lnbk_gemm_stream(g, epi, g_num_cus, st);
     return lnbk_gemm(g, epi, st);
 }
 static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t st_other = nullptr, int lds_pad = 0) {
@@ -1011,6 +1016,10 @@ extern "C" int lnb_model_enable_batch(lnb_model* m) {
     }
     if (!rc && m->last()) rc = m16_copy(m, m->output, m->a.vocab_size, &m->m_output);
     hipError_t e = hipStreamSynchronize(m->stream);
+    if (!rc && e == hipSuccess) {                            // the prefill products find the copy through the matrix descriptors
+        for (auto& L : m->layers) { L.wqkv.w16 = L.m_wqkv; L.wo.w16 = L.m_wo; L.w13.w16 = L.m_w13; L.w2.w16 = L.m_w2; }
+        m->output.w16 = m->m_output;
+    }
     if (rc || e != hipSuccess) {                             // (out of memory on a model that fills the HBM: the single-sequence paths stay usable)
         for (auto& L : m->layers) { hipFree(L.m_wqkv); hipFree(L.m_wo); hipFree(L.m_w13); hipFree(L.m_w2); L.m_wqkv = L.m_wo = L.m_w13 = L.m_w2 = nullptr; }
         hipFree(m->m_output); m->m_output = nullptr; m->batch_bytes = 0;
@@ -1683,6 +1692,12 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     HIPCHK(hipMemcpy(dw, w, (size_t)n_out * k_in * 2, hipMemcpyHostToDevice));
     if (norm_w) { HIPCHK(hipMalloc((void**)&dn, (size_t)k_in * 2)); HIPCHK(hipMemcpy(dn, norm_w, (size_t)k_in * 2, hipMemcpyHostToDevice)); }
     HIPCHK(lnbk_tile(dw, t.w, n_out, k_in, 0, 0, rw, 1, 0, nullptr));
+    if (use_mfma(rows) && env_int("LNB_OP_STREAM", 0) && k_in % 128 == 0) {      // (tests: the same operator through gemm_stream_kernel)
+        HIPCHK(lnbk_batch_prepare());
+        const size_t mb = m16_elems(n_out, k_in, 1) * 2;
+        HIPCHK(hipMalloc((void**)&t.w16, mb)); HIPCHK(hipMemset(t.w16, 0, mb));
+        HIPCHK(lnbk_m16_from_tiled(t.w, t.w16, n_out, k_in, rw, 1, nullptr));
+    }
     if (use_mfma(rows)) {                                   // 16 or more rows: the matrix-core path of the prefill
         uint16_t* dxn = nullptr;
         if (norm_w) { HIPCHK(hipMalloc((void**)&dxn, (size_t)rows * k_in * 2)); HIPCHK(lnbk_rmsnorm_rows(dx, dn, dxn, rows, k_in, eps, nullptr)); }
@@ -1698,7 +1713,7 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     }
     HIPCHK(hipDeviceSynchronize());
     HIPCHK(hipMemcpy(y, dy, (size_t)rows * n_out * 2, hipMemcpyDeviceToHost));
-    hipFree(dx); hipFree(dw); hipFree(dy); hipFree(st); hipFree(t.w); if (dn) hipFree(dn);
+    hipFree(dx); hipFree(dw); hipFree(dy); hipFree(st); hipFree(t.w); if (dn) hipFree(dn); if (t.w16) hipFree(t.w16);
     return 0;
 }
 // ml.Argmax (operations_impl.go:513-548) of one row of bf16 logits through argmax_kernel, the kernel of the greedy loop

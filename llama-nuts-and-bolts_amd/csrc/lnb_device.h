@@ -28,6 +28,7 @@ struct TiledDesc {
     int rw;           // rows per wave block: 16 / 32 / 64
     int nch;          // chains per lane: 1 / 2
     int n_blocks;     // ceil(n_rows / rw)
+    uint16_t* w16;    // the same matrix in the M16 layout (below), once lnb_model_enable_batch has built it; else nullptr
 };
 //
 // RW == 4 selects the ROW-BROADCAST layout of rowcast_kernel (thin matrices, K % 128 == 0, NCH == 1):
@@ -102,6 +103,9 @@ struct GemmParams {
     const StepState* st;
     uint16_t* out; const uint16_t* res; const float* silu;            // EPI_STORE / EPI_RESID / EPI_SILU_MUL
     const float* cis; uint16_t* q_out; uint16_t* cache_k; uint16_t* cache_v; int seq_len, q_dim, kv_dim, head_dim;   // EPI_QKV_ROPE
+    // gemm_stream_kernel (lnb_batch_kernels.h): the same product with the weights streamed from their M16 copy straight into the A operand
+    const uint16_t* w16;        // M16 copy of w (lnb_model_enable_batch), or nullptr
+    int csplit;                 // waves of a workgroup that share one 16-row weight tile and split the batch rows among them (1, 2 or 4)
 };
 
 struct AttnParams {

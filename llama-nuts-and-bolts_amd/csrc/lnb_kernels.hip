@@ -2253,8 +2253,11 @@ extern "C" hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int 
 #undef LNB_STREAM
     return hipGetLastError();
 }
-extern "C" hipError_t lnbk_batch_prepare(void) {             // raise the dynamic-LDS limit once, outside any stream capture
-    return hipFuncSetAttribute((const void*)batch_rmsnorm_xt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+extern "C" hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream_t st);
+extern "C" hipError_t lnbk_batch_prepare(void) {             // raise the dynamic-LDS limits once, outside any stream capture
+    hipError_t e = hipFuncSetAttribute((const void*)batch_rmsnorm_xt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    for (int ep = EPI_STORE; ep <= EPI_SILU_MUL && e == hipSuccess; ep++) e = lnbk_gemm_stream(nullptr, ep, 0, nullptr);
+    return e;
 }
 extern "C" hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K, int nseq, hipStream_t st) {
     const size_t lds = bn_scratch() + ((size_t)bn_kpad(K) + 8) * 4;
@@ -2281,4 +2284,44 @@ extern "C" hipError_t lnbk_batch_scatter_ring(const BatchTab* tab, const int32_t
 extern "C" hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st) {
     hipLaunchKernelGGL(batch_advance_kernel, dim3(1), dim3(64), 0, st, tab);
     return hipGetLastError();
+}
+
+// prefill product on the streaming matrix-core feed (gemm_stream_kernel): one weight tile per wave and NTW batch tiles; csplit waves of a
+// workgroup share a tile so that thin matrices still occupy every SIMD
+template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParams* p, int num_cus, hipStream_t st) {
+    if (!p) {
+        hipError_t e = hipSuccess;
+#define LNB_GS_PREP(N) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, NCH, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        LNB_GS_PREP(1); LNB_GS_PREP(2); LNB_GS_PREP(4); LNB_GS_PREP(8);
+#undef LNB_GS_PREP
+        return e;
+    }
+    if (!p->w16 || (p->K & 127) || p->S < 1) return hipErrorInvalidValue;
+    const int n_tiles = (p->n_rows + 15) / 16;
+    int ct = (p->S + 15) / 16; if (ct > 8) ct = 8;          // batch tiles of 16 rows handled per workgroup pass (up to 128 rows)
+    int csplit = 1;
+    while (csplit < 4 && n_tiles * csplit < 3 * num_cus && ct >= 2 * csplit) csplit *= 2;
+    int ntw = (ct + csplit - 1) / csplit; ntw = ntw <= 1 ? 1 : ntw <= 2 ? 2 : ntw <= 4 ? 4 : 8;
+    GemmParams q = *p; q.csplit = csplit;
+    const int tpw = 4 / csplit, rows_wg = 16 * ntw * csplit;
+    unsigned gx = (unsigned)((n_tiles + tpw - 1) / tpw); if (gx > (unsigned)num_cus) gx = (unsigned)num_cus;
+    const dim3 grid(gx, (unsigned)((p->S + rows_wg - 1) / rows_wg));
+    const size_t lds = (size_t)2 * rows_wg * GS_PITCH * 4;
+    switch (ntw) {
+    case 1: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 1>), grid, dim3(256), lds, st, q); break;
+    case 2: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 2>), grid, dim3(256), lds, st, q); break;
+    case 4: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 4>), grid, dim3(256), lds, st, q); break;
+    default: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 8>), grid, dim3(256), lds, st, q); break;
+    }
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream_t st) {
+    const int nch = p ? p->nch : 0;
+    switch (epi) {
+        case EPI_STORE: return launch_gemm_stream<EPI_STORE, 1>(p, num_cus, st);
+        case EPI_RESID: return launch_gemm_stream<EPI_RESID, 1>(p, num_cus, st);
+        case EPI_QKV_ROPE: return launch_gemm_stream<EPI_QKV_ROPE, 1>(p, num_cus, st);
+        case EPI_SILU_MUL: return (p && nch != 2) ? hipErrorInvalidValue : launch_gemm_stream<EPI_SILU_MUL, 2>(p, num_cus, st);
+        default: return hipErrorInvalidValue;
+    }
 }

@@ -134,3 +134,88 @@ def test_batch_argument_checks(lnb):
         odd.enable_batch()
     for x in (b, c0, c1, co, other, odd, gm):
         x.close()
+
+
+def _bf(a):
+    return orc.f32_to_bf16(np.asarray(a, dtype=np.float32))
+
+
+def _orc_linear(x, w):
+    y = np.empty((x.shape[0], w.shape[0]), dtype=np.uint16)
+    orc.lib().orc_linear_bf16(orc._p(np.ascontiguousarray(x)), orc._p(np.ascontiguousarray(w)), orc._p(y), x.shape[0], w.shape[0], x.shape[1], 0)
+    return y
+
+
+@pytest.mark.parametrize("rows,n,k,rw", [(16, 48, 128, 16), (17, 100, 512, 32), (40, 64, 4096, 64), (100, 272, 1024, 4), (128, 96, 256, 16),
+                                         (130, 33, 384, 32), (300, 130, 640, 4), (64, 1000, 128, 64)])
+def test_prefill_product_on_the_streaming_matrix_core_feed_is_bit_exact(lnb, rows, n, k, rw):
+    """gemm_stream_kernel (weights from their M16 copy straight into the A operand, activations as f32 rows in the LDS, 1..8 batch tiles per
+    wave, 1 / 2 / 4 waves per weight tile) against the oracle's k-ordered loop: ragged row counts, ragged tile counts, several row groups,
+    every source layout the copy is made from"""
+    rng = np.random.default_rng(rows * 31 + n + k + rw)
+    x = _bf(rng.standard_normal((rows, k)) * 10 ** rng.uniform(-2, 2))
+    w = _bf(rng.standard_normal((n, k)) * 0.05)
+    os.environ["LNB_OP_STREAM"] = "1"
+    try:
+        y = lnb.op_linear(x, w, rw=rw)
+    finally:
+        del os.environ["LNB_OP_STREAM"]
+    assert (y == _orc_linear(x, w)).all()
+
+
+@pytest.mark.parametrize("name", ["tiny_hd64", "odd_tiles", "h8kv2_hd128"])
+def test_prefill_of_a_batch_enabled_model_equals_the_oracle(lnb, name):
+    """with the matrix-core copy present, Forward of 16 or more rows runs every product on gemm_stream_kernel: logits of all rows, KV cache
+    and a chunked continuation (start_pos > 0) bit for bit against the oracle; the same model without the copy gives the same bits"""
+    cfg = CFGS[name]
+    om = orc.Model(**cfg).fill_synthetic(808).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(808).finalize().enable_batch()
+    g0 = lnb.LlamaTransformer(**cfg).fill_synthetic(808).finalize()
+    for chunks in ((16,), (37,), (150,), (48, 48), (20, 20, 20)):
+        total = sum(chunks)
+        toks = orc.synth_tokens(4000 + total, total, cfg["vocab_size"])
+        oc, gc, c0 = orc.Context(om, total + 4), lnb.InferenceContext(gm, total + 4), lnb.InferenceContext(g0, total + 4)
+        pos = 0
+        for nrows in chunks:
+            lo, ao = oc.forward(toks[pos:pos + nrows], pos)
+            lg, ag = gc.Forward(toks[pos:pos + nrows], pos)
+            l0, a0 = c0.Forward(toks[pos:pos + nrows], pos)
+            assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag, (name, chunks, pos)
+            assert (l0.view(np.uint32) == lg.view(np.uint32)).all() and a0 == ag
+            pos += nrows
+        for layer in range(cfg["n_layers"]):
+            assert (oc.cache(layer, 0)[:total] == gc.CacheK(layer)[:total]).all() and (oc.cache(layer, 1)[:total] == gc.CacheV(layer)[:total]).all()
+        got, _ = gc.decode_greedy(ag, total, 3)
+        ref = []
+        t = ao
+        for i in range(3):
+            _, t = oc.forward([t], total + i, want_logits=False)
+            ref.append(t)
+        assert [int(v) for v in got] == ref
+        oc.close(); gc.close(); c0.close()
+    gm.close(); g0.close(); om.close()
+
+
+def test_prefill_at_the_8b_shape_on_the_streaming_feed_reproduces_the_golden(lnb):
+    """configs[1]'s 128-token prompt through a batch-enabled 8B model (every prefill product on gemm_stream_kernel), then the greedy loop:
+    the oracle's golden continuation; prefill time printed next to the LDS-tiled kernel's"""
+    import time
+    cfg = dict(lnb.LLAMA_8B)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "configs1_tokens.json")))["tokens"]
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1234).finalize()
+    prompt = lnb.synth_tokens(99, 128, cfg["vocab_size"])
+    c = lnb.InferenceContext(gm, 192)
+    times = {}
+    for label in ("LDS-tiled gemm_mfma_kernel", "streaming gemm_stream_kernel"):
+        if label.startswith("streaming"):
+            gm.enable_batch()
+        for rep in range(2):
+            c.reset()
+            t0 = time.perf_counter()
+            _, first = c.Forward(prompt, 0, want_logits=False)
+            times[label] = round(1e3 * (time.perf_counter() - t0), 2)
+        assert first == gold[0], label
+        got, _ = c.decode_greedy(first, 128, 40)
+        assert [first] + [int(t) for t in got] == gold[:41], label
+    print("128-row prefill of the 8B shape, ms:", times)
+    c.close(); gm.close()

@@ -150,7 +150,7 @@ def main(asm_path=None):
         txt = open(asm).read().split("\n")
     funcs, cur = {}, None
     for i, ln in enumerate(txt):
-        m = re.match(r"^(_Z1[478](?:gemv_chain|attn_exact|rowcast|mfma_stream)_kernel\S*):", ln)
+        m = re.match(r"^(_Z1[478](?:gemv_chain|attn_exact|rowcast|mfma_stream|gemm_stream)_kernel\S*):", ln)
         if m:
             cur = []; funcs[m.group(1)] = cur
             continue
@@ -173,7 +173,7 @@ def main(asm_path=None):
         for no, t, bad in v[:6]:
             print("    line %d: %s   <- in-flight v%s" % (no, t, bad))
         # (mfma_stream_kernel's accumulators LIVE in AGPRs -- the matrix cores write them there: accvgpr moves are its epilogue, not a spill)
-        total += len(v) + (0 if "mfma_stream" in name else accv)
+        total += len(v) + (0 if ("mfma_stream" in name or "gemm_stream" in name) else accv)
     spills = [l for l in txt if re.search(r"\.(vgpr|sgpr)_spill_count:\s+[1-9]", l) or re.search(r"\.private_segment_fixed_size:\s+[1-9]", l)]
     print("TOTAL violations:", total, "in", len(funcs), "kernels; spill/scratch metadata lines:", len(spills))
     return 1 if (total or spills or not funcs) else 0
