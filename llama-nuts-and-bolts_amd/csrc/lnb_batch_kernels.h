@@ -272,51 +272,67 @@ __global__ void batch_advance_kernel(const BatchTab* tab) {
 
 // ------------------------------------------------------------------------------------------------
 // gemm_stream_kernel<EPI, NCH, NTW>: the prefill product (S >= 16 rows of ONE sequence) on the matrix-core feed of mfma_stream_kernel.
-// gemm_mfma_kernel (lnb_kernels.hip) stages BOTH operand tiles through the LDS (65-72 % of the f32 matrix rate at S >= 2048, 38 % at
+// gemm_mfma_kernel (lnb_kernels.hip) stages BOTH operand tiles through the LDS (62-66 % of the f32 matrix rate at S >= 2048, 38 % at
 // S = 128: 30 ms for the 128-row prompt); here the weights never touch the LDS -- M16 units HBM -> VGPR -> A operand, one unpack op per
-// matrix instruction and chain, shared by all the batch columns of the wave -- and the activations are staged once per 128-step chunk and
+// matrix instruction and chain, shared by all the batch tiles of the wave -- and the activations are staged once per 128-step chunk and
 // workgroup as f32 rows (pitch 130 floats: the 16 rows x 2 k of a 32-lane read group hit 32 different banks), so a B operand is one
 // 4-byte LDS read, no unpack.  A wave owns NCH chains of one 16-row weight tile x NTW batch tiles of 16 rows (NCH * NTW independent
 // accumulators: the matrix instructions of a k-group issue back to back at the pipe's 32 cycles, the LDS reads and the unpack op ride
-// in between -- the single chain's forwarding cliff, 5.11, does not exist here); csplit waves of a workgroup share a weight tile and split
-// the batch tiles, so that thin matrices (256-384 tiles) still put a wave on every SIMD.  One barrier per chunk (double-buffered tile).
-// grid (persistent workgroups, ceil(S / (16 * NTW * csplit))), block 256, dynamic LDS = 2 * 16 * NTW * csplit * 130 * 4 bytes.
+// in between -- the single chain's forwarding cliff, 5.11, does not exist here); the four waves of a workgroup take four neighbouring
+// weight tiles and share the 16 * NTW activation rows.  One barrier per chunk (double-buffered tile).
+// Staging map: lane l of wave w loads, for every batch tile u, the 16 bytes (row 16u + (l & 15), k-unit 4w + (l >> 4)): a 16-lane write
+// group of ds_write_b64 is then 16 ROWS of one k-unit = bank pairs 2 * row: conflict-free (the row-major map -- 16 k-units of one row per
+// write group -- was 4-way conflicted: tools/gemmstream_bench.hip, staging alone cost 10-12 % of the kernel).
+// NTW <= 4: two workgroups per CU (LDS 2 x 33 KB, <= 256 registers): one's staging / barrier hides under the other's matrix instructions.
+// grid (persistent workgroups over the weight tiles, ceil(S / (16 * NTW))), block 256, dynamic LDS = 2 * 16 * NTW * 130 * 4 bytes.
 // ------------------------------------------------------------------------------------------------
 constexpr int GS_PITCH = 130;
-template <int N, int L> DEVINL void wait_chunk_wide(u32x4 (&b)[L]) {    // 12 or 16 loads per chunk (one or two weight chains + 8 activation units)
-    static_assert(L == 12 || L == 16, "loads per chunk");
-    if constexpr (L == 12) wait_chunk<N, 12>(b);
-    if constexpr (L == 16) asm volatile("s_waitcnt vmcnt(%16) ; RING_RETIRE %0 %1 %2 %3 %4 %5 %6 %7 %8 %9 %10 %11 %12 %13 %14 %15"
-                                        : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]), "+v"(b[8]), "+v"(b[9]),
-                                          "+v"(b[10]), "+v"(b[11]), "+v"(b[12]), "+v"(b[13]), "+v"(b[14]), "+v"(b[15]) : "n"(N) : "memory");
+#ifndef GS_DBG
+#define GS_DBG 0                                             // tools/gemmstream_bench.hip: 1 = stage only the first two chunks, 2 = no barriers, 4 = no LDS operand reads
+#endif
+template <int I, int N, class F> DEVINL void static_for(F&& f) { if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); } }
+template <int N, int L> DEVINL void wait_slot(u32x4 (&b)[L]) {           // any number of loads per slot: one counted wait, then every register of the slot is handed back
+    asm volatile("s_waitcnt vmcnt(%0)" :: "n"(N) : "memory");            // (volatile asm statements keep their order; every use of b[i] hangs off its own retire)
+#pragma unroll
+    for (int i = 0; i < L; i++) asm volatile("; RING_RETIRE %0" : "+v"(b[i]));
 }
 DEVINL void ld_plain(u32x4& d, const void* a) { asm volatile("global_load_dwordx4 %0, %1, off ; RING_LOAD" : "=v"(d) : "v"(a) : "memory"); }
+#ifndef GS_R1
+#define GS_R1 3                                              // ring depth at NTW = 1 / NTW = 2 (one chain)
+#define GS_R2 3
+#endif
+#ifndef GS_OCC1
+#define GS_OCC1 2                                            // waves per SIMD the register budget is set for at NTW = 1 / NTW = 2 (tools/gemmstream_bench.hip sweeps them)
+#define GS_OCC2 2
+#endif
 template <int EPI, int NCH, int NTW>
-__global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p) {
+__global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW == 4 ? 2 : 1) void gemm_stream_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int R = NCH == 2 ? 2 : 3;                      // chunks in flight: per chunk NCH * 4 weight units + 8 activation units per lane (two chains
-                                                             // with three chunks need more than the 256 architectural VGPRs: hipcc then parks ring
-                                                             // registers in AGPRs BEFORE their wait -- tools/isa_audit.py caught it)
-    static_assert(R * (NCH * 4 + 8) <= 60, "vmcnt is a 6-bit counter");
+    constexpr int L = NCH * 4 + NTW;                         // loads per chunk and lane: NCH * 4 weight units + NTW activation units
+    constexpr int R = NCH == 1 ? (NTW == 1 ? GS_R1 : NTW == 2 ? GS_R2 : 3) : 3;   // chunks in flight.  A chunk of one batch tile is 32 matrix instructions = ~1.5k
+                                                             // cycles of a wave: three of them in flight are less than HBM's latency under load
+    static_assert(R * L <= 60, "vmcnt is a 6-bit counter");
+    constexpr int D = NTW == 1 ? 3 : NTW == 2 ? 2 : 1;       // B-operand reads run this many steps (of four k-groups) ahead of their matrix instructions
+    static_assert(D * 2 * NTW <= 15, "lgkmcnt is a 4-bit counter");
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int csplit = p.csplit, tpw = 4 / csplit;           // weight tiles per workgroup and round
-    const int rows_wg = 16 * NTW * csplit;                   // batch rows of this workgroup's tile
+    constexpr int rows_wg = 16 * NTW;                        // batch rows of this workgroup
     const int m0 = blockIdx.y * rows_wg;
     const int nchunks = p.K >> 7, n_tiles = (p.n_rows + 15) >> 4;
-    const int rounds = (n_tiles + (int)gridDim.x * tpw - 1) / ((int)gridDim.x * tpw);
+    const int rounds = (n_tiles + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
     const int T = rounds * nchunks;
     const size_t chain_bytes = (size_t)nchunks * 4096;
     const unsigned aoff = (unsigned)(((lane & 15) * 4 + (lane >> 4)) * 16);
-    const int wt = wave / csplit, wc = wave % csplit;        // this wave's tile slot inside the workgroup, its share of the batch tiles
     float* Bs = (float*)smem;                                // [2][rows_wg][GS_PITCH]
-    const size_t bs_stride = (size_t)rows_wg * GS_PITCH;
-    // x staging: the chunk's rows_wg x 128 bf16 = rows_wg * 16 units of 16 B; thread t takes units t, t + 256, ... (XLr = rows_wg / 16 of them <= 8)
-    const int XLr = rows_wg >> 4;
-    u32x4 buf[R][NCH * 4 + 8];
+    constexpr size_t bs_stride = (size_t)rows_wg * GS_PITCH;
+    const int srow = lane & 15, scol = wave * 4 + (lane >> 4);                     // staging: row inside a batch tile, 16-byte k-unit of the chunk
+    const uint16_t* xrow[NTW];
+#pragma unroll
+    for (int u = 0; u < NTW; u++) { int row = m0 + u * 16 + srow; row = row < p.S ? row : p.S - 1; xrow[u] = p.x + (size_t)row * p.K + scol * 8; }
+    u32x4 buf[R][L];
     int ir = 0, ic = 0, issued = 0;                          // issue cursor: (round, chunk)
-    auto tile_of = [&](int round) { int t = (round * (int)gridDim.x + (int)blockIdx.x) * tpw + wt; return t < n_tiles ? t : n_tiles - 1; };
-    auto issue_next = [&](u32x4 (&dst)[NCH * 4 + 8]) {
+    auto tile_of = [&](int round) { int t = (round * (int)gridDim.x + (int)blockIdx.x) * 4 + wave; return t < n_tiles ? t : n_tiles - 1; };
+    auto issue_next = [&](u32x4 (&dst)[L]) {
         const int tile = tile_of(ir);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
@@ -325,11 +341,7 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p) {
             ld_unit_nt<2>(dst[c * 4 + 2], aoff, wb); ld_unit_nt<3>(dst[c * 4 + 3], aoff, wb);
         }
 #pragma unroll
-        for (int u = 0; u < 8; u++) {                        // (always 8 loads per slot so that the wait count is a constant; the surplus ones re-read unit 0)
-            const int q = u < XLr ? u * 256 + tid : tid;
-            int row = m0 + (q >> 4); row = row < p.S ? row : p.S - 1;
-            ld_plain(dst[NCH * 4 + u], p.x + (size_t)row * p.K + (size_t)ic * 128 + (q & 15) * 8);
-        }
+        for (int u = 0; u < NTW; u++) ld_plain(dst[NCH * 4 + u], xrow[u] + (size_t)ic * 128);
         if (issued + 1 < T) { issued++; if (++ic == nchunks) { ic = 0; ir++; } }
     };
 #pragma unroll
@@ -345,40 +357,61 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p) {
 #pragma unroll
         for (int j = 0; j < R; j++) {
             if (t0 + j < T) {
-                wait_chunk_wide<(R - 1) * (NCH * 4 + 8), NCH * 4 + 8>(buf[j]);
+                wait_slot<(R - 1) * L, L>(buf[j]);
                 float* bw = Bs + (size_t)((t0 + j) & 1) * bs_stride;
+                if (!(GS_DBG & 1) || t0 + j < 2) {
 #pragma unroll
-                for (int u = 0; u < 8; u++) {
-                    if (u < XLr) {                           // widen once per element: bf16 -> f32 is a shift / a mask
-                        const int q = u * 256 + tid;
+                    for (int u = 0; u < NTW; u++) {          // widen once per element: bf16 -> f32 is a shift / a mask
                         const u32x4 v = buf[j][NCH * 4 + u];
-                        float* d = bw + (size_t)(q >> 4) * GS_PITCH + (q & 15) * 8;
+                        float* d = bw + (size_t)(u * 16 + srow) * GS_PITCH + scol * 8;
                         *(float2*)(d) = make_float2(bf_lo(v[0]), bf_hi(v[0])); *(float2*)(d + 2) = make_float2(bf_lo(v[1]), bf_hi(v[1]));
                         *(float2*)(d + 4) = make_float2(bf_lo(v[2]), bf_hi(v[2])); *(float2*)(d + 6) = make_float2(bf_lo(v[3]), bf_hi(v[3]));
                     }
                 }
-                __syncthreads();                             // the chunk's activations are in the LDS (the other buffer is still being read by slower waves)
-                const float* br = bw + (size_t)(wc * NTW * 16 + bcol) * GS_PITCH + bk;
+                if (!(GS_DBG & 2)) __syncthreads();          // the chunk's activations are in the LDS (the other buffer is still being read by slower waves)
+                // B operands: hand-issued ds_read2_b32 (two k-groups of one batch tile each), D steps of four k-groups ahead of the matrix
+                // instructions that consume them (left to hipcc, a read at NTW = 1 / 2 is issued right in front of its use: ~100 cycles of LDS
+                // latency per two matrix instructions, 55 % of the matrix rate at 128 rows); counted lgkmcnt waits, registers handed back
+                // through the same RING markers tools/isa_audit.py checks
+                const unsigned ba = (unsigned)(size_t)(bw + (size_t)bcol * GS_PITCH + bk);       // LDS byte address of this lane's (row, kk) at k-group 0, batch tile 0
+                float bq[D + 1][2 * NTW][2];
+                auto lds_issue = [&](auto ec) __attribute__((always_inline)) {
+                    constexpr int e = decltype(ec)::value;
 #pragma unroll
-                for (int e = 0; e < 8; e++) {
+                    for (int h = 0; h < 2; h++)
+#pragma unroll
+                        for (int t = 0; t < NTW; t++) {
+                            typedef float f32x2 __attribute__((ext_vector_type(2)));
+                            f32x2 v;
+                            asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%3 ; RING_LOAD" : "=v"(v) : "v"(ba + (unsigned)(t * 16 * GS_PITCH * 4)), "n"(16 * e + 8 * h), "n"(16 * e + 8 * h + 4) : "memory");
+                            bq[e % (D + 1)][h * NTW + t][0] = v[0]; bq[e % (D + 1)][h * NTW + t][1] = v[1];
+                        }
+                };
+                static_for<0, D>(lds_issue);
+                static_for<0, 8>([&](auto ec) __attribute__((always_inline)) {
+                    constexpr int e = decltype(ec)::value;
+                    if constexpr (e + D < 8) lds_issue(std::integral_constant<int, e + D>{});
                     float av[NCH][4];
 #pragma unroll
                     for (int m = 0; m < 4; m++)
 #pragma unroll
                         for (int cc = 0; cc < NCH; cc++) av[cc][m] = unit_elem(buf[j][cc * 4 + m], e);
-                    if (e == 7) {                            // every weight register of the slot has been read (the x registers were consumed above): refill
+                    if constexpr (e == 7) {                  // every weight register of the slot has been read (the x registers were consumed above): refill
 #pragma unroll
                         for (int m = 0; m < 4; m++)
 #pragma unroll
                             for (int cc = 0; cc < NCH; cc++) asm volatile("" : "+v"(av[cc][m]));
                         issue_next(buf[j]);
                     }
+                    constexpr int ahead = (e + D < 8 ? D : 7 - e) * 2 * NTW;             // ds_read2 instructions issued after the ones of step e
+                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(ahead) : "memory");
+#pragma unroll
+                    for (int q = 0; q < 2 * NTW; q++) { asm volatile("; RING_RETIRE %0" : "+v"(bq[e % (D + 1)][q][0])); asm volatile("; RING_RETIRE %0" : "+v"(bq[e % (D + 1)][q][1])); }
 #pragma unroll
                     for (int m = 0; m < 4; m++) {            // k-group g = 4e + m: k = 128C + 4g + kk, ascending (operations_lineartransform.go:46-65)
-                        const int g = 4 * e + m;
 #pragma unroll
                         for (int t = 0; t < NTW; t++) {
-                            const float b = br[(size_t)t * 16 * GS_PITCH + 4 * g];
+                            const float b = (GS_DBG & 4) ? __int_as_float(0x3f800000 + lane + m + t) : bq[e % (D + 1)][(m >> 1) * NTW + t][m & 1];
 #pragma unroll
                             for (int cc = 0; cc < NCH; cc++) {
                                 if (e == 0 && m == 0 && c == 0) acc[cc][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][m], b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
@@ -386,13 +419,13 @@ __global__ __launch_bounds__(256) void gemm_stream_kernel(GemmParams p) {
                             }
                         }
                     }
-                }
+                });
                 if (++c == nchunks) {                        // D layout: column lane & 15 of the batch tile, rows (lane >> 4) * 4 + r of the weight tile
-                    const int tile = (round * (int)gridDim.x + (int)blockIdx.x) * tpw + wt;
+                    const int tile = (round * (int)gridDim.x + (int)blockIdx.x) * 4 + wave;
                     if (tile < n_tiles) {
 #pragma unroll
                         for (int t = 0; t < NTW; t++)
-                            gemm_epilogue4<EPI>(p, acc[0][t], acc[NCH - 1][t], m0 + (wc * NTW + t) * 16 + (lane & 15), tile * 16 + (lane >> 4) * 4);
+                            gemm_epilogue4<EPI>(p, acc[0][t], acc[NCH - 1][t], m0 + t * 16 + (lane & 15), tile * 16 + (lane >> 4) * 4);
                     }
                     c = 0; round++;
                 }

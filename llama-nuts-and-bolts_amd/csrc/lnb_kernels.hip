@@ -2286,32 +2286,40 @@ extern "C" hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st) {
     return hipGetLastError();
 }
 
-// prefill product on the streaming matrix-core feed (gemm_stream_kernel): one weight tile per wave and NTW batch tiles; csplit waves of a
-// workgroup share a tile so that thin matrices still occupy every SIMD
+// prefill product on the streaming matrix-core feed (gemm_stream_kernel): one weight tile per wave and NTW batch tiles of 16 rows.
+// Batch tiles per wave (tools/gemmstream_bench.hip over the 8B shapes, profiles/r03_gemmstream_bench.log): 4 -- four matrix instructions per
+// unpack op, two workgroups per CU -- as long as the grid still has two workgroups per CU (1.5 for the gate|up pairs, whose waves carry
+// two chains); fewer for short prompts / thin matrices, down to 1 (one chain per wave, two or three waves per SIMD: 55-60 % of the f32
+// matrix rate at 128 rows, where a 16 x 16 output tile's one k-ordered chain leaves only 2-3 chains per SIMD to interleave).
+static int gemm_stream_ntw(int n_tiles, int ct, int nch, int num_cus) {
+    const long need = nch == 2 ? 3L * num_cus / 2 : 2L * num_cus;
+    int ntw = 4;
+    while (ntw > 1 && (ntw > ct || (long)((n_tiles + 3) / 4) * ((ct + ntw - 1) / ntw) < need)) ntw >>= 1;
+    return ntw;
+}
 template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParams* p, int num_cus, hipStream_t st) {
     if (!p) {
         hipError_t e = hipSuccess;
 #define LNB_GS_PREP(N) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, NCH, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        LNB_GS_PREP(1); LNB_GS_PREP(2); LNB_GS_PREP(4); LNB_GS_PREP(8);
+        LNB_GS_PREP(1); LNB_GS_PREP(2); LNB_GS_PREP(4);
 #undef LNB_GS_PREP
         return e;
     }
     if (!p->w16 || (p->K & 127) || p->S < 1) return hipErrorInvalidValue;
     const int n_tiles = (p->n_rows + 15) / 16;
-    int ct = (p->S + 15) / 16; if (ct > 8) ct = 8;          // batch tiles of 16 rows handled per workgroup pass (up to 128 rows)
-    int csplit = 1;
-    while (csplit < 4 && n_tiles * csplit < 3 * num_cus && ct >= 2 * csplit) csplit *= 2;
-    int ntw = (ct + csplit - 1) / csplit; ntw = ntw <= 1 ? 1 : ntw <= 2 ? 2 : ntw <= 4 ? 4 : 8;
-    GemmParams q = *p; q.csplit = csplit;
-    const int tpw = 4 / csplit, rows_wg = 16 * ntw * csplit;
-    unsigned gx = (unsigned)((n_tiles + tpw - 1) / tpw); if (gx > (unsigned)num_cus) gx = (unsigned)num_cus;
+    const int ct = (p->S + 15) / 16;                         // batch tiles of 16 rows
+    int ntw = gemm_stream_ntw(n_tiles, ct, NCH, num_cus);
+    static const int force = getenv("LNB_GS_NTW") ? atoi(getenv("LNB_GS_NTW")) : 0;    // (tools / experiments)
+    if (force == 1 || force == 2 || force == 4) ntw = force;
+    GemmParams q = *p; q.csplit = 1;
+    const int rows_wg = 16 * ntw;
+    unsigned gx = (unsigned)((n_tiles + 3) / 4); if (gx > (unsigned)num_cus) gx = (unsigned)num_cus;
     const dim3 grid(gx, (unsigned)((p->S + rows_wg - 1) / rows_wg));
     const size_t lds = (size_t)2 * rows_wg * GS_PITCH * 4;
     switch (ntw) {
     case 1: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 1>), grid, dim3(256), lds, st, q); break;
     case 2: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 2>), grid, dim3(256), lds, st, q); break;
-    case 4: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 4>), grid, dim3(256), lds, st, q); break;
-    default: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 8>), grid, dim3(256), lds, st, q); break;
+    default: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 4>), grid, dim3(256), lds, st, q); break;
     }
     return hipGetLastError();
 }

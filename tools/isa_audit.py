@@ -69,6 +69,8 @@ def build_cfg(lines, execz_both=False):
             in_asm = True; continue
         if t.startswith(";;#ASMEND"):
             in_asm = False; continue
+        if in_asm and t.startswith(";") and "RING_" in t:      # a marker-only asm statement (wait_slot's per-register retires)
+            cur.ins.append((no, "s_nop 0 " + t, True)); continue
         if not t or t.startswith(";") or t.startswith("."):
             continue
         cur.ins.append((no, t, in_asm))
