@@ -195,6 +195,9 @@ __global__ __launch_bounds__(256) void mfma_stream_kernel(StreamParams p) {
 constexpr int BN_NH = 6;
 __host__ __device__ inline int bn_kpad(int K) { return ((K + 7) & ~7) + 320; }
 __host__ __device__ inline size_t bn_scratch() { return (rms_scratch_bytes(BN_NH) + 255) & ~(size_t)255; }
+// XT false: the same norm with plain row-major bf16 output [row][K] -- the prefill's rows (rmsnorm_rows_kernel walks the serial sum with
+// one wave per row, 24 us per launch at K = 4096 whatever the row count; this evaluation takes 9).
+template <bool XT>
 __global__ __launch_bounds__((1 + BN_NH) * 64) void batch_rmsnorm_xt_kernel(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NH = BN_NH, NS = 1 + NH, CW = 3;
@@ -231,6 +234,14 @@ __global__ __launch_bounds__((1 + BN_NH) * 64) void batch_rmsnorm_xt_kernel(cons
         x_normalize<NS>(p, xs, kpad, r, 0, lane, xv, nv);
     }
     __syncthreads();                                         // B3: xs holds trunc(trunc(x*r)*w) as f32 (bf16-exact)
+    if constexpr (!XT) {
+        for (int u = threadIdx.x; u < (K >> 3); u += (1 + NH) * 64) {
+            const float* v = xs + 8 * u;
+            *(uint4*)(xt + (size_t)s * K + 8 * u) = make_uint4((uint32_t)bf_trunc(v[0]) | ((uint32_t)bf_trunc(v[1]) << 16), (uint32_t)bf_trunc(v[2]) | ((uint32_t)bf_trunc(v[3]) << 16),
+                                                               (uint32_t)bf_trunc(v[4]) | ((uint32_t)bf_trunc(v[5]) << 16), (uint32_t)bf_trunc(v[6]) | ((uint32_t)bf_trunc(v[7]) << 16));
+        }
+        return;
+    }
     // 16 B units of the B-operand layout: unit (C, m, kk) of sequence s = the eight k = 128C + 16e + 4m + kk, e = 0..7
     for (int u = threadIdx.x; u < (K >> 3); u += (1 + NH) * 64) {
         const int C = u >> 4, m = (u >> 2) & 3, kk = u & 3, kb = 128 * C + 4 * m + kk;

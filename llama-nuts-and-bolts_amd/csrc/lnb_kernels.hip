@@ -2116,6 +2116,12 @@ extern "C" hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st) {
     }
 }
 extern "C" hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps, hipStream_t st) {
+    static const int wide = getenv("LNB_NORM_ROWS_WIDE") ? atoi(getenv("LNB_NORM_ROWS_WIDE")) : 1;
+    const size_t lds_w = bn_scratch() + ((size_t)bn_kpad(K) + 8) * 4;                  // one workgroup of seven waves per row: the exact parallel evaluation of the serial sum
+    if (wide && !(K & 127) && lds_w <= 64 * 1024 && (size_t)bn_kpad(K) <= (size_t)XCh<true>::value * (1 + BN_NH) * 512 && seq_leaf_size(K, BN_NH * 64) <= 256) {
+        hipLaunchKernelGGL(batch_rmsnorm_xt_kernel<false>, dim3((unsigned)S), dim3((1 + BN_NH) * 64), lds_w, st, x, w, eps, out, K);
+        return hipGetLastError();
+    }
     if (((size_t)K + 64) * 4 > 150 * 1024) return hipErrorInvalidValue;
     hipLaunchKernelGGL(rmsnorm_rows_kernel, dim3((unsigned)S), dim3(64), ((size_t)K + 64) * 4, st, x, w, out, S, K, eps);
     return hipGetLastError();
@@ -2255,14 +2261,14 @@ extern "C" hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int 
 }
 extern "C" hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream_t st);
 extern "C" hipError_t lnbk_batch_prepare(void) {             // raise the dynamic-LDS limits once, outside any stream capture
-    hipError_t e = hipFuncSetAttribute((const void*)batch_rmsnorm_xt_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipError_t e = hipFuncSetAttribute((const void*)batch_rmsnorm_xt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int ep = EPI_STORE; ep <= EPI_SILU_MUL && e == hipSuccess; ep++) e = lnbk_gemm_stream(nullptr, ep, 0, nullptr);
     return e;
 }
 extern "C" hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K, int nseq, hipStream_t st) {
     const size_t lds = bn_scratch() + ((size_t)bn_kpad(K) + 8) * 4;
     if ((K & 127) || lds > 160 * 1024 || (size_t)bn_kpad(K) > (size_t)XCh<true>::value * (1 + BN_NH) * 512 || seq_leaf_size(K, BN_NH * 64) > 256) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(batch_rmsnorm_xt_kernel, dim3((unsigned)nseq), dim3((1 + BN_NH) * 64), lds, st, x, norm_w, eps, xt, K);
+    hipLaunchKernelGGL(batch_rmsnorm_xt_kernel<true>, dim3((unsigned)nseq), dim3((1 + BN_NH) * 64), lds, st, x, norm_w, eps, xt, K);
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_batch_embed(const uint16_t* emb, const BatchTab* tab, uint16_t* x, int nseq, int dim, int vocab, int* err, hipStream_t st) {
