@@ -985,7 +985,7 @@ struct lnb_batch {
     hipStream_t stream = nullptr; hipEvent_t ev0 = nullptr, ev1 = nullptr;
     BatchTab* tab = nullptr; BatchKV* kv = nullptr;
     uint16_t *x = nullptr, *h = nullptr, *xt = nullptr, *q = nullptr, *att_xt = nullptr, *ffn_xt = nullptr, *logits = nullptr;
-    int* derr = nullptr; int32_t *d_tokens = nullptr, *d_pos = nullptr; int32_t* h_io = nullptr;   // pinned: [0..15] tokens, [16..31] positions, [32] error word
+    int* derr = nullptr; int32_t *d_tokens = nullptr, *d_pos = nullptr; int32_t* h_io = nullptr;   // pinned: [0..MAX) tokens, [MAX..2 MAX) positions, [2 MAX] error word (MAX = LNB_BATCH_MAX)
     hipGraphExec_t graph = nullptr; int lds_T = 0;
     // pipeline stage (lnb_pipeline_tick_batch): the contiguous token words exchanged between the last and the first stage, the stage step
     // as a captured graph, events towards / from the exchange stream (as lnb_ctx has them for single-sequence ticks)
@@ -1053,7 +1053,7 @@ static int batch_alloc(lnb_batch* b) {
     lnb_model* m = b->m; const int n = b->n;
     HIPCHK(hipStreamCreateWithFlags(&b->stream, hipStreamNonBlocking));
     HIPCHK(hipEventCreate(&b->ev0)); HIPCHK(hipEventCreate(&b->ev1));
-    HIPCHK(hipHostMalloc((void**)&b->h_io, 64 * 4, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&b->h_io, (2 * LNB_BATCH_MAX + 8) * 4, hipHostMallocDefault));
     BatchTab t{}; t.n = n;
     std::vector<BatchKV> kv(m->layers.size());
     for (int s = 0; s < LNB_BATCH_MAX; s++) {
@@ -1065,14 +1065,14 @@ static int batch_alloc(lnb_batch* b) {
     HIPCHK(hipMalloc((void**)&b->kv, kv.size() * sizeof(BatchKV)));
     HIPCHK(hipMemcpyAsync(b->kv, kv.data(), kv.size() * sizeof(BatchKV), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));                 // (the host copies above are stack / vector memory)
-    const size_t N = LNB_BATCH_MAX, dim = m->a.dim;
+    const size_t N = std::max(n, LNB_STREAM_COLS), dim = m->a.dim;
     auto zalloc = [&](uint16_t** p, size_t elems) -> int { HIPCHK(hipMalloc((void**)p, elems * 2)); HIPCHK(hipMemsetAsync(*p, 0, elems * 2, b->stream)); return 0; };
-    // activations in the B-operand layout are [K][16 sequences]: the columns past n stay zero for ever
+    // up to 16 sequences: activations in the B-operand layout [K][16 sequences], the columns past n stay zero for ever; more: plain rows [n][K]
     if (zalloc(&b->x, N * dim) || zalloc(&b->h, N * dim) || zalloc(&b->xt, N * dim) || zalloc(&b->q, N * m->q_dim) || zalloc(&b->att_xt, N * m->q_dim) ||
         zalloc(&b->ffn_xt, N * m->ffn_hidden) || (m->last() && zalloc(&b->logits, N * (size_t)m->a.vocab_size))) return -1;
     HIPCHK(hipMalloc((void**)&b->derr, 16)); HIPCHK(hipMemsetAsync(b->derr, 0, 16, b->stream));
-    HIPCHK(hipMalloc((void**)&b->d_tokens, 64)); HIPCHK(hipMalloc((void**)&b->d_pos, 64));
-    HIPCHK(hipMalloc((void**)&b->ring, 64)); HIPCHK(hipMemsetAsync(b->ring, 0, 64, b->stream));
+    HIPCHK(hipMalloc((void**)&b->d_tokens, LNB_BATCH_MAX * 4)); HIPCHK(hipMalloc((void**)&b->d_pos, LNB_BATCH_MAX * 4));
+    HIPCHK(hipMalloc((void**)&b->ring, LNB_BATCH_MAX * 4)); HIPCHK(hipMemsetAsync(b->ring, 0, LNB_BATCH_MAX * 4, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
@@ -1107,8 +1107,51 @@ static StreamParams stream_of(const lnb_batch* b, const uint16_t* w, const uint1
     return p;
 }
 static bool stream_acc2(const StreamParams& p) { return p.nch == 2 || p.n_chains > 4 * g_num_cus; }   // thin matrices: one tile per wave, every tile on its own SIMD
+// More than 16 sequences: the batch's rows through the prefill's streaming product (gemm_stream_kernel: weights M16 -> A operand, 1 / 2 / 4
+// batch tiles of 16 sequences per wave), plain row-major activations.  Same chains per sequence; EPI_QKV_ROPE and the attention take each
+// row's position and caches from the batch tables.  (xt / att_xt / ffn_xt hold rows here, not the B-operand layout.)
+static GemmParams wide_of(const lnb_batch* b, const uint16_t* w16, const uint16_t* x, int K, int n_rows, int nch) {
+    GemmParams g{}; g.w16 = w16; g.nch = nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = b->n; g.csplit = 1;
+    return g;
+}
+static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {
+    lnb_model* m = b->m; const lnb_model_args& a = m->a; hipStream_t st = b->stream;
+    const int n = b->n, dim = a.dim, F = m->ffn_hidden;
+    if (which == K_HEAD) {
+        HIPCHK(lnbk_rmsnorm_rows(b->x, m->norm, b->xt, n, dim, a.norm_eps, st));
+        GemmParams g = wide_of(b, m->m_output, b->xt, dim, a.vocab_size, 1); g.out = b->logits;
+        HIPCHK(lnbk_gemm_stream(&g, EPI_STORE, g_num_cus, st));
+        return 0;
+    }
+    LayerW& L = m->layers[l - m->layer_begin];
+    switch (which) {
+    case K_QKV: {
+        HIPCHK(lnbk_rmsnorm_rows(b->x, L.attn_norm, b->xt, n, dim, a.norm_eps, st));
+        GemmParams g = wide_of(b, L.m_wqkv, b->xt, dim, L.wqkv.n_rows, 1);
+        g.cis = m->cis; g.q_out = b->q; g.btab = b->tab; g.bkv = b->kv + (l - m->layer_begin); g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
+        HIPCHK(lnbk_gemm_stream(&g, EPI_QKV_ROPE, g_num_cus, st)); return 0; }
+    case K_ATTN: {
+        AttnParams ap{}; ap.q = b->q; ap.out = b->att_xt; ap.out_xt = nullptr; ap.btab = b->tab; ap.bkv = b->kv + (l - m->layer_begin); ap.dbg = nullptr;
+        ap.S = n; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = b->lds_T; ap.lds_T = b->lds_T; ap.host_T = 0;
+        ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));
+        ap.force_zseq = 0; ap.zseq_count = b->ctxs[0]->zseq_count;
+        HIPCHK(lnbk_attn(&ap, st)); return 0; }
+    case K_WO: {
+        GemmParams g = wide_of(b, L.m_wo, b->att_xt, m->q_dim, dim, 1); g.out = b->h; g.res = b->x;
+        HIPCHK(lnbk_gemm_stream(&g, EPI_RESID, g_num_cus, st)); return 0; }
+    case K_W13: {
+        HIPCHK(lnbk_rmsnorm_rows(b->h, L.ffn_norm, b->xt, n, dim, a.norm_eps, st));
+        GemmParams g = wide_of(b, L.m_w13, b->xt, dim, F, 2); g.out = b->ffn_xt; g.silu = m->silu;
+        HIPCHK(lnbk_gemm_stream(&g, EPI_SILU_MUL, g_num_cus, st)); return 0; }
+    case K_W2: {
+        GemmParams g = wide_of(b, L.m_w2, b->ffn_xt, F, dim, 1); g.out = b->x; g.res = b->h;
+        HIPCHK(lnbk_gemm_stream(&g, EPI_RESID, g_num_cus, st)); return 0; }
+    }
+    return fail("bad kernel id");
+}
 // which: K_QKV (attention norm + wq|wk|wv + RoPE + KV append), K_ATTN, K_WO, K_W13 (ffn norm + w1|w3 + SiLU*up), K_W2, K_HEAD (norm + output)
 static int enqueue_batch_kernel(lnb_batch* b, int l, int which) {
+    if (b->n > LNB_STREAM_COLS) return enqueue_batch_kernel_wide(b, l, which);
     lnb_model* m = b->m; const lnb_model_args& a = m->a; hipStream_t st = b->stream;
     const int n = b->n, dim = a.dim, F = m->ffn_hidden;
     if (which == K_HEAD) {
@@ -1188,9 +1231,9 @@ extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32
         HIPCHK(hipGraphInstantiate(&b->graph, g, nullptr, nullptr, 0));
         HIPCHK(hipGraphDestroy(g));
     }
-    memcpy(b->h_io, tokens, (size_t)b->n * 4); memcpy(b->h_io + 16, start_pos, (size_t)b->n * 4);
+    memcpy(b->h_io, tokens, (size_t)b->n * 4); memcpy(b->h_io + LNB_BATCH_MAX, start_pos, (size_t)b->n * 4);
     HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + 16, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + LNB_BATCH_MAX, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(b->derr, 0, 4, st));
     HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, b->ring, st));
     HIPCHK(hipEventRecord(b->ev0, st));
@@ -1201,10 +1244,10 @@ extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32
     HIPCHK(hipEventRecord(b->ev1, st));
     for (int s = 0; s < b->n; s++)
         HIPCHK(hipMemcpyAsync(out_tokens + (size_t)s * n_steps, b->ctxs[s]->dout, (size_t)n_steps * 4, hipMemcpyDeviceToHost, st));
-    HIPCHK(hipMemcpyAsync(b->h_io + 32, b->derr, 4, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipMemcpyAsync(b->h_io + 2 * LNB_BATCH_MAX, b->derr, 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, b->ev0, b->ev1));
-    if (b->h_io[32]) return fail("sequence %d: generated token id is outside the vocabulary", b->h_io[32] - 1);
+    if (b->h_io[2 * LNB_BATCH_MAX]) return fail("sequence %d: generated token id is outside the vocabulary", b->h_io[2 * LNB_BATCH_MAX] - 1);
     return 0;
 }
 // Every sequence's position (and, on the first stage, optionally its next input token) before a run of lnb_pipeline_tick_batch steps: the
@@ -1222,9 +1265,9 @@ extern "C" int lnb_batch_set_state(lnb_batch* b, const int32_t* tokens, const in
     HIPCHK(hipDeviceSynchronize());                          // a setup call: whatever the contexts' streams and the pipe's exchange stream still do
                                                              // (the prefill's token hand-off into the contexts' token words) comes first
     if (tokens) memcpy(b->h_io, tokens, (size_t)b->n * 4);
-    memcpy(b->h_io + 16, start_pos, (size_t)b->n * 4);
+    memcpy(b->h_io + LNB_BATCH_MAX, start_pos, (size_t)b->n * 4);
     if (tokens) HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + 16, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
+    HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + LNB_BATCH_MAX, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
     HIPCHK(lnbk_batch_set_state(b->tab, tokens ? b->d_tokens : nullptr, b->d_pos, b->ring, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
@@ -1237,10 +1280,10 @@ extern "C" int lnb_batch_profile_kernel(lnb_batch* b, int which, int pos, int it
     HIPCHK(hipSetDevice(m->device));
     if (iters <= 0 || which < 0 || which > K_LAYER) return fail("bad arguments");
     if (which == K_HEAD && !m->last()) return fail("this stage does not own output.weight");
-    for (int s = 0; s < b->n; s++) { if (check_call(b->ctxs[s], 1, pos)) return -1; b->h_io[s] = 0; b->h_io[16 + s] = pos; b->ctxs[s]->dev_pos = -1; }
+    for (int s = 0; s < b->n; s++) { if (check_call(b->ctxs[s], 1, pos)) return -1; b->h_io[s] = 0; b->h_io[LNB_BATCH_MAX + s] = pos; b->ctxs[s]->dev_pos = -1; }
     hipStream_t st = b->stream;
     HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + 16, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + LNB_BATCH_MAX, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, b->ring, st));
     const int nl = m->layer_end - m->layer_begin;
     auto run = [&](int i) -> int {

@@ -105,6 +105,9 @@ struct GemmParams {
     const float* cis; uint16_t* q_out; uint16_t* cache_k; uint16_t* cache_v; int seq_len, q_dim, kv_dim, head_dim;   // EPI_QKV_ROPE
     // gemm_stream_kernel (lnb_batch_kernels.h): the same product with the weights streamed from their M16 copy straight into the A operand
     const uint16_t* w16;        // M16 copy of w (lnb_model_enable_batch), or nullptr
+    // rows = the one new token of each SEQUENCE of a batch (lnb_batch_*, more than 16 sequences): EPI_QKV_ROPE takes row m's position, caches
+    // and cache length from the batch tables instead of st / cache_k / cache_v / seq_len
+    const struct BatchTab* btab; const struct BatchKV* bkv;
     int csplit;                 // waves of a workgroup that share one 16-row weight tile and split the batch rows among them (1, 2 or 4)
 };
 
@@ -141,7 +144,8 @@ struct AttnParams {
 // tiles: a wave-wide 16 B-per-lane load of unit (C, m) is 1 KiB contiguous and matrix-core lane (i, kk) finds in it, as elements
 // e = 0..7, its A operands of the k-groups g = 4e + m of the chunk (k = 128C + 4g + kk).  Activations of the batch ("xt"):
 //   [C][m][kk][s = sequence 0..15][e]   -- lane (s, kk) loads its B operands of the same k-groups with the same instruction shape.
-constexpr int LNB_BATCH_MAX = 16;
+constexpr int LNB_BATCH_MAX = 128;          // sequences per batch
+constexpr int LNB_STREAM_COLS = 16;         // ... of which mfma_stream_kernel carries up to 16 as the columns of ONE matrix instruction; larger batches are rows of gemm_stream_kernel
 LNB_HD size_t m16_index(int n, int k, int c, int K, int NCH) {
     const int t = n >> 4, i = n & 15, C = k >> 7, e = (k >> 4) & 7, m = (k >> 2) & 3, kk = k & 3;
     return ((((((size_t)t * NCH + c) * (size_t)(K >> 7) + C) * 4 + m) * 16 + i) * 4 + kk) * 8 + e;

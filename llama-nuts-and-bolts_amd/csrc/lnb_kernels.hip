@@ -923,7 +923,11 @@ template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& 
             const uint16_t gs = bf_trunc(p.silu[bf_trunc(g[r])]);
             p.out[o] = bf_trunc(bf_wide(gs) * bf_wide(bf_trunc(u[r])));
         } else if (EPI == EPI_QKV_ROPE) {                                                                         // llamatransformer.go:297-403
-            const int pos = p.st->pos + m;
+            // rows of one sequence: consecutive positions of its cache; rows of a batch (btab): row m is sequence m's one new token
+            const int pos = p.btab ? p.btab->st[m]->pos : p.st->pos + m;
+            const int seq_len = p.btab ? p.btab->seq_len[m] : p.seq_len;
+            uint16_t* const cache_k = p.btab ? p.bkv->ck[m] : p.cache_k;
+            uint16_t* const cache_v = p.btab ? p.bkv->cv[m] : p.cache_v;
             const uint16_t mine = bf_trunc(g[r]), other = bf_trunc(g[r ^ 1]);                                      // RoPE partner 2i <-> 2i+1: same lane
             if (n < p.q_dim + p.kv_dim) {
                 const int d = n % p.head_dim, i = d >> 1;
@@ -935,9 +939,9 @@ template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& 
                 if (n < p.q_dim) p.q_out[(size_t)m * p.q_dim + n] = r16;
                 else {
                     const int kc = n - p.q_dim, kh = kc / p.head_dim;
-                    p.cache_k[(((size_t)kh * (p.head_dim >> 3) + (d >> 3)) * p.seq_len + pos) * 8 + (d & 7)] = r16;
+                    cache_k[(((size_t)kh * (p.head_dim >> 3) + (d >> 3)) * seq_len + pos) * 8 + (d & 7)] = r16;
                 }
-            } else p.cache_v[(size_t)pos * p.kv_dim + (n - p.q_dim - p.kv_dim)] = mine;
+            } else cache_v[(size_t)pos * p.kv_dim + (n - p.q_dim - p.kv_dim)] = mine;
         }
     }
 }
@@ -1646,7 +1650,7 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     if (wave < 2) {
         const int d = wave * 64 + lane;
         if (d < HD) {
-            if (bt) p.out_xt[xt_index(i, h * HD + d)] = bf_trunc(acc);         // batch: straight into the B-operand layout of the wo product
+            if (bt && p.out_xt) p.out_xt[xt_index(i, h * HD + d)] = bf_trunc(acc);   // batch of up to 16: straight into the B-operand layout of the wo product
             else p.out[((size_t)i * p.H + h) * HD + d] = bf_trunc(acc);        // [S, H*hd] (:508-514)
         }
     }
@@ -2243,7 +2247,7 @@ extern "C" hipError_t lnbk_m16_from_tiled(const uint16_t* src, uint16_t* dst, in
 }
 // acc2: two tile-chains per wave (fat matrices and the gate|up pairs); else one (thin matrices: every tile on its own SIMD)
 extern "C" hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int num_cus, hipStream_t st) {
-    if ((p->K & 127) || p->nseq < 1 || p->nseq > LNB_BATCH_MAX || p->n_chains < 1) return hipErrorInvalidValue;
+    if ((p->K & 127) || p->nseq < 1 || p->nseq > LNB_STREAM_COLS || p->n_chains < 1) return hipErrorInvalidValue;
     StreamParams q = *p;
     const int ACC = acc2 ? 2 : 1;
     q.n_jobs = (p->n_chains + ACC - 1) / ACC;
@@ -2280,15 +2284,15 @@ extern "C" hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const Bat
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring, hipStream_t st) {
-    hipLaunchKernelGGL(batch_set_state_kernel, dim3(1), dim3(64), 0, st, tab, tokens, pos, ring);
+    hipLaunchKernelGGL(batch_set_state_kernel, dim3(1), dim3(LNB_BATCH_MAX), 0, st, tab, tokens, pos, ring);
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_batch_scatter_ring(const BatchTab* tab, const int32_t* ring, hipStream_t st) {
-    hipLaunchKernelGGL(batch_scatter_ring_kernel, dim3(1), dim3(64), 0, st, tab, ring);
+    hipLaunchKernelGGL(batch_scatter_ring_kernel, dim3(1), dim3(LNB_BATCH_MAX), 0, st, tab, ring);
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st) {
-    hipLaunchKernelGGL(batch_advance_kernel, dim3(1), dim3(64), 0, st, tab);
+    hipLaunchKernelGGL(batch_advance_kernel, dim3(1), dim3(LNB_BATCH_MAX), 0, st, tab);
     return hipGetLastError();
 }
 

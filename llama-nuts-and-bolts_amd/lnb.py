@@ -398,7 +398,7 @@ class InferenceContext:
 
 
 class Batch:
-    """1..16 InferenceContexts of one transformer decoded together: one pass over the weights per step for all of them, every sequence
+    """1..128 InferenceContexts of one transformer decoded together: one pass over the weights per step for all of them, every sequence
     bit-identical to its single-sequence run (lnb_batch_*).  The contexts keep their own caches and positions."""
 
     def __init__(self, contexts):

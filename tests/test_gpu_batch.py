@@ -37,7 +37,7 @@ def test_every_sequence_of_a_batch_equals_its_own_oracle_run(lnb, name):
     gm = lnb.LlamaTransformer(**cfg).fill_synthetic(606).finalize().enable_batch()
     assert gm.batch_bytes() > 0
     steps = 11
-    for n in (1, 2, 5, 16):
+    for n in (1, 2, 5, 16, 17, 40):                                                # up to 16: columns of one matrix instruction; more: rows of the streaming product
         plens = [4 + 3 * s + (17 if s % 4 == 1 else 0) for s in range(n)]           # different prompt lengths: different positions per column
         prompts = [orc.synth_tokens(100 * n + s, plens[s], cfg["vocab_size"]) for s in range(n)]
         refs, ocs = [], []
@@ -103,6 +103,37 @@ def test_batch_decode_at_the_8b_shape_equals_single_sequence_runs_and_the_golden
     gm.close()
 
 
+def test_wide_batch_decode_at_the_8b_shape_equals_single_sequence_runs_and_the_golden(lnb):
+    """64 prompts in flight at the Llama-3.1-8B shape (rows of gemm_stream_kernel, 4 tiles of 16 sequences per wave where the grid allows):
+    sequences 1, 30, 63 equal their own runs through lnb_decode_greedy, sequence 0 the configs[1] golden; different prompt lengths"""
+    cfg = dict(lnb.LLAMA_8B)
+    steps, n = 12, 64
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1234).finalize().enable_batch()
+    plens = [128 if s == 0 else 24 + (s * 7) % 50 for s in range(n)]
+    prompts = [lnb.synth_tokens(99 + s, plens[s], cfg["vocab_size"]) for s in range(n)]
+    ctxs = [lnb.InferenceContext(gm, plens[s] + steps + 8) for s in range(n)]
+    firsts = [ctxs[s].Forward(prompts[s], 0, want_logits=False)[1] for s in range(n)]
+    b = lnb.Batch(ctxs)
+    got, ms = b.decode(firsts, plens, steps)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "configs1_tokens.json")))["tokens"]
+    assert [firsts[0]] + [int(t) for t in got[0]] == gold[:steps + 1]
+    for s in (1, 30, 63):
+        solo = lnb.InferenceContext(gm, plens[s] + steps + 8)
+        _, f = solo.Forward(prompts[s], 0, want_logits=False)
+        assert f == firsts[s]
+        ref, _ = solo.decode_greedy(f, plens[s], steps)
+        assert [int(t) for t in got[s]] == [int(t) for t in ref], s
+        T = plens[s] + steps
+        for layer in (0, 31):
+            assert (solo.CacheK(layer)[:T] == ctxs[s].CacheK(layer)[:T]).all() and (solo.CacheV(layer)[:T] == ctxs[s].CacheV(layer)[:T]).all()
+        solo.close()
+    print("8B shape, 64 sequences: %.3f ms per step = %.0f tokens/s aggregate" % (ms / steps, 1e3 * n * steps / ms))
+    b.close()
+    for c in ctxs:
+        c.close()
+    gm.close()
+
+
 def test_batch_argument_checks(lnb):
     cfg = dict(orc.TINY)
     gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1).finalize()
@@ -112,8 +143,8 @@ def test_batch_argument_checks(lnb):
     gm.enable_batch()
     with pytest.raises(lnb.LnbError, match="twice"):
         lnb.Batch([c0, c0])
-    with pytest.raises(lnb.LnbError, match="1..16"):
-        lnb.Batch([lnb.InferenceContext(gm, 16) for _ in range(17)])
+    with pytest.raises(lnb.LnbError, match="1..128"):
+        lnb.Batch([lnb.InferenceContext(gm, 16) for _ in range(129)])
     with pytest.raises(lnb.LnbError, match="enable_batch"):
         gm.fill_synthetic(2)                                 # the second copy would go stale
     c1.set_mode("fast")

@@ -330,7 +330,7 @@ def test_batched_schedule_posts_matching_sends_and_receives(world, n_decode):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("cuts,n", [((0, 6), 3), ((0, 3, 6), 3), ((0, 3, 6), 16), ((0, 3, 6, 9), 2)])
+@pytest.mark.parametrize("cuts,n", [((0, 6), 3), ((0, 3, 6), 3), ((0, 3, 6), 16), ((0, 3, 6, 9), 2), ((0, 3, 6), 20)])     # 20: the batches are rows of the streaming product
 def test_batched_pipeline_ticks_through_the_in_process_transport(lnb, cuts, n):
     """Pipeline stages of whole blocks on one GPU, BATCHES of n sequences as the unit that moves through them (lnb_pipeline_tick_batch):
     prompts prefilled with single-sequence ticks, then every decode step of a group is one pass over each stage's weights for all its
