@@ -299,7 +299,8 @@ __global__ void batch_advance_kernel(const BatchTab* tab) {
 // ------------------------------------------------------------------------------------------------
 constexpr int GS_PITCH = 130;
 #ifndef GS_DBG
-#define GS_DBG 0                                             // tools/gemmstream_bench.hip: 1 = stage only the first two chunks, 2 = no barriers, 4 = no LDS operand reads
+#define GS_DBG 0                                             // tools/gemmstream_bench.hip: 1 = stage only the first two chunks, 2 = no barriers, 4 = LDS operands unused,
+                                                             // 8 = activation loads always hit one line, 16 = weight loads always re-read chunk 0, 32 = no unpack, 64 = no LDS reads issued
 #endif
 template <int I, int N, class F> DEVINL void static_for(F&& f) { if constexpr (I < N) { f(std::integral_constant<int, I>{}); static_for<I + 1, N>(f); } }
 template <int N, int L> DEVINL void wait_slot(u32x4 (&b)[L]) {           // any number of loads per slot: one counted wait, then every register of the slot is handed back
@@ -347,12 +348,12 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
         const int tile = tile_of(ir);
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
-            const char* wb = (const char*)p.w16 + (size_t)(tile * NCH + c) * chain_bytes + (size_t)ic * 4096;
+            const char* wb = (const char*)p.w16 + (size_t)(tile * NCH + c) * chain_bytes + ((GS_DBG & 16) ? 0 : (size_t)ic * 4096);
             ld_unit_nt<0>(dst[c * 4 + 0], aoff, wb); ld_unit_nt<1>(dst[c * 4 + 1], aoff, wb);
             ld_unit_nt<2>(dst[c * 4 + 2], aoff, wb); ld_unit_nt<3>(dst[c * 4 + 3], aoff, wb);
         }
 #pragma unroll
-        for (int u = 0; u < NTW; u++) ld_plain(dst[NCH * 4 + u], xrow[u] + (size_t)ic * 128);
+        for (int u = 0; u < NTW; u++) ld_plain(dst[NCH * 4 + u], (GS_DBG & 8) ? p.x : xrow[u] + (size_t)ic * 128);
         if (issued + 1 < T) { issued++; if (++ic == nchunks) { ic = 0; ir++; } }
     };
 #pragma unroll
@@ -398,15 +399,15 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                             bq[e % (D + 1)][h * NTW + t][0] = v[0]; bq[e % (D + 1)][h * NTW + t][1] = v[1];
                         }
                 };
-                static_for<0, D>(lds_issue);
+                if constexpr (!(GS_DBG & 64)) static_for<0, D>(lds_issue);
                 static_for<0, 8>([&](auto ec) __attribute__((always_inline)) {
                     constexpr int e = decltype(ec)::value;
-                    if constexpr (e + D < 8) lds_issue(std::integral_constant<int, e + D>{});
+                    if constexpr (e + D < 8 && !(GS_DBG & 64)) lds_issue(std::integral_constant<int, e + D>{});
                     float av[NCH][4];
 #pragma unroll
                     for (int m = 0; m < 4; m++)
 #pragma unroll
-                        for (int cc = 0; cc < NCH; cc++) av[cc][m] = unit_elem(buf[j][cc * 4 + m], e);
+                        for (int cc = 0; cc < NCH; cc++) av[cc][m] = (GS_DBG & 32) ? __uint_as_float(buf[j][cc * 4 + m][e >> 1]) : unit_elem(buf[j][cc * 4 + m], e);
                     if constexpr (e == 7) {                  // every weight register of the slot has been read (the x registers were consumed above): refill
 #pragma unroll
                         for (int m = 0; m < 4; m++)
@@ -415,9 +416,9 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                         issue_next(buf[j]);
                     }
                     constexpr int ahead = (e + D < 8 ? D : 7 - e) * 2 * NTW;             // ds_read2 instructions issued after the ones of step e
-                    asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(ahead) : "memory");
+                    if constexpr (!(GS_DBG & 64)) asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(ahead) : "memory");
 #pragma unroll
-                    for (int q = 0; q < 2 * NTW; q++) { asm volatile("; RING_RETIRE %0" : "+v"(bq[e % (D + 1)][q][0])); asm volatile("; RING_RETIRE %0" : "+v"(bq[e % (D + 1)][q][1])); }
+                    for (int q = 0; q < ((GS_DBG & 64) ? 0 : 2 * NTW); q++) { asm volatile("; RING_RETIRE %0" : "+v"(bq[e % (D + 1)][q][0])); asm volatile("; RING_RETIRE %0" : "+v"(bq[e % (D + 1)][q][1])); }
 #pragma unroll
                     for (int m = 0; m < 4; m++) {            // k-group g = 4e + m: k = 128C + 4g + kk, ascending (operations_lineartransform.go:46-65)
 #pragma unroll
