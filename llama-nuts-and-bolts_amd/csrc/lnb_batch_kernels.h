@@ -28,17 +28,17 @@ __global__ void m16_from_tiled_kernel(const uint16_t* src, uint16_t* dst, int ro
 // the immediate offset selects the unit m of the chunk: it must be a literal in the asm text
 template <int M> DEVINL void ld_unit_nt(u32x4& d, unsigned voff, const char* sb) {
     static_assert(M >= 0 && M < 4, "unit");
-    if constexpr (M == 0) asm volatile("global_load_dwordx4 %0, %1, %2 nt ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
-    if constexpr (M == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
-    if constexpr (M == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 nt ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
-    if constexpr (M == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072 nt ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 0) asm volatile("global_load_dwordx4 %0, %1, %2 nt ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 nt ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 nt ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072 nt ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
 }
 template <int M> DEVINL void ld_unit(u32x4& d, unsigned voff, const char* sb) {       // activations: every CU reads them, keep them cached
     static_assert(M >= 0 && M < 4, "unit");
-    if constexpr (M == 0) asm volatile("global_load_dwordx4 %0, %1, %2 ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
-    if constexpr (M == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
-    if constexpr (M == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
-    if constexpr (M == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072 ; RING_LOAD" : "=v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 0) asm volatile("global_load_dwordx4 %0, %1, %2 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:1024 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:2048 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:3072 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
 }
 template <int N, int L> DEVINL void wait_chunk(u32x4 (&b)[L]) {
     static_assert(L == 8 || L == 12, "loads per chunk");
@@ -308,7 +308,7 @@ template <int N, int L> DEVINL void wait_slot(u32x4 (&b)[L]) {           // any 
 #pragma unroll
     for (int i = 0; i < L; i++) asm volatile("; RING_RETIRE %0" : "+v"(b[i]));
 }
-DEVINL void ld_plain(u32x4& d, const void* a) { asm volatile("global_load_dwordx4 %0, %1, off ; RING_LOAD" : "=v"(d) : "v"(a) : "memory"); }
+DEVINL void ld_plain(u32x4& d, const void* a) { asm volatile("global_load_dwordx4 %0, %1, off ; RING_LOAD" : "=&v"(d) : "v"(a) : "memory"); }
 #ifndef GS_R1
 #define GS_R1 3                                              // ring depth at NTW = 1 / NTW = 2 (one chain)
 #define GS_R2 3

@@ -355,7 +355,7 @@ DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, i
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // asm loads are invisible to hipcc's s_waitcnt bookkeeping: the ring below is waited for by hand (wait_ring)
 // saddr form: wave-uniform 64-bit base in SGPRs + per-lane 32-bit byte offset -> no per-load VALU address arithmetic
-DEVINL void ld_nt_asm(u32x4& dst, unsigned voff, const char* sbase) { asm volatile("global_load_dwordx4 %0, %1, %2 nt ; RING_LOAD" : "=v"(dst) : "v"(voff), "s"(sbase) : "memory"); }
+DEVINL void ld_nt_asm(u32x4& dst, unsigned voff, const char* sbase) { asm volatile("global_load_dwordx4 %0, %1, %2 nt ; RING_LOAD" : "=&v"(dst) : "v"(voff), "s"(sbase) : "memory"); }
 // the "; RING_RETIRE ..." comment names the registers this wait retires: tools/isa_audit.py checks on the compiled
 // code that hipcc touches no ring register between its asm load and the wait that retires it
 template <int N, int NP> DEVINL void wait_ring(u32x4 (&b)[NP]) {
@@ -1403,7 +1403,7 @@ DEVINL void attn_load_v(u32x4 (&v)[ATT_VU], const uint16_t* vbase, uint32_t row_
         int j = c * ATT_JC + (ATT_NPROD * u + pwv) * 4 + (lane >> 4);
         j = j < T ? j : T - 1;
         const char* a = (const char*)vbase + ((size_t)(uint32_t)j * row_bytes + dq);
-        asm volatile("global_load_dwordx4 %0, %1, off ; RING_LOAD" : "=v"(v[u]) : "v"(a) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off ; RING_LOAD" : "=&v"(v[u]) : "v"(a) : "memory");
     }
 }
 template <int N> DEVINL void attn_retire_v(u32x4 (&v)[ATT_VU]) {      // v's loads are done once at most N younger ones are outstanding
