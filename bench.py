@@ -362,7 +362,7 @@ def main():
     ap.add_argument("--profile-iters", type=int, default=64)
     ap.add_argument("--concurrent", type=int, default=8, help="also time this many independent prompts in flight on the one GPU (0/1 = skip)")
     ap.add_argument("--batch-sizes", type=lambda v: [int(x) for x in v.split(",") if x], default=[2, 4, 8, 16, 32, 64, 128],
-                    help="also time BATCHED exact decode of this many prompts (comma list, each 1..16; empty = skip)")
+                    help="also time BATCHED exact decode of this many prompts (comma list, each 1..128; empty = skip)")
     ap.add_argument("--no-traffic-probe", action="store_true", help="do not run the rocprofv3 FETCH_SIZE pass of the dominant kernel")
     ap.add_argument("--traffic-child", type=int, default=-1, help=argparse.SUPPRESS)      # internal: kernel class to loop under rocprofv3
     ap.add_argument("--traffic-pos", type=int, default=0, help=argparse.SUPPRESS)

@@ -824,10 +824,13 @@ extern "C" int lnb_forward(lnb_ctx* c, const int32_t* tokens, int seq, int start
 // one decode step = embed(token on device) -> layers -> head -> argmax that feeds the next step
 static int enqueue_decode_step(lnb_ctx* c) {
     lnb_model* m = c->m;
-    HIPCHK(lnbk_embed(m->tok_embd, c->dtok, c->x, 1, m->a.dim, m->a.vocab_size, c->derr, c->stream));
+    // LNB_MEASURE_SKIP_TOKEN_KERNELS=1 (timing only, the tokens are garbage): the step without its embedding gather and argmax launches =
+    // the most that fusing them into the neighbouring products could return
+    const bool skip = env_int("LNB_MEASURE_SKIP_TOKEN_KERNELS", 0) != 0;
+    if (!skip) HIPCHK(lnbk_embed(m->tok_embd, c->dtok, c->x, 1, m->a.dim, m->a.vocab_size, c->derr, c->stream));
     if (enqueue_layers(c, 1, false)) return -1;
     if (enqueue_head(c, 0, 1)) return -1;
-    HIPCHK(lnbk_argmax(c->logits, m->a.vocab_size, c->dtok, c->st, c->dout, c->dout_cap, 1, c->stream));
+    if (!skip) HIPCHK(lnbk_argmax(c->logits, m->a.vocab_size, c->dtok, c->st, c->dout, c->dout_cap, 1, c->stream));
     return 0;
 }
 
