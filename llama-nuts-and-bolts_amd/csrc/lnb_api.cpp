@@ -1114,7 +1114,7 @@ static bool stream_acc2(const StreamParams& p) { return p.nch == 2 || p.n_chains
 // batch tiles of 16 sequences per wave), plain row-major activations.  Same chains per sequence; EPI_QKV_ROPE and the attention take each
 // row's position and caches from the batch tables.  (xt / att_xt / ffn_xt hold rows here, not the B-operand layout.)
 static GemmParams wide_of(const lnb_batch* b, const uint16_t* w16, const uint16_t* x, int K, int n_rows, int nch) {
-    GemmParams g{}; g.w16 = w16; g.nch = nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = b->n; g.csplit = 1;
+    GemmParams g{}; g.w16 = w16; g.nch = nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = b->n;
     return g;
 }
 static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {

@@ -108,7 +108,7 @@ struct GemmParams {
     // rows = the one new token of each SEQUENCE of a batch (lnb_batch_*, more than 16 sequences): EPI_QKV_ROPE takes row m's position, caches
     // and cache length from the batch tables instead of st / cache_k / cache_v / seq_len
     const struct BatchTab* btab; const struct BatchKV* bkv;
-    int csplit;                 // waves of a workgroup that share one 16-row weight tile and split the batch rows among them (1, 2 or 4)
+    int rows_fastest;           // dispatch order of gemm_stream_kernel's workgroups: 1 = row groups fastest (set by the launcher for many row groups), 0 = weight-tile groups fastest
 };
 
 struct AttnParams {

@@ -2321,10 +2321,17 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
     int ntw = gemm_stream_ntw(n_tiles, ct, NCH, num_cus);
     static const int force = getenv("LNB_GS_NTW") ? atoi(getenv("LNB_GS_NTW")) : 0;    // (tools / experiments)
     if (force == 1 || force == 2 || force == 4) ntw = force;
-    GemmParams q = *p; q.csplit = 1;
+    GemmParams q = *p;
     const int rows_wg = 16 * ntw;
     unsigned gx = (unsigned)((n_tiles + 3) / 4); if (gx > (unsigned)num_cus) gx = (unsigned)num_cus;
     const dim3 grid(gx, (unsigned)((p->S + rows_wg - 1) / rows_wg));
+    // Dispatch order (workgroup id % 8 = XCD, each with its own L2).  Weight-tile groups fastest: an XCD owns 1/8 of the tile groups for every
+    // row group -- right while all row groups are in flight together (<= 8 of them: short prompts, batches), each weight byte is then fetched
+    // once; with many row groups the same tile group comes back once per row group (4096 rows: 15.6 GB of fabric reads per gate|up launch
+    // for 235 MB of weights, rocprofv3 FETCH_SIZE).  Row groups fastest: the workgroups in flight cover ~8 tile groups x all row groups, a
+    // weight tile is fetched once per XCD and shared through its L2 (4.8 GB; 1-4 % faster at 4096 rows, 2-3 % slower at 512).
+    static const int order = getenv("LNB_GS_ORDER") ? atoi(getenv("LNB_GS_ORDER")) : -1;
+    q.rows_fastest = order >= 0 ? order : (grid.y > 8 ? 1 : 0);
     const size_t lds = (size_t)2 * rows_wg * GS_PITCH * 4;
     switch (ntw) {
     case 1: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 1>), grid, dim3(256), lds, st, q); break;
