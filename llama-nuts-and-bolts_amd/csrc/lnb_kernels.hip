@@ -1500,7 +1500,10 @@ DEVINL float cert_p(double e, const CertZ& c, int& bad) {
     }
     return pj;
 }
-template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(AttnParams p) {
+// DENSE = the batched decode's heads x sequences grids (thousands of workgroups): registers for TWO workgroups per CU (4 waves per SIMD, 128
+// VGPRs) instead of one -- the K rows of the next 512 positions are then NOT kept in flight during a pass's score chains (the ping-pong
+// buffer is 64 of the 178 VGPRs of the single stream's form, which launches 32 workgroups on 256 CUs and wants every register)
+template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE ? 4 : 2) void attn_exact_kernel(AttnParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NK = HD / 8;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -1536,6 +1539,13 @@ template <int HD> __global__ __launch_bounds__(ATT_NT) void attn_exact_kernel(At
     ATT_STAMP(1);
 
     // scores: ATT_NT positions per pass, the next pass's rows in flight during this pass's chains (registers ping-pong)
+    if constexpr (DENSE) {
+        for (int j0 = 0; j0 < T; j0 += ATT_NT) {
+            const int j = j0 + tid;
+            if (j0 > 0) attn_load_k<NK>(ka, kbase, seq_len, j < T ? j : T - 1);
+            attn_score<NK>(ka, qf, j, T, S, i, p.divisor, e);
+        }
+    } else
     for (int j0 = 0; j0 < T; j0 += 2 * ATT_NT) {
         const int j = j0 + tid;
         const bool more = j0 + ATT_NT < T, more2 = j0 + 2 * ATT_NT < T;       // block-uniform
@@ -2163,6 +2173,7 @@ extern "C" hipError_t lnbk_init(void) {
     }
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
@@ -2187,6 +2198,7 @@ static hipError_t launch_attn_long(const AttnParams* p, hipStream_t st) {
 extern "C" size_t lnbk_attn_long_lds(int seq_len) { return alp_lds_bytes(seq_len); }
 extern "C" size_t lnbk_attn_short_lds(int seq_len, int hd);
 
+static bool attn_batch_dense() { static const int v = getenv("LNB_ATTN_BATCH_DENSE") ? atoi(getenv("LNB_ATTN_BATCH_DENSE")) : 1; return v != 0; }
 extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     if (p->longctx && p->S == 1) return launch_attn_long(p, st);
     if (p->mfma && p->S >= 16 && (p->hd == 128 || p->hd == 64)) {       // prefill: 16 query rows per wave on the matrix cores
@@ -2198,7 +2210,10 @@ extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     if (lds > 160 * 1024 || p->lds_T <= 0 || p->lds_T > p->seq_len) return hipErrorInvalidValue;
     if (p->host_T > p->lds_T) return hipErrorInvalidValue;      // e[] / pw[] are sized for lds_T positions: never launch past them (lnb_api.cpp check_call refuses first)
     switch (p->hd) {
-    case 128: hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
+    case 128:
+        if (p->btab && (long)p->H * p->S > 256 && attn_batch_dense())   // more workgroups than CUs hipLaunchKernelGGL((attn_exact_kernel<128, true>), dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p);
+        else hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p);
+        break;
     case 64: hipLaunchKernelGGL(attn_exact_kernel<64>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
     case 32: hipLaunchKernelGGL(attn_exact_kernel<32>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
     default: return hipErrorInvalidValue;
