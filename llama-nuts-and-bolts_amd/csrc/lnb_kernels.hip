@@ -2211,7 +2211,8 @@ extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     if (p->host_T > p->lds_T) return hipErrorInvalidValue;      // e[] / pw[] are sized for lds_T positions: never launch past them (lnb_api.cpp check_call refuses first)
     switch (p->hd) {
     case 128:
-        if (p->btab && (long)p->H * p->S > 256 && attn_batch_dense())   // more workgroups than CUs hipLaunchKernelGGL((attn_exact_kernel<128, true>), dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p);
+        if (p->btab && (long)p->H * p->S > 256 && attn_batch_dense())   // more workgroups than CUs
+            hipLaunchKernelGGL((attn_exact_kernel<128, true>), dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p);
         else hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p);
         break;
     case 64: hipLaunchKernelGGL(attn_exact_kernel<64>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
