@@ -177,3 +177,18 @@ struct StreamParams {              // mfma_stream_kernel: Y[s][n] = trunc(sum_k 
     const float* cis; uint16_t* q_out; const BatchTab* tab; const BatchKV* kv; int q_dim, kv_dim, head_dim;   // EPI_QKV_ROPE
     long long* dbg;
 };
+
+// ---- launch plan of gemm_stream_kernel (host logic; lnb_kernels.hip: launch_gemm_stream) ------------------------------------------------
+// Batch tiles of 16 rows per wave (tools/gemmstream_bench.hip over the 8B shapes, profiles/r03_gemmstream_bench.log): 4 -- four matrix
+// instructions per unpack op, two workgroups per CU -- as long as the grid still has two workgroups per CU (1.5 for the gate|up pairs, whose
+// waves carry two chains); fewer for short prompts / thin matrices, down to 1 (one chain per wave, two or three waves per SIMD: 55-60 % of
+// the f32 matrix rate at 128 rows, where a 16 x 16 output tile's one k-ordered chain leaves only 2-3 chains per SIMD to interleave).
+// n_tiles = ceil(output rows / 16), ct = ceil(batch rows / 16).
+LNB_HD int lnb_gemm_stream_ntw(int n_tiles, int ct, int nch, int num_cus) {
+    const long need = nch == 2 ? 3L * num_cus / 2 : 2L * num_cus;
+    int ntw = 4;
+    while (ntw > 1 && (ntw > ct || (long)((n_tiles + 3) / 4) * ((ct + ntw - 1) / ntw) < need)) ntw >>= 1;
+    return ntw;
+}
+// Dispatch order: row groups fastest once there are more than 8 of them (traffic)
+LNB_HD int lnb_gemm_stream_rows_fastest(int row_groups) { return row_groups > 8 ? 1 : 0; }

@@ -2313,16 +2313,7 @@ extern "C" hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st) {
 }
 
 // prefill product on the streaming matrix-core feed (gemm_stream_kernel): one weight tile per wave and NTW batch tiles of 16 rows.
-// Batch tiles per wave (tools/gemmstream_bench.hip over the 8B shapes, profiles/r03_gemmstream_bench.log): 4 -- four matrix instructions per
-// unpack op, two workgroups per CU -- as long as the grid still has two workgroups per CU (1.5 for the gate|up pairs, whose waves carry
-// two chains); fewer for short prompts / thin matrices, down to 1 (one chain per wave, two or three waves per SIMD: 55-60 % of the f32
-// matrix rate at 128 rows, where a 16 x 16 output tile's one k-ordered chain leaves only 2-3 chains per SIMD to interleave).
-static int gemm_stream_ntw(int n_tiles, int ct, int nch, int num_cus) {
-    const long need = nch == 2 ? 3L * num_cus / 2 : 2L * num_cus;
-    int ntw = 4;
-    while (ntw > 1 && (ntw > ct || (long)((n_tiles + 3) / 4) * ((ct + ntw - 1) / ntw) < need)) ntw >>= 1;
-    return ntw;
-}
+// (batch tiles per wave and dispatch order: lnb_gemm_stream_ntw / lnb_gemm_stream_rows_fastest, lnb_device.h -- host logic, tests/test_layouts.py)
 template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParams* p, int num_cus, hipStream_t st) {
     if (!p) {
         hipError_t e = hipSuccess;
@@ -2334,7 +2325,7 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
     if (!p->w16 || (p->K & 127) || p->S < 1) return hipErrorInvalidValue;
     const int n_tiles = (p->n_rows + 15) / 16;
     const int ct = (p->S + 15) / 16;                         // batch tiles of 16 rows
-    int ntw = gemm_stream_ntw(n_tiles, ct, NCH, num_cus);
+    int ntw = lnb_gemm_stream_ntw(n_tiles, ct, NCH, num_cus);
     static const int force = getenv("LNB_GS_NTW") ? atoi(getenv("LNB_GS_NTW")) : 0;    // (tools / experiments)
     if (force == 1 || force == 2 || force == 4) ntw = force;
     GemmParams q = *p;
@@ -2347,7 +2338,7 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
     // for 235 MB of weights, rocprofv3 FETCH_SIZE).  Row groups fastest: the workgroups in flight cover ~8 tile groups x all row groups, a
     // weight tile is fetched once per XCD and shared through its L2 (4.8 GB; 1-4 % faster at 4096 rows, 2-3 % slower at 512).
     static const int order = getenv("LNB_GS_ORDER") ? atoi(getenv("LNB_GS_ORDER")) : -1;
-    q.rows_fastest = order >= 0 ? order : (grid.y > 8 ? 1 : 0);
+    q.rows_fastest = order >= 0 ? order : lnb_gemm_stream_rows_fastest((int)grid.y);
     const size_t lds = (size_t)2 * rows_wg * GS_PITCH * 4;
     switch (ntw) {
     case 1: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 1>), grid, dim3(256), lds, st, q); break;

@@ -79,6 +79,22 @@ int main() {
                     for (int j = 1; j < 8; j++) CHECK(tiled_index(n5, 8 * k8 + j, 0, K, RW, NCH) == tiled_index(n5, 8 * k8, 0, K, RW, NCH) + j, "8 consecutive k contiguous");
             }
         }
+    // ---- launch plan of the streaming product: the choices measured on the 8B shapes (profiles/r03_gemmstream_bench.log) ---------------------
+    {
+        const int cus = 256;
+        struct { int n_rows, nch; } shp[4] = {{6144, 1}, {4096, 1}, {14336, 2}, {4096, 1}};      // wq|wk|wv, wo, gate|up pairs, w2
+        for (int S : {16, 17, 64, 128, 256, 512, 1024, 4096})
+            for (auto sh : shp) {
+                const int nt = (sh.n_rows + 15) / 16, ct = (S + 15) / 16, ntw = lnb_gemm_stream_ntw(nt, ct, sh.nch, cus);
+                CHECK(ntw == 1 || ntw == 2 || ntw == 4, "ntw %d", ntw);
+                CHECK(ntw <= (ct >= 4 ? 4 : ct >= 2 ? 2 : 1), "more batch tiles per wave than the call has: S=%d ntw=%d", S, ntw);
+                if (S >= 512) CHECK(ntw == 4, "S=%d rows=%d: four batch tiles per wave", S, sh.n_rows);
+                if (S == 128) CHECK(ntw == (sh.nch == 2 ? 4 : 1), "S=128 rows=%d nch=%d: ntw %d", sh.n_rows, sh.nch, ntw);
+                if (S == 256) CHECK(ntw == (sh.nch == 2 ? 4 : 2), "S=256 rows=%d nch=%d: ntw %d", sh.n_rows, sh.nch, ntw);
+                const int groups = (S + 16 * ntw - 1) / (16 * ntw);
+                CHECK(lnb_gemm_stream_rows_fastest(groups) == (S >= 1024 ? 1 : 0), "dispatch order at S=%d (%d row groups)", S, groups);
+            }
+    }
     CHECK(LNB_BATCH_MAX >= LNB_STREAM_COLS && LNB_STREAM_COLS == 16, "batch limits");
     printf(fails ? "layout_test: %d FAILURES\n" : "layout_test: ok\n", fails);
     return fails ? 1 : 0;

@@ -55,11 +55,11 @@ int main(int argc, char** argv) {
     (void)hipMemcpy(x, h.data(), (size_t)S * K * 2, hipMemcpyHostToDevice);
     float* silu; (void)hipMalloc((void**)&silu, 65536 * 4); (void)hipMemset(silu, 0x3c, 65536 * 4);
     GemmParams p{}; p.silu = silu; p.w16 = w; p.nch = nch; p.x = x; p.K = K; p.n_rows = N; p.S = S; p.out = out;
-    if (ntw == 0) ntw = gemm_stream_ntw(n_tiles, (S + 15) / 16, nch, num_cus);
+    if (ntw == 0) ntw = lnb_gemm_stream_ntw(n_tiles, (S + 15) / 16, nch, num_cus);
     const int rows_wg = 16 * ntw;
     unsigned gx = (unsigned)((n_tiles + 3) / 4); if (gx > (unsigned)num_cus) gx = num_cus;
     const dim3 grid(gx, (unsigned)((S + rows_wg - 1) / rows_wg));
-    p.rows_fastest = getenv("GS_ORDER") ? atoi(getenv("GS_ORDER")) : (grid.y > 8 ? 1 : 0);
+    p.rows_fastest = getenv("GS_ORDER") ? atoi(getenv("GS_ORDER")) : lnb_gemm_stream_rows_fastest((int)grid.y);
     const size_t lds = lds_force ? lds_force : (size_t)2 * rows_wg * GS_PITCH * 4;
     auto go = [&]() {
         if (nch == 1) switch (ntw) { case 1: launch<1, 1>(grid, lds, p); break; case 2: launch<1, 2>(grid, lds, p); break; default: launch<1, 4>(grid, lds, p); }
