@@ -840,6 +840,166 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// rowcast_lds_kernel (round 4): the row-broadcast chain with its PRODUCER work moved to a second wave.
+//
+// tools/chainbench3.hip: a dependent v_add_f32_dpp row_newbcast costs 5.3 cycles when nothing else is issued between the adds,
+// and whatever the chain wave issues besides them is paid in full (a wave issues one instruction per ~4.4 cycles): rowcast_kernel's
+// chain wave also unpacks and multiplies its weights, reads x and refills its register ring -- 6.2-6.6 cycles per step.  Every
+// way of handing a lane its OWN operand per step is worse (ds_read_b128 per 4 steps: 9.0 cycles per step with 64, 32 or 16 lanes
+// active -- the returning data occupies the SIMD's register write port like four VALU ops; products made by the matrix pipe with a
+// one-hot selector operand: 7.5), but a DPP operand serves 16 lanes, so here one ds_read_b128 feeds 64 steps: 5.56 measured.
+//   waves 0..3  chain : 4 rows each, one per DPP row; per 128-step chunk two ds_read_b128 (the next chunk's products) + 128 adds;
+//   waves 4..7  helper: wave 4+c streams the weights of chain wave c (same lane mapping as rowcast_kernel: lane (q, j) holds the
+//                       eight weights of row q with k = j mod 16), multiplies them by x (exact products) and leaves them in a
+//                       lane-private LDS ring -- wave w and w+4 share a SIMD, the helper is the younger wave there and only takes
+//                       the issue slots the chain's DPP latency leaves free (5.3 cycles per step beside a younger
+//                       vector-heavy wave);
+// stages of RL_SC chunks in a three-slot ring, one s_barrier per stage: at iteration t the helpers write stage t while the chain
+// waves add stage t-2 and prefetch the first chunk of stage t-1 (complete since the previous barrier), so no LDS round trip is
+// exposed at a stage boundary.  x lives in the LDS as raw bf16 (K * 2 bytes), transposed per chunk like the weights.
+// Same weight layout as rowcast_kernel (tag RW 4); requires K % (128 * RL_SC) == 0 (the launcher falls back otherwise).
+// grid.x = S * n_wg, block = 512, dynamic LDS = rl_lds_bytes(K).
+// ------------------------------------------------------------------------------------------------
+constexpr int RL_SC = 4;                                    // 128-step chunks per stage
+constexpr int RL_SLOTS = 3;
+constexpr int RL_R = 12;                                    // 1 KiB weight chunks in flight per helper wave (a multiple of RL_SC * RL_SLOTS' unroll)
+constexpr int RL_STAGE = 4 * RL_SC * 2048;                  // bytes of products per stage: 4 pairs x RL_SC chunks x 2 KiB
+__host__ __device__ constexpr size_t rl_lds_bytes(int K) { return (size_t)RL_SLOTS * RL_STAGE + (size_t)K * 2; }
+template <int EPI>
+__global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
+    static_assert(RL_R == RL_SC * RL_SLOTS, "the helper's ring index and the product slot are static inside a three-stage unroll");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    char* ring = smem;
+    uint16_t* xb = (uint16_t*)(smem + RL_SLOTS * RL_STAGE);  // x[128c + 16i + j] at xb[(c*16 + j)*8 + i]
+    const long long t_begin = p.dbg ? clock64() : 0;         // LNB_GEMV_TIMING: [wg][wave] = {total, barrier wait, prologue, -}
+    long long t_x = 0, t_wait = 0;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), pair = wave & 3;
+    const int K = p.K, S = p.S, nchunks = K >> 7, nst = nchunks / RL_SC;
+    const int m = (S == 1) ? 0 : (int)(blockIdx.x % (unsigned)S);
+    const int wg = (S == 1) ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)S);
+    const int nb_mine = (p.n_blocks - wg + p.n_wg - 1) / p.n_wg;       // 16-row blocks wg, wg+n_wg, ...
+    const int NS = nb_mine * nst;                                      // stages this workgroup walks
+    // x first, all of its loads in flight at once; the weight stream starts once x has landed
+    constexpr int RL_XU = 4;                                 // 16 B units of x per thread: K <= 16384
+    const uint16_t* xrow = p.x + (size_t)m * K;
+    uint4 xv[RL_XU];
+#pragma unroll
+    for (int i = 0; i < RL_XU; i++) {
+        const int u = tid + i * 512;
+        xv[i] = *(const uint4*)(xrow + (size_t)(u < (K >> 3) ? u : 0) * 8);      // unconditional (clamped) loads
+    }
+    __builtin_amdgcn_s_waitcnt(0x0F70);                      // vmcnt(0): hipcc then needs no wait of its own below (it would drain the weight ring too)
+    u32x4 buf[RL_R];
+    const size_t tile_bytes = (size_t)nchunks * 1024;        // one wave tile (4 rows)
+    const char* sb = (const char*)p.w + ((size_t)wg * 4 + pair) * tile_bytes;
+    const size_t blk_jump = (size_t)p.n_wg * 4 * tile_bytes - tile_bytes;
+    const unsigned voff = (unsigned)lane * 16u;
+    const int T = NS * RL_SC;
+    int ic = 0, issued = 0;
+    auto issue_next = [&](u32x4& dst) {
+        ld_nt_asm(dst, voff, sb);
+        if (issued + 1 < T) { issued++; sb += 1024; if (++ic == nchunks) { ic = 0; sb += blk_jump; } }
+    };
+    if (wave >= 4) {
+#pragma unroll
+        for (int j = 0; j < RL_R; j++) issue_next(buf[j]);
+    }
+#pragma unroll
+    for (int i = 0; i < RL_XU; i++) {
+        const int u = tid + i * 512;
+        if (u < (K >> 3)) {
+            const uint4 v = xv[i];
+            const int k = u * 8, c = k >> 7, ii = (k & 127) >> 4, j0 = k & 15;
+            uint16_t* d = xb + ((size_t)(c * 16 + j0) * 8 + ii);
+            d[0] = (uint16_t)v.x; d[8] = (uint16_t)(v.x >> 16); d[16] = (uint16_t)v.y; d[24] = (uint16_t)(v.y >> 16);
+            d[32] = (uint16_t)v.z; d[40] = (uint16_t)(v.z >> 16); d[48] = (uint16_t)v.w; d[56] = (uint16_t)(v.w >> 16);
+        }
+    }
+    __syncthreads();
+    if (p.dbg) t_x = clock64() - t_begin;
+#define RL_BARRIER() do { if (p.dbg) { const long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
+    if (wave >= 4) {
+        // ================================ helper: products of chain wave `pair` ======================================
+        const char* xl = (const char*)xb + (size_t)(lane & 15) * 16;
+        char* const dst0 = ring + (size_t)pair * (RL_SC * 2048) + (size_t)lane * 16;
+        int c = 0;
+        for (int it0 = 0; it0 < NS + 2; it0 += RL_SLOTS) {
+#pragma unroll
+            for (int u = 0; u < RL_SLOTS; u++) {
+                const int it = it0 + u;
+                if (it < NS + 2) {
+                    if (it < NS) {
+                        char* dst = dst0 + (size_t)u * RL_STAGE;
+#pragma unroll
+                        for (int cc = 0; cc < RL_SC; cc++) {
+                            u32x4& b = buf[u * RL_SC + cc];
+                            asm volatile("s_waitcnt vmcnt(%1) ; RING_RETIRE %0" : "+v"(b) : "n"(RL_R - 1) : "memory");
+                            const uint4 xq = *(const uint4*)(xl + (size_t)c * 256);
+                            // exact products (8-bit x 8-bit significands): val1F32 * val2F32, operations_lineartransform.go:60
+                            float4 pa = mul4(make_float4(bf_lo(xq.x), bf_hi(xq.x), bf_lo(xq.y), bf_hi(xq.y)), bf_lo(b.x), bf_hi(b.x), bf_lo(b.y), bf_hi(b.y));
+                            float4 pb = mul4(make_float4(bf_lo(xq.z), bf_hi(xq.z), bf_lo(xq.w), bf_hi(xq.w)), bf_lo(b.z), bf_hi(b.z), bf_lo(b.w), bf_hi(b.w));
+                            // pin the products in front of the refill (else hipcc sinks the unpack behind the asm that reloads b)
+                            asm volatile("" : "+v"(pa.x), "+v"(pa.y), "+v"(pa.z), "+v"(pa.w), "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w));
+                            issue_next(b);
+                            *(float4*)(dst + cc * 2048) = pa; *(float4*)(dst + cc * 2048 + 1024) = pb;
+                            if (++c == nchunks) c = 0;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // ds_writes complete before the barrier
+                    RL_BARRIER();
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
+    } else {
+        // ================================ chain wave: 4 rows, one per DPP row =========================================
+        __builtin_amdgcn_s_setprio(3);
+        const char* const src0 = ring + (size_t)pair * (RL_SC * 2048) + (size_t)lane * 16;
+        float acc = 0.0f;
+        float4 ba[2], bb[2];                                 // products of the chunk being added / of the next one
+        int sdone = 0, blk = wg;
+        for (int it0 = 0; it0 < NS + 2; it0 += RL_SLOTS) {
+#pragma unroll
+            for (int u = 0; u < RL_SLOTS; u++) {
+                const int it = it0 + u;
+                if (it < NS + 2) {
+                    if (it >= 2) {
+                        // stage it-2 lives in slot (u+1) % 3, stage it-1 (complete since the last barrier) in slot (u+2) % 3
+                        const char* cur = src0 + (size_t)((u + 1) % RL_SLOTS) * RL_STAGE;
+                        const char* nxt = src0 + (size_t)((u + 2) % RL_SLOTS) * RL_STAGE;
+                        if (it == 2) { ba[0] = *(const float4*)cur; bb[0] = *(const float4*)(cur + 1024); }
+#pragma unroll
+                        for (int cc = 0; cc < RL_SC; cc++) {
+                            const char* q = cc + 1 < RL_SC ? cur + (cc + 1) * 2048 : nxt;      // past the last stage: stale bytes, never added
+                            ba[(cc + 1) & 1] = *(const float4*)q; bb[(cc + 1) & 1] = *(const float4*)(q + 1024);
+                            __builtin_amdgcn_sched_barrier(0);         // the reads are issued HERE, in front of the chunk's 128 adds
+                            const float4 a = ba[cc & 1], b = bb[cc & 1];
+                            const float pr[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                            chain128(acc, pr);                         // valDstF32 += p, k ascending (operations_lineartransform.go:63)
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                        if (++sdone == nst) {                          // end of this wave's 4 rows
+                            const int n = blk * 16 + pair * 4 + (lane >> 4);
+                            if ((lane & 15) == 0 && n < p.n_rows) {
+                                const size_t o = (size_t)m * p.n_rows + n;
+                                if (EPI == EPI_RESID) p.out[o] = bf_trunc(bf_wide(p.res[o]) + bf_wide(bf_trunc(acc)));   // ml.Add, operations_impl.go:320-332
+                                else p.out[o] = bf_trunc(acc);
+                            }
+                            acc = 0.0f; sdone = 0; blk += p.n_wg;
+                        }
+                    }
+                    RL_BARRIER();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                }
+            }
+        }
+    }
+#undef RL_BARRIER
+    if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; d_[3] = 0; }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Prefill (S >= 16 rows per call): the same exact chains on the f32 MATRIX cores.
 //
 // v_mfma_f32_16x16x4_f32 is, bit for bit, the k-ordered chain  D = fma(a_k3,b_k3, fma(a_k2,b_k2, fma(a_k1,b_k1, fma(a_k0,b_k0, C))))
@@ -2068,8 +2228,18 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
 
 template <int EPI> static hipError_t launch_rowcast(const GemvParams* p, hipStream_t st) {
     auto kfn = rowcast_kernel<EPI>;
-    if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    auto kl = rowcast_lds_kernel<EPI>;
+    if (!p) {
+        hipError_t e = hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
     if ((p->K & 127) || p->K > 16384) return hipErrorInvalidValue;              // x staging: 8 x 16 B per thread, K*4 bytes of LDS
+    // helper-fed chain waves (rowcast_lds_kernel) whenever K is a whole number of its 512-step stages; LNB_ROWCAST_LDS=0: the self-feeding kernel
+    static const int use_lds = [] { const char* s = getenv("LNB_ROWCAST_LDS"); return s && *s ? atoi(s) : 1; }();
+    if (use_lds && p->K % (128 * RL_SC) == 0 && rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0) <= 160 * 1024) {
+        hipLaunchKernelGGL(kl, dim3((unsigned)(p->S * p->n_wg)), dim3(512), rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0), st, *p);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3(256), (size_t)p->K * 4 + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0), st, *p);
     return hipGetLastError();
 }

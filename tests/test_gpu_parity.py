@@ -57,6 +57,9 @@ def test_linear_reference_kat_on_gpu(lnb):
     # rw 4 = the row-broadcast kernel (wo / w2): one chunk, ragged N (not a multiple of 4 / 16), more blocks than CUs, model shapes
     (1, 16, 128, 4), (3, 100, 896, 4), (2, 5000, 256, 4), (1, 4096, 4096, 4), (1, 4096, 14336, 4), (4, 50, 1536, 4),
     (1, 96, 28672, 32), (2, 40, 28672, 16),                       # 70B-like w2 rows: the four-helper configuration for very long K
+    # rw 4 with K a multiple of 512 = rowcast_lds_kernel (helper-fed chain waves): one stage, stage counts 2, 3 (the ring's unroll), 4, 5;
+    # ragged N; more 16-row blocks than CUs (persistent blocks); several x rows; the longest K it accepts
+    (1, 16, 512, 4), (1, 64, 1024, 4), (3, 100, 1536, 4), (1, 37, 2048, 4), (2, 24, 2560, 4), (2, 5000, 512, 4), (1, 8200, 1024, 4), (1, 48, 16384, 4),
 ])
 def test_linear_bit_exact(lnb, rows, n, k, rw):
     rng = np.random.default_rng(rows * 1000003 + n * 101 + k + rw)

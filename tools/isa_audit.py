@@ -152,7 +152,7 @@ def main(asm_path=None):
         txt = open(asm).read().split("\n")
     funcs, cur = {}, None
     for i, ln in enumerate(txt):
-        m = re.match(r"^(_Z1[478](?:gemv_chain|attn_exact|rowcast|mfma_stream|gemm_stream)_kernel\S*):", ln)
+        m = re.match(r"^(_Z1[478](?:gemv_chain|attn_exact|rowcast|rowcast_lds|mfma_stream|gemm_stream)_kernel\S*):", ln)
         if m:
             cur = []; funcs[m.group(1)] = cur
             continue
