@@ -901,26 +901,28 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
         ld_nt_asm(dst, voff, sb);
         if (issued + 1 < T) { issued++; sb += 1024; if (++ic == nchunks) { ic = 0; sb += blk_jump; } }
     };
-    if (wave >= 4) {
+    auto stage_x = [&]() {
 #pragma unroll
-        for (int j = 0; j < RL_R; j++) issue_next(buf[j]);
-    }
-#pragma unroll
-    for (int i = 0; i < RL_XU; i++) {
-        const int u = tid + i * 512;
-        if (u < (K >> 3)) {
-            const uint4 v = xv[i];
-            const int k = u * 8, c = k >> 7, ii = (k & 127) >> 4, j0 = k & 15;
-            uint16_t* d = xb + ((size_t)(c * 16 + j0) * 8 + ii);
-            d[0] = (uint16_t)v.x; d[8] = (uint16_t)(v.x >> 16); d[16] = (uint16_t)v.y; d[24] = (uint16_t)(v.y >> 16);
-            d[32] = (uint16_t)v.z; d[40] = (uint16_t)(v.z >> 16); d[48] = (uint16_t)v.w; d[56] = (uint16_t)(v.w >> 16);
+        for (int i = 0; i < RL_XU; i++) {
+            const int u = tid + i * 512;
+            if (u < (K >> 3)) {
+                const uint4 v = xv[i];
+                const int k = u * 8, c = k >> 7, ii = (k & 127) >> 4, j0 = k & 15;
+                uint16_t* d = xb + ((size_t)(c * 16 + j0) * 8 + ii);
+                d[0] = (uint16_t)v.x; d[8] = (uint16_t)(v.x >> 16); d[16] = (uint16_t)v.y; d[24] = (uint16_t)(v.y >> 16);
+                d[32] = (uint16_t)v.z; d[40] = (uint16_t)(v.z >> 16); d[48] = (uint16_t)v.w; d[56] = (uint16_t)(v.w >> 16);
+            }
         }
-    }
-    __syncthreads();
-    if (p.dbg) t_x = clock64() - t_begin;
+        __syncthreads();
+        if (p.dbg) t_x = clock64() - t_begin;
+    };
 #define RL_BARRIER() do { if (p.dbg) { const long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
     if (wave >= 4) {
         // ================================ helper: products of chain wave `pair` ======================================
+        // (the two roles are separate straight-line paths from here on: tools/isa_audit.py follows the ring registers on this one only)
+#pragma unroll
+        for (int j = 0; j < RL_R; j++) issue_next(buf[j]);
+        stage_x();
         const char* xl = (const char*)xb + (size_t)(lane & 15) * 16;
         char* const dst0 = ring + (size_t)pair * (RL_SC * 2048) + (size_t)lane * 16;
         int c = 0;
@@ -954,6 +956,7 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
         asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
     } else {
         // ================================ chain wave: 4 rows, one per DPP row =========================================
+        stage_x();
         __builtin_amdgcn_s_setprio(3);
         const char* const src0 = ring + (size_t)pair * (RL_SC * 2048) + (size_t)lane * 16;
         float acc = 0.0f;
