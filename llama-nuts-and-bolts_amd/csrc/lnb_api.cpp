@@ -159,7 +159,7 @@ static void drop_graphs(lnb_ctx* c) {
 static int env_int(const char* name, int dflt) { const char* s = getenv(name); return s && *s ? atoi(s) : dflt; }
 static int auto_rw(int lane_rows, const char* env, int K = 0, bool plain = false) {
     int v = env_int(env, 0);
-    if (v == 16 || v == 32 || v == 64 || (v == 4 && plain && K % 128 == 0 && K <= 16384) || ((v == 56 || v == 28) && lane_rows % v == 0)) return v;
+    if (v == 16 || v == 32 || v == 64 || (v == 4 && plain && K % 128 == 0 && K <= 16384) || ((v == 56 || v == 28) && lane_rows % v == 0) || (v == 24 && K > 0 && K % 256 == 0)) return v;
     // thin matrices without a fused norm / rope epilogue: the row-broadcast kernel (products stay in registers)
     if (plain && lane_rows <= 16 * 256 && K > 0 && K % 128 == 0 && K <= 16384) return 4;
     // thin matrices: one workgroup (16 or 32 rows) per CU, all resident at once on the 256 CUs -- a second round of
@@ -258,7 +258,10 @@ static int model_alloc(lnb_model* m) {
         char nm[128]; uint32_t base = 16u * (uint32_t)(l + 1);
         if (m->has_attn(l)) {
             if (alloc_linear(&L.attn_norm, dim, wb)) return -1;
-            if (alloc_tiled(L.wqkv, m->q_dim + 2 * m->kv_dim, dim, auto_rw(m->q_dim + 2 * m->kv_dim, "LNB_RW_QKV"), 1, wb)) return -1;
+            // wq|wk|wv: 24-row blocks (gemv_quad_kernel: quad-DPP chain waves, one block on every CU) when the rows divide that way -- the 8B shape
+            int rwq = auto_rw(m->q_dim + 2 * m->kv_dim, "LNB_RW_QKV", dim);
+            if (env_int("LNB_RW_QKV", 0) == 0 && m->q_dim + 2 * m->kv_dim == 24 * g_num_cus && dim % 256 == 0) rwq = 24;
+            if (alloc_tiled(L.wqkv, m->q_dim + 2 * m->kv_dim, dim, rwq, 1, wb)) return -1;
             if (alloc_tiled(L.wo, dim, m->q_dim, auto_rw(dim, "LNB_RW_WO", m->q_dim, true), 1, wb)) return -1;
             snprintf(nm, sizeof nm, "layers.%d.attention_norm.weight", l); reg_linear(m, nm, L.attn_norm, dim, base + 0, 1);
             snprintf(nm, sizeof nm, "layers.%d.attention.wq.weight", l); reg_tiled(m, nm, &L.wqkv, m->q_dim, dim, 0, 0, base + 1);
@@ -955,22 +958,25 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
         }
     }
     if (env_int("LNB_GEMV_TIMING", 0) && which != K_ATTN && which != K_LAYER) {
-        const size_t n = (size_t)4096 * 8 * 4;
+        const size_t n = (size_t)4096 * 8 * 4, n2 = (size_t)4096 * 8 * 8;       // + 8 phase stamps per wave behind the four totals (LNB_STAMP in lnb_kernels.hip)
         long long* dbuf = nullptr;
-        HIPCHK(hipMalloc((void**)&dbuf, n * 8)); HIPCHK(hipMemsetAsync(dbuf, 0, n * 8, st));
+        HIPCHK(hipMalloc((void**)&dbuf, (n + n2) * 8)); HIPCHK(hipMemsetAsync(dbuf, 0, (n + n2) * 8, st));
         g_dbg = dbuf;
         int rc = run(7);
         g_dbg = nullptr;
         if (rc) { hipFree(dbuf); return -1; }
         HIPCHK(hipStreamSynchronize(st));
-        std::vector<long long> h(n);
-        HIPCHK(hipMemcpy(h.data(), dbuf, n * 8, hipMemcpyDeviceToHost));
+        std::vector<long long> h(n + n2);
+        HIPCHK(hipMemcpy(h.data(), dbuf, (n + n2) * 8, hipMemcpyDeviceToHost));
         hipFree(dbuf);
         fprintf(stderr, "[timing] kernel class %d: per-wave s_memtime ticks (avg over workgroups)\n", which);
         for (int w = 0; w < 8; w++) {
             double tot = 0, wait = 0, tx = 0, mx = 0, aux = 0; int cnt = 0;
             for (int g = 0; g < 4096; g++) { const long long* d = &h[((size_t)g * 8 + w) * 4]; if (d[0] > 0) { tot += d[0]; wait += d[1]; tx += d[2]; aux += d[3]; if (d[0] > mx) mx = (double)d[0]; cnt++; } }
             if (cnt) fprintf(stderr, "[timing]   wave %d: n=%d total=%.0f (max %.0f) barrier_wait=%.0f x_or_vmwait=%.0f rms_fold_or_walk=%.0f\n", w, cnt, tot / cnt, mx, wait / cnt, tx / cnt, aux / cnt);
+            double sm[8] = {0}; int sc = 0;
+            for (int g = 0; g < 4096; g++) { const long long* d = &h[n + ((size_t)g * 8 + w) * 8]; if (d[0] > 0) { for (int k = 0; k < 8; k++) sm[k] += (double)d[k]; sc++; } }
+            if (sc) { fprintf(stderr, "[timing]     stamps (since kernel start):"); for (int k = 0; k < 8; k++) fprintf(stderr, " %.0f", sm[k] / sc); fprintf(stderr, "\n"); }
         }
     }
     return 0;
@@ -1726,7 +1732,8 @@ static int op_linear_impl(int device, const uint16_t* x, const uint16_t* norm_w,
     HIPCHK(lnbk_fast_init());
     if (mode != LNB_MODE_EXACT && mode != LNB_MODE_FAST) return fail("unknown mode %d", mode);
     if (rw == 0) rw = auto_rw(n_out, "LNB_RW_OP", k_in, norm_w == nullptr);
-    if (rw != 16 && rw != 32 && rw != 64 && !(rw == 4 && !norm_w && k_in % 128 == 0 && k_in <= 16384)) return fail("rw must be 16, 32 or 64 (or 4: row-broadcast layout, no fused norm, in_features a multiple of 128)");
+    if (rw != 16 && rw != 32 && rw != 64 && !(rw == 4 && !norm_w && k_in % 128 == 0 && k_in <= 16384) && !(rw == 24 && k_in % 256 == 0))
+        return fail("rw must be 16, 32 or 64 (or 4: row-broadcast layout, no fused norm, in_features a multiple of 128; or 24: quad layout, in_features a multiple of 256)");
     if ((size_t)k_in * 4 > 120 * 1024) return fail("in_features %d does not fit the LDS staging", k_in);
     TiledDesc t{}; int64_t bytes = 0;
     if (alloc_tiled(t, n_out, k_in, rw, 1, bytes)) return -1;

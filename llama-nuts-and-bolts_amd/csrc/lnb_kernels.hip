@@ -133,8 +133,8 @@ DEVINL void x_store(const GemvParams& p, float* xs, int kpad, int sidx, int lane
 // lane; on the GPU: tests/test_gpu_parity.py through lnb_op_rmsnorm_linear); ~17 items + ~5 replayed leaves for gaussian x.
 // A leaf is seq_leaf_size(K, NH*64) terms (one leaf per folding lane; the last one may run into the zero padding).
 constexpr int RMS_HEAD = 256;
-__host__ __device__ inline size_t rms_scratch_bytes(int NH) { return (size_t)NH * (512 + 8 + 4) + 64; }
-// LDS scratch (the idle product ring): SeqNode rec[NH][64] | uint64 items[NH] | float wtot[NH]
+__host__ __device__ inline size_t rms_scratch_bytes(int NH) { return (size_t)NH * (512 + 8 + 4 + 4) + 64; }
+// LDS scratch (the idle product ring): SeqNode rec[NH][64] | uint64 items[NH] | float wtot[NH] | uint32 scan_failed[NH]
 
 // wave scans on DPP data movement (VALU, no LDS round trip like ds_bpermute): in-row shifts by 1, 2, 4, 8, then lane 15 of a row
 // into the next row (rows 1, 3) and lane 31 into rows 2, 3 -- the classic gfx9 inclusive-scan order.  `old` is what lanes
@@ -175,7 +175,15 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
 #pragma unroll
     for (int w = 0; w < NH; w++) { const float v = wtot[w]; base += w < hw ? v : 0.0f; }
     SeqNode n; n.a = 0u; n.b = 0u;
-    if (b < nleaf) n = seq_leaf(q, LEAF, base + (incl - bsum), base + incl);
+    {   // the leaf's parity map from two simulated f32 running sums (lnb_seqsum.h: seq_leaf): 2 adds per term
+        const int32_t e = b < nleaf ? seq_guess(base + (incl - bsum), base + incl) : 0;
+        float s0, s1; seq_sim_init(e, s0, s1);
+        for (int i = 0; i < LEAF; i += 4) {
+            const float4 v = *(const float4*)(q + i);
+            s0 = s0 + v.x; s1 = s1 + v.x; s0 = s0 + v.y; s1 = s1 + v.y; s0 = s0 + v.z; s1 = s1 + v.z; s0 = s0 + v.w; s1 = s1 + v.w;
+        }
+        if (b < nleaf) n = seq_sim_node(e, s0, s1);
+    }
     if (b < nleaf && bsum == 0.0f && (n.a >> 24) == 0u) n.a = SEQ_ZERO_LEAF;      // nothing to add, whatever the running sum is
     SeqNode left; left.a = (uint32_t)dpp_wave_shr1((int)n.a, 0); left.b = 0u;
     int f = seq_is_start(lane, n, left, b == headleaf);
@@ -184,14 +192,16 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
     if (lane == 0) items[hw] = mask;
     int start = lane;
     // segmented inclusive scan of the leaf maps (associative: a run absorbs the run that ends right in front of it), six DPP steps
+    int failed = 0;                                                      // a composition that did not go through (cannot happen inside a verified binade)
 #define LNB_SEG_STEP(MOV, VALID) { SeqNode o_; o_.a = (uint32_t)MOV((int)n.a, 0); o_.b = (uint32_t)MOV((int)n.b, 0); const int ofs_ = MOV((f << 8) | start, 0); \
-                                   if ((VALID) && !f) seq_scan_step(n, f, start, o_, ofs_ >> 8, ofs_ & 0xFF); }
+                                   if ((VALID) && !f) failed |= seq_scan_step(n, f, start, o_, ofs_ >> 8, ofs_ & 0xFF) ^ 1; }
     LNB_SEG_STEP(dpp_row_shr<1>, (lane & 15) >= 1) LNB_SEG_STEP(dpp_row_shr<2>, (lane & 15) >= 2)
     LNB_SEG_STEP(dpp_row_shr<4>, (lane & 15) >= 4) LNB_SEG_STEP(dpp_row_shr<8>, (lane & 15) >= 8)
     LNB_SEG_STEP(dpp_bcast15, (lane & 16) != 0) LNB_SEG_STEP(dpp_bcast31, lane >= 32)
 #undef LNB_SEG_STEP
     n.b |= (uint32_t)start << 24;                                        // c1 < 2^24: the run's first leaf rides in the top byte
     rec[hw * 64 + lane] = n;
+    { const unsigned long long fm = __ballot(failed != 0); if (lane == 0) ((uint32_t*)(scratch + (size_t)NH * 524))[hw] = fm ? 1u : 0u; }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     if (p.dbg) t_dbg = clock64() - tf0_;                                 // fold time incl. the X1 wait
     __builtin_amdgcn_s_barrier();                                        // X2: records published
@@ -228,6 +238,62 @@ DEVINL uint32_t rms_walk_heap(uint32_t sb, const SeqNode& rc, unsigned long long
     return sb;
 }
 
+// The same walk without the per-item bookkeeping (round 4: 280 -> ~90 cycles per item, 6.8 k -> ~2.5 k cycles per norm).  The items of a wave
+// TILE its leaves by construction -- every non-zero leaf is either invalid (an item of its own) or belongs to exactly one run, and a run's
+// record covers [its first leaf, the item's lane] -- unless a composition inside the segmented scan failed, which the folding wave reports
+// (scan_failed: then rms_walk_heap above, which checks every record's start, is used).  So an item only has to match the running sum's
+// binade and keep the sum inside it; anything else is replayed from the leaf behind the previous item (leaves of exact zeros in between
+// add nothing).  A replay fetches up to 16 terms at once (one LDS round trip per 16 terms instead of one per 4).
+// tq: this wave-set's x^2 terms, lane l holding leaf l's (up to 12) terms -- loaded by the walker while it waits for the fold; `regs` says
+// whether they are there (LEAF <= 12).  A replayed leaf then costs a v_readlane + v_add per term (~120 cycles) instead of an LDS round trip
+// behind a cold branch (~750 measured).
+DEVINL uint32_t rms_walk_fast(uint32_t sb, const SeqNode& rc, unsigned long long mask, int pos, int nloc, const float* sq, int LEAF, const float4 (&tq)[3], bool regs, int& cnt) {
+    mask &= ~0ull << pos;
+    if (nloc < 64) mask &= ~(~0ull << nloc);
+    mask &= ~__ballot(rc.a == SEQ_ZERO_LEAF);
+    // (tools/chainbench4.hip: what this loop pays for is the hand-offs between the vector and the scalar unit -- a dynamic v_readlane
+    //  between scalar ops ~50 cycles, a branch on a vector result ~40 even when not taken, a taken branch ~22 -- not the arithmetic:
+    //  the same recurrence on the vector unit measured no faster)
+    while (mask) {
+        const int i = __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const uint32_t na = (uint32_t)__builtin_amdgcn_readlane((int)rc.a, i), nb = (uint32_t)__builtin_amdgcn_readlane((int)rc.b, i);
+        // M + c on the f32 BITS of the running sum: no carry into the exponent field <=> the sum stays inside the binade
+        const uint32_t e = na >> 24;
+        const uint32_t t = sb + (((sb & 1u) ? nb : na) & 0xFFFFFFu);
+        const uint32_t bad = ((t ^ sb) >> 23) | (e ^ (sb >> 23)) | (uint32_t)(e == 0u);
+        cnt += 0x10000;                                                  // (diagnostics: items << 16 | replays)
+        if (__builtin_expect(bad == 0u, 1)) sb = t;
+        else {                                                           // replay leaves pos..i term by term
+            cnt += 1;
+            float f = __uint_as_float(sb);
+            if (regs) {
+#define LNB_RL(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l))
+                for (int l = pos; l <= i; l++) {
+                    f = f + LNB_RL(tq[0].x); f = f + LNB_RL(tq[0].y); f = f + LNB_RL(tq[0].z); f = f + LNB_RL(tq[0].w);
+                    f = f + LNB_RL(tq[1].x); f = f + LNB_RL(tq[1].y); f = f + LNB_RL(tq[1].z); f = f + LNB_RL(tq[1].w);
+                    if (LEAF > 8) { f = f + LNB_RL(tq[2].x); f = f + LNB_RL(tq[2].y); f = f + LNB_RL(tq[2].z); f = f + LNB_RL(tq[2].w); }
+                }
+#undef LNB_RL
+            } else {
+                const float* qe = sq + (size_t)(i + 1) * LEAF;
+                for (const float* q = sq + (size_t)pos * LEAF; q < qe; q += 16) {
+                    // (reads past qe stay inside the zero-padded x buffer; what lies past the range is replaced by +0, and f + 0 == f)
+                    float4 v0 = *(const float4*)q, v1 = *(const float4*)(q + 4), v2 = *(const float4*)(q + 8), v3 = *(const float4*)(q + 12);
+                    const float4 z = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (q + 4 >= qe) v1 = z;
+                    if (q + 8 >= qe) v2 = z;
+                    if (q + 12 >= qe) v3 = z;
+                    f = add4(f, v0); f = add4(f, v1); f = add4(f, v2); f = add4(f, v3);
+                }
+            }
+            sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(f));
+        }
+        pos = i + 1;
+    }
+    return sb;
+}
+
 template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* xs, const char* scratch, int lane, long long& t_dbg) {
     const int K = p.K, LEAF = seq_leaf_size(K, NH * 64), nleaf = (K + LEAF - 1) / LEAF;
     const SeqNode* rec = (const SeqNode*)scratch;
@@ -237,23 +303,42 @@ template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* 
     const int headleaf = (K < RMS_HEAD ? K : RMS_HEAD) / LEAF, head = headleaf * LEAF;
     float sum = 0.0f;
     for (int k0 = 0; k0 < head; k0 += 4) sum = add4(sum, *(const float4*)(xs + k0));
+    // all x^2 terms into registers while the helpers fold (lane l of set w: leaf 64 w + l), for the replays of the walk
+    const bool regs = LEAF == 8 || LEAF == 12;
+    float4 tq[NH][3];
+    if (regs) {
+#pragma unroll
+        for (int w = 0; w < NH; w++) {
+            const int lf = w * 64 + lane;
+            const float* q = xs + (size_t)(lf < nleaf ? lf : nleaf - 1) * LEAF;      // (the last leaf may run into the zero padding)
+            tq[w][0] = *(const float4*)q; tq[w][1] = *(const float4*)(q + 4); tq[w][2] = *(const float4*)(q + 8);
+        }
+    }
     __builtin_amdgcn_s_barrier();                                        // X2 (the records)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
     const long long tw0_ = p.dbg ? clock64() : 0;
     SeqNode rc[NH];
     unsigned long long mk[NH];
+    int cnt = 0;
 #pragma unroll
     for (int w = 0; w < NH; w++) { rc[w] = rec[w * 64 + lane]; mk[w] = items[w]; }
+    const uint32_t badv = ((const uint32_t*)(scratch + (size_t)NH * 524))[lane < NH ? lane : 0];      // scan_failed[w] in lane w
+    const unsigned long long badm = __ballot(badv != 0u);
+#define LNB_WSTAMP(i) do { if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + 7) * 8 + (i)] = clock64() - tw0_ + 1; } while (0)
+    LNB_WSTAMP(0);
 #pragma unroll
     for (int w = 0; w < NH; w++) {
         int nloc = nleaf - w * 64; nloc = nloc < 0 ? 0 : (nloc > 64 ? 64 : nloc);
         int pos = headleaf - w * 64; pos = pos < 0 ? 0 : pos;
         const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mk[w]);
         const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mk[w] >> 32));
-        sb = rms_walk_heap(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF);
+        if (__builtin_expect((badm >> w) & 1ull, 0)) sb = rms_walk_heap(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF);
+        else sb = rms_walk_fast(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF, tq[w], regs, cnt);
+        if (w < 7) LNB_WSTAMP(1 + w);
     }
     if (p.dbg) t_dbg = clock64() - tw0_;                                 // walk time
+    if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + 0) * 8 + 7] = cnt;   // stamp slot 7 of the walker
     float mean = __fdiv_rn(__uint_as_float(sb), (float)K);
     mean = mean + p.eps;
     return (float)(1.0 / sqrt((double)mean));
@@ -284,7 +369,8 @@ DEVINL void x_normalize(const GemvParams& p, float* xs, int kpad, float r, int s
     }
 }
 
-template <int NCH, int EPI>
+// PX: lane distance of the RoPE partner row (2i <-> 2i+1): 1 when a lane is a row, 4 in gemv_quad_kernel (four lanes per row)
+template <int NCH, int EPI, int PX = 1>
 DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, int n, bool valid) {
     if (EPI == EPI_STORE) {
         if (valid) p.out[(size_t)m * p.n_rows + n] = bf_trunc(acc[0]);
@@ -305,7 +391,7 @@ DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, i
         // rows [0,q_dim) = xq, [q_dim,q_dim+kv_dim) = xk, rest = xv (llamatransformer.go:297-384)
         const int pos = p.st->pos + m;
         const uint16_t mine = bf_trunc(acc[0]);
-        const uint16_t other = (uint16_t)__shfl_xor((int)mine, 1);       // RoPE partner (2i <-> 2i+1)
+        const uint16_t other = (uint16_t)__shfl_xor((int)mine, PX);      // RoPE partner (2i <-> 2i+1)
         if (valid) {
             if (n < p.q_dim + p.kv_dim) {
                 // applyRotaryEmbeddings (:753-790): complex64 product evaluated in f64, narrowed, truncated
@@ -350,6 +436,8 @@ DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, i
 // ------------------------------------------------------------------------------------------------
 // optional per-wave timing (GemvParams.dbg != nullptr): [wg][wave][4] = {total, barrier wait, x staging / vm wait, -} in s_memtime ticks
 #define TIMED_BARRIER() do { if (p.dbg) { long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
+// phase stamp i (0..7) of this wave, cycles since the kernel started: a second region behind the [4096][8][4] totals (lnb_api.cpp prints the averages)
+#define LNB_STAMP(i) do { if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = clock64() - t_begin; } while (0)
 #define DBG_EXIT() do { if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; d_[3] = t_aux; } } while (0)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
@@ -430,14 +518,24 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
             for (int i = 0; i < NP; i++) ld_nt_asm(dst[i], loff[i] < lim ? loff[i] : lim, sb);
             if (issued + 1 < T) { issued++; if (++is == nstages) { is = 0; ib += p.n_wg; } }
         };
+            // norm-fused kernels start the weight stream BEHIND the norm's fold (round 4): issuing R stages per helper into a cold memory
+            // pipeline stalls the issuing waves ~3 k cycles -- the waves that fold; behind the fold they only wait for the walker anyway
+            // (measured: wq|wk|wv -1.0 us, w1|w3 -2.3 us, output -1 us)
+            constexpr bool late = NORM;
+            if (!late) {
 #pragma unroll
-            for (int j = 0; j < R; j++) issue_next(buf[j]);
+                for (int j = 0; j < R; j++) issue_next(buf[j]);
+            }
             x_store<NORM, NS>(p, xs, kpad, 1 + hw, lane, xv);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             TIMED_BARRIER();                                           // B1: xs (or the squares) are in LDS
             if (NORM) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 rms_fold<NH>(p, xs, ringB, hw, lane, t_aux);                  // X1, X2 inside
+                if (late) {                                            // the walker walks now: the issue stall costs nothing here
+#pragma unroll
+                    for (int j = 0; j < R; j++) issue_next(buf[j]);
+                }
                 TIMED_BARRIER();                                       // B2: r published
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 if constexpr (NORM) x_normalize<NS>(p, xs, kpad, xs[kpad], 1 + hw, lane, xv, nv);
@@ -581,6 +679,217 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
 #pragma unroll
                 for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
                 st = 0; blk += p.n_wg;
+            }
+        }
+        TIMED_BARRIER();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
+    DBG_EXIT();
+}
+
+// ------------------------------------------------------------------------------------------------
+// gemv_quad_kernel (round 4): the norm-fused thin product wq|wk|wv on ALL CUs, its chains fed through the LDS AND by DPP.
+//
+// gemv_chain_kernel gives a chain lane its own products (one ds_read_b128 per 4 steps: 8.7-9.0 cycles per step, the returning data
+// occupies the SIMD's register write port) and 6144 rows in 32-row blocks fill 192 of the 256 CUs.  A DPP operand serves several
+// lanes at once: with quad_perm a row lives in FOUR lanes, lane j of the quad receives the products k = 16g + 4j .. 4j + 3 of a
+// 16-step group in one ds_read_b128 and every lane of the quad adds all sixteen in k order,
+//     v_add_f32_dpp acc, p_e, acc quad_perm:[j,j,j,j]     e = 0..3 inside j = 0..3,
+// i.e. one LDS read per 16 steps and 16 rows per chain wave: 6.8 cycles per step (tools/chainbench3.hip; 7.5 with helpers hammering
+// the LDS).  A block is RW = n_rows / 256 rows (24 for the 8B shape): ceil(RW / 16) chain waves, each on its own SIMD.
+//   waves 0 .. NCW-1    chain  : rows 16w .. 16w+15 of the block (lanes past the last row shadow earlier ones: every lane stays active);
+//   waves NCW .. NCW+NH-1 helper: stream the block's bf16 weights (layout [N/RW][K/8][RW][8], the register ring of gemv_chain_kernel),
+//                                  multiply by x and leave the exact f32 products in the LDS as [16-step group][row][4 x 16 B], the
+//                                  16-byte slots of a row XOR-swizzled with (row >> 1) & 3 so that both the helpers' ds_write_b128
+//                                  (eight consecutive rows of one k-chunk) and the chain waves' ds_read_b128 are conflict-free;
+// stages of KS steps in a three-slot ring, one s_barrier per stage, the chain waves two stages behind the helpers so that their
+// prefetch (three groups ahead) runs across stage boundaries (as in rowcast_lds_kernel).  The fused RMSNorm prologue is
+// gemv_chain_kernel's: the helpers fold, chain wave 0 walks.
+// grid.x = S * n_wg, block = (NCW + NH) * 64, dynamic LDS = 3 * RW * KS * 4 + x.
+// ------------------------------------------------------------------------------------------------
+#define LNB_QP(j) " quad_perm:[" #j "," #j "," #j "," #j "] row_mask:0xf bank_mask:0xf\n\t"
+#define LNB_QADD4(j) "v_add_f32_dpp %0, %1, %0" LNB_QP(j) "v_add_f32_dpp %0, %2, %0" LNB_QP(j) "v_add_f32_dpp %0, %3, %0" LNB_QP(j) "v_add_f32_dpp %0, %4, %0" LNB_QP(j)
+// the 16 dependent adds of one group in ONE asm statement (separate statements get an s_nop each from hipcc's hazard recognizer);
+// the leading s_nop covers the VGPR-write -> DPP-read wait states for whatever was scheduled last
+DEVINL void chain16q(float& acc, const float4& q) {
+    asm volatile("s_nop 1\n\t" LNB_QADD4(0) LNB_QADD4(1) LNB_QADD4(2) LNB_QADD4(3) : "+v"(acc) : "v"(q.x), "v"(q.y), "v"(q.z), "v"(q.w));
+}
+constexpr int GQ_SLOTS = 3;
+__host__ __device__ constexpr int gq_ncw(int RW) { return (RW + 15) / 16; }
+template <int RW, int KS, int NH, int R, int EPI, bool NORM>
+__global__ __launch_bounds__((gq_ncw(RW) + NH) * 64) void gemv_quad_kernel(GemvParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    long long t_begin = p.dbg ? clock64() : 0, t_wait = 0, t_x = 0, t_aux = 0;
+    constexpr int NCW = gq_ncw(RW), NW = NCW + NH;
+    constexpr int KC = KS / 8;                            // 8-wide k chunks per stage
+    constexpr int GS = KS / 16;                           // 16-step groups per stage
+    constexpr int SA = RW * KS * 2;                       // bf16 bytes per stage
+    constexpr int SB = 2 * SA;                            // f32 product bytes per stage
+    constexpr int UNITS = RW * KC;                        // 16-byte weight units per stage
+    constexpr int NP = UNITS / (64 * NH);                 // loads per lane per stage per helper
+    static_assert(RW % 8 == 0 && KS % 16 == 0, "rows in eights (conflict-free product writes), whole 16-step groups");
+    static_assert(UNITS % (64 * NH) == 0 && R * NP <= 60, "vmcnt is a 6-bit counter");
+    static_assert(NH >= 2 && GS >= 4 && GS % 4 == 0, "stage geometry");
+    char* ringB = smem;
+    float* xs = (float*)(smem + GQ_SLOTS * SB);
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int K = p.K, S = p.S;
+    const int m = (S == 1) ? 0 : (int)(blockIdx.x % (unsigned)S);
+    const int wg = (S == 1) ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)S);
+    const size_t stream_bytes = (size_t)K * RW * 2;
+    const int nstages = (int)((stream_bytes + SA - 1) / SA);
+    const int nb_mine = (p.n_blocks - wg + p.n_wg - 1) / p.n_wg;       // row blocks wg, wg+n_wg, ...
+    const int T = nb_mine * nstages;                                   // stages of this workgroup
+    constexpr int NS = NW;                                             // every wave stages x
+    const int kpad = nstages * KS + 320;                               // launcher guarantees kpad <= X_CH*NS*512
+    const uint16_t* xrow = p.x + (size_t)m * K;
+
+    if (wave >= NCW) {
+        // ================================ helper waves ============================================
+        const int hw = wave - NCW;
+        u32x4 buf[R][NP];
+        uint4 xv[XCh<NORM>::value], nv[XCh<NORM>::value];
+        x_issue<NORM, NS>(p, xrow, wave, lane, xv, nv);
+        __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): x (and the norm weights) have landed (see gemv_chain_kernel)
+        const size_t last16 = stream_bytes - 16;
+        unsigned loff[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) loff[i] = (unsigned)(((i * NH + hw) * 64 + lane) * 16);
+        int ib = wg, is = 0, issued = 0;
+        auto issue_next = [&](u32x4 (&dst)[NP]) {
+            const size_t soff = (size_t)is * SA;
+            const char* sb = (const char*)p.w + (size_t)ib * stream_bytes + soff;     // wave-uniform
+            const unsigned lim = (soff + SA <= stream_bytes) ? 0xFFFFFFFFu : (unsigned)(last16 - soff);
+#pragma unroll
+            for (int i = 0; i < NP; i++) ld_nt_asm(dst[i], loff[i] < lim ? loff[i] : lim, sb);
+            if (issued + 1 < T) { issued++; if (++is == nstages) { is = 0; ib += p.n_wg; } }
+        };
+        constexpr bool late = NORM;                                    // the weight stream starts behind the norm's fold (see gemv_chain_kernel)
+        if (!late) {
+#pragma unroll
+            for (int j = 0; j < R; j++) issue_next(buf[j]);
+        }
+        x_store<NORM, NS>(p, xs, kpad, wave, lane, xv);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        TIMED_BARRIER();                                               // B1: xs (or the squares) are in LDS
+        if (NORM) {
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            rms_fold<NH>(p, xs, ringB, hw, lane, t_aux);               // X1, X2 inside
+            if (late) {                                                // the walker walks now: the issue stall costs nothing here
+#pragma unroll
+                for (int j = 0; j < R; j++) issue_next(buf[j]);
+            }
+            TIMED_BARRIER();                                           // B2: r published
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            if constexpr (NORM) x_normalize<NS>(p, xs, kpad, xs[kpad], wave, lane, xv, nv);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            TIMED_BARRIER();                                           // B3: xs normalised
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        // unit of load i: q = kc*RW + r (stage-local k-chunk kc, row r); its eight products are the slots j0, j0+1 of group kc/2
+        unsigned doff[NP]; int xoff[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            const int q = (i * NH + hw) * 64 + lane, kc = q / RW, r = q % RW;
+            const int j0 = (kc & 1) * 2, sw = (r >> 1) & 3;
+            doff[i] = (unsigned)((((kc >> 1) * RW + r) * 4 + (j0 ^ sw)) * 16);      // slot j0+1 sits at doff ^ 16 (j0 is even)
+            xoff[i] = kc * 8;
+        }
+        int st = 0;                                        // stage-in-block of the stage being converted
+        for (int it0 = 0; it0 <= T + 1; it0 += R) {
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const int t = it0 + j;
+                if (t <= T + 1) {
+                    if (t < T) {
+                        const long long tb_ = p.dbg ? clock64() : 0;
+                        wait_ring<(R - 1) * NP, NP>(buf[j]);           // stage t landed; R-1 younger stages stay in flight
+                        if (p.dbg) t_x += clock64() - tb_;
+                        char* dst = ringB + (size_t)(t % GQ_SLOTS) * SB;
+                        const float* xst = xs + (size_t)st * KS;
+                        float4 xa[NP], xb[NP];
+#pragma unroll
+                        for (int i = 0; i < NP; i++) { xa[i] = *(const float4*)(xst + xoff[i]); xb[i] = *(const float4*)(xst + xoff[i] + 4); }
+#pragma unroll
+                        for (int i = 0; i < NP; i++) {
+                            const u32x4 v = buf[j][i];
+                            // exact products (8-bit x 8-bit significands): val1F32 * val2F32, operations_lineartransform.go:60
+                            *(float4*)(dst + doff[i]) = mul4(xa[i], bf_lo(v.x), bf_hi(v.x), bf_lo(v.y), bf_hi(v.y));
+                            *(float4*)(dst + (doff[i] ^ 16u)) = mul4(xb[i], bf_lo(v.z), bf_hi(v.z), bf_lo(v.w), bf_hi(v.w));
+                        }
+                        if (++st == nstages) st = 0;
+                        __builtin_amdgcn_sched_barrier(0);             // refill AFTER the slot has been consumed (no register copies)
+                        issue_next(buf[j]);
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // ds_writes complete before the barrier
+                    TIMED_BARRIER();
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
+        DBG_EXIT();
+        return;
+    }
+    // ==================================== chain waves ==================================================
+    {
+        uint4 xv[XCh<NORM>::value], nv[XCh<NORM>::value];
+        x_issue<NORM, NS>(p, xrow, wave, lane, xv, nv);
+        LNB_STAMP(0);
+        x_store<NORM, NS>(p, xs, kpad, wave, lane, xv);
+        LNB_STAMP(1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        TIMED_BARRIER();                                               // B1
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        LNB_STAMP(2);
+        if (NORM) {
+            float r;
+            if (wave == 0) {
+                r = rms_scale_wide<NH>(p, xs, ringB, lane, t_aux);     // X1, X2 inside
+                LNB_STAMP(3);
+                if (lane == 0) xs[kpad] = r;
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                TIMED_BARRIER();                                       // B2
+                LNB_STAMP(4);
+            } else {
+                __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier();     // X1, X2
+                TIMED_BARRIER();                                       // B2
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                r = xs[kpad];
+            }
+            if constexpr (NORM) x_normalize<NS>(p, xs, kpad, r, wave, lane, xv, nv);
+            LNB_STAMP(5);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            TIMED_BARRIER();                                           // B3
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            LNB_STAMP(6);
+        }
+    }
+    if (p.dbg) { t_x = clock64() - t_begin; t_wait = 0; }              // (chain waves report the barrier wait of the main loop only)
+    __builtin_amdgcn_s_setprio(3);
+    constexpr int last_rows = RW - 16 * (NCW - 1);                     // rows of the last chain wave
+    const int rows_here = wave == NCW - 1 ? last_rows : 16;
+    const int rq = (lane >> 2) % rows_here, row = wave * 16 + rq, jq = lane & 3;
+    const char* const src0 = ringB + (size_t)((row * 4 + (jq ^ ((row >> 1) & 3))) * 16);
+    float acc[1] = {0.0f};
+    float4 pq[4];
+    int st = 0, blk = wg;
+    for (int it = 0; it <= T + 1; it++) {
+        if (it >= 2) {
+            const char* cur = src0 + (size_t)((it - 2) % GQ_SLOTS) * SB;
+            const char* nxt = src0 + (size_t)((it - 1) % GQ_SLOTS) * SB;       // complete since the last barrier (past the end: stale bytes, never added)
+            if (it == 2) { pq[0] = *(const float4*)cur; pq[1] = *(const float4*)(cur + RW * 64); pq[2] = *(const float4*)(cur + 2 * RW * 64); }
+#pragma unroll
+            for (int g = 0; g < GS; g++) {
+                pq[(g + 3) & 3] = g + 3 < GS ? *(const float4*)(cur + (g + 3) * (RW * 64)) : *(const float4*)(nxt + (g + 3 - GS) * (RW * 64));
+                __builtin_amdgcn_sched_barrier(0);                     // the read is issued HERE, three groups ahead of its adds
+                chain16q(acc[0], pq[g & 3]);                           // valDstF32 += p, k ascending (operations_lineartransform.go:63)
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if (++st == nstages) {                                     // end of a row block: write it out, start the next
+                gemv_epilogue<1, EPI, 4>(p, acc, m, blk * RW + row, jq == 0 && lane < rows_here * 4 && blk * RW + row < p.n_rows);
+                acc[0] = 0.0f; st = 0; blk += p.n_wg;
             }
         }
         TIMED_BARRIER();
@@ -2205,8 +2514,26 @@ static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
     return hipGetLastError();
 }
 
+template <int RW, int KS, int NH, int R, int EPI, bool NORM>
+static hipError_t launch_quad_t(const GemvParams* p, hipStream_t st) {
+    auto kfn = gemv_quad_kernel<RW, KS, NH, R, EPI, NORM>;
+    if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    constexpr int NW = gq_ncw(RW) + NH;
+    constexpr size_t SB = (size_t)RW * KS * 4;
+    if (p->K % KS) return hipErrorInvalidValue;                                  // whole stages only (auto_rw in lnb_api.cpp picks this layout accordingly)
+    const size_t lds = GQ_SLOTS * SB + xs_bytes(p->K, KS);
+    if (lds > 160 * 1024) return hipErrorInvalidValue;
+    if (xs_bytes(p->K, KS) / 4 > (size_t)XCh<NORM>::value * NW * 512) return hipErrorInvalidValue;     // x staging registers
+    if (NORM && (rms_scratch_bytes(NH) > GQ_SLOTS * SB || seq_leaf_size(p->K, NH * 64) > 256)) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3(NW * 64), lds, st, *p);
+    return hipGetLastError();
+}
+
 template <int EPI, bool NORM, int NCH>
 static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
+    // RW 24 (one chain; the 8B wq|wk|wv: 6144 rows = 256 blocks of 24, one per CU): quad-DPP chain waves fed through the LDS, 256-step
+    // stages, six helpers x 2 loads x 5 stages = 60 KiB in flight per CU
+    if constexpr (NCH == 1) if (rw == 24) return launch_quad_t<24, 256, 6, 5, EPI, NORM>(p, st);
     // stage geometry (one workgroup per CU).  SA = bf16 bytes per stage, R = stages in flight per helper.
     //  RW 16/32 plain (thin; chain bound): 8 KiB stages, 2 helpers x 4 loads x 7 stages = 56 KiB in flight per CU.
     //  RW 32 with the fused RMSNorm (wq|wk|wv): six helpers so that the exact parallel norm sum has 384 folding lanes, and

@@ -111,10 +111,29 @@ SEQ_HD int seq_apply_node(uint32_t& sb, const SeqNode& n) {
 // 4 (float4 reads), at least 8.  The last leaf may run past K: the terms there are +0 and change nothing.
 SEQ_HD int seq_leaf_size(int K, int lanes) { int l = (K + lanes - 1) / lanes; l = (l + 3) & ~3; return l < 8 ? 8 : l; }
 // fold `n` consecutive terms into a leaf node for the binade guessed from the approximate sums around them
-SEQ_HD SeqNode seq_leaf(const float* p, int n, float lo, float hi) {
+SEQ_HD SeqNode seq_leaf_steps(const float* p, int n, float lo, float hi) {      // the integer evaluation, term by term (kept as the checker of seq_leaf)
     SeqBlock b; b.c0 = 0; b.c1 = 0; b.e = seq_guess(lo, hi); b.ok = b.e != 0;
     for (int i = 0; i < n; i++) seq_step(b, p[i]);
     return seq_pack(b);
+}
+// The same node from TWO FLOATING-POINT SUMS (round 4; ~2 operations per term instead of ~27): the map M -> M + c_{M&1} holds for every
+// M of the binade, so c0 and c1 can be read off two simulated running sums, one started at the binade's smallest even significand
+// (s = 2^e, M = 2^23) and one at the smallest odd one (M = 2^23 + 1) -- the hardware's own round-to-nearest-even add does the work:
+//     c0 = bits(fl(..fl(2^e + p_0) + ..p_{n-1})) - bits(2^e),   c1 likewise from 2^e (1 + 2^-23).
+// Valid iff both sums are still inside the binade at the end (the terms are non-negative, so then they never left it; a term >= 2^e, an
+// infinity or a NaN ends outside).  f32 adds must be IEEE (denormals honoured, no contraction): -ffp-contract=off, as everywhere.
+SEQ_HD void seq_sim_init(int32_t e, float& s0, float& s1) { s0 = seq_u2f((uint32_t)e << 23); s1 = seq_u2f(((uint32_t)e << 23) | 1u); }
+SEQ_HD SeqNode seq_sim_node(int32_t e, float s0, float s1) {
+    const uint32_t u0 = seq_f2u(s0), u1 = seq_f2u(s1), B0 = (uint32_t)e << 23;
+    SeqNode n; n.a = 0; n.b = 0;
+    if (e > 0 && (u0 >> 23) == (uint32_t)e && (u1 >> 23) == (uint32_t)e) { n.a = ((uint32_t)e << 24) | (u0 - B0); n.b = u1 - (B0 | 1u); }
+    return n;
+}
+SEQ_HD SeqNode seq_leaf(const float* p, int n, float lo, float hi) {
+    const int32_t e = seq_guess(lo, hi);
+    float s0, s1; seq_sim_init(e, s0, s1);
+    for (int i = 0; i < n; i++) { s0 = s0 + p[i]; s1 = s1 + p[i]; }
+    return seq_sim_node(e, s0, s1);
 }
 
 // ---- segmented inclusive scan of leaf maps (one wave = 64 leaves) -------------------------------------------------
@@ -124,8 +143,11 @@ SEQ_HD int seq_is_start(int lane, const SeqNode& me, const SeqNode& left, int fo
     return (lane == 0 || e == 0u || el == 0u || e != el || forced) ? 1 : 0;
 }
 // one Hillis-Steele step for a lane that is not cut yet (f == 0): absorb the run that ends right in front of this one
-SEQ_HD void seq_scan_step(SeqNode& n, int& f, int& start, const SeqNode& o, int of, int ostart) {
+// returns 0 when the composition did not go through (cannot happen inside a verified binade): the lane is cut there, the leaves in
+// front of it are then covered by no item, and the folding wave reports it so that the walker checks every record's `start` (rms_walk_heap)
+SEQ_HD int seq_scan_step(SeqNode& n, int& f, int& start, const SeqNode& o, int of, int ostart) {
     const SeqNode h = seq_compose(o, n);
-    if (h.a >> 24) { n = h; f = of; start = ostart; }
-    else f = 1;                                   // (cannot happen inside a verified binade; the walker checks `start` anyway)
+    if (h.a >> 24) { n = h; f = of; start = ostart; return 1; }
+    f = 1;
+    return 0;
 }

@@ -39,6 +39,8 @@ extern "C" float seqsum_scan(const float* p, int K, int nb, int* n_fast_out) {
 // walker adds the first `head` terms one by one, then visits only the run ends and the invalid leaves (item mask),
 // applying the run's composed map when it starts exactly at the walker's position and verifies, else replaying the
 // leaves' terms.  Returns the sum; *visits = items visited, *raw = leaves replayed.
+static long leaf_mismatch = 0;
+extern "C" long seqsum_leaf_mismatches() { return leaf_mismatch; }
 extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, int* visits, int* raw) {
     const int LEAF = seq_leaf_size(K, NH * 64), nleaf = (K + LEAF - 1) / LEAF, TB = NH * 64;
     std::vector<float> pv((size_t)TB * LEAF + 64, 0.0f);
@@ -62,12 +64,19 @@ extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, in
     head = headleaf * LEAF;
     std::vector<SeqNode> rec((size_t)TB);
     std::vector<uint64_t> items(NH);
+    std::vector<int> scan_failed(NH, 0);
     for (int g = 0; g < NH; g++) {
         SeqNode n[64]; int f[64], st[64];
         for (int l = 0; l < 64; l++) {
             const int b = g * 64 + l;
             n[l].a = 0; n[l].b = 0;
-            if (b < nleaf) n[l] = seq_leaf(p + (size_t)b * LEAF, LEAF, lo[b], hi[b]);
+            if (b < nleaf) {
+                n[l] = seq_leaf(p + (size_t)b * LEAF, LEAF, lo[b], hi[b]);
+                // the two-sums evaluation (device path) against the integer one, term by term: same node whenever the integer one is valid;
+                // where only the simulated one is valid (it may accept what the conservative integer test rejects) the walk still verifies it
+                const SeqNode chk = seq_leaf_steps(p + (size_t)b * LEAF, LEAF, lo[b], hi[b]);
+                if ((chk.a >> 24) && (chk.a != n[l].a || chk.b != n[l].b)) leaf_mismatch++;
+            }
             if (b < nleaf && bs[b] == 0.0f && !(n[l].a >> 24)) n[l].a = SEQ_ZERO_LEAF;
         }
         for (int l = 0; l < 64; l++) f[l] = seq_is_start(l, n[l], l ? n[l - 1] : n[l], g * 64 + l == headleaf);
@@ -78,7 +87,7 @@ extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, in
             SeqNode nn[64]; int ff[64], ss[64];
             for (int l = 0; l < 64; l++) {
                 nn[l] = n[l]; ff[l] = f[l]; ss[l] = st[l];
-                if (l >= d && !f[l]) seq_scan_step(nn[l], ff[l], ss[l], n[l - d], f[l - d], st[l - d]);
+                if (l >= d && !f[l]) scan_failed[g] |= !seq_scan_step(nn[l], ff[l], ss[l], n[l - d], f[l - d], st[l - d]);
             }
             for (int l = 0; l < 64; l++) { n[l] = nn[l]; f[l] = ff[l]; st[l] = ss[l]; }
         }
@@ -101,8 +110,11 @@ extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, in
             if (i >= nloc) break;
             nv++;
             SeqNode n = rec[(size_t)g * 64 + i];
-            const int st = (int)(n.b >> 24); n.b &= 0xFFFFFFu;
-            if (st > pos && ((((1ull << st) - 1ull) & (~0ull << pos)) & ~zm) == 0ull) pos = st;   // zeros: nothing to add
+            int st = (int)(n.b >> 24); n.b &= 0xFFFFFFu;
+            // rms_walk_fast (lnb_kernels.hip): the items tile the leaves by construction unless a composition of the scan failed, so the
+            // record's start is only checked then (rms_walk_heap); a replay starts behind the previous item either way
+            if (!scan_failed[g]) st = pos;
+            else if (st > pos && ((((1ull << st) - 1ull) & (~0ull << pos)) & ~zm) == 0ull) pos = st;   // zeros: nothing to add
             if (!(st == pos && seq_apply_node(sb, n))) {
                 float f = seq_u2f(sb);
                 for (int l = pos; l <= i; l++) { const float* q = p + ((size_t)g * 64 + l) * LEAF; for (int t = 0; t < LEAF; t++) f += q[t]; nr++; }

@@ -60,6 +60,9 @@ def test_linear_reference_kat_on_gpu(lnb):
     # rw 4 with K a multiple of 512 = rowcast_lds_kernel (helper-fed chain waves): one stage, stage counts 2, 3 (the ring's unroll), 4, 5;
     # ragged N; more 16-row blocks than CUs (persistent blocks); several x rows; the longest K it accepts
     (1, 16, 512, 4), (1, 64, 1024, 4), (3, 100, 1536, 4), (1, 37, 2048, 4), (2, 24, 2560, 4), (2, 5000, 512, 4), (1, 8200, 1024, 4), (1, 48, 16384, 4),
+    # rw 24 = gemv_quad_kernel (quad-DPP chain waves fed through the LDS; K a multiple of its 256-step stages): one / two / three / many
+    # stages, ragged N (the second chain wave's shadow lanes, a partial last block), more blocks than CUs, several x rows, the 8B wq|wk|wv
+    (1, 24, 256, 24), (1, 48, 512, 24), (3, 100, 768, 24), (1, 17, 1024, 24), (2, 7000, 512, 24), (1, 6144, 4096, 24), (2, 50, 8192, 24),
 ])
 def test_linear_bit_exact(lnb, rows, n, k, rw):
     rng = np.random.default_rng(rows * 1000003 + n * 101 + k + rw)
@@ -103,7 +106,7 @@ def _same_bits_or_both_nan(a, b):
     return bool(((a == b) | (np.isnan(fa) & np.isnan(fb))).all())
 
 
-@pytest.mark.parametrize("rows,rw", [(1, 16), (1, 64), (1, 4), (3, 32), (20, 16), (20, 4), (130, 64)])
+@pytest.mark.parametrize("rows,rw", [(1, 16), (1, 64), (1, 4), (3, 32), (20, 16), (20, 4), (130, 64), (1, 24), (2, 24)])
 def test_linear_special_values(lnb, rows, rw):
     """Values outside the comfortable range, through every exact kernel family (chain GEMV, row-broadcast GEMV, f32 matrix-core GEMM):
     signed zeros (the chain starts at +0, so a sum of -0 products is +0), +-inf and NaN in weights and activations (inf - inf, 0 * inf),
@@ -170,7 +173,8 @@ def test_linear_order_sensitivity_guard(lnb):
     assert (y == orc_linear(x, w)).all()
 
 
-@pytest.mark.parametrize("rows,n,k,rw", [(1, 256, 256, 16), (4, 96, 512, 32), (1, 6144, 4096, 16), (2, 1024, 4096, 64)])
+@pytest.mark.parametrize("rows,n,k,rw", [(1, 256, 256, 16), (4, 96, 512, 32), (1, 6144, 4096, 16), (2, 1024, 4096, 64),
+                                         (1, 48, 256, 24), (3, 100, 1024, 24), (1, 6144, 4096, 24)])
 def test_rmsnorm_linear_bit_exact(lnb, rows, n, k, rw):
     rng = np.random.default_rng(n + k + rw)
     x = bf(rng.standard_normal((rows, k)) * 3.0)
@@ -182,7 +186,7 @@ def test_rmsnorm_linear_bit_exact(lnb, rows, n, k, rw):
     assert (y == orc_linear(xn, w)).all()
 
 
-@pytest.mark.parametrize("k,rw", [(4096, 16), (4096, 64), (8192, 32), (512, 16), (3072, 64), (64, 16)])
+@pytest.mark.parametrize("k,rw", [(4096, 16), (4096, 64), (8192, 32), (512, 16), (3072, 64), (64, 16), (4096, 24), (512, 24)])
 def test_rmsnorm_exact_parallel_sum_adversarial(lnb, k, rw):
     """The RMSNorm sum of squares is evaluated by the exact parity-map tree (rms_scale_wide); inputs chosen to stress it:
     huge dynamic range, ties everywhere (powers of two), sparse rows, subnormal squares, outliers, leading zeros."""
@@ -211,7 +215,7 @@ def test_rmsnorm_exact_parallel_sum_adversarial(lnb, k, rw):
     assert (y == orc_linear(xn, w)).all()
 
 
-@pytest.mark.parametrize("k,rw,reps", [(4096, 32, 1), (512, 16, 1), (4096, 64, 1), (4096, 32, 2)])
+@pytest.mark.parametrize("k,rw,reps", [(4096, 32, 1), (512, 16, 1), (4096, 64, 1), (4096, 32, 2), (4096, 24, 1), (1024, 24, 2)])
 def test_rmsnorm_rows_with_non_finite_and_overflowing_squares(lnb, k, rw, reps):
     """Rows the parity-map evaluation of the norm sum was not designed around: inf / NaN activations, squares that overflow f32
     (|x| > 1.8e19), a running sum that overflows after a few terms, squares that underflow to zero.  The reference just keeps adding
@@ -523,6 +527,36 @@ def test_prefill_attention_tiles_ragged_rows_and_head_dims(lnb, heads, kv_heads,
         assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and to == tg
         tok = to
     gc.close(); oc.close(); gm.close(); om.close()
+
+
+def test_rw24_quad_chain_blocks_bit_exact(lnb, tiny_pair, monkeypatch):
+    """The 8B wq|wk|wv matrix is stored as 256 blocks of 24 rows (gemv_quad_kernel: four lanes per row, RoPE partner four lanes away,
+    the second chain wave half full).  Force the same kernel on the tiny model (dim 256 = one 256-step stage; q + k + v rows not a
+    multiple of 24: a partial last block) and compare prefill, decode, the KV cache and the captured greedy loop with the oracle."""
+    om, _ = tiny_pair
+    monkeypatch.setenv("LNB_RW_QKV", "24")
+    gm = lnb.LlamaTransformer(**TINY).fill_synthetic(1234).finalize()
+    monkeypatch.delenv("LNB_RW_QKV")
+    oc, gc = orc.Context(om, 48), lnb.InferenceContext(gm, 48)
+    toks = orc.synth_tokens(5, 7, TINY["vocab_size"])
+    lo, ao = oc.forward(toks, 0)
+    lg, ag = gc.Forward(toks, 0)
+    assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag
+    tok = ag
+    for i in range(8):
+        lo, to = oc.forward([tok], 7 + i)
+        lg, tg = gc.Forward(np.array([tok], dtype=np.int32), 7 + i)
+        assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and to == tg
+        tok = to
+    for l in range(TINY["n_layers"]):
+        assert (oc.cache(l, 0)[:15] == gc.CacheK(l)[:15]).all() and (oc.cache(l, 1)[:15] == gc.CacheV(l)[:15]).all(), l
+    more, _ = gc.decode_greedy(tok, 15, 6)
+    ref = []
+    for i in range(6):
+        _, tok = oc.forward([tok], 15 + i, want_logits=False)
+        ref.append(tok)
+    assert [int(t) for t in more] == [int(t) for t in ref]
+    gc.close(); oc.close(); gm.close()
 
 
 def test_rw56_two_chain_blocks_bit_exact(lnb, tiny_pair, monkeypatch):

@@ -20,6 +20,7 @@ def lib():
     L = C.CDLL(SO)
     L.seqsum_ref.restype = C.c_float; L.seqsum_scan.restype = C.c_float
     L.seqsum_ref.argtypes = [C.c_void_p, C.c_int]; L.seqsum_scan.argtypes = [C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.seqsum_leaf_mismatches.restype = C.c_long
     L.seqsum_tree.restype = C.c_float
     L.seqsum_tree.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]
     return L
@@ -86,3 +87,6 @@ def test_tree_walk_is_bit_identical_to_the_sequential_sum(lib):
             visits.append(nv.value); raws.append(nr.value)
     # gaussian activations: the serial part is a few dozen node visits instead of 4096 dependent adds
     assert np.mean(visits) < 40 and np.mean(raws) < 12, (np.mean(visits), np.mean(raws))
+    # the device's two-sums leaf evaluation (seq_leaf) never disagreed with the term-by-term integer evaluation (seq_leaf_steps)
+    assert lib.seqsum_leaf_mismatches() == 0
+    print("items per row %.1f, replayed leaves per row %.1f" % (np.mean(visits), np.mean(raws)))

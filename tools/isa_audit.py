@@ -152,7 +152,7 @@ def main(asm_path=None):
         txt = open(asm).read().split("\n")
     funcs, cur = {}, None
     for i, ln in enumerate(txt):
-        m = re.match(r"^(_Z1[478](?:gemv_chain|attn_exact|rowcast|rowcast_lds|mfma_stream|gemm_stream)_kernel\S*):", ln)
+        m = re.match(r"^(_Z1[4678](?:gemv_chain|gemv_quad|attn_exact|rowcast|rowcast_lds|mfma_stream|gemm_stream)_kernel\S*):", ln)
         if m:
             cur = []; funcs[m.group(1)] = cur
             continue
@@ -166,7 +166,7 @@ def main(asm_path=None):
     for name, lines in funcs.items():
         # gemv_chain_kernel: the ring lives in helper waves that always run with a full EXEC mask, so the structurizer's
         # execz skip-edges are dead there; the other kernels are analysed with both edges
-        v = audit_function(lines, execz_both=not name.startswith("_Z17gemv_chain"))
+        v = audit_function(lines, execz_both=not (name.startswith("_Z17gemv_chain") or name.startswith("_Z16gemv_quad")))
         reach = sum(1 for _, l in lines if "RING_RETIRE" in l)
         body = "\n".join(l for _, l in lines)
         n_loads = body.count("RING_LOAD")
