@@ -1166,7 +1166,7 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
 // stages of RL_SC chunks in a three-slot ring, one s_barrier per stage: at iteration t the helpers write stage t while the chain
 // waves add stage t-2 and prefetch the first chunk of stage t-1 (complete since the previous barrier), so no LDS round trip is
 // exposed at a stage boundary.  x lives in the LDS as raw bf16 (K * 2 bytes), transposed per chunk like the weights.
-// Same weight layout as rowcast_kernel (tag RW 4); requires K % (128 * RL_SC) == 0 (the launcher falls back otherwise).
+// Same weight layout as rowcast_kernel (tag RW 4); requires K % (128 * RL_SC) == 0 and at least two stages (the launcher falls back otherwise).
 // grid.x = S * n_wg, block = 512, dynamic LDS = rl_lds_bytes(K).
 // ------------------------------------------------------------------------------------------------
 constexpr int RL_SC = 4;                                    // 128-step chunks per stage
@@ -1206,10 +1206,6 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
     const unsigned voff = (unsigned)lane * 16u;
     const int T = NS * RL_SC;
     int ic = 0, issued = 0;
-    auto issue_next = [&](u32x4& dst) {
-        ld_nt_asm(dst, voff, sb);
-        if (issued + 1 < T) { issued++; sb += 1024; if (++ic == nchunks) { ic = 0; sb += blk_jump; } }
-    };
     auto stage_x = [&]() {
 #pragma unroll
         for (int i = 0; i < RL_XU; i++) {
@@ -1226,36 +1222,55 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
         if (p.dbg) t_x = clock64() - t_begin;
     };
 #define RL_BARRIER() do { if (p.dbg) { const long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
+    // Schedule (iterations it = 0 .. NS, one s_barrier each).  Iteration 0 fills the ring from BOTH sides: the helper makes stage 0, the
+    // chain wave -- idle until there is something to add -- makes stage 1 from four weight loads of its own (otherwise it sits through
+    // two helper stages, ~4 k cycles per launch measured).  From then on: iteration it, the helper writes stage it+1 (slot (it+1) % 3),
+    // the chain wave adds stage it-1 (slot (it-1) % 3) and prefetches the first chunk of stage it (complete since the previous barrier),
+    // so no LDS round trip is exposed at a stage boundary.
+    auto products = [&](float4& pa, float4& pb, const u32x4& b, const uint4& xq) {      // exact: 8-bit x 8-bit significands (operations_lineartransform.go:60)
+        pa = mul4(make_float4(bf_lo(xq.x), bf_hi(xq.x), bf_lo(xq.y), bf_hi(xq.y)), bf_lo(b.x), bf_hi(b.x), bf_lo(b.y), bf_hi(b.y));
+        pb = mul4(make_float4(bf_lo(xq.z), bf_hi(xq.z), bf_lo(xq.w), bf_hi(xq.w)), bf_lo(b.z), bf_hi(b.z), bf_lo(b.w), bf_hi(b.w));
+    };
+    const char* xl = (const char*)xb + (size_t)(lane & 15) * 16;
     if (wave >= 4) {
-        // ================================ helper: products of chain wave `pair` ======================================
-        // (the two roles are separate straight-line paths from here on: tools/isa_audit.py follows the ring registers on this one only)
+        // ================================ helper: stage 0, then stages 2, 3, ... of chain wave `pair` ===================
+        // (the two roles are separate straight-line paths from here on: tools/isa_audit.py follows each role's ring registers on its own path)
+        const int Th = T - RL_SC;                            // loads of this wave: every chunk but the four of stage 1
+        auto advance = [&]() { sb += 1024; if (++ic == nchunks) { ic = 0; sb += blk_jump; } };
+        auto issue_h = [&](u32x4& dst) {
+            ld_nt_asm(dst, voff, sb);
+            if (issued + 1 < Th) { issued++; advance(); if (issued == RL_SC) { for (int j = 0; j < RL_SC; j++) advance(); } }   // past the last chunk: stays put, re-reads
+        };
+        // the first stage's loads in front of the x scatter, the rest of the ring behind it: twelve loads per wave issued into the cold
+        // memory pipeline stall the issuing wave, and with it the scatter every wave waits for (prologue 2.9 k -> 4.4 k cycles measured)
 #pragma unroll
-        for (int j = 0; j < RL_R; j++) issue_next(buf[j]);
+        for (int j = 0; j < RL_SC; j++) issue_h(buf[j]);
         stage_x();
-        const char* xl = (const char*)xb + (size_t)(lane & 15) * 16;
+#pragma unroll
+        for (int j = RL_SC; j < RL_R; j++) issue_h(buf[j]);
         char* const dst0 = ring + (size_t)pair * (RL_SC * 2048) + (size_t)lane * 16;
         int c = 0;
-        for (int it0 = 0; it0 < NS + 2; it0 += RL_SLOTS) {
+        for (int it0 = 0; it0 <= NS; it0 += RL_SLOTS) {
 #pragma unroll
             for (int u = 0; u < RL_SLOTS; u++) {
                 const int it = it0 + u;
-                if (it < NS + 2) {
-                    if (it < NS) {
-                        char* dst = dst0 + (size_t)u * RL_STAGE;
+                if (it <= NS) {
+                    if (it == 0 || it + 1 < NS) {
+                        char* dst = dst0 + (size_t)(it == 0 ? 0 : (u + 1) % RL_SLOTS) * RL_STAGE;
 #pragma unroll
                         for (int cc = 0; cc < RL_SC; cc++) {
                             u32x4& b = buf[u * RL_SC + cc];
                             asm volatile("s_waitcnt vmcnt(%1) ; RING_RETIRE %0" : "+v"(b) : "n"(RL_R - 1) : "memory");
                             const uint4 xq = *(const uint4*)(xl + (size_t)c * 256);
-                            // exact products (8-bit x 8-bit significands): val1F32 * val2F32, operations_lineartransform.go:60
-                            float4 pa = mul4(make_float4(bf_lo(xq.x), bf_hi(xq.x), bf_lo(xq.y), bf_hi(xq.y)), bf_lo(b.x), bf_hi(b.x), bf_lo(b.y), bf_hi(b.y));
-                            float4 pb = mul4(make_float4(bf_lo(xq.z), bf_hi(xq.z), bf_lo(xq.w), bf_hi(xq.w)), bf_lo(b.z), bf_hi(b.z), bf_lo(b.w), bf_hi(b.w));
+                            float4 pa, pb;
+                            products(pa, pb, b, xq);
                             // pin the products in front of the refill (else hipcc sinks the unpack behind the asm that reloads b)
                             asm volatile("" : "+v"(pa.x), "+v"(pa.y), "+v"(pa.z), "+v"(pa.w), "+v"(pb.x), "+v"(pb.y), "+v"(pb.z), "+v"(pb.w));
-                            issue_next(b);
+                            issue_h(b);
                             *(float4*)(dst + cc * 2048) = pa; *(float4*)(dst + cc * 2048 + 1024) = pb;
                             if (++c == nchunks) c = 0;
                         }
+                        if (it == 0) c = (2 * RL_SC) % nchunks;            // stage 1 is the chain wave's
                     }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");     // ds_writes complete before the barrier
                     RL_BARRIER();
@@ -1265,41 +1280,59 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
         asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
     } else {
         // ================================ chain wave: 4 rows, one per DPP row =========================================
+        u32x4 cb[RL_SC];
+#pragma unroll
+        for (int j = 0; j < RL_SC; j++) ld_nt_asm(cb[j], voff, sb + (size_t)(RL_SC + j) * 1024);      // stage 1: chunks 4 .. 7 of this wave's first tile (K >= 1024)
         stage_x();
-        __builtin_amdgcn_s_setprio(3);
         const char* const src0 = ring + (size_t)pair * (RL_SC * 2048) + (size_t)lane * 16;
+        {   // iteration 0: stage 1 into slot 1
+            char* dst = ring + (size_t)pair * (RL_SC * 2048) + (size_t)lane * 16 + (size_t)1 * RL_STAGE;
+#pragma unroll
+            for (int cc = 0; cc < RL_SC; cc++) {
+                if (cc == 0) asm volatile("s_waitcnt vmcnt(3) ; RING_RETIRE %0" : "+v"(cb[0]) :: "memory");
+                if (cc == 1) asm volatile("s_waitcnt vmcnt(2) ; RING_RETIRE %0" : "+v"(cb[1]) :: "memory");
+                if (cc == 2) asm volatile("s_waitcnt vmcnt(1) ; RING_RETIRE %0" : "+v"(cb[2]) :: "memory");
+                if (cc == 3) asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE %0" : "+v"(cb[3]) :: "memory");
+                const uint4 xq = *(const uint4*)(xl + (size_t)(RL_SC + cc) * 256);
+                float4 pa, pb;
+                products(pa, pb, cb[cc], xq);
+                *(float4*)(dst + cc * 2048) = pa; *(float4*)(dst + cc * 2048 + 1024) = pb;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            RL_BARRIER();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+        __builtin_amdgcn_s_setprio(3);
         float acc = 0.0f;
         float4 ba[2], bb[2];                                 // products of the chunk being added / of the next one
+        ba[0] = *(const float4*)src0; bb[0] = *(const float4*)(src0 + 1024);     // stage 0, chunk 0
         int sdone = 0, blk = wg;
-        for (int it0 = 0; it0 < NS + 2; it0 += RL_SLOTS) {
+        for (int it0 = 0; it0 <= NS; it0 += RL_SLOTS) {
 #pragma unroll
             for (int u = 0; u < RL_SLOTS; u++) {
                 const int it = it0 + u;
-                if (it < NS + 2) {
-                    if (it >= 2) {
-                        // stage it-2 lives in slot (u+1) % 3, stage it-1 (complete since the last barrier) in slot (u+2) % 3
-                        const char* cur = src0 + (size_t)((u + 1) % RL_SLOTS) * RL_STAGE;
-                        const char* nxt = src0 + (size_t)((u + 2) % RL_SLOTS) * RL_STAGE;
-                        if (it == 2) { ba[0] = *(const float4*)cur; bb[0] = *(const float4*)(cur + 1024); }
+                if (it >= 1 && it <= NS) {
+                    // stage it-1 lives in slot (u+2) % 3, stage it (complete since the last barrier) in slot u
+                    const char* cur = src0 + (size_t)((u + 2) % RL_SLOTS) * RL_STAGE;
+                    const char* nxt = src0 + (size_t)u * RL_STAGE;
 #pragma unroll
-                        for (int cc = 0; cc < RL_SC; cc++) {
-                            const char* q = cc + 1 < RL_SC ? cur + (cc + 1) * 2048 : nxt;      // past the last stage: stale bytes, never added
-                            ba[(cc + 1) & 1] = *(const float4*)q; bb[(cc + 1) & 1] = *(const float4*)(q + 1024);
-                            __builtin_amdgcn_sched_barrier(0);         // the reads are issued HERE, in front of the chunk's 128 adds
-                            const float4 a = ba[cc & 1], b = bb[cc & 1];
-                            const float pr[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
-                            chain128(acc, pr);                         // valDstF32 += p, k ascending (operations_lineartransform.go:63)
-                            __builtin_amdgcn_sched_barrier(0);
+                    for (int cc = 0; cc < RL_SC; cc++) {
+                        const char* q = cc + 1 < RL_SC ? cur + (cc + 1) * 2048 : nxt;      // past the last stage: stale bytes, never added
+                        ba[(cc + 1) & 1] = *(const float4*)q; bb[(cc + 1) & 1] = *(const float4*)(q + 1024);
+                        __builtin_amdgcn_sched_barrier(0);         // the reads are issued HERE, in front of the chunk's 128 adds
+                        const float4 a = ba[cc & 1], b = bb[cc & 1];
+                        const float pr[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+                        chain128(acc, pr);                         // valDstF32 += p, k ascending (operations_lineartransform.go:63)
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    if (++sdone == nst) {                          // end of this wave's 4 rows
+                        const int n = blk * 16 + pair * 4 + (lane >> 4);
+                        if ((lane & 15) == 0 && n < p.n_rows) {
+                            const size_t o = (size_t)m * p.n_rows + n;
+                            if (EPI == EPI_RESID) p.out[o] = bf_trunc(bf_wide(p.res[o]) + bf_wide(bf_trunc(acc)));   // ml.Add, operations_impl.go:320-332
+                            else p.out[o] = bf_trunc(acc);
                         }
-                        if (++sdone == nst) {                          // end of this wave's 4 rows
-                            const int n = blk * 16 + pair * 4 + (lane >> 4);
-                            if ((lane & 15) == 0 && n < p.n_rows) {
-                                const size_t o = (size_t)m * p.n_rows + n;
-                                if (EPI == EPI_RESID) p.out[o] = bf_trunc(bf_wide(p.res[o]) + bf_wide(bf_trunc(acc)));   // ml.Add, operations_impl.go:320-332
-                                else p.out[o] = bf_trunc(acc);
-                            }
-                            acc = 0.0f; sdone = 0; blk += p.n_wg;
-                        }
+                        acc = 0.0f; sdone = 0; blk += p.n_wg;
                     }
                     RL_BARRIER();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -2566,7 +2599,7 @@ template <int EPI> static hipError_t launch_rowcast(const GemvParams* p, hipStre
     if ((p->K & 127) || p->K > 16384) return hipErrorInvalidValue;              // x staging: 8 x 16 B per thread, K*4 bytes of LDS
     // helper-fed chain waves (rowcast_lds_kernel) whenever K is a whole number of its 512-step stages; LNB_ROWCAST_LDS=0: the self-feeding kernel
     static const int use_lds = [] { const char* s = getenv("LNB_ROWCAST_LDS"); return s && *s ? atoi(s) : 1; }();
-    if (use_lds && p->K % (128 * RL_SC) == 0 && rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0) <= 160 * 1024) {
+    if (use_lds && p->K % (128 * RL_SC) == 0 && p->K >= 2 * 128 * RL_SC && rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0) <= 160 * 1024) {
         hipLaunchKernelGGL(kl, dim3((unsigned)(p->S * p->n_wg)), dim3(512), rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0), st, *p);
         return hipGetLastError();
     }
