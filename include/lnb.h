@@ -144,7 +144,8 @@ int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int
  *   most ~7.8 K positions (head_dim 128).  A context must not be used by another call while a batch call that contains it runs.
  * lnb_batch_decode: sequence s continues from tokens[s] at position start_pos[s] (different positions are fine); n_steps greedy steps for
  *   all of them as replays of one captured hipGraph; out_tokens[s * n_steps + i] = token i of sequence s.  Afterwards every context's
- *   cache holds its new rows: lnb_forward / lnb_decode_greedy / another batch may continue it. */
+ *   cache holds its new rows: lnb_forward / lnb_decode_greedy / another batch may continue it.  * Lifetime: a batch holds its member contexts' device pointers (tables, captured graphs): lnb_ctx_destroy on a member FAILS while the
+ * batch is alive -- destroy the batch first (the Go binding's Close does it in that order). */
 typedef struct lnb_batch lnb_batch;
 int lnb_model_enable_batch(lnb_model* m);
 int64_t lnb_model_batch_bytes(lnb_model* m);
@@ -208,6 +209,11 @@ int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, cons
  * the n tokens go to the pinned log, *token_slot_out = the first of n consecutive slots), send = hidden states [n, dim] to rank + 1 (last
  * rank: the n token words to rank 0), recv = the mirror image.  Same grouping, events and transports as lnb_pipeline_tick. */
 int lnb_batch_set_state(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos);
+/* pipeline ticks only enqueue: a token id outside the vocabulary (its embedding row is not gathered) or an all-NaN logits row (argmax -1,
+ * operations_impl.go:529-541) is latched in a device word instead of failing a call.  lnb_batch_check_error waits for the batch's stream,
+ * returns an error if the word was set since the last check (or the last lnb_batch_set_state) and clears it.  Call it after
+ * lnb_pipeline_sync, before trusting lnb_pipeline_read_tokens.  (lnb_batch_decode checks for itself.) */
+int lnb_batch_check_error(lnb_batch* b);
 int lnb_pipeline_tick_batch(lnb_pipe* p, lnb_batch* run, lnb_batch* send, lnb_batch* recv, int* token_slot_out);
 int lnb_pipeline_sync(lnb_pipe* p);
 /* the number of ranks the exchange spans as the TRANSPORT reports it (ncclCommCount of the communicator; pipes joined to an in-process

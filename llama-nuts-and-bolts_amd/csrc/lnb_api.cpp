@@ -116,6 +116,7 @@ struct lnb_ctx {
     int32_t* h_io = nullptr;               // pinned host words of lnb_forward_stage_begin/_end: [0] argmax, [1] token error, [2..] tokens
     bool pending = false, pending_tokens = false, pending_argmax = false;
     int mode = LNB_MODE_EXACT;             // LNB_MODE_FAST: split-K kernels of lnb_fast.hip (tolerance mode, opt-in)
+    int batch_users = 0;                   // live lnb_batch handles this context is a member of: their device tables and captured graphs hold its raw pointers
     // long-context decode attention (attn_long_*_kernel): used for one-token calls whose context exceeds attn_long_T
     double* e_buf = nullptr; double* z_part = nullptr; int* zseq_count = nullptr;
     int attn_long_T = 0; int force_zseq = 0;
@@ -510,6 +511,9 @@ static int ctx_alloc(lnb_ctx* c) {
 
 extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     if (!c) return 0;
+    // a batch bakes its members' device pointers (state words, token words, caches) into its tables and captured graphs: freeing a member
+    // under it would make the next lnb_batch_decode / lnb_pipeline_tick_batch read and write freed memory.  Destroy the batch first.
+    if (c->batch_users > 0) return fail("context is a member of %d live batch(es): lnb_batch_destroy them first", c->batch_users);
     hipSetDevice(c->m->device);
     if (c->stream) hipStreamSynchronize(c->stream);
     drop_graphs(c);
@@ -985,7 +989,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
 
 // ---- batched exact decode: several independent sequences per pass over the weights --------------------------------------------------
 // The reference runs one generation per InferenceContext (src/inference/inference.go:174) and shares the weight matrix across the rows of
-// a call (src/ml/operations_lineartransform.go:173-193).  A batch groups up to 16 contexts of ONE whole-model handle: per step every
+// a call (src/ml/operations_lineartransform.go:173-193).  A batch groups up to LNB_BATCH_MAX (128) contexts of ONE whole-model handle: per step every
 // sequence's one-token Forward + Argmax happens in a single pass over the weights -- the sequences are the 16 columns of
 // v_mfma_f32_16x16x4_f32, which evaluates each column's k-ordered chain exactly (lnb_batch_kernels.h) -- with per-sequence position, RoPE
 // row, KV append and attention.  Every sequence's tokens and caches are bit-identical to its single-sequence run.
@@ -995,7 +999,7 @@ struct lnb_batch {
     BatchTab* tab = nullptr; BatchKV* kv = nullptr;
     uint16_t *x = nullptr, *h = nullptr, *xt = nullptr, *q = nullptr, *att_xt = nullptr, *ffn_xt = nullptr, *logits = nullptr;
     int* derr = nullptr; int32_t *d_tokens = nullptr, *d_pos = nullptr; int32_t* h_io = nullptr;   // pinned: [0..MAX) tokens, [MAX..2 MAX) positions, [2 MAX] error word (MAX = LNB_BATCH_MAX)
-    hipGraphExec_t graph = nullptr; int lds_T = 0;
+    hipGraphExec_t graph = nullptr; int lds_T = 0; bool counted = false;
     // pipeline stage (lnb_pipeline_tick_batch): the contiguous token words exchanged between the last and the first stage, the stage step
     // as a captured graph, events towards / from the exchange stream (as lnb_ctx has them for single-sequence ticks)
     int32_t* ring = nullptr; hipGraphExec_t stage_graph = nullptr;
@@ -1032,6 +1036,7 @@ extern "C" int lnb_model_enable_batch(lnb_model* m) {
     if (rc || e != hipSuccess) {                             // (out of memory on a model that fills the HBM: the single-sequence paths stay usable)
         for (auto& L : m->layers) { hipFree(L.m_wqkv); hipFree(L.m_wo); hipFree(L.m_w13); hipFree(L.m_w2); L.m_wqkv = L.m_wo = L.m_w13 = L.m_w2 = nullptr; }
         hipFree(m->m_output); m->m_output = nullptr; m->batch_bytes = 0;
+        (void)hipGetLastError();                             // the failed hipMalloc leaves the thread's last-error set: every launcher ends with hipGetLastError()
         if (!rc) return fail("lnb_model_enable_batch: %s", hipGetErrorString(e));
         return -1;
     }
@@ -1044,6 +1049,7 @@ extern "C" int lnb_batch_destroy(lnb_batch* b) {
     if (!b) return 0;
     hipSetDevice(b->m->device);
     if (b->stream) hipStreamSynchronize(b->stream);
+    if (b->counted) for (lnb_ctx* c : b->ctxs) c->batch_users--;
     if (b->graph) hipGraphExecDestroy(b->graph);
     hipFree(b->tab); hipFree(b->kv); hipFree(b->x); hipFree(b->h); hipFree(b->xt); hipFree(b->q); hipFree(b->att_xt); hipFree(b->ffn_xt); hipFree(b->logits);
     hipFree(b->derr); hipFree(b->d_tokens); hipFree(b->d_pos); hipFree(b->ring);
@@ -1076,7 +1082,7 @@ static int batch_alloc(lnb_batch* b) {
     HIPCHK(hipStreamSynchronize(b->stream));                 // (the host copies above are stack / vector memory)
     const size_t N = std::max(n, LNB_STREAM_COLS), dim = m->a.dim;
     auto zalloc = [&](uint16_t** p, size_t elems) -> int { HIPCHK(hipMalloc((void**)p, elems * 2)); HIPCHK(hipMemsetAsync(*p, 0, elems * 2, b->stream)); return 0; };
-    // up to 16 sequences: activations in the B-operand layout [K][16 sequences], the columns past n stay zero for ever; more: plain rows [n][K]
+    // 1..16 sequences: activations in the B-operand layout [K][16 sequences], the columns past n stay zero for ever; 17..128: plain rows [n][K]
     if (zalloc(&b->x, N * dim) || zalloc(&b->h, N * dim) || zalloc(&b->xt, N * dim) || zalloc(&b->q, N * m->q_dim) || zalloc(&b->att_xt, N * m->q_dim) ||
         zalloc(&b->ffn_xt, N * m->ffn_hidden) || (m->last() && zalloc(&b->logits, N * (size_t)m->a.vocab_size))) return -1;
     HIPCHK(hipMalloc((void**)&b->derr, 16)); HIPCHK(hipMemsetAsync(b->derr, 0, 16, b->stream));
@@ -1108,6 +1114,8 @@ extern "C" int lnb_batch_create(lnb_ctx* const* ctxs, int n, lnb_batch** out) {
         b->lds_T = std::max(b->lds_T, ctxs[s]->seq_len);
     }
     if (batch_alloc(b)) { lnb_batch_destroy(b); return -1; }
+    for (lnb_ctx* c : b->ctxs) c->batch_users++;
+    b->counted = true;
     *out = b;
     return 0;
 }
@@ -1262,9 +1270,22 @@ extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32
 // Every sequence's position (and, on the first stage, optionally its next input token) before a run of lnb_pipeline_tick_batch steps: the
 // positions then advance on the device with every step.  tokens == NULL keeps what each context's token word holds (what the
 // single-sequence prefill ticks left there).
+extern "C" int lnb_batch_check_error(lnb_batch* b) {
+    if (!b) return fail("null argument");
+    HIPCHK(hipSetDevice(b->m->device));
+    HIPCHK(hipStreamSynchronize(b->stream));
+    int h = 0;
+    HIPCHK(hipMemcpy(&h, b->derr, 4, hipMemcpyDeviceToHost));
+    if (h) {
+        HIPCHK(hipMemset(b->derr, 0, 4));
+        return fail("batched pipeline step: a token id outside the vocabulary (or an all-NaN logits row) in one of the batch's sequences since the last check");
+    }
+    return 0;
+}
 extern "C" int lnb_batch_set_state(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos) {
     if (!b || !start_pos) return fail("null argument");
     HIPCHK(hipSetDevice(b->m->device));
+    HIPCHK(hipMemsetAsync(b->derr, 0, 4, b->stream));        // a fresh run: forget what an earlier one latched
     for (int s = 0; s < b->n; s++) {
         lnb_ctx* c = b->ctxs[s];
         if (check_call(c, 1, start_pos[s])) return -1;

@@ -1,4 +1,4 @@
-// lnb_batch_kernels.h -- batched EXACT decode: up to 16 independent sequences per pass over the weights.  Included at the end of
+// lnb_batch_kernels.h -- batched EXACT decode: up to 128 independent sequences per pass over the weights (16 as matrix-instruction columns, more as rows).  Included at the end of
 // lnb_kernels.hip (one translation unit: it reuses the RMSNorm prologue, the epilogue arithmetic and the ring-load idiom defined there).
 //
 // Reference: the reference shares W across the rows of a call (src/ml/operations_lineartransform.go:173-193) and creates one context per

@@ -2731,7 +2731,7 @@ static hipError_t launch_attn_long(const AttnParams* p, hipStream_t st) {
 extern "C" size_t lnbk_attn_long_lds(int seq_len) { return alp_lds_bytes(seq_len); }
 extern "C" size_t lnbk_attn_short_lds(int seq_len, int hd);
 
-static bool attn_batch_dense() { static const int v = getenv("LNB_ATTN_BATCH_DENSE") ? atoi(getenv("LNB_ATTN_BATCH_DENSE")) : 1; return v != 0; }
+static bool attn_batch_dense() { const char* e = getenv("LNB_ATTN_BATCH_DENSE"); return !(e && *e && atoi(e) == 0); }   // (read per launch: a test switches it inside one process)
 extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     if (p->longctx && p->S == 1) return launch_attn_long(p, st);
     if (p->mfma && p->S >= 16 && (p->hd == 128 || p->hd == 64)) {       // prefill: 16 query rows per wave on the matrix cores

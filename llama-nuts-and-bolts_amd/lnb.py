@@ -59,7 +59,7 @@ EXPORTS = [
     "lnb_tokenizer_load", "lnb_tokenizer_free", "lnb_tokenizer_vocab_size", "lnb_tokenizer_special", "lnb_tokenizer_token_id",
     "lnb_tokenizer_piece", "lnb_tokenizer_encode", "lnb_tokenizer_encode_chat",
     "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens", "lnb_pipeline_selftest", "lnb_pipeline_comm_count",
-    "lnb_model_enable_batch", "lnb_model_batch_bytes", "lnb_batch_create", "lnb_batch_destroy", "lnb_batch_decode", "lnb_batch_profile_kernel", "lnb_batch_set_state", "lnb_pipeline_tick_batch",
+    "lnb_model_enable_batch", "lnb_model_batch_bytes", "lnb_batch_create", "lnb_batch_destroy", "lnb_batch_decode", "lnb_batch_profile_kernel", "lnb_batch_set_state", "lnb_batch_check_error", "lnb_pipeline_tick_batch",
 ]
 
 
@@ -122,6 +122,7 @@ def lib():
     L.lnb_batch_decode.argtypes = [vp, i32p, i32p, C.c_int, vp, f32p]
     L.lnb_batch_profile_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p]
     L.lnb_batch_set_state.argtypes = [vp, i32p, i32p]
+    L.lnb_batch_check_error.argtypes = [vp]
     L.lnb_pipeline_tick_batch.argtypes = [vp, vp, vp, vp, C.POINTER(C.c_int)]
     L.lnb_pipeline_read_tokens.argtypes = [vp, C.c_int, C.c_int, vp]
     L.lnb_op_linear_mode.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
@@ -428,6 +429,11 @@ class Batch:
         pos = np.ascontiguousarray(start_pos, dtype=np.int32)
         tok = None if tokens is None else np.ascontiguousarray(tokens, dtype=np.int32)
         _chk(self.L.lnb_batch_set_state(self.h, None if tok is None else tok.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_int32))))
+        return self
+
+    def check_error(self):
+        """after Pipeline.sync(): raises if a pipeline tick of this batch met a token outside the vocabulary / an all-NaN logits row"""
+        _chk(self.L.lnb_batch_check_error(self.h))
         return self
 
     def close(self):

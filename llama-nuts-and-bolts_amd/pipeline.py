@@ -556,6 +556,57 @@ def _golden_check(tokens, prompt_len, model_name):
     return {"compared": n, "identical_prefix": agree, "golden": "tests/golden/configs1_tokens.json (CPU oracle)"}
 
 
+def one_gpu_anchor(lnb, grp, rank, world, cfg, local, mode, P, W, K, n_seq, seq_len, batched):
+    """The same workloads on ONE GPU holding the whole model, measured in this run on rank 0's GPU while the other ranks wait: the anchor
+    of the line's efficiency figures (value_N / (N x anchor)).  Unbatched: n_seq sequences in flight through the one-GPU form of the tick
+    path.  Batched (if the pipeline ran it): G groups of nb sequences.  Short timed windows (the anchor needs no more than a few percent)."""
+    out = {}
+    if rank == 0:
+        try:
+            Ka, Wa = min(K, 24), min(W, 2)
+            m = lnb.LlamaTransformer(device=local, **cfg).fill_synthetic(1234).finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"]))
+            ctxs = [lnb.InferenceContext(m, seq_len).set_mode(mode) for _ in range(n_seq)]
+            pp = lnb.Pipeline(m, 0, 1, None)
+            prm = [lnb.synth_tokens(99 + q, P, cfg["vocab_size"]) for q in range(n_seq)]
+            n_dec = Wa + Ka
+            st = run_ticks_native(0, 1, pp, ctxs, prm, n_dec, 0, n_seq * (1 + Wa))
+            pp.sync()
+            t0 = time.perf_counter()
+            run_ticks_native(0, 1, pp, ctxs, prm, n_dec, n_seq * (1 + Wa), n_seq * (1 + Wa + Ka), st)
+            pp.sync()
+            out["unbatched_tokens_per_s"] = round(Ka * n_seq / (time.perf_counter() - t0), 2)
+            out["unbatched_sequences_in_flight"] = n_seq
+            pp.close()
+            for c in ctxs:
+                c.close()
+            if batched and mode == "exact":
+                G, nb = batched
+                m.enable_batch()
+                cb = [lnb.InferenceContext(m, seq_len) for _ in range(G * nb)]
+                firsts = [c.Forward(lnb.synth_tokens(99 + q, P, cfg["vocab_size"]), 0, want_logits=False)[1] for q, c in enumerate(cb)]
+                bats = [lnb.Batch(cb[g * nb:(g + 1) * nb]) for g in range(G)]
+                toks = []
+                for g, b in enumerate(bats):
+                    w_, _ = b.decode(firsts[g * nb:(g + 1) * nb], [P] * nb, Wa) if Wa > 0 else (None, 0.0)
+                    toks.append([int(w_[q][-1]) for q in range(nb)] if Wa > 0 else firsts[g * nb:(g + 1) * nb])
+                lnb._chk(lnb.lib().lnb_ctx_synchronize(cb[0].h))
+                t0 = time.perf_counter()
+                for g, b in enumerate(bats):                 # (one GPU: the groups one after another -- a batch step already fills the chip)
+                    b.decode(toks[g], [P + Wa] * nb, Ka)
+                out["batched_tokens_per_s"] = round(Ka * G * nb / (time.perf_counter() - t0), 2)
+                out["batched_sequences_in_flight"] = G * nb
+                for b in bats:
+                    b.close()
+                for c in cb:
+                    c.close()
+            m.close()
+            out["note"] = "whole model on rank 0's GPU alone, %d timed steps; the other ranks wait at a barrier" % Ka
+        except lnb.LnbError as e:
+            out = {"skipped": str(e)}
+    grp.barrier()
+    return grp.broadcast(out if rank == 0 else None)
+
+
 def bench_main(args, cfg, name):
     """bench.py --gpus N under torchrun: weak scaling, 2N sequences in flight, one rank per GPU.
 
@@ -651,8 +702,19 @@ def bench_main(args, cfg, name):
             flight, each decode step of a group = ONE pass over a stage's weights for its nb sequences (exact per sequence).  Whole-block stages."""
             lb, le = stage_layers(rank, world, cfg["n_layers"], head_cost=(costs[3] / max(1e-9, sum(costs[:3])) if costs else 1.2))
             G = 2 * world if world > 1 else int(os.environ.get("LNB_PIPELINE_SEQS", "2"))
-            st = LnbStage(lnb, None, cfg, rank, world, G * nb, seq_len, local, parts=(3 * lb, 3 * le), costs=costs)
-            st.model.enable_batch()
+            # every rank must take the same path through the collectives below: set the stage up, then AGREE that it worked everywhere
+            # (enable_batch can fail on one rank only -- the head rank holds the extra output.weight copy) before anything is exchanged
+            st, err = None, None
+            try:
+                st = LnbStage(lnb, None, cfg, rank, world, G * nb, seq_len, local, parts=(3 * lb, 3 * le), costs=costs)
+                st.model.enable_batch()
+            except lnb.LnbError as e:
+                err = str(e)
+            if grp.all_reduce(0 if err else 1, min) == 0:
+                errs = grp.all_reduce([(rank, err)], lambda vs: sorted(sum(vs, [])))
+                if st is not None:
+                    st.close()
+                return {"skipped": "; ".join("rank %d: %s" % (r, e) for r, e in errs if e)}
             uid2 = grp.broadcast(lnb.Pipeline.unique_id() if (rank == 0 and world > 1) else None)
             pp = lnb.Pipeline(st.model, rank, world, uid2)
             prm = [lnb.synth_tokens(99 + q, P, cfg["vocab_size"]) for q in range(G * nb)]          # sequence 0 = the headline's prompt
@@ -671,11 +733,15 @@ def bench_main(args, cfg, name):
             t_host = time.perf_counter() - t0
             pp.sync(); grp.barrier()
             wall_b = grp.all_reduce(time.perf_counter() - t0, max)
+            for b_ in bats:
+                b_.check_error()                             # ticks only enqueue: a bad token / all-NaN row is latched on the device, not raised
             toks0 = None
             if rank == world - 1:
                 toks0 = [int(pp.read_tokens(first_slot0, 1)[0])] + [int(pp.read_tokens(q, 1)[0]) for q in sb["slots"][0]]
             info = grp.all_reduce([(rank, pp.comm_count(), toks0)], lambda vs: sorted(sum(vs, [])))
-            res_b = {"wall": wall_b, "sequences_in_flight": G * nb, "groups": G, "batch": nb, "blocks_per_gpu": le - lb,
+            cuts = grp.all_reduce([(rank, lb, le)], lambda vs: sorted(sum(vs, [])))
+            res_b = {"wall": wall_b, "sequences_in_flight": G * nb, "groups": G, "batch": nb, "blocks_per_gpu": [e_ - b_ for _, b_, e_ in cuts],
+                     "cut": "whole blocks (lnb_model_enable_batch refuses a stage cut inside a block: the batched hand-off is [n, dim] only)",
                      "tokens_per_s": round(K * G * nb / wall_b, 2), "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * G), 1),
                      "rccl_comm_count_per_rank": [c for _, c, _ in info], "tokens_vs_oracle_golden": _golden_check(info[-1][2], P, name) if info[-1][2] else None}
             for b_ in bats:
@@ -705,16 +771,34 @@ def bench_main(args, cfg, name):
             extra["literal_blocks_split"] = dict(m_lit, blocks_per_gpu=cfg["n_layers"] // world, tokens_per_s=round(K * n_seq / m_lit.pop("wall"), 2))
             pipe.close()
         nb = int(os.environ.get("LNB_PIPELINE_BATCH", "64" if mode == "exact" else "0"))      # (more than 16: the groups are rows of the streaming product; 64: 4.7 tokens per ms of an 8B-shape step against 3.1 at 32)
+        mb = None
         if nb > 0:
-            try:
-                mb = measure_batched(min(nb, 128))
-            except lnb.LnbError as e:                         # (setup errors are the same on every rank: e.g. dims that are no multiples of 128)
-                mb = {"skipped": str(e)}
+            mb = measure_batched(min(nb, 128))
             extra["batched"] = dict(mb)
-            if "wall" in mb:
-                extra["unbatched_ticks"] = {"tokens_per_s": round(K * n_seq / wall, 2), "sequences_in_flight": n_seq}
-                wall, n_seq = mb["wall"], mb["sequences_in_flight"]     # the line's value: the batched pipeline
-                extra["batched"].pop("wall")
+            extra["batched"].pop("wall", None)
+        # The line's `value` is the UNBATCHED figure -- 2N independent sequences in flight, one-token ticks, the kernels of the N = 1 line --
+        # so that the 1 -> 8 curve compares like with like; the batched pipeline (a serving workload: one pass over a stage's weights per
+        # group of sequences) is reported next to it, each with a same-workload ONE-GPU anchor measured in this run on rank 0's GPU.
+        extra["value_definition"] = "%d independent sequences in flight, one-token ticks through the %d stages (exact single-sequence kernels, as the N = 1 line)" % (n_seq, world)
+        extra["value_single_stream"] = m_bal["single_stream"]["tokens_per_s"]
+        extra["value_batched"] = mb.get("tokens_per_s") if isinstance(mb, dict) else None
+        tick_us = 1e6 * wall / max(1, K * n_seq)
+        pred = []
+        for r in range(world):
+            pb_, pe_ = stage_parts(r, world, cfg["n_layers"], *stage.costs)
+            c3 = stage.costs
+            pred.append(round(sum(c3[q % 3] for q in range(pb_, pe_)) + (c3[3] if r == world - 1 else 0.0), 1))
+        extra["stage_time_us"] = {"predicted_per_rank_from_the_probe": pred, "slowest_predicted": max(pred), "measured_tick": round(tick_us, 1),
+                                  "note": "a tick = one sequence's one-token step on one stage; with 2N sequences in flight the pipeline's period is the slowest stage"}
+        if os.environ.get("LNB_PIPELINE_ANCHOR", "1") != "0":
+            extra["one_gpu_anchor"] = one_gpu_anchor(lnb, grp, rank, world, cfg, local, mode, P, W, K, n_seq, seq_len,
+                                                     (mb["groups"], mb["batch"]) if isinstance(mb, dict) and "groups" in mb else None)
+            an = extra["one_gpu_anchor"]
+            if an.get("unbatched_tokens_per_s"):
+                extra["efficiency_vs_one_gpu"] = {"unbatched": round((K * n_seq / wall) / (world * an["unbatched_tokens_per_s"]), 4)}
+                if an.get("batched_tokens_per_s") and extra["value_batched"]:
+                    extra["efficiency_vs_one_gpu"]["batched"] = round(extra["value_batched"] / (world * an["batched_tokens_per_s"]), 4)
+                extra["efficiency_vs_one_gpu"]["definition"] = "value_N / (N x the same number of sequences in flight on ONE GPU holding the whole model)"
         grp.close()
     else:
         import datetime
@@ -768,13 +852,6 @@ def bench_main(args, cfg, name):
         a = {k: cfg[k] for k in ("dim", "n_layers", "n_heads", "n_kv_heads", "vocab_size")}
         Tbar = P + W + (K - 1) / 2.0 + 1.0
         B = _b.algorithmic_bytes_per_token(a, stage.model.ffn_hidden, Tbar)
-        if isinstance(extra.get("batched"), dict) and "batch" in extra["batched"]:
-            # a batched step reads the weights ONCE for the group's sequences: the bytes really needed per token = weights / batch + the
-            # sequence's own KV / embedding traffic
-            hd = a["dim"] // a["n_heads"]
-            kvb = a["n_layers"] * 2 * (a["n_kv_heads"] * hd) * 2
-            own = a["dim"] * 2 + kvb * Tbar + kvb
-            B = (B - own) / extra["batched"]["batch"] + own
         res = {"metric": "decode tokens/s Llama-3.1-8B bf16 @1/2/4/8 MI355X; % HBM roofline", "value": round(tps, 2), "unit": "tokens/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",

@@ -250,3 +250,72 @@ def test_prefill_at_the_8b_shape_on_the_streaming_feed_reproduces_the_golden(lnb
         assert [first] + [int(t) for t in got] == gold[:41], label
     print("128-row prefill of the 8B shape, ms:", times)
     c.close(); gm.close()
+
+
+def test_dense_batch_attention_beyond_one_pass_of_512_positions(lnb, monkeypatch):
+    """attn_exact_kernel<HD, DENSE> (chosen for a batch when heads x sequences > 256) reloads its K rows per 512-position pass; the
+    other batch tests stop at ~150 positions.  Here: 70 sequences x 4 heads on the tiny shape with prompts of 480..1100 positions -- some
+    cross 512 and 1024 INSIDE the decode window -- against each sequence's own single-sequence run (lnb_decode_greedy: the oracle-checked
+    path), against the oracle itself for three of them, and against the non-DENSE form (LNB_ATTN_BATCH_DENSE=0)."""
+    cfg = dict(orc.TINY)
+    n, steps = 70, 10
+    plens = [480 + (s * 97) % 620 for s in range(n)]
+    plens[0], plens[1], plens[2], plens[3] = 507, 1019, 511, 1100          # cross 512 / 1024 within the window; exactly at the edge; the longest
+    seqmax = max(plens) + steps + 6
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(606).finalize(rope_rows=seqmax + 8).enable_batch()
+    om = orc.Model(**cfg).fill_synthetic(606).finalize()
+    prompts = [orc.synth_tokens(7000 + s, plens[s], cfg["vocab_size"]) for s in range(n)]
+
+    def run(dense):
+        if dense is not None:
+            monkeypatch.setenv("LNB_ATTN_BATCH_DENSE", dense)
+        ctxs = [lnb.InferenceContext(gm, seqmax) for _ in range(n)]
+        firsts = [ctxs[s].Forward(prompts[s], 0, want_logits=False)[1] for s in range(n)]
+        b = lnb.Batch(ctxs)
+        got, _ = b.decode(firsts, plens, steps)
+        toks = [[firsts[s]] + [int(t) for t in got[s]] for s in range(n)]
+        kv = [ctxs[s].CacheK(1)[:plens[s] + steps].copy() for s in (0, 1, 3)]
+        b.close()
+        for c in ctxs:
+            c.close()
+        if dense is not None:
+            monkeypatch.delenv("LNB_ATTN_BATCH_DENSE")
+        return toks, kv
+
+    toks, kv = run(None)
+    toks0, kv0 = run("0")
+    assert toks == toks0 and all((a == b_).all() for a, b_ in zip(kv, kv0))
+    solo = lnb.InferenceContext(gm, seqmax)
+    for s in (0, 1, 2, 3, 17, 69):
+        solo.reset()
+        _, f = solo.Forward(prompts[s], 0, want_logits=False)
+        ref, _ = solo.decode_greedy(f, plens[s], steps)
+        assert toks[s] == [f] + [int(t) for t in ref], s
+    solo.close()
+    rope_ok = seqmax + 8 <= 2 * cfg["max_seq_len"]                       # the oracle's RoPE table has the reference's 2 x max_seq_len rows
+    if rope_ok:
+        for s in (0, 2):
+            oc = orc.Context(om, seqmax)
+            r, _ = oc.generate(prompts[s], steps + 1)
+            assert toks[s] == [int(t) for t in r][:steps + 1], s
+            oc.close()
+    om.close(); gm.close()
+
+
+def test_a_member_context_cannot_be_destroyed_under_a_live_batch(lnb):
+    """a batch bakes its members' device pointers into its tables and graphs -- lnb_ctx_destroy on a member must fail until the
+    batch is gone (then succeed); the context and the batch stay usable after the refused call"""
+    cfg = dict(orc.TINY)
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(5).finalize().enable_batch()
+    ctxs = [lnb.InferenceContext(gm, 40) for _ in range(3)]
+    firsts = [c.Forward(orc.synth_tokens(s, 5, cfg["vocab_size"]), 0, want_logits=False)[1] for s, c in enumerate(ctxs)]
+    b = lnb.Batch(ctxs)
+    L = lnb.lib()
+    assert L.lnb_ctx_destroy(ctxs[1].h) != 0 and b"live batch" in L.lnb_last_error()
+    got, _ = b.decode(firsts, [5, 5, 5], 3)                              # still works
+    assert got.shape == (3, 3)
+    b.check_error()
+    b.close()
+    for c in ctxs:
+        c.close()                                                        # now fine
+    gm.close()

@@ -35,8 +35,12 @@ def test_single_gpu_bench_prints_one_json_line_with_the_contract_keys(mode):
     sf = d["sequences_in_flight"]
     assert sf["n"] == 3 and sf["tokens_per_s"] > 0
     assert sf["sequence0_tokens_vs_single_run"]["identical_prefix"] == sf["sequence0_tokens_vs_single_run"]["compared"] > 0
-    cf = rf["chain_floor"]
-    assert cf["tokens_per_s"] > 0 and 0 < cf["achieved_frac_of_attainable"] <= 1.0
+    pf = rf["practical_floor"]                              # measured step costs, prologues and boundaries: what the exact order can reach
+    assert pf["tokens_per_s"] > 0 and pf["achieved_frac_of_floor"] > 0 and set(pf["per_kernel"]) >= {"wo+residual GEMV", "w2+residual GEMV", "norm+output GEMV"}
+    ls = rf["largest_symbol_by_gpu_time"]
+    assert 0 < ls["share_of_gpu_time"] <= 1 and ls["symbol"] in ls["all"]
+    rp = d["config"]["timed_region_repeats_ms_per_step"]   # three repeats of the same K steps, the median one reported
+    assert len(rp) == 3 and sorted(rp)[1] == pytest.approx(d["ms_per_step"], rel=1e-3)
     if mode == "exact":                                    # batched exact decode: n prompts per pass over the weights, sequence 0 = the single run's prompt
         sb = d["sequences_in_flight_batched"]
         assert [r["n"] for r in sb["runs"]] == [2, 4, 8, 16, 32, 64, 128] and sb["weights_second_copy_bytes"] > 0
@@ -69,3 +73,12 @@ def test_forced_pipeline_line_carries_the_single_stream_figure_and_the_transport
     c = d["config"]
     assert c["rccl_comm_count_per_rank"] == [1] and c["single_stream"]["tokens_per_s"] > 0 and c["single_stream"]["tokens_equal_sequence0_of_the_batch"] is True
     assert d["cpu_baseline"]["value"] > 0
+    # the value is the UNBATCHED figure (comparable with the N = 1 line); single-stream and batched sit next to it, each workload with its
+    # one-GPU anchor measured in the same run, the efficiency derived from it, and the predicted stage times next to the measured tick
+    assert abs(d["value"] - d["steps"] * c["sequences_in_flight"] / (d["ms_per_step"] * d["steps"] / 1e3)) / d["value"] < 1e-3
+    assert c["value_single_stream"] == c["single_stream"]["tokens_per_s"] and c["value_batched"] == c["batched"]["tokens_per_s"] > 0
+    an = c["one_gpu_anchor"]
+    assert an["unbatched_tokens_per_s"] > 0 and an["unbatched_sequences_in_flight"] == c["sequences_in_flight"] and an["batched_tokens_per_s"] > 0
+    assert c["efficiency_vs_one_gpu"]["unbatched"] > 0 and c["efficiency_vs_one_gpu"]["batched"] > 0
+    assert c["stage_time_us"]["measured_tick"] > 0 and len(c["stage_time_us"]["predicted_per_rank_from_the_probe"]) == 1
+    assert "whole blocks" in c["batched"]["cut"]
