@@ -129,6 +129,13 @@ int lnb_forward(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, float
  * any host round trip; out_tokens[i] is the token generated by step i.  ms_out (optional) = device time of
  * the n_steps measured with HIP events on the library's stream. */
 int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int32_t* out_tokens, float* ms_out);
+/* Stop ids ON THE DEVICE (inference.go:233-252: generation ends with the first token that is one of model.StopTokenIds -- <|eot_id|>,
+ * <|eom_id|> -- and that token is emitted).  lnb_ctx_set_stop_ids gives a context up to 8 of them (0: none); the token-feedback kernel then
+ * freezes the generation (position, token word, token log) at the first match, so a run of any length can be enqueued without a host check
+ * per token.  lnb_decode_greedy_until = lnb_decode_greedy that reports how far it got: *n_generated tokens are valid (max_steps unless a
+ * stop id ended the run; the stop token is the last of them), *finished (optional) = 1 if one did.  Same tokens whatever the chunking. */
+int lnb_ctx_set_stop_ids(lnb_ctx* c, const int32_t* ids, int n);
+int lnb_decode_greedy_until(lnb_ctx* c, int32_t token, int start_pos, int max_steps, int32_t* out_tokens, int* n_generated, int* finished, float* ms_out);
 
 /* ---- batched exact decode: several generations per pass over the weights ----------------------------------
  * The reference runs one generation per InferenceContext (src/inference/inference.go:174) and shares the weight matrix across the rows of a
@@ -152,6 +159,9 @@ int64_t lnb_model_batch_bytes(lnb_model* m);
 int lnb_batch_create(lnb_ctx* const* ctxs, int n, lnb_batch** out);
 int lnb_batch_destroy(lnb_batch* b);
 int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, float* ms_out);
+/* ... with per-sequence stop ids (lnb_ctx_set_stop_ids on the member contexts, below): n_generated[s] tokens of row s are valid, the last one
+ * the stop token if the sequence finished before max_steps; a finished sequence's position and caches stay where they stopped */
+int lnb_batch_decode_until(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int max_steps, int32_t* out_tokens, int32_t* n_generated, float* ms_out);
 /* measurement aid: average HIP-event time of one kernel class of the batched step (which as lnb_profile_kernel; a norm launch counts
  * with the product it feeds), every sequence placed at `pos`; overwrites the caches' row `pos` */
 int lnb_batch_profile_kernel(lnb_batch* b, int which, int pos, int iters, float* avg_ms_out);
@@ -288,6 +298,16 @@ int lnb_tokenizer_encode(const lnb_tokenizer* t, const char* text, int len, int3
  * "\n\n" content <|eot_id|>, then the open assistant header */
 int lnb_tokenizer_encode_chat(const lnb_tokenizer* t, const char* const* headers, const char* const* contents, int n_parts,
                               int32_t* out, int cap);
+/* Detokeniser = InferenceEngine.TokenToString (src/inference/tokenize.go:197-239) with its generationDecodingContext.waitingBytes
+ * (inference.go:35): a piece that is not valid UTF-8 by itself (byte-fallback tokens; pieces ending inside a character) is buffered until the
+ * buffered bytes are valid UTF-8, then ONE rune is released; valid pieces pass through.  lnb_tokenizer_decode_stream returns the number of
+ * bytes written to out (0 while waiting; *added_to_waiting = the reference's third result), < 0 on error.  One stream per generation.
+ * Not restated: processEmoji's aliases and its buffering of combining marks / ZWJ sequences (emoji.go) -- those pieces come out as text. */
+typedef struct lnb_detok lnb_detok;
+int lnb_tokenizer_stream_create(const lnb_tokenizer* t, lnb_detok** out);
+void lnb_tokenizer_stream_free(lnb_detok* d);
+int lnb_tokenizer_decode_stream(lnb_detok* d, int32_t token_id, char* out, int cap, int* added_to_waiting);
+int lnb_tokenizer_stream_pending(const lnb_detok* d, const char** bytes, int* len);       /* the bytes still waiting */
 
 #ifdef __cplusplus
 }

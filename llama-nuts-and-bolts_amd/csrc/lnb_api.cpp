@@ -30,6 +30,7 @@ hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out
 hipError_t lnbk_embed(const uint16_t* emb, const int32_t* tokens, uint16_t* x, int S, int dim, int vocab, int* err, hipStream_t st);
 hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_token, StepState* state, int32_t* out_tokens, int out_cap, int advance, hipStream_t st);
 hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st);
+hipError_t lnbk_set_stop(StepState* state, const int32_t* ids, int n, hipStream_t st);
 hipError_t lnbk_advance_state(StepState* state, int rows, hipStream_t st);
 hipError_t lnbk_tile(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, int gather, hipStream_t st);
 hipError_t lnbk_synth_fill(uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, uint64_t seed, uint32_t tensor_id, int kind, float sigma, hipStream_t st);
@@ -841,7 +842,28 @@ static int enqueue_decode_step(lnb_ctx* c) {
     return 0;
 }
 
+// Stop ids on the device (inference.go:233-252: generation ends with the first token that is one of model.StopTokenIds, and that token is
+// emitted): the argmax kernel compares every generated token with the context's stop ids and freezes the generation -- position, token
+// word, token log -- when one matches; whatever was enqueued behind it recomputes the same step and changes nothing.  0 ids = never stops.
+extern "C" int lnb_ctx_set_stop_ids(lnb_ctx* c, const int32_t* ids, int n) {
+    if (!c || (n > 0 && !ids)) return fail("null argument");
+    if (n < 0 || n > LNB_MAX_STOP_IDS) return fail("a context takes 0..%d stop ids (got %d)", LNB_MAX_STOP_IDS, n);
+    HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(lnbk_set_stop(c->st, ids, n, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    return 0;
+}
+static int decode_greedy_impl(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int32_t* out_tokens, int* n_generated, int* finished, float* ms_out);
 extern "C" int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int32_t* out_tokens, float* ms_out) {
+    return decode_greedy_impl(c, token, start_pos, n_steps, out_tokens, nullptr, nullptr, ms_out);
+}
+// the same loop, reporting how far it got: *n_generated tokens are valid in out_tokens (max_steps unless a stop id ended the generation;
+// the stop token is the last of them), *finished = 1 if a stop id did
+extern "C" int lnb_decode_greedy_until(lnb_ctx* c, int32_t token, int start_pos, int max_steps, int32_t* out_tokens, int* n_generated, int* finished, float* ms_out) {
+    if (!n_generated) return fail("null argument");
+    return decode_greedy_impl(c, token, start_pos, max_steps, out_tokens, n_generated, finished, ms_out);
+}
+static int decode_greedy_impl(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int32_t* out_tokens, int* n_generated, int* finished, float* ms_out) {
     if (!c || !out_tokens) return fail("null argument");
     lnb_model* m = c->m;
     if (!m->first() || !m->last()) return fail("lnb_decode_greedy needs a whole-model handle");
@@ -882,9 +904,12 @@ extern "C" int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n
     HIPCHK(hipEventRecord(c->ev1, st));
     HIPCHK(hipMemcpyAsync(out_tokens, c->dout, (size_t)n_steps * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(c->h_io + 1, c->derr, 4, hipMemcpyDeviceToHost, st));
+    StepState hs{};
+    if (n_generated) HIPCHK(hipMemcpyAsync(&hs, c->st, sizeof(StepState), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, c->ev0, c->ev1));
     if (c->h_io[1]) return fail("generated token id is outside the vocabulary");
+    if (n_generated) { *n_generated = hs.n_out; if (finished) *finished = hs.finished; c->dev_pos = -1; }     // (a stopped run leaves the device position short of start_pos + n_steps)
     return 0;
 }
 
@@ -1221,7 +1246,17 @@ static int enqueue_batch_step(lnb_batch* b, bool ring_in = false) {
     } else HIPCHK(lnbk_batch_advance(b->tab, b->stream));
     return 0;
 }
+static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, int32_t* n_generated, float* ms_out);
 extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, float* ms_out) {
+    return batch_decode_impl(b, tokens, start_pos, n_steps, out_tokens, nullptr, ms_out);
+}
+// with per-sequence stop ids (lnb_ctx_set_stop_ids on the member contexts): n_generated[s] tokens of row s of out_tokens are valid; a finished
+// sequence's column keeps computing its last step (the pass over the weights is shared), its state and caches stay where they stopped
+extern "C" int lnb_batch_decode_until(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int max_steps, int32_t* out_tokens, int32_t* n_generated, float* ms_out) {
+    if (!n_generated) return fail("null argument");
+    return batch_decode_impl(b, tokens, start_pos, max_steps, out_tokens, n_generated, ms_out);
+}
+static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, int32_t* n_generated, float* ms_out) {
     if (!b || !tokens || !start_pos || !out_tokens) return fail("null argument");
     lnb_model* m = b->m;
     if (!m->first() || !m->last()) return fail("lnb_batch_decode needs a whole-model handle; pipeline stages run their batches through lnb_pipeline_tick_batch");
@@ -1262,9 +1297,12 @@ extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32
     for (int s = 0; s < b->n; s++)
         HIPCHK(hipMemcpyAsync(out_tokens + (size_t)s * n_steps, b->ctxs[s]->dout, (size_t)n_steps * 4, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(b->h_io + 2 * LNB_BATCH_MAX, b->derr, 4, hipMemcpyDeviceToHost, st));
+    std::vector<StepState> hs(n_generated ? b->n : 0);
+    for (int s = 0; s < (int)hs.size(); s++) HIPCHK(hipMemcpyAsync(&hs[s], b->ctxs[s]->st, sizeof(StepState), hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, b->ev0, b->ev1));
     if (b->h_io[2 * LNB_BATCH_MAX]) return fail("sequence %d: generated token id is outside the vocabulary", b->h_io[2 * LNB_BATCH_MAX] - 1);
+    for (int s = 0; s < (int)hs.size(); s++) n_generated[s] = hs[s].n_out;
     return 0;
 }
 // Every sequence's position (and, on the first stage, optionally its next input token) before a run of lnb_pipeline_tick_batch steps: the

@@ -268,7 +268,7 @@ __global__ void batch_set_state_kernel(const BatchTab* tab, const int32_t* token
     if (s >= tab->n) return;
     if (tokens) *tab->dtok[s] = tokens[s];
     if (ring) ring[s] = *tab->dtok[s];
-    tab->st[s]->pos = pos[s]; tab->st[s]->n_out = 0;
+    tab->st[s]->pos = pos[s]; tab->st[s]->n_out = 0; tab->st[s]->finished = 0;
 }
 // pipeline, first stage: the tokens the last stage sent (contiguous) -> every sequence's own token word
 __global__ void batch_scatter_ring_kernel(const BatchTab* tab, const int32_t* ring) {

@@ -60,10 +60,14 @@ LNB_HD int32_t lnb_synth_isum(uint64_t base, uint64_t idx) {
 }
 
 // per-decode-step device state: lets one captured hipGraph be replayed for every position
+constexpr int LNB_MAX_STOP_IDS = 8;
 struct StepState {
     int32_t pos;        // start position of the current call (tokens already in the KV cache)
     int32_t n_out;      // tokens appended to out_tokens so far
-    int32_t pad[2];
+    int32_t finished;   // 1 once a generated token was one of the stop ids (inference.go:233-252): position, token word and token log are frozen from
+                        // then on -- the remaining steps of an enqueued run recompute the same step into the same KV row and change nothing visible
+    int32_t n_stop;     // stop ids in use (0: never finishes)
+    int32_t stop[LNB_MAX_STOP_IDS];
 };
 
 enum { EPI_STORE = 0, EPI_QKV_ROPE = 1, EPI_RESID = 2, EPI_SILU_MUL = 3 };

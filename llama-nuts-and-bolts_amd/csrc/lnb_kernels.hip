@@ -2458,12 +2458,14 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, in
     __shared__ int si[1024];
     const int tok = argmax_block(logits, V, sv, si);
     if (threadIdx.x == 0) {
-        next_token[0] = tok;
-        if (advance) {
+        if (!advance) next_token[0] = tok;
+        else if (!st->finished) {                            // (a finished generation: nothing moves any more, see StepState)
+            next_token[0] = tok;
             int n = st->n_out;
             if (n < out_cap) out_tokens[n] = tok;
             st->n_out = n + 1;
             st->pos = st->pos + 1;
+            for (int k = 0; k < st->n_stop; k++) if (tok == st->stop[k]) st->finished = 1;     // the stop token itself is emitted (GSFinishedByReachingEOS)
         }
     }
 }
@@ -2474,17 +2476,22 @@ __global__ __launch_bounds__(1024) void batch_argmax_kernel(const uint16_t* logi
     const int s = blockIdx.x;
     const int tok = argmax_block(logits + (size_t)s * V, V, sv, si);
     if (threadIdx.x == 0) {
-        *tab->dtok[s] = tok;
-        if (ring) ring[s] = tok;                             // (pipeline: the contiguous words the last stage sends to the first)
         StepState* st = tab->st[s];
-        const int n = st->n_out;
-        if (n < tab->dout_cap[s]) tab->dout[s][n] = tok;
-        st->n_out = n + 1;
-        st->pos = st->pos + 1;
+        if (!st->finished) {                                 // a finished sequence keeps its token word, log and position (its column goes on computing the same step)
+            *tab->dtok[s] = tok;
+            if (ring) ring[s] = tok;                         // (pipeline: the contiguous words the last stage sends to the first)
+            const int n = st->n_out;
+            if (n < tab->dout_cap[s]) tab->dout[s][n] = tok;
+            st->n_out = n + 1;
+            st->pos = st->pos + 1;
+            for (int k = 0; k < st->n_stop; k++) if (tok == st->stop[k]) st->finished = 1;
+        }
     }
 }
 
-__global__ void set_state_kernel(StepState* st, int pos, int n_out) { st->pos = pos; st->n_out = n_out; }
+__global__ void set_state_kernel(StepState* st, int pos, int n_out) { st->pos = pos; st->n_out = n_out; st->finished = 0; }
+struct StopIds { int32_t n; int32_t id[LNB_MAX_STOP_IDS]; };
+__global__ void set_stop_kernel(StepState* st, StopIds s) { st->n_stop = s.n; for (int k = 0; k < LNB_MAX_STOP_IDS; k++) st->stop[k] = k < s.n ? s.id[k] : -1; st->finished = 0; }
 __global__ void advance_state_kernel(StepState* st, int rows) { st->pos = st->pos + rows; }   // end of a captured pipeline-stage step
 
 // ---- weight re-tiling (load time, once) ------------------------------------------------------------
@@ -2766,6 +2773,11 @@ extern "C" hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_t
 }
 extern "C" hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st) {
     hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, state, pos, n_out);
+    return hipGetLastError();
+}
+extern "C" hipError_t lnbk_set_stop(StepState* state, const int32_t* ids, int n, hipStream_t st) {
+    StopIds s{}; s.n = n; for (int k = 0; k < n && k < LNB_MAX_STOP_IDS; k++) s.id[k] = ids[k];
+    hipLaunchKernelGGL(set_stop_kernel, dim3(1), dim3(1), 0, st, state, s);
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_advance_state(StepState* state, int rows, hipStream_t st) {

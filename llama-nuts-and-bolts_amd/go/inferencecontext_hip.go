@@ -139,6 +139,37 @@ func (ic *InferenceContext) SyncCachesFromDevice() error {
 	return nil
 }
 
+// SetStopTokenIds hands model.Vocabulary.StopTokenIds to the device (lnb_ctx_set_stop_ids): the greedy loop then ends ON THE DEVICE with the
+// first stop token (which is emitted, as inference.go:233-252 does), however many steps were enqueued behind it.  Up to 8 ids.
+func (ic *InferenceContext) SetStopTokenIds(lt *LlamaTransformer, ids []TokenId) error {
+	if err := ic.attach(lt); err != nil {
+		return err
+	}
+	var p *C.int32_t
+	if len(ids) > 0 {
+		p = (*C.int32_t)(unsafe.Pointer(&ids[0]))
+	}
+	return lnbCall(func() C.int { return C.lnb_ctx_set_stop_ids(ic.handle, p, C.int(len(ids))) })
+}
+
+// DecodeGreedyUntil is the decode half of generateTokensInternal (inference.go:194-252) as ONE call: starting from `token` at position
+// startPos it runs up to maxSteps Forward(1 token)+Argmax steps on the device and returns the tokens generated -- maxSteps of them unless a
+// stop id ended the run (finished == true; the stop token is the last one).  The host loop that feeds generatedTokensCh calls it in chunks
+// of any size: the tokens do not depend on the chunking.
+func (ic *InferenceContext) DecodeGreedyUntil(lt *LlamaTransformer, token TokenId, startPos int, maxSteps int) (tokens []TokenId, finished bool, err error) {
+	if err = ic.attach(lt); err != nil {
+		return nil, false, err
+	}
+	out := make([]TokenId, maxSteps)
+	var n, fin C.int
+	if err = lnbCall(func() C.int {
+		return C.lnb_decode_greedy_until(ic.handle, C.int32_t(token), C.int(startPos), C.int(maxSteps), (*C.int32_t)(unsafe.Pointer(&out[0])), &n, &fin, nil)
+	}); err != nil {
+		return nil, false, err
+	}
+	return out[:int(n)], fin != 0, nil
+}
+
 // Close frees the device buffers of this context (idempotent; also run by the finalizer, before the transformer's).
 func (ic *InferenceContext) Close() error {
 	if ic.handle == nil {

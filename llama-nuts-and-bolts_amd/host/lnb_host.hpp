@@ -218,8 +218,16 @@ public:
     InferenceContext* CreateInferenceContext() { return new InferenceContext(t_, ia_, logFn_); }       // :256-258
     // generateTokensInternal (:173-254): prefill through Forward, then the decode loop (Forward(1 token) + Argmax +
     // token feedback) as hipGraph replays on the device; onToken receives (state, token) like generatedTokensCh.
-    void GenerateTokens(const std::vector<TokenId>& promptTokens, const std::function<void(GenerationState, TokenId)>& onToken) {
+    // chunk = tokens enqueued per lnb_decode_greedy_until call.  The stop ids are checked ON THE DEVICE (lnb_ctx_set_stop_ids: the token-feedback
+    // kernel freezes the generation at the first stop token), so the chunk size changes nothing but the latency of the callback: the tokens
+    // are the same for chunk 1 and chunk 32 (tests/native/host_mirror_test.cpp).
+    void GenerateTokens(const std::vector<TokenId>& promptTokens, const std::function<void(GenerationState, TokenId)>& onToken, int chunk = 32) {
         std::unique_ptr<InferenceContext> ctx(CreateInferenceContext());
+        {
+            std::vector<TokenId> stops(model_.StopTokenIds.begin(), model_.StopTokenIds.end());
+            if (stops.size() > 8) stops.resize(8);
+            check(lnb_ctx_set_stop_ids(ctx->handle(), stops.empty() ? nullptr : stops.data(), (int)stops.size()));
+        }
         const int promptLength = (int)promptTokens.size();
         if (promptLength >= ctx->SequenceLength)
             throw std::runtime_error("context SequenceLength " + std::to_string(ctx->SequenceLength) +
@@ -233,14 +241,16 @@ public:
             onToken(GSInProgress, tok); return true;
         };
         if (!emit(next)) return;
-        const int chunk = 32;                                         // tokens generated on the device between host stop-id checks
+        if (chunk < 1) chunk = 1;
         while (true) {
             const int remaining = ctx->SequenceLength - 1 - curPos;
             const int n = remaining < chunk ? remaining : chunk;
             if (n <= 0) return;
             std::vector<TokenId> out(n);
-            check(lnb_decode_greedy(ctx->handle(), next, curPos, n, out.data(), nullptr));
-            for (int i = 0; i < n; i++) { curPos++; next = out[i]; if (!emit(next)) return; }
+            int got = 0, fin = 0;
+            check(lnb_decode_greedy_until(ctx->handle(), next, curPos, n, out.data(), &got, &fin, nullptr));
+            for (int i = 0; i < got; i++) { curPos++; next = out[i]; if (!emit(next)) return; }
+            if (fin) return;                                          // (emit() has reported the stop token: StopTokenIds are the device's stop ids)
         }
     }
 private:

@@ -58,8 +58,9 @@ EXPORTS = [
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
     "lnb_tokenizer_load", "lnb_tokenizer_free", "lnb_tokenizer_vocab_size", "lnb_tokenizer_special", "lnb_tokenizer_token_id",
     "lnb_tokenizer_piece", "lnb_tokenizer_encode", "lnb_tokenizer_encode_chat",
+    "lnb_tokenizer_stream_create", "lnb_tokenizer_stream_free", "lnb_tokenizer_decode_stream", "lnb_tokenizer_stream_pending",
     "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens", "lnb_pipeline_selftest", "lnb_pipeline_comm_count",
-    "lnb_model_enable_batch", "lnb_model_batch_bytes", "lnb_batch_create", "lnb_batch_destroy", "lnb_batch_decode", "lnb_batch_profile_kernel", "lnb_batch_set_state", "lnb_batch_check_error", "lnb_pipeline_tick_batch",
+    "lnb_model_enable_batch", "lnb_model_batch_bytes", "lnb_batch_create", "lnb_batch_destroy", "lnb_batch_decode", "lnb_batch_decode_until", "lnb_ctx_set_stop_ids", "lnb_decode_greedy_until", "lnb_batch_profile_kernel", "lnb_batch_set_state", "lnb_batch_check_error", "lnb_pipeline_tick_batch",
 ]
 
 
@@ -120,6 +121,9 @@ def lib():
     L.lnb_batch_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
     L.lnb_batch_destroy.argtypes = [vp]
     L.lnb_batch_decode.argtypes = [vp, i32p, i32p, C.c_int, vp, f32p]
+    L.lnb_batch_decode_until.argtypes = [vp, i32p, i32p, C.c_int, vp, vp, f32p]
+    L.lnb_ctx_set_stop_ids.argtypes = [vp, vp, C.c_int]
+    L.lnb_decode_greedy_until.argtypes = [vp, C.c_int32, C.c_int, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]
     L.lnb_batch_profile_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p]
     L.lnb_batch_set_state.argtypes = [vp, i32p, i32p]
     L.lnb_batch_check_error.argtypes = [vp]
@@ -147,6 +151,11 @@ def lib():
     L.lnb_tokenizer_piece.argtypes = [vp, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     L.lnb_tokenizer_encode.argtypes = [vp, C.c_char_p, C.c_int, i32p, C.c_int]
     L.lnb_tokenizer_encode_chat.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p), C.c_int, i32p, C.c_int]
+    L.lnb_tokenizer_stream_create.argtypes = [vp, C.POINTER(vp)]
+    L.lnb_tokenizer_stream_free.argtypes = [vp]
+    L.lnb_tokenizer_stream_free.restype = None
+    L.lnb_tokenizer_decode_stream.argtypes = [vp, C.c_int32, C.c_char_p, C.c_int, C.POINTER(C.c_int)]
+    L.lnb_tokenizer_stream_pending.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_int)]
     _lib = L
     return L
 
@@ -244,9 +253,39 @@ class Tokenizer:
     def token_id(self, piece_bytes):
         return self.L.lnb_tokenizer_token_id(self.h, piece_bytes, len(piece_bytes))
 
+    def stream(self):
+        """a TokenToString decoding context (one per generation): .feed(token_id) -> (bytes released, added_to_waiting)"""
+        return DecodeStream(self)
+
     def close(self):
         if self.h:
             self.L.lnb_tokenizer_free(self.h)
+            self.h = C.c_void_p()
+
+
+class DecodeStream:
+    """InferenceEngine.TokenToString + generationDecodingContext.waitingBytes (src/inference/tokenize.go:197-239)"""
+
+    def __init__(self, tok):
+        self.L, self.h = tok.L, C.c_void_p()
+        _chk(self.L.lnb_tokenizer_stream_create(tok.h, C.byref(self.h)))
+        self.buf = C.create_string_buffer(1 << 16)
+
+    def feed(self, tid):
+        w = C.c_int(0)
+        n = self.L.lnb_tokenizer_decode_stream(self.h, int(tid), self.buf, len(self.buf), C.byref(w))
+        if n < 0:
+            raise LnbError(self.L.lnb_last_error().decode("utf-8", "replace"))
+        return self.buf.raw[:n], bool(w.value)
+
+    def pending(self):
+        p, n = C.c_void_p(), C.c_int()
+        _chk(self.L.lnb_tokenizer_stream_pending(self.h, C.byref(p), C.byref(n)))
+        return C.string_at(p.value, n.value) if n.value else b""
+
+    def close(self):
+        if self.h:
+            self.L.lnb_tokenizer_stream_free(self.h)
             self.h = C.c_void_p()
 
 
@@ -377,6 +416,19 @@ class InferenceContext:
         _chk(self.L.lnb_profile_kernel(self.h, which, pos, iters, C.byref(ms)))
         return ms.value
 
+    def set_stop_ids(self, ids):
+        """model.StopTokenIds on the device (inference.go:233-252)"""
+        a = np.ascontiguousarray(ids, dtype=np.int32)
+        _chk(self.L.lnb_ctx_set_stop_ids(self.h, _p(a) if a.size else None, int(a.size)))
+        return self
+
+    def decode_greedy_until(self, token, start_pos, max_steps):
+        """-> (tokens generated: max_steps of them unless a stop id ended the run, finished flag, device ms)"""
+        out = np.empty(max_steps, dtype=np.int32)
+        ms, n, fin = C.c_float(0), C.c_int(0), C.c_int(0)
+        _chk(self.L.lnb_decode_greedy_until(self.h, int(token), start_pos, max_steps, _p(out), C.byref(n), C.byref(fin), C.byref(ms)))
+        return out[:n.value].copy(), bool(fin.value), ms.value
+
     def CacheK(self, layer):
         return self._kv(layer, 0)
 
@@ -418,6 +470,16 @@ class Batch:
         ms = C.c_float(0)
         _chk(self.L.lnb_batch_decode(self.h, tok.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_int32)), n_steps, _p(out), C.byref(ms)))
         return out, ms.value
+
+    def decode_until(self, tokens, start_pos, max_steps):
+        """decode with the member contexts' stop ids: -> (list of per-sequence token arrays (their valid lengths differ), device ms)"""
+        n = len(self.ctxs)
+        tok = np.ascontiguousarray(tokens, dtype=np.int32); pos = np.ascontiguousarray(start_pos, dtype=np.int32)
+        out = np.empty((n, max_steps), dtype=np.int32)
+        cnt = np.zeros(n, dtype=np.int32)
+        ms = C.c_float(0)
+        _chk(self.L.lnb_batch_decode_until(self.h, tok.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_int32)), max_steps, _p(out), _p(cnt), C.byref(ms)))
+        return [out[s, :cnt[s]].copy() for s in range(n)], ms.value
 
     def profile_kernel(self, which, pos, iters):
         ms = C.c_float(0)

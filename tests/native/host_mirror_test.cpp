@@ -17,6 +17,10 @@ int main(int argc, char** argv) {
     model.Args.MultipleOf = 64; model.Args.FFNDimMultiplier = 1.3; model.Args.UseScaledRope = true;
     model.Synthetic = true; model.SyntheticSeed = 1234;
     }
+    if (const char* stops = getenv("LNB_STOP_IDS")) {        // "a,b": model.StopTokenIds (the synthetic model has no tokenizer to take them from)
+        for (const char* q = stops; *q;) { model.StopTokenIds.insert(atoi(q)); while (*q && *q != ',') q++; if (*q) q++; }
+    }
+    const int chunk = getenv("LNB_CHUNK") ? atoi(getenv("LNB_CHUNK")) : 32;      // tokens enqueued per device call (the stop check is on the device)
     int seq_len = argc > 1 ? atoi(argv[1]) : 40;
     try {
         std::unique_ptr<lnb::LlamaTransformer> t(lnb::LlamaTransformer::New(model, 0));
@@ -25,7 +29,7 @@ int main(int argc, char** argv) {
         std::vector<lnb::TokenId> prompt;
         for (int i = 2; i < argc; i++) prompt.push_back(atoi(argv[i]));
         printf("tokens:");
-        engine.GenerateTokens(prompt, [&](lnb::GenerationState st, lnb::TokenId tok) { printf(" %d", tok); if (st != lnb::GSInProgress) printf(" state=%d", (int)st); });
+        engine.GenerateTokens(prompt, [&](lnb::GenerationState st, lnb::TokenId tok) { printf(" %d", tok); if (st != lnb::GSInProgress) printf(" state=%d", (int)st); }, chunk);
         printf("\nlayers_logged: %d\n", layers_logged);
     } catch (const std::exception& e) {
         printf("error: %s\n", e.what());

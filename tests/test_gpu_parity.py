@@ -842,6 +842,64 @@ def test_cpp_host_mirror_generates_the_oracle_tokens(lnb, tiny_pair):
     assert logged == 2                                               # Logf fired once per layer of the prefill Forward
 
 
+def test_stop_ids_are_checked_on_the_device(lnb, tiny_pair):
+    """inference.go:233-252: generation ends with the first stop token, which is emitted.  lnb_ctx_set_stop_ids + lnb_decode_greedy_until:
+    the same tokens whether the run is enqueued one step, seven steps or all at once per call; the frozen context can be continued by hand
+    from where it stopped; lnb_batch_decode_until with a different stop id per sequence; and the C++ mirror's GenerateTokens with chunk 1 / 32."""
+    import subprocess
+    om, gm = tiny_pair
+    prompt = orc.synth_tokens(77, 9, TINY["vocab_size"])
+    ref, _ = orc.Context(om, 64).generate(prompt, 40)
+    ref = [int(t) for t in ref]
+    k = next(i for i in range(6, 30) if ref[i] not in ref[:i])      # a token that first appears at step k: the stop id
+    stop = ref[k]
+    for chunk in (1, 7, 64):
+        gc = lnb.InferenceContext(gm, 64).set_stop_ids([1023 if stop != 1023 else 1022, stop])
+        _, first = gc.Forward(prompt, 0, want_logits=False)
+        got, pos, tok, fin = [first], len(prompt), first, (first == stop)
+        while not fin and pos < 50:
+            out, fin, _ = gc.decode_greedy_until(tok, pos, min(chunk, 50 - pos))
+            got += [int(t) for t in out]; pos += len(out); tok = got[-1]
+        assert got == ref[:k + 1] and fin, (chunk, got, ref[:k + 1])
+        # the stopped context goes on by hand exactly where the reference would be after emitting the stop token
+        gc.set_stop_ids([])
+        more, _ = gc.decode_greedy(tok, pos, 5)
+        assert [int(t) for t in more] == ref[k + 1:k + 6]
+        gc.close()
+    # batch: every sequence its own stop id (or none); finished sequences keep their caches and positions
+    gb = lnb.LlamaTransformer(**TINY).fill_synthetic(1234).finalize().enable_batch()
+    n, steps = 5, 20
+    prompts = [orc.synth_tokens(300 + s, 6 + s, TINY["vocab_size"]) for s in range(n)]
+    refs = [[int(t) for t in orc.Context(om, 64).generate(prompts[s], steps + 2)[0]] for s in range(n)]
+    ctxs = [lnb.InferenceContext(gb, 64) for _ in range(n)]
+    firsts = [ctxs[s].Forward(prompts[s], 0, want_logits=False)[1] for s in range(n)]
+    ks = []
+    for s in range(n):
+        ks.append(None if s == 3 else next((i for i in range(2 + 3 * s, steps) if refs[s][i] not in refs[s][:i]), None))
+        ctxs[s].set_stop_ids([] if ks[s] is None else [refs[s][ks[s]]])
+    b = lnb.Batch(ctxs)
+    outs, _ = b.decode_until(firsts, [len(p) for p in prompts], steps)
+    for s in range(n):
+        want = refs[s][1:1 + steps] if ks[s] is None else refs[s][1:ks[s] + 1]
+        assert [int(t) for t in outs[s]] == want, (s, ks[s])
+    b.close()
+    for c in ctxs:
+        c.close()
+    gb.close()
+    # the C++ mirror of generateTokensInternal: chunk sizes 1 and 32 end at the same stop token with GSFinishedByReachingEOS
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "tests", "native", "host_mirror_test")
+    subprocess.check_call(["g++", "-std=c++17", "-O2", os.path.join(root, "tests", "native", "host_mirror_test.cpp"), "-o", exe,
+                           "-L" + os.path.join(root, "llama-nuts-and-bolts_amd"), "-llnb_hip", "-Wl,-rpath," + os.path.join(root, "llama-nuts-and-bolts_amd"),
+                           "-L/opt/rocm/lib", "-lamdhip64", "-Wl,-rpath,/opt/rocm/lib"])
+    lines = []
+    for chunk in ("1", "32"):
+        r = subprocess.run([exe, "64"] + [str(int(t)) for t in prompt], capture_output=True, text=True, check=True, env=dict(os.environ, LNB_STOP_IDS=str(stop), LNB_CHUNK=chunk))
+        lines.append([l for l in r.stdout.splitlines() if l.startswith("tokens:")][0])
+    assert lines[0] == lines[1] and "state=2" in lines[0]              # GSFinishedByReachingEOS (inference.go:13-17)
+    assert [int(t) for t in lines[0].split()[1:] if t.lstrip("-").isdigit()] == ref[:k + 1]
+
+
 def test_cpp_host_mirror_loadmodel_from_a_model_directory(lnb, tmp_path):
     """lnb::LoadModel(dir) = model.LoadModel (src/model/loader.go:18-70) without the tokenizer: consolidated.00.pth written by
     torch.save + params.json -> NewLlamaTransformer -> GenerateTokens; tokens must equal the oracle's with the same tensors."""

@@ -249,3 +249,81 @@ def test_encode_matches_huggingface_tokenizers(tok):
     cases += ["".join(rng.choice(alphabet) for _ in range(int(rng.integers(0, 48)))) for _ in range(1500)]
     for s in cases:
         assert t.encode(s) == hf.encode(s, add_special_tokens=False).ids, repr(s)
+
+
+# ---- detokeniser: TokenToString + waitingBytes (src/inference/tokenize.go:197-239, without processEmoji) -------------------------------
+def ref_token_to_string(piece, state):
+    """Python restatement of the reference function: returns (result bytes, addedToWaiting); state["w"] = waitingBytes"""
+    def valid(b):
+        try:
+            b.decode("utf-8"); return True
+        except UnicodeDecodeError:
+            return False
+    if not valid(piece):
+        state["w"] += piece
+        if valid(state["w"]):
+            first = state["w"].decode("utf-8")[0].encode("utf-8")      # utf8.DecodeRune: ONE rune
+            state["w"] = state["w"][len(first):]
+            return first, False
+        return b"", True
+    return piece, False
+
+
+def test_decode_stream_assembles_split_multibyte_characters_like_an_incremental_utf8_decoder(tok):
+    """byte-fallback tokens (every byte is a token of its own) and learned pieces that end inside a character: whenever each run of invalid
+    pieces completes ONE character at a time -- the only way the Llama-3 vocabulary's byte pieces occur in practice -- the stream's output
+    is what Python's incremental UTF-8 decoder produces for the same byte stream"""
+    import codecs
+    t, ranks = tok
+    rng = np.random.default_rng(11)
+    alphabet = list("abc xyz,.!\n") + list("éüßñ") + list("東京こんにちは") + list("🙂👍🏽🦙") + ["́", "‍"]
+    for trial in range(300):
+        text = "".join(alphabet[i] for i in rng.integers(0, len(alphabet), rng.integers(1, 40)))
+        raw = text.encode("utf-8")
+        if trial % 3 == 0:
+            ids = [t.token_id(bytes([b])) for b in raw]                                      # pure byte fallback
+        else:
+            ids = t.encode(text)                                                             # learned pieces (the pattern may split inside a character's bytes)
+        st = t.stream()
+        inc = codecs.getincrementaldecoder("utf-8")()
+        got, want, ok = b"", "", True
+        for tid in ids:
+            out, waiting = st.feed(tid)
+            piece = t.piece(tid)
+            want += inc.decode(piece)
+            got += out
+            assert waiting == (out == b"" and len(st.pending()) > 0) or not waiting
+        # the reference releases one rune per byte-piece: equal to the incremental decoder unless a single piece completed two characters at once
+        state = {"w": b""}
+        emu = b"".join(ref_token_to_string(t.piece(tid), state)[0] for tid in ids)
+        assert got == emu and st.pending() == state["w"]
+        if st.pending() == b"" and all(len(p) == 1 or _valid(p) for p in (t.piece(i) for i in ids)):
+            assert got.decode("utf-8") == want == text
+        st.close()
+
+
+def _valid(b):
+    try:
+        b.decode("utf-8"); return True
+    except UnicodeDecodeError:
+        return False
+
+
+def test_decode_stream_follows_the_reference_where_it_differs_from_a_plain_decoder(tok):
+    """the reference's own quirks, restated (not "fixed"): ONE rune is released per call even if the waiting bytes hold two complete ones; a
+    valid piece passes through while bytes are still waiting; Go's utf8.Valid rejects overlong forms, surrogates and > U+10FFFF"""
+    t, _ = tok
+    b = lambda *bs: [t.token_id(bytes([x])) for x in bs]
+    st = t.stream()
+    outs = [st.feed(i) for i in b(0xE2, 0x82)]                       # "€" = E2 82 AC: two bytes wait
+    assert outs == [(b"", True), (b"", True)] and st.pending() == b"\xe2\x82"
+    assert st.feed(t.token_id(b"a")) == (b"a", False) and st.pending() == b"\xe2\x82"        # a valid piece does not flush them
+    assert st.feed(b(0xAC)[0]) == ("€".encode(), False) and st.pending() == b""
+    # an overlong / surrogate / out-of-range sequence never becomes valid: it waits for ever, as in the reference
+    for seq in ((0xC0, 0xAF), (0xED, 0xA0, 0x80), (0xF4, 0x90, 0x80, 0x80)):
+        s2 = t.stream()
+        assert all(s2.feed(i) == (b"", True) for i in b(*seq)) and s2.pending() == bytes(seq)
+        s2.close()
+    with pytest.raises(lnb.LnbError):
+        st.feed(t.vocab_size + 5)
+    st.close()
