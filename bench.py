@@ -101,7 +101,7 @@ def pmc_traffic(kernel_name, model_name, mode):
     return None, None, None
 
 
-GOLDENS = {("llama8b", 128): "configs1_tokens.json", ("llama8b-2l", 4096): "configs2_2layer_tokens.json"}
+GOLDENS = {("llama8b", 128): "configs1_tokens.json", ("llama8b-2l", 4096): "configs2_2layer_tokens.json", ("llama8b-8l", 4096): "configs2_8layer_tokens.json"}
 
 
 def check_golden(args, first_tok, warm_toks, timed_toks):
@@ -252,7 +252,7 @@ def batched_sequences(lnb, model, cfg, args, a, single_run_tokens):
 # ONE chain wave with nothing else in its way, and what a launch cannot avoid paying around them
 CHAIN_NS = {"row_newbcast": 2.372,     # v_add_f32_dpp row_newbcast, products fetched from the LDS 64 steps per ds_read_b128 (5.56 cycles): wo, w2
             "quad_perm": 2.922}        # v_add_f32_dpp quad_perm, 16 steps per ds_read_b128 (6.81 cycles): wq|wk|wv (24 rows per CU need 16 rows per chain wave)
-HBM_ACHIEVABLE_GBS = 6290.0            # MI355X_MICROARCH.md: 6.29 TB/s measured streaming copy (79 % of the 8 TB/s spec)
+HBM_ACHIEVABLE_GBS = 6700.0            # the best streaming READ rate on record for this chip (MI355X_MICROARCH.md price list: 6.5-6.8 TB/s for an nt weight stream; the float4 COPY figure is 6.29)
 BOUNDARY_US = 1.4                      # dependent kernel boundary inside the captured graph (MI355X_MICROARCH.md price list: 1.2-1.45 us)
 X_PROLOGUE_US = 1.2                    # x row: global load + LDS staging + first weights (2.9 k cycles measured, rowcast_lds_kernel)
 NORM_PROLOGUE_US = 3.9                 # norm-fused kernels: x 1.2 k + fold 2.0 k (two waves per SIMD) + walk 2.5 k (15 items at the measured vector<->scalar
@@ -285,7 +285,7 @@ def practical_floor(a, ffn_hidden, Tbar, kernels):
             "constants": {"chain_ns_per_step": CHAIN_NS, "hbm_achievable_GBps": HBM_ACHIEVABLE_GBS, "boundary_us": BOUNDARY_US,
                           "x_prologue_us": X_PROLOGUE_US, "norm_prologue_us": NORM_PROLOGUE_US},
             "verdict": ("the practical floor of the exact order is %.3f of the 8 TB/s roofline: the 0.50 target is %s it" % (frac, "inside" if frac >= 0.5 else "ABOVE")),
-            "note": "per launch: max(K x measured DPP chain step, bytes / 6.29 TB/s) + measured prologue + one 1.4 us boundary; attention as measured"}
+            "note": "per launch: max(K x measured DPP chain step, bytes / 6.7 TB/s) + measured prologue + one 1.4 us boundary; attention as measured"}
 
 
 def traffic_child(lnb, cfg, args):
@@ -387,7 +387,7 @@ def main():
     ap.add_argument("--no-traffic-probe", action="store_true", help="do not run the rocprofv3 FETCH_SIZE pass of the dominant kernel")
     ap.add_argument("--traffic-child", type=int, default=-1, help=argparse.SUPPRESS)      # internal: kernel class to loop under rocprofv3
     ap.add_argument("--traffic-pos", type=int, default=0, help=argparse.SUPPRESS)
-    ap.add_argument("--model", default="llama8b", choices=["llama8b", "llama8b-2l", "tiny", "llama70b-like"])
+    ap.add_argument("--model", default="llama8b", choices=["llama8b", "llama8b-2l", "llama8b-8l", "tiny", "llama70b-like"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"],
                     help="exact (default, headline): the reference's k-ordered chains, token-identical to the CPU path; "
                          "fast: split-K / bf16-MFMA tolerance mode (opt-in, measured distance in DESIGN.md 6.2)")
@@ -411,9 +411,9 @@ def main():
     if args.model == "tiny":
         cfg.update(dim=256, n_layers=2, n_heads=4, n_kv_heads=2, vocab_size=1024, multiple_of=64)
         name = "tiny-256x2"
-    elif args.model == "llama8b-2l":
-        cfg.update(n_layers=2)                               # the 8B shape's geometry on two layers: the size the CPU oracle reaches at a 4096-token prompt
-        name = "Llama-3.1-8B shape cut to 2 layers"
+    elif args.model in ("llama8b-2l", "llama8b-8l"):
+        cfg.update(n_layers=2 if args.model == "llama8b-2l" else 8)   # the 8B shape's geometry on 2 / 8 layers: the sizes the CPU oracle reaches at a 4096-token prompt
+        name = "Llama-3.1-8B shape cut to %d layers" % cfg["n_layers"]
     elif args.model == "llama70b-like":
         cfg.update(dim=8192, n_layers=80, n_heads=64, n_kv_heads=8, multiple_of=4096)
         name = "random-init Llama-shape dim=8192 n_layers=80"
@@ -428,7 +428,7 @@ def main():
     P, W, K = args.prompt_len, args.warmup, args.steps
     # a short timed region (the driver passes --steps 20) is followed by a 256-step one, reported next to it (not under rocprofv3: its kernel
     # trace has crashed inside the tool on runs of tens of thousands of graph-launched kernels)
-    K_LONG = 256 if (K < 64 and args.model in ("llama8b", "llama8b-2l") and not os.environ.get("ROCP_TOOL_LIBRARIES")) else 0
+    K_LONG = 256 if (K < 64 and args.model in ("llama8b", "llama8b-2l", "llama8b-8l") and not os.environ.get("ROCP_TOOL_LIBRARIES")) else 0
     seq_len = P + W + K + K_LONG + 8
     t_load = time.time()
     model = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"]))
@@ -518,7 +518,7 @@ def main():
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "%s bf16, 1xMI355X, single-prompt greedy decode, seq_len=%d -> +%d tokens (%s)"
                                   % (name, P, K, ("configs[2] decode" if P >= 4096 else "configs[1]") if args.model == "llama8b" else "shape of configs[4] on one GPU" if args.model == "llama70b-like" else
-                                     "configs[2] workload on the two-layer cut the CPU oracle reaches" if args.model == "llama8b-2l" else "test shape"),
+                                     "configs[2] workload on the %d-layer cut the CPU oracle reaches" % cfg["n_layers"] if args.model in ("llama8b-2l", "llama8b-8l") else "test shape"),
                       "prompt_len": P, "sequences_in_flight": 1, "parallelism": "single GPU",
                       "mode": "exact-order (token-id identical to the CPU reference path)" if args.mode == "exact" else
                               "fast (opt-in tolerance mode: split-K f32 sums, same bf16 truncation points; NOT token-identical, see DESIGN.md 6.2)",

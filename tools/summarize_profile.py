@@ -20,7 +20,7 @@ os.makedirs(DST, exist_ok=True)
 
 # decode kernel classes of the 8B shape: (substring of the kernel name, LDS bytes or None) -> class name of bench.py
 CLASSES = [
-    ("gemv_chain_kernel<32, 1,", None, "attn_norm+wqkv+rope GEMV"), ("attn_exact_kernel", None, "attention"),
+    ("gemv_chain_kernel<32, 1,", None, "attn_norm+wqkv+rope GEMV"), ("gemv_quad_kernel<24,", None, "attn_norm+wqkv+rope GEMV"), ("attn_exact_kernel", None, "attention"),
     ("attn_long_scores_kernel", None, "attention (long-context: scores)"), ("attn_long_pv_kernel", None, "attention (long-context: PV)"),
 
     ("gemv_chain_kernel<56, 2,", None, "ffn_norm+w1|w3+silu GEMV"), ("gemv_chain_kernel<64, 1,", None, "norm+output GEMV"),
@@ -34,7 +34,7 @@ CLASSES = [
 
 # wo and w2 run through ONE kernel symbol with the same grid (rocprofv3 reports only static LDS, which is 0 for both): their launches are
 # told apart by size -- durations in the trace pass, bytes in the PMC pass -- at the geometric mean of the extremes (K = 4096 against 14336)
-SPLIT = {"rowcast_kernel<2>": ("wo+residual GEMV", "w2+residual GEMV"), "fast_gemv_b<2>": ("wo+residual GEMV", "w2+residual GEMV"),
+SPLIT = {"rowcast_kernel<2>": ("wo+residual GEMV", "w2+residual GEMV"), "rowcast_lds_kernel<2>": ("wo+residual GEMV", "w2+residual GEMV"), "fast_gemv_b<2>": ("wo+residual GEMV", "w2+residual GEMV"),
          "mfma_stream_kernel<1, 2>": ("batch: wo+residual stream", "batch: w2+residual stream")}
 
 
