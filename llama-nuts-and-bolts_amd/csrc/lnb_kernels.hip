@@ -261,7 +261,7 @@ DEVINL uint32_t rms_walk_fast(uint32_t sb, const SeqNode& rc, unsigned long long
         // M + c on the f32 BITS of the running sum: no carry into the exponent field <=> the sum stays inside the binade
         const uint32_t e = na >> 24;
         const uint32_t t = sb + (((sb & 1u) ? nb : na) & 0xFFFFFFu);
-        const uint32_t bad = ((t ^ sb) >> 23) | (e ^ (sb >> 23)) | (uint32_t)(e == 0u);
+        const uint32_t bad = ((t ^ sb) >> 23) | (e ^ (sb >> 23)) | ((e - 1u) >> 31);      // (e == 0 as integer arithmetic: hipcc sent the comparison through the vector unit and back)
         cnt += 0x10000;                                                  // (diagnostics: items << 16 | replays)
         if (__builtin_expect(bad == 0u, 1)) sb = t;
         else {                                                           // replay leaves pos..i term by term
