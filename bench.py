@@ -390,7 +390,7 @@ def main():
     ap.add_argument("--model", default="llama8b", choices=["llama8b", "llama8b-2l", "llama8b-8l", "tiny", "llama70b-like"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"],
                     help="exact (default, headline): the reference's k-ordered chains, token-identical to the CPU path; "
-                         "fast: split-K / bf16-MFMA tolerance mode (opt-in, measured distance in DESIGN.md 6.2)")
+                         "fast: split-K / bf16-MFMA tolerance mode (opt-in, measured distance in NOTES.md 6.2)")
     ap.add_argument("--dry-run", action="store_true", help=argparse.SUPPRESS)   # launcher check without a GPU: every rank reports its environment and exits
     args = ap.parse_args()
 
@@ -521,7 +521,7 @@ def main():
                                      "configs[2] workload on the %d-layer cut the CPU oracle reaches" % cfg["n_layers"] if args.model in ("llama8b-2l", "llama8b-8l") else "test shape"),
                       "prompt_len": P, "sequences_in_flight": 1, "parallelism": "single GPU",
                       "mode": "exact-order (token-id identical to the CPU reference path)" if args.mode == "exact" else
-                              "fast (opt-in tolerance mode: split-K f32 sums, same bf16 truncation points; NOT token-identical, see DESIGN.md 6.2)",
+                              "fast (opt-in tolerance mode: split-K f32 sums, same bf16 truncation points; NOT token-identical, see NOTES.md 6.2)",
                       "tokens_vs_oracle_golden": golden_ok, "device_self_check": self_check,
                       "hip_event_ms_per_step": round(ev_ms / K, 4),
                       "timed_region_repeats_ms_per_step": [round(1e3 * r[0] / K, 4) for r in reps], "reported_repeat": "median",

@@ -95,7 +95,7 @@ int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which /*0=K 1=V*/, uint16_t* host
  * operators and bf16 truncation points with split-K f32 sums (decode) and bf16 matrix-core GEMMs (prefill): HBM / MFMA bound instead
  * of add-latency bound.  NOT a parity mode: per operator it stays within one bf16 ulp of the chain, but after 32 blocks the logits are
  * NOT within the north star's 1e-2 of the reference's (measured on the 8B shape: max |dlogit| 0.578, argmax differs in 13.9 % of
- * teacher-forced steps -- DESIGN.md 6.2) and token ids diverge.  Opt-in, per context, switchable between calls; the KV cache is
+ * teacher-forced steps -- NOTES.md 6.2) and token ids diverge.  Opt-in, per context, switchable between calls; the KV cache is
  * shared by both modes. */
 enum { LNB_MODE_EXACT = 0, LNB_MODE_FAST = 1 };
 int lnb_ctx_set_mode(lnb_ctx* c, int mode);

@@ -833,7 +833,7 @@ extern "C" int lnb_forward(lnb_ctx* c, const int32_t* tokens, int seq, int start
 static int enqueue_decode_step(lnb_ctx* c) {
     lnb_model* m = c->m;
     // LNB_MEASURE_SKIP_TOKEN_KERNELS=1 (timing only, the tokens are garbage): the step without its embedding gather and argmax launches =
-    // the most that fusing them into the neighbouring products could return
+    // the most that fusing them into the neighbouring products could return (NOTES 5.8)
     const bool skip = env_int("LNB_MEASURE_SKIP_TOKEN_KERNELS", 0) != 0;
     if (!skip) HIPCHK(lnbk_embed(m->tok_embd, c->dtok, c->x, 1, m->a.dim, m->a.vocab_size, c->derr, c->stream));
     if (enqueue_layers(c, 1, false)) return -1;
@@ -919,7 +919,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     HIPCHK(hipSetDevice(m->device));
     // which 7 / 8 (measurement only): the gate|up kernel and the down kernel of a block launched CONCURRENTLY on two streams (7: w2 first, i.e.
     // its waves are the older ones on every SIMD; 8: w1|w3 first), w2's LDS request padded so that exactly one workgroup of each kernel sits on
-    // every CU -- what co-residency would cost a w1|w3 -> w2 row-band pipeline; results are NOT meaningful (w2 reads stale input)
+    // every CU -- what co-residency would cost a w1|w3 -> w2 row-band pipeline (NOTES.md 6.1); results are NOT meaningful (w2 reads stale input)
     if (iters <= 0 || which < 0 || which > K_LAYER + 2) return fail("bad arguments");
     if (check_call(c, 1, pos)) return -1;
     if (which == K_HEAD && !m->last()) return fail("this stage does not own output.weight");

@@ -4,7 +4,7 @@
 // Reference: the reference shares W across the rows of a call (src/ml/operations_lineartransform.go:173-193) and creates one context per
 // generation (src/inference/inference.go:174); N generations in flight are N independent one-token Forward calls per step.  Here their
 // tokens are the COLUMNS of one matrix product: v_mfma_f32_16x16x4_f32 is bit for bit the reference's k-ordered chain
-// acc = fma(x_k, w_k, acc) for each of its 16 x 16 outputs (tools/mfma_exact.hip), so column s carries sequence s's chains
+// acc = fma(x_k, w_k, acc) for each of its 16 x 16 outputs (NOTES.md 5.6, tools/mfma_exact.hip), so column s carries sequence s's chains
 // unchanged -- same bits as its single-sequence run -- while the weights are streamed from HBM ONCE for all of them.
 //
 //   mfma_stream_kernel   weights (M16 layout, lnb_device.h) HBM -> VGPR -> matrix-core A operand, activations of the batch (B-operand

@@ -140,7 +140,7 @@ struct AttnParams {
 };
 
 // ---- batched exact decode: up to 16 independent sequences per pass over the weights (lnb_batch_kernels.h) --------------------------
-// v_mfma_f32_16x16x4_f32 IS the reference's k-ordered chain; its 16 batch columns carry 16 SEQUENCES' decode tokens,
+// v_mfma_f32_16x16x4_f32 IS the reference's k-ordered chain (NOTES.md 5.6); its 16 batch columns carry 16 SEQUENCES' decode tokens,
 // so one pass over the weights serves all of them, each with its own bit-exact chains.  The matrix cores are fed straight from HBM:
 // M16 weight layout of a logical [N, K] matrix (K % 128 == 0), NCH chains per 16-row tile:
 //   [tile t = n / 16][chain c][chunk C = k / 128][m = (k % 16) / 4][i = n % 16][kk = k % 4][e = (k % 128) / 16]      (bf16)
@@ -194,5 +194,5 @@ LNB_HD int lnb_gemm_stream_ntw(int n_tiles, int ct, int nch, int num_cus) {
     while (ntw > 1 && (ntw > ct || (long)((n_tiles + 3) / 4) * ((ct + ntw - 1) / ntw) < need)) ntw >>= 1;
     return ntw;
 }
-// Dispatch order: row groups fastest once there are more than 8 of them (traffic)
+// Dispatch order: row groups fastest once there are more than 8 of them (NOTES.md 5.12, traffic)
 LNB_HD int lnb_gemm_stream_rows_fastest(int row_groups) { return row_groups > 8 ? 1 : 0; }

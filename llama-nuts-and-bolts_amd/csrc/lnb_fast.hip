@@ -3,7 +3,7 @@
 // sum instead of the reference's single k-ordered chain (src/ml/operations_lineartransform.go:46-65), so these kernels are
 // HBM-bound instead of add-latency-bound.  Results are NOT bit-identical to the reference (f32 addition is not associative and
 // every bf16 truncation amplifies a last-bit difference to 2^-8 relative); the mode is opt-in (lnb_ctx_set_mode) and its
-// distance from the oracle is MEASURED (tools/fast_mode_stats.py) -- the default stays the exact-order path.
+// distance from the oracle is MEASURED (tools/fast_mode_stats.py, NOTES.md section 6.2) -- the default stays the exact-order path.
 //
 // The weights are read IN PLACE from the layouts the exact-order kernels stream (lnb_device.h: tiled_index), one resident copy:
 //   layout A  [N/RW][K/8][NCH][RW][8]   (wq|wk|wv, w1|w3, output; every matrix of the 70B-like shape)

@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
 //   waves 4..7  helper: wave 4+c streams the weights of chain wave c (same lane mapping as rowcast_kernel: lane (q, j) holds the
 //                       eight weights of row q with k = j mod 16), multiplies them by x (exact products) and leaves them in a
 //                       lane-private LDS ring -- wave w and w+4 share a SIMD, the helper is the younger wave there and only takes
-//                       the issue slots the chain's DPP latency leaves free (5.3 cycles per step beside a younger
+//                       the issue slots the chain's DPP latency leaves free (NOTES.md 5.8: 5.3 cycles per step beside a younger
 //                       vector-heavy wave);
 // stages of RL_SC chunks in a three-slot ring, one s_barrier per stage: at iteration t the helpers write stage t while the chain
 // waves add stage t-2 and prefetch the first chunk of stage t-1 (complete since the previous barrier), so no LDS round trip is
@@ -1189,7 +1189,7 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
     const int wg = (S == 1) ? (int)blockIdx.x : (int)(blockIdx.x / (unsigned)S);
     const int nb_mine = (p.n_blocks - wg + p.n_wg - 1) / p.n_wg;       // 16-row blocks wg, wg+n_wg, ...
     const int NS = nb_mine * nst;                                      // stages this workgroup walks
-    // x first, all of its loads in flight at once; the weight stream starts once x has landed
+    // x first, all of its loads in flight at once; the weight stream starts once x has landed (NOTES.md 5.1)
     constexpr int RL_XU = 4;                                 // 16 B units of x per thread: K <= 16384
     const uint16_t* xrow = p.x + (size_t)m * K;
     uint4 xv[RL_XU];
@@ -1985,7 +1985,7 @@ template <int HD> DEVINL void attn_pv_add(int c, int nchunks, int d, const char*
 // function of Z.  The quotient is formed as e * (1 / Zt) (within 2 ulps of e / Zt); it must not lie within delta32 = 4T + 12 ulps of the
 // one point per bf16 cell where the result changes (low 45 mantissa bits = 2^45 - 2^28); f32-denormal quotients are certified by
 // evaluating both ends of the interval.  Returns p; sets bad when the element cannot be certified (the caller then walks the serial sum).
-// (Header of attn_long_pv_kernel / DESIGN.md 5.9.)
+// (Header of attn_long_pv_kernel / NOTES.md 5.9.)
 struct CertZ { double rzt, zlo, zhi; unsigned delta32; };
 DEVINL CertZ cert_z(double zt, int T) {
     const double epsr = (double)(4 * T + 8) * 1.1102230246251565e-16;
@@ -2591,7 +2591,7 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     // seven helpers (448 lanes = one (k-chunk, row) pair each), 64-step stages
     if constexpr (NCH == 2) if (rw == 56) return launch_chain_t<56, 2, 14336, 7, 8, EPI, NORM>(p, st);
     // RW 28 (two chains, LNB_RW_W13=28): the same stream cut into 512 half-height blocks, two per workgroup -- rows [0, F/2) are complete
-    // after the first block of every workgroup: the row-band order a w1|w3 -> w2 pipeline needs (measurement)
+    // after the first block of every workgroup: the row-band order a w1|w3 -> w2 pipeline needs (measurement, NOTES.md 6.1)
     if constexpr (NCH == 2) if (rw == 28) return launch_chain_t<28, 2, 14336, 7, 8, EPI, NORM>(p, st);
     return hipErrorInvalidValue;
 }

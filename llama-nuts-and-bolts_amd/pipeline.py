@@ -770,7 +770,7 @@ def bench_main(args, cfg, name):
             m_lit.pop("tokens_seq0")
             extra["literal_blocks_split"] = dict(m_lit, blocks_per_gpu=cfg["n_layers"] // world, tokens_per_s=round(K * n_seq / m_lit.pop("wall"), 2))
             pipe.close()
-        nb = int(os.environ.get("LNB_PIPELINE_BATCH", "64" if mode == "exact" else "0"))      # (more than 16: the groups are rows of the streaming product; 64: 4.7 tokens per ms of an 8B-shape step against 3.1 at 32)
+        nb = int(os.environ.get("LNB_PIPELINE_BATCH", "64" if mode == "exact" else "0"))      # (more than 16: the groups are rows of the streaming product, NOTES 5.11; 64: 4.7 tokens per ms of an 8B-shape step against 3.1 at 32)
         mb = None
         if nb > 0:
             mb = measure_batched(min(nb, 128))

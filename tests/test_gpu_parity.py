@@ -114,7 +114,7 @@ def test_linear_special_values(lnb, rows, rw):
     operands give a subnormal, inexactly rounded product -- operations_lineartransform.go:60 multiplies in float32), and sums that
     cancel to exactly zero.  Bits must match the oracle; for NaN results only the NaN-ness.
     The GEMVs multiply, then add, like the reference, and match everywhere.  The f32 matrix-core instruction of the prefill GEMM
-    (16 or more rows) FUSES the multiply: same bits whenever every single product is a normal f32 -- its rows
+    (16 or more rows) FUSES the multiply: same bits whenever every single product is a normal f32 (NOTES.md section 2) -- its rows
     here keep sums that overflow and subnormal partial sums, but no single product outside [2^-126, 2^128)."""
     k, n = 512, 96
     rng = np.random.default_rng(rows * 131 + rw)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""What would a w1|w3 -> w2 row-band pipeline have to work with?  (run on the GPU box.)
+"""What would a w1|w3 -> w2 row-band pipeline have to work with?  (NOTES.md 6.1; run on the GPU box.)
  1. the gate|up kernel cut into half-height row blocks, two per workgroup (LNB_RW_W13=28: rows [0, F/2) complete after the first block of
     every workgroup -- the band order a pipeline needs) against the production 56-row blocks;
  2. the gate|up kernel and the down kernel of a block launched CONCURRENTLY, one workgroup of each on every CU (lnb_profile_kernel 7 / 8):
