@@ -133,8 +133,11 @@ DEVINL void x_store(const GemvParams& p, float* xs, int kpad, int sidx, int lane
 // lane; on the GPU: tests/test_gpu_parity.py through lnb_op_rmsnorm_linear); ~17 items + ~5 replayed leaves for gaussian x.
 // A leaf is seq_leaf_size(K, NH*64) terms (one leaf per folding lane; the last one may run into the zero padding).
 constexpr int RMS_HEAD = 256;
-__host__ __device__ inline size_t rms_scratch_bytes(int NH) { return (size_t)NH * (512 + 8 + 4 + 4) + 64; }
-// LDS scratch (the idle product ring): SeqNode rec[NH][64] | uint64 items[NH] | float wtot[NH] | uint32 scan_failed[NH]
+__host__ __device__ inline size_t rms_scratch_bytes(int NH) { return (size_t)NH * (512 + 8 + 4 + 4 + 2048 + 8) + 64; }
+// LDS scratch (the idle product ring): SeqNode rec[NH][64] | uint64 items[NH] | float wtot[NH] | uint32 scan_failed[NH] |
+//                                      SeqItem list[NH][128] (each wave's items of the branch-free walk, in leaf order) | uint32 {count, uncovered}[NH]
+__host__ __device__ inline size_t rms_list_off(int NH) { return (size_t)NH * 528; }
+__host__ __device__ inline size_t rms_meta_off(int NH) { return (size_t)NH * (528 + 2048); }
 
 // wave scans on DPP data movement (VALU, no LDS round trip like ds_bpermute): in-row shifts by 1, 2, 4, 8, then lane 15 of a row
 // into the next row (rows 1, 3) and lane 31 into rows 2, 3 -- the classic gfx9 inclusive-scan order.  `old` is what lanes
@@ -175,8 +178,9 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
 #pragma unroll
     for (int w = 0; w < NH; w++) { const float v = wtot[w]; base += w < hw ? v : 0.0f; }
     SeqNode n; n.a = 0u; n.b = 0u;
+    const float lo = base + (incl - bsum), hi = base + incl;           // approximate running sum in front of / behind this leaf
     {   // the leaf's parity map from two simulated f32 running sums (lnb_seqsum.h: seq_leaf): 2 adds per term
-        const int32_t e = b < nleaf ? seq_guess(base + (incl - bsum), base + incl) : 0;
+        const int32_t e = b < nleaf ? seq_guess_tight(lo, hi) : 0;
         float s0, s1; seq_sim_init(e, s0, s1);
         for (int i = 0; i < LEAF; i += 4) {
             const float4 v = *(const float4*)(q + i);
@@ -185,6 +189,14 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
         if (b < nleaf) n = seq_sim_node(e, s0, s1);
     }
     if (b < nleaf && bsum == 0.0f && (n.a >> 24) == 0u) n.a = SEQ_ZERO_LEAF;      // nothing to add, whatever the running sum is
+    // A leaf that enters the next binade: split at the crossing term (lnb_seqsum.h: seq_split_leaf, here branch-free for the whole wave --
+    // only waves that hold such a leaf run it): map of the terms before x*, x*, map of the terms after it.
+    SeqItem sa, sb2; sa.x = sa.c0 = 0u; sa.d = 0; sa.e = 0u; sb2 = sa;
+    bool split_ok = false;
+    {
+        const bool cand = b < nleaf && (n.a >> 24) == 0u && n.a != SEQ_ZERO_LEAF && seq_split_candidate(lo, hi);
+        if (__ballot(cand)) { const SeqSplit sp = seq_split_leaf(q, LEAF, lo, hi); split_ok = cand && sp.ok; sa = sp.a; sb2 = sp.b; }
+    }
     SeqNode left; left.a = (uint32_t)dpp_wave_shr1((int)n.a, 0); left.b = 0u;
     int f = seq_is_start(lane, n, left, b == headleaf);
     const int fnext = dpp_wave_shl1(f, 1);
@@ -199,6 +211,26 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
     LNB_SEG_STEP(dpp_row_shr<4>, (lane & 15) >= 4) LNB_SEG_STEP(dpp_row_shr<8>, (lane & 15) >= 8)
     LNB_SEG_STEP(dpp_bcast15, (lane & 16) != 0) LNB_SEG_STEP(dpp_bcast31, lane >= 32)
 #undef LNB_SEG_STEP
+    {   // the wave's items of the branch-free walk, in leaf order: the end of every run (its composed map), the two items of every split leaf;
+        // leaves of exact zeros emit nothing; a leaf that nothing covers marks the row for the old walk
+        const bool pick = ((mask >> lane) & 1ull) && b >= headleaf && b < nleaf && n.a != SEQ_ZERO_LEAF;
+        const bool valid = (n.a >> 24) != 0u;
+        const unsigned long long m1 = __ballot(pick && (valid || split_ok)), m2 = __ballot(pick && !valid && split_ok);
+        const unsigned long long mu = __ballot(pick && !valid && !split_ok);
+        const unsigned rank = __builtin_amdgcn_mbcnt_hi((unsigned)(m1 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m1, 0u)) +
+                              __builtin_amdgcn_mbcnt_hi((unsigned)(m2 >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m2, 0u));
+        uint4* list = (uint4*)(scratch + rms_list_off(NH)) + hw * 128;
+        if (pick && valid) { const SeqItem it = seq_item_of_node(n); list[rank] = make_uint4(it.x, it.c0, (uint32_t)it.d, it.e); }
+        if (pick && !valid && split_ok) {
+            list[rank] = make_uint4(sa.x, sa.c0, (uint32_t)sa.d, sa.e);
+            list[rank + 1] = make_uint4(sb2.x, sb2.c0, (uint32_t)sb2.d, sb2.e);
+        }
+        if (lane == 0) {
+            uint32_t* meta = (uint32_t*)(scratch + rms_meta_off(NH)) + hw * 2;
+            meta[0] = (uint32_t)(__builtin_popcountll(m1) + __builtin_popcountll(m2));
+            meta[1] = mu ? 1u : 0u;
+        }
+    }
     n.b |= (uint32_t)start << 24;                                        // c1 < 2^24: the run's first leaf rides in the top byte
     rec[hw * 64 + lane] = n;
     { const unsigned long long fm = __ballot(failed != 0); if (lane == 0) ((uint32_t*)(scratch + (size_t)NH * 524))[hw] = fm ? 1u : 0u; }
@@ -318,27 +350,72 @@ template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* 
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
     const long long tw0_ = p.dbg ? clock64() : 0;
-    SeqNode rc[NH];
-    unsigned long long mk[NH];
     int cnt = 0;
+    // ---- the row's item list (rms_fold), walked WITHOUT a branch per item -------------------------------------------------------
+    // lane w < NH: wave w's item count and "something uncovered" flag; lane g: global item g, fetched from its wave's list segment
+    bool done = false;
+    {
+        const uint2 meta = ((const uint2*)(scratch + rms_meta_off(NH)))[lane < NH ? lane : 0];
+        const uint32_t failv = ((const uint32_t*)(scratch + (size_t)NH * 524))[lane < NH ? lane : 0];
+        const unsigned long long badm = __ballot(lane < NH && (meta.y != 0u || failv != 0u));
+        int tot = 0, wsel = 0, below = 0;                                // items in front of lane g's wave
 #pragma unroll
-    for (int w = 0; w < NH; w++) { rc[w] = rec[w * 64 + lane]; mk[w] = items[w]; }
-    const uint32_t badv = ((const uint32_t*)(scratch + (size_t)NH * 524))[lane < NH ? lane : 0];      // scan_failed[w] in lane w
-    const unsigned long long badm = __ballot(badv != 0u);
-#define LNB_WSTAMP(i) do { if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + 7) * 8 + (i)] = clock64() - tw0_ + 1; } while (0)
-    LNB_WSTAMP(0);
+        for (int w = 0; w < NH; w++) {
+            const int cw = __builtin_amdgcn_readlane((int)meta.x, w);
+            tot += cw;
+            if (w + 1 < NH) { const bool past = lane >= tot; wsel += past ? 1 : 0; below = past ? tot : below; }
+        }
+        if (badm == 0ull && tot <= 64) {
+            const uint4 it = ((const uint4*)(scratch + rms_list_off(NH)))[wsel * 128 + (lane < tot ? lane - below : 0)];
+            const float ix = __uint_as_float(lane < tot ? it.x : 0u);    // lanes past the list: identity items (never reached anyway)
+            const uint32_t ic0 = lane < tot ? it.y : 0u;
+            const int id = lane < tot ? (int)it.z : 0;
+            // systolic recurrence: the running sum hops one lane per step (DPP wave_shr:1); lane g holds its true input at step g, computes
+            // u = bits(f32(s) + x), t = u + c0 + (u & 1) d, latches t and hands it on.  Seven vector instructions per item, no scalar work.
+            uint32_t sv = sb, lat = 0u;
+#define LNB_ITEM_STEP(G) { const uint32_t u_ = __float_as_uint(__uint_as_float(sv) + ix); \
+                           const uint32_t t_ = (uint32_t)(__mul24((int)(u_ & 1u), id) + (int)u_) + ic0; \
+                           lat = lane == (G) ? t_ : lat; sv = (uint32_t)dpp_wave_shr1((int)t_, 0); }
+#define LNB_ITEM_STEP4(G) LNB_ITEM_STEP(G) LNB_ITEM_STEP((G) + 1) LNB_ITEM_STEP((G) + 2) LNB_ITEM_STEP((G) + 3)
 #pragma unroll
-    for (int w = 0; w < NH; w++) {
-        int nloc = nleaf - w * 64; nloc = nloc < 0 ? 0 : (nloc > 64 ? 64 : nloc);
-        int pos = headleaf - w * 64; pos = pos < 0 ? 0 : pos;
-        const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mk[w]);
-        const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mk[w] >> 32));
-        if (__builtin_expect((badm >> w) & 1ull, 0)) sb = rms_walk_heap(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF);
-        else sb = rms_walk_fast(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF, tq[w], regs, cnt);
-        if (w < 7) LNB_WSTAMP(1 + w);
+            for (int G = 0; G < 64; G += 4) if (G < tot) { LNB_ITEM_STEP4(G) }
+#undef LNB_ITEM_STEP4
+#undef LNB_ITEM_STEP
+            // every item's check at once: lane g redoes its step from the latched output of lane g-1 (lane 0: the head's sum)
+            const uint32_t sin = lane == 0 ? sb : (uint32_t)dpp_wave_shr1((int)lat, 0);
+            const uint32_t u = __float_as_uint(__uint_as_float(sin) + ix);
+            const uint32_t t = (uint32_t)(__mul24((int)(u & 1u), id) + (int)u) + ic0;
+            const uint32_t bad = lane < tot ? (((t ^ u) >> 23) | (it.w ^ (u >> 23)) | (t ^ lat)) : 0u;
+            if (__ballot(bad != 0u) == 0ull) {
+                if (tot > 0) sb = (uint32_t)__builtin_amdgcn_readlane((int)lat, tot - 1);
+                done = true;
+                cnt = tot << 16;
+            }
+        }
+    }
+    if (!done) {
+        // ---- the old walk (every record's binade verified item by item, crossing leaves replayed term by term): rows with a leaf that is
+        // neither a run member nor cleanly split (non-finite terms, jumps of several binades, a crossing too close to call), with a guess
+        // that did not hold, or with more than 64 items
+        SeqNode rc[NH];
+        unsigned long long mk[NH];
+#pragma unroll
+        for (int w = 0; w < NH; w++) { rc[w] = rec[w * 64 + lane]; mk[w] = items[w]; }
+        const uint32_t badv = ((const uint32_t*)(scratch + (size_t)NH * 524))[lane < NH ? lane : 0];      // scan_failed[w] in lane w
+        const unsigned long long badm = __ballot(badv != 0u);
+        cnt = 1;
+#pragma unroll
+        for (int w = 0; w < NH; w++) {
+            int nloc = nleaf - w * 64; nloc = nloc < 0 ? 0 : (nloc > 64 ? 64 : nloc);
+            int pos = headleaf - w * 64; pos = pos < 0 ? 0 : pos;
+            const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mk[w]);
+            const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mk[w] >> 32));
+            if (__builtin_expect((badm >> w) & 1ull, 0)) sb = rms_walk_heap(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF);
+            else sb = rms_walk_fast(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF, tq[w], regs, cnt);
+        }
     }
     if (p.dbg) t_dbg = clock64() - tw0_;                                 // walk time
-    if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + 0) * 8 + 7] = cnt;   // stamp slot 7 of the walker
+    if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + 0) * 8 + 7] = cnt;   // stamp slot 7 of the walker: items << 16 | (old walk: 1 + ...)
     float mean = __fdiv_rn(__uint_as_float(sb), (float)K);
     mean = mean + p.eps;
     return (float)(1.0 / sqrt((double)mean));

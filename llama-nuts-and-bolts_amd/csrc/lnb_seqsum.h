@@ -136,6 +136,73 @@ SEQ_HD SeqNode seq_leaf(const float* p, int n, float lo, float hi) {
     return seq_sim_node(e, s0, s1);
 }
 
+// ---- items of the branch-free walk (round 4) ----------------------------------------------------------------------------
+// The serial part of the multi-wave form used to visit its items with scalar code and to REPLAY every leaf that crosses into the next
+// binade term by term; both are slow for reasons that have nothing to do with arithmetic (a v_readlane with a computed lane ~50 cycles,
+// a branch on a vector result ~40, the replay's cold path ~500).  An ITEM advances the running sum s (f32 bits, s >= +0) by
+//     u = bits(f32(s) + x);   t = u + c0 + (u & 1) * d;        valid iff u and t lie in binade e
+// -- one exact f32 add followed by a parity map -- which covers both kinds of step: a run of leaves (x = +0: the add is the identity) and
+// a leaf that CROSSES a binade edge, split at the crossing term x*: (0, map of the terms before x*, e) then (x*, map of the terms after
+// x*, e + 1).  Where the sum crosses is guessed from the approximate prefix sums like every binade here, and like every guess it is
+// verified when applied: the first item's check says every term before x* kept the sum inside binade e, the second's that s + x* is in
+// binade e + 1 and stays there.  Every item of a row is applied unconditionally (no branch), the checks are OR-ed, and a row with any
+// failed check -- or with a leaf that is neither a run member nor cleanly split -- is walked again the old way (seq_apply_node + replays).
+struct SeqItem { uint32_t x, c0; int32_t d; uint32_t e; };
+SEQ_HD SeqItem seq_item_of_node(const SeqNode& n) {             // a node of the scan (its b may carry the run's first leaf in the top byte)
+    SeqItem it; it.x = 0u; it.c0 = n.a & 0xFFFFFFu; it.d = (int32_t)(n.b & 0xFFFFFFu) - (int32_t)it.c0; it.e = n.a >> 24;
+    return it;
+}
+SEQ_HD uint32_t seq_item_apply(uint32_t s, const SeqItem& it, uint32_t& bad) {
+    const uint32_t u = seq_f2u(seq_u2f(s) + seq_u2f(it.x));
+    const uint32_t t = u + it.c0 + (uint32_t)((int32_t)(u & 1u) * it.d);
+    bad |= ((t ^ u) >> 23) | (it.e ^ (u >> 23));
+    return t;
+}
+// binade guess with a margin just above the error of the approximate prefix sums (f32 tree sums of a few thousand non-negative terms:
+// ~1e-6 relative): a wrong guess costs a fallback, never a wrong result
+SEQ_HD int32_t seq_guess_tight(float lo, float hi) {
+    const uint32_t ul = seq_f2u(lo * 0.999998f), uh = seq_f2u(hi * 1.000002f);
+    const int32_t el = (int32_t)((ul >> 23) & 0xFF), eh = (int32_t)((uh >> 23) & 0xFF);
+    if (el != eh || el == 0 || el == 0xFF) return 0;
+    return el;
+}
+// a leaf whose approximate prefix sums say "enters the next binade here": split at the term that takes the approximate running sum across
+// the edge, if that is unambiguous (no approximate sum of the leaf -- the one in front of it included -- within 2e-6 of the edge: several
+// times the error of the approximate prefix).  One pass, no data-dependent branch: the device runs it for a whole wave at once (terms in
+// front of the crossing feed the sums of binade el, terms behind it those of el + 1; + 0 leaves a sum unchanged).  p: 16-byte aligned,
+// n a multiple of 4.  A wrong split costs a fallback, never a wrong result -- the walk verifies every item.
+struct SeqSplit { int ok; SeqItem a, b; };
+SEQ_HD int seq_split_candidate(float lo, float hi) {
+    const uint32_t el = (seq_f2u(lo) >> 23) & 0xFFu, eh = (seq_f2u(hi) >> 23) & 0xFFu;
+    return (el >= 1u && eh == el + 1u && eh < 0xFFu) ? 1 : 0;
+}
+SEQ_HD SeqSplit seq_split_leaf(const float* p, int n, float lo, float hi) {
+    SeqSplit r;
+    const int cand = seq_split_candidate(lo, hi);
+    const int32_t el = cand ? (int32_t)((seq_f2u(lo) >> 23) & 0xFFu) : 1, eh = el + 1;
+    const float edge = seq_u2f((uint32_t)eh << 23), e_lo = edge * 0.999998f, e_hi = edge * 1.000002f;
+    float a0, a1, b0, b1; seq_sim_init(el, a0, a1); seq_sim_init(eh, b0, b1);
+    float run = lo, xs = 0.0f;
+    int amb = !(lo <= e_lo);
+    const float* q = (const float*)__builtin_assume_aligned(p, 16);
+    for (int i = 0; i < n; i += 4) {
+        const float vv[4] = {q[i], q[i + 1], q[i + 2], q[i + 3]};
+        for (int j = 0; j < 4; j++) {
+            const float v = vv[j], nx = run + v;
+            const int was = run >= edge, is = nx >= edge;
+            amb |= (nx > e_lo && nx < e_hi) ? 1 : 0;
+            const float ta = is ? 0.0f : v, tb = was ? v : 0.0f;
+            xs = (is && !was) ? v : xs;
+            a0 = a0 + ta; a1 = a1 + ta; b0 = b0 + tb; b1 = b1 + tb;
+            run = nx;
+        }
+    }
+    const SeqNode na = seq_sim_node(el, a0, a1), nb = seq_sim_node(eh, b0, b1);
+    r.ok = (cand && !amb && run >= edge && (na.a >> 24) != 0u && (nb.a >> 24) != 0u) ? 1 : 0;
+    r.a = seq_item_of_node(na); r.b = seq_item_of_node(nb); r.b.x = seq_f2u(xs);
+    return r;
+}
+
 // ---- segmented inclusive scan of leaf maps (one wave = 64 leaves) -------------------------------------------------
 // a leaf starts a new run when it or its left neighbour is invalid, when the binade changes, or when forced
 SEQ_HD int seq_is_start(int lane, const SeqNode& me, const SeqNode& left, int forced) {

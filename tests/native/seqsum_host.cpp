@@ -127,3 +127,72 @@ extern "C" float seqsum_tree(const float* pin, int K, int NH, int head_terms, in
     if (raw) *raw = nr;
     return seq_u2f(sb);
 }
+
+
+// ---- round 4: the branch-free walk over a row's ITEM LIST (rms_fold's emission + rms_scale_wide's fast path), emulated -------------------
+// Same leaves, same per-wave segmented scan as seqsum_tree; binades guessed with the tight margin; a leaf that crosses a binade edge is
+// split (seq_split_leaf) instead of being replayed.  Items in leaf order: the end of every run (x = 0, the run's composed map) and the two
+// items of every split leaf; leaves of exact zeros emit nothing; anything else that is not covered marks the row for the old walk.
+// Every item is applied unconditionally, the checks OR-ed: a row whose checks all pass is done, any other row is handed to seqsum_tree.
+// *fast = 1 if the list was enough, *n_items = its length.
+static int dbg_reason = 0;
+extern "C" int seqsum_dbg_reason() { return dbg_reason; }
+extern "C" float seqsum_items(const float* pin, int K, int NH, int head_terms, int* fast, int* n_items) {
+    const int LEAF = seq_leaf_size(K, NH * 64), nleaf = (K + LEAF - 1) / LEAF, TB = NH * 64;
+    std::vector<float> pv((size_t)TB * LEAF + 64, 0.0f);
+    for (int k = 0; k < K; k++) pv[k] = pin[k];
+    const float* p = pv.data();
+    std::vector<float> bs(TB, 0.0f), lo(TB), hi(TB);
+    for (int b = 0; b < nleaf; b++) { const float* q = p + (size_t)b * LEAF; float v = 0.0f; for (int i = 0; i < LEAF; i += 4) v += (q[i] + q[i + 1]) + (q[i + 2] + q[i + 3]); bs[b] = v; }
+    float run = 0.0f;
+    for (int g = 0; g < NH; g++) { float incl = 0.0f; for (int l = 0; l < 64; l++) { const int b = g * 64 + l; lo[b] = run + incl; incl += bs[b]; hi[b] = run + incl; } run += incl; }
+    int head = head_terms < K ? head_terms : K;
+    const int headleaf = head / LEAF;
+    head = headleaf * LEAF;
+    std::vector<SeqItem> list;
+    bool row_bad = false;
+    dbg_reason = 0;
+    for (int g = 0; g < NH; g++) {
+        SeqNode n[64]; int f[64], st[64]; SeqSplit sp[64]; bool zero[64];
+        for (int l = 0; l < 64; l++) {
+            const int b = g * 64 + l;
+            n[l].a = 0; n[l].b = 0; sp[l].ok = 0; zero[l] = false;
+            if (b < nleaf) {
+                const int32_t e = seq_guess_tight(lo[b], hi[b]);
+                float s0, s1; seq_sim_init(e, s0, s1);
+                for (int i = 0; i < LEAF; i++) { s0 = s0 + p[(size_t)b * LEAF + i]; s1 = s1 + p[(size_t)b * LEAF + i]; }
+                n[l] = seq_sim_node(e, s0, s1);
+                if (bs[b] == 0.0f && !(n[l].a >> 24)) { n[l].a = SEQ_ZERO_LEAF; zero[l] = true; }
+                else if (!(n[l].a >> 24)) sp[l] = seq_split_leaf(p + (size_t)b * LEAF, LEAF, lo[b], hi[b]);
+            }
+        }
+        for (int l = 0; l < 64; l++) f[l] = seq_is_start(l, n[l], l ? n[l - 1] : n[l], g * 64 + l == headleaf);
+        uint64_t mask = 0;
+        for (int l = 0; l < 64; l++) if (!(n[l].a >> 24) || l == 63 || f[l + 1 < 64 ? l + 1 : 63] || l == 63) mask |= 1ull << l;
+        for (int l = 0; l + 1 < 64; l++) if (f[l + 1]) mask |= 1ull << l;
+        for (int l = 0; l < 64; l++) st[l] = l;
+        int failed = 0;
+        for (int d = 1; d < 64; d <<= 1) {
+            SeqNode nn[64]; int ff[64], ss[64];
+            for (int l = 0; l < 64; l++) { nn[l] = n[l]; ff[l] = f[l]; ss[l] = st[l]; if (l >= d && !f[l]) failed |= !seq_scan_step(nn[l], ff[l], ss[l], n[l - d], f[l - d], st[l - d]); }
+            for (int l = 0; l < 64; l++) { n[l] = nn[l]; f[l] = ff[l]; st[l] = ss[l]; }
+        }
+        if (failed) { row_bad = true; dbg_reason |= 1; }
+        for (int l = 0; l < 64; l++) {
+            const int b = g * 64 + l;
+            if (!((mask >> l) & 1) || b < headleaf || b >= nleaf || zero[l]) continue;
+            if (n[l].a >> 24) list.push_back(seq_item_of_node(n[l]));            // the end of a run: its composed map
+            else if (sp[l].ok) { list.push_back(sp[l].a); list.push_back(sp[l].b); }
+            else { row_bad = true; dbg_reason |= 2; }                             // a leaf nothing covers: old walk
+        }
+    }
+    if (n_items) *n_items = (int)list.size();
+    float s = 0.0f;
+    for (int k = 0; k < head; k++) s += p[k];
+    uint32_t sb = seq_f2u(s), bad = 0;
+    for (const SeqItem& it : list) sb = seq_item_apply(sb, it, bad);
+    if (bad) dbg_reason |= 4;
+    if (row_bad || bad || list.size() > 64) { if (fast) *fast = 0; return seqsum_tree(pin, K, NH, head_terms, nullptr, nullptr); }
+    if (fast) *fast = 1;
+    return seq_u2f(sb);
+}
