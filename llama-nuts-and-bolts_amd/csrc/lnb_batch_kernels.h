@@ -217,7 +217,7 @@ __global__ __launch_bounds__((1 + BN_NH) * 64) void batch_rmsnorm_xt_kernel(cons
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier();                        // B1: the squares are in LDS
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        rms_fold<NH>(p, xs, scratch, hw, lane, t_aux);       // X1, X2 inside
+        rms_fold<rms_nf(NH)>(p, xs, scratch, hw < rms_nf(NH) ? hw : -1, lane, t_aux);       // X1, X2 inside
         __builtin_amdgcn_s_barrier();                        // B2: r published
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         x_normalize<NS>(p, xs, kpad, xs[kpad], 1 + hw, lane, xv, nv);
@@ -227,7 +227,7 @@ __global__ __launch_bounds__((1 + BN_NH) * 64) void batch_rmsnorm_xt_kernel(cons
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier();                        // B1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        const float r = rms_scale_wide<NH>(p, xs, scratch, lane, t_aux);     // X1, X2 inside
+        const float r = rms_scale_wide<rms_nf(NH)>(p, xs, scratch, lane, t_aux);     // X1, X2 inside
         if (lane == 0) xs[kpad] = r;
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_s_barrier();                        // B2

@@ -136,6 +136,13 @@ constexpr int RMS_HEAD = 256;
 __host__ __device__ inline size_t rms_scratch_bytes(int NH) { return (size_t)NH * (512 + 8 + 4 + 4 + 2048 + 8) + 64; }
 // LDS scratch (the idle product ring): SeqNode rec[NH][64] | uint64 items[NH] | float wtot[NH] | uint32 scan_failed[NH] |
 //                                      SeqItem list[NH][128] (each wave's items of the branch-free walk, in leaf order) | uint32 {count, uncovered}[NH]
+// Folding waves: every helper (-DLNB_RMS_NF_MAX=4 restricts the fold to four waves on four different SIMDs -- waves w and w+4 of a workgroup
+// share one: HW_ID read per wave, round 4 -- with leaves of 16 terms instead of 12: measured SLOWER, wq|wk|wv 21.2 vs 20.1 us; the fold's time
+// follows its instruction count per wave, not the number of waves on a SIMD).  Helpers past the limit only pass the fold's two barriers.
+#ifndef LNB_RMS_NF_MAX
+#define LNB_RMS_NF_MAX 8
+#endif
+__host__ __device__ constexpr int rms_nf(int NH) { return NH > LNB_RMS_NF_MAX ? LNB_RMS_NF_MAX : NH; }
 __host__ __device__ inline size_t rms_list_off(int NH) { return (size_t)NH * 528; }
 __host__ __device__ inline size_t rms_meta_off(int NH) { return (size_t)NH * (528 + 2048); }
 
@@ -157,7 +164,19 @@ DEVINL float wave_inclusive_sum(float v) {
     return v;
 }
 
+DEVINL void rms_load16(float (&tv)[16], const float* q, int c, int LEAF) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c + 4 * i < LEAF) v = *(const float4*)(q + c + 4 * i);       // (wave-uniform)
+        tv[4 * i] = v.x; tv[4 * i + 1] = v.y; tv[4 * i + 2] = v.z; tv[4 * i + 3] = v.w;
+    }
+}
+DEVINL float rms_tree16(const float (&tv)[16]) {
+    return (((tv[0] + tv[1]) + (tv[2] + tv[3])) + ((tv[4] + tv[5]) + (tv[6] + tv[7]))) + (((tv[8] + tv[9]) + (tv[10] + tv[11])) + ((tv[12] + tv[13]) + (tv[14] + tv[15])));
+}
 template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, char* scratch, int hw, int lane, long long& t_dbg) {
+    if (hw < 0) { __builtin_amdgcn_s_barrier(); __builtin_amdgcn_s_barrier(); return; }      // a helper that does not fold: X1, X2
     const long long tf0_ = p.dbg ? clock64() : 0;
     const int LEAF = seq_leaf_size(p.K, NH * 64), nleaf = (p.K + LEAF - 1) / LEAF;
     SeqNode* rec = (SeqNode*)scratch;
@@ -166,8 +185,13 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
     const int headleaf = (p.K < RMS_HEAD ? p.K : RMS_HEAD) / LEAF;
     const int b = hw * 64 + lane;
     const float* q = xs + (size_t)(b < nleaf ? b : nleaf - 1) * LEAF;    // (xs is zero padded past K: the last leaf may over-read)
-    float bsum = 0.0f;
-    for (int i = 0; i < LEAF; i += 4) { const float4 v = *(const float4*)(q + i); bsum += (v.x + v.y) + (v.z + v.w); }   // only feeds the guess
+    // the leaf's terms are read from LDS ONCE, into registers (16 per pass; what lies past the leaf is replaced by +0, which changes no sum):
+    // the three passes below were bound by their LDS reads (a loop of dependent ds_read_b128 -> wait -> add; lanes 48 or 64 bytes apart
+    // conflict 3- or 4-way), not by their arithmetic.  Leaves of more than 16 terms (K > 4096) re-read chunk by chunk.
+    float tv[16];
+    rms_load16(tv, q, 0, LEAF);
+    float bsum = rms_tree16(tv);                                         // only feeds the guess
+    for (int c = 16; c < LEAF; c += 16) { rms_load16(tv, q, c, LEAF); bsum += rms_tree16(tv); }
     bsum = b < nleaf ? bsum : 0.0f;
     const float incl = wave_inclusive_sum(bsum);             // (x + 0.0f for lanes without a source: only feeds the guess)
     if (lane == 63) wtot[hw] = incl;
@@ -182,9 +206,18 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
     {   // the leaf's parity map from two simulated f32 running sums (lnb_seqsum.h: seq_leaf): 2 adds per term
         const int32_t e = b < nleaf ? seq_guess_tight(lo, hi) : 0;
         float s0, s1; seq_sim_init(e, s0, s1);
-        for (int i = 0; i < LEAF; i += 4) {
-            const float4 v = *(const float4*)(q + i);
-            s0 = s0 + v.x; s1 = s1 + v.x; s0 = s0 + v.y; s1 = s1 + v.y; s0 = s0 + v.z; s1 = s1 + v.z; s0 = s0 + v.w; s1 = s1 + v.w;
+        for (int c = 0; c < LEAF; c += 16) {
+            if (LEAF > 16) rms_load16(tv, q, c, LEAF);
+#pragma unroll
+            for (int i = 0; i < 8; i++) { s0 = s0 + tv[i]; s1 = s1 + tv[i]; }
+            if (LEAF > 8) {                                              // (wave-uniform: the terms past the leaf are zeros, skipped instead of added)
+#pragma unroll
+                for (int i = 8; i < 12; i++) { s0 = s0 + tv[i]; s1 = s1 + tv[i]; }
+            }
+            if (LEAF > 12) {
+#pragma unroll
+                for (int i = 12; i < 16; i++) { s0 = s0 + tv[i]; s1 = s1 + tv[i]; }
+            }
         }
         if (b < nleaf) n = seq_sim_node(e, s0, s1);
     }
@@ -195,7 +228,10 @@ template <int NH> DEVINL void rms_fold(const GemvParams& p, const float* xs, cha
     bool split_ok = false;
     {
         const bool cand = b < nleaf && (n.a >> 24) == 0u && n.a != SEQ_ZERO_LEAF && seq_split_candidate(lo, hi);
-        if (__ballot(cand)) { const SeqSplit sp = seq_split_leaf(q, LEAF, lo, hi); split_ok = cand && sp.ok; sa = sp.a; sb2 = sp.b; }
+        if (__ballot(cand)) {
+            const SeqSplit sp = LEAF <= 12 ? seq_split_leaf(tv, 12, lo, hi) : LEAF <= 16 ? seq_split_leaf(tv, 16, lo, hi) : seq_split_leaf(q, LEAF, lo, hi);
+            split_ok = cand && sp.ok; sa = sp.a; sb2 = sp.b;
+        }
     }
     SeqNode left; left.a = (uint32_t)dpp_wave_shr1((int)n.a, 0); left.b = 0u;
     int f = seq_is_start(lane, n, left, b == headleaf);
@@ -279,7 +315,7 @@ DEVINL uint32_t rms_walk_heap(uint32_t sb, const SeqNode& rc, unsigned long long
 // tq: this wave-set's x^2 terms, lane l holding leaf l's (up to 12) terms -- loaded by the walker while it waits for the fold; `regs` says
 // whether they are there (LEAF <= 12).  A replayed leaf then costs a v_readlane + v_add per term (~120 cycles) instead of an LDS round trip
 // behind a cold branch (~750 measured).
-DEVINL uint32_t rms_walk_fast(uint32_t sb, const SeqNode& rc, unsigned long long mask, int pos, int nloc, const float* sq, int LEAF, const float4 (&tq)[3], bool regs, int& cnt) {
+DEVINL uint32_t rms_walk_fast(uint32_t sb, const SeqNode& rc, unsigned long long mask, int pos, int nloc, const float* sq, int LEAF, int& cnt) {
     mask &= ~0ull << pos;
     if (nloc < 64) mask &= ~(~0ull << nloc);
     mask &= ~__ballot(rc.a == SEQ_ZERO_LEAF);
@@ -299,15 +335,7 @@ DEVINL uint32_t rms_walk_fast(uint32_t sb, const SeqNode& rc, unsigned long long
         else {                                                           // replay leaves pos..i term by term
             cnt += 1;
             float f = __uint_as_float(sb);
-            if (regs) {
-#define LNB_RL(v) __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l))
-                for (int l = pos; l <= i; l++) {
-                    f = f + LNB_RL(tq[0].x); f = f + LNB_RL(tq[0].y); f = f + LNB_RL(tq[0].z); f = f + LNB_RL(tq[0].w);
-                    f = f + LNB_RL(tq[1].x); f = f + LNB_RL(tq[1].y); f = f + LNB_RL(tq[1].z); f = f + LNB_RL(tq[1].w);
-                    if (LEAF > 8) { f = f + LNB_RL(tq[2].x); f = f + LNB_RL(tq[2].y); f = f + LNB_RL(tq[2].z); f = f + LNB_RL(tq[2].w); }
-                }
-#undef LNB_RL
-            } else {
+            {
                 const float* qe = sq + (size_t)(i + 1) * LEAF;
                 for (const float* q = sq + (size_t)pos * LEAF; q < qe; q += 16) {
                     // (reads past qe stay inside the zero-padded x buffer; what lies past the range is replaced by +0, and f + 0 == f)
@@ -335,17 +363,6 @@ template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* 
     const int headleaf = (K < RMS_HEAD ? K : RMS_HEAD) / LEAF, head = headleaf * LEAF;
     float sum = 0.0f;
     for (int k0 = 0; k0 < head; k0 += 4) sum = add4(sum, *(const float4*)(xs + k0));
-    // all x^2 terms into registers while the helpers fold (lane l of set w: leaf 64 w + l), for the replays of the walk
-    const bool regs = LEAF == 8 || LEAF == 12;
-    float4 tq[NH][3];
-    if (regs) {
-#pragma unroll
-        for (int w = 0; w < NH; w++) {
-            const int lf = w * 64 + lane;
-            const float* q = xs + (size_t)(lf < nleaf ? lf : nleaf - 1) * LEAF;      // (the last leaf may run into the zero padding)
-            tq[w][0] = *(const float4*)q; tq[w][1] = *(const float4*)(q + 4); tq[w][2] = *(const float4*)(q + 8);
-        }
-    }
     __builtin_amdgcn_s_barrier();                                        // X2 (the records)
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     uint32_t sb = (uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(sum));
@@ -354,6 +371,7 @@ template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* 
     // ---- the row's item list (rms_fold), walked WITHOUT a branch per item -------------------------------------------------------
     // lane w < NH: wave w's item count and "something uncovered" flag; lane g: global item g, fetched from its wave's list segment
     bool done = false;
+    int why = 0;
     {
         const uint2 meta = ((const uint2*)(scratch + rms_meta_off(NH)))[lane < NH ? lane : 0];
         const uint32_t failv = ((const uint32_t*)(scratch + (size_t)NH * 524))[lane < NH ? lane : 0];
@@ -365,6 +383,7 @@ template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* 
             tot += cw;
             if (w + 1 < NH) { const bool past = lane >= tot; wsel += past ? 1 : 0; below = past ? tot : below; }
         }
+        why = (badm ? 1 << 28 : 0) | (tot > 64 ? 2 << 28 : 0) | ((tot & 0xFF) << 8) | (int)((badm & 0xFF) << 20);
         if (badm == 0ull && tot <= 64) {
             const uint4 it = ((const uint4*)(scratch + rms_list_off(NH)))[wsel * 128 + (lane < tot ? lane - below : 0)];
             const float ix = __uint_as_float(lane < tot ? it.x : 0u);    // lanes past the list: identity items (never reached anyway)
@@ -372,25 +391,37 @@ template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* 
             const int id = lane < tot ? (int)it.z : 0;
             // systolic recurrence: the running sum hops one lane per step (DPP wave_shr:1); lane g holds its true input at step g, computes
             // u = bits(f32(s) + x), t = u + c0 + (u & 1) d, latches t and hands it on.  Seven vector instructions per item, no scalar work.
-            uint32_t sv = sb, lat = 0u;
-#define LNB_ITEM_STEP(G) { const uint32_t u_ = __float_as_uint(__uint_as_float(sv) + ix); \
-                           const uint32_t t_ = (uint32_t)(__mul24((int)(u_ & 1u), id) + (int)u_) + ic0; \
-                           lat = lane == (G) ? t_ : lat; sv = (uint32_t)dpp_wave_shr1((int)t_, 0); }
+            // (inline asm: the compiler turns (u & 1) * d into v_cmp + v_cndmask and the latch into v_cmp + v_cndmask -- two SGPR round trips
+            // with their wait states per item; here: add (DPP), bfe, and, add3, latch through a constant lane mask in SGPRs, and the two
+            // wait states a DPP read of a just-written VGPR needs -- s_nop 1: whatever the compiler put in front of the first step)
+            uint32_t tv, lat = 0u, tmp;
+            {   // item 0: every lane from the head's sum
+                const uint32_t u0 = __float_as_uint(__uint_as_float(sb) + ix);
+                tv = u0 + ic0 + (uint32_t)(-(int)(u0 & 1u) & id);
+                lat = lane == 0 ? tv : 0u;
+            }
+#define LNB_ITEM_STEP(G) asm volatile("s_nop 1\n\tv_add_f32_dpp %0, %0, %3 wave_shr:1 row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t" \
+                                      "v_bfe_i32 %2, %0, 0, 1\n\tv_and_b32 %2, %2, %4\n\tv_add3_u32 %0, %0, %5, %2\n\t" \
+                                      "v_cndmask_b32_e64 %1, %1, %0, %6" \
+                                      : "+v"(tv), "+v"(lat), "=&v"(tmp) : "v"(ix), "v"(id), "v"(ic0), "s"(1ull << (G)));
 #define LNB_ITEM_STEP4(G) LNB_ITEM_STEP(G) LNB_ITEM_STEP((G) + 1) LNB_ITEM_STEP((G) + 2) LNB_ITEM_STEP((G) + 3)
+            if (tot > 1) { LNB_ITEM_STEP(1) LNB_ITEM_STEP(2) LNB_ITEM_STEP(3) }
 #pragma unroll
-            for (int G = 0; G < 64; G += 4) if (G < tot) { LNB_ITEM_STEP4(G) }
+            for (int G = 4; G < 64; G += 4) if (G < tot) { LNB_ITEM_STEP4(G) }
 #undef LNB_ITEM_STEP4
 #undef LNB_ITEM_STEP
-            // every item's check at once: lane g redoes its step from the latched output of lane g-1 (lane 0: the head's sum)
-            const uint32_t sin = lane == 0 ? sb : (uint32_t)dpp_wave_shr1((int)lat, 0);
+            // every item's check at once: lane g redoes its step from the latched output of lane g-1 (lane 0: the head's sum).  (The DPP move
+            // is NOT inside a conditional: a lane masked off by the condition would be read as "no source lane".)
+            const uint32_t lprev = (uint32_t)dpp_wave_shr1((int)lat, 0);
+            const uint32_t sin = lane == 0 ? sb : lprev;
             const uint32_t u = __float_as_uint(__uint_as_float(sin) + ix);
-            const uint32_t t = (uint32_t)(__mul24((int)(u & 1u), id) + (int)u) + ic0;
+            const uint32_t t = u + ic0 + (uint32_t)(-(int)(u & 1u) & id);
             const uint32_t bad = lane < tot ? (((t ^ u) >> 23) | (it.w ^ (u >> 23)) | (t ^ lat)) : 0u;
             if (__ballot(bad != 0u) == 0ull) {
                 if (tot > 0) sb = (uint32_t)__builtin_amdgcn_readlane((int)lat, tot - 1);
                 done = true;
                 cnt = tot << 16;
-            }
+            } else why |= 4 << 28;
         }
     }
     if (!done) {
@@ -411,10 +442,11 @@ template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* 
             const unsigned lo32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)mk[w]);
             const unsigned hi32 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(mk[w] >> 32));
             if (__builtin_expect((badm >> w) & 1ull, 0)) sb = rms_walk_heap(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF);
-            else sb = rms_walk_fast(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF, tq[w], regs, cnt);
+            else sb = rms_walk_fast(sb, rc[w], ((unsigned long long)hi32 << 32) | lo32, pos, nloc, xs + (size_t)w * 64 * LEAF, LEAF, cnt);
         }
     }
     if (p.dbg) t_dbg = clock64() - tw0_;                                 // walk time
+    if (!done) cnt = why;
     if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + 0) * 8 + 7] = cnt;   // stamp slot 7 of the walker: items << 16 | (old walk: 1 + ...)
     float mean = __fdiv_rn(__uint_as_float(sb), (float)K);
     mean = mean + p.eps;
@@ -608,7 +640,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
             TIMED_BARRIER();                                           // B1: xs (or the squares) are in LDS
             if (NORM) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-                rms_fold<NH>(p, xs, ringB, hw, lane, t_aux);                  // X1, X2 inside
+                rms_fold<rms_nf(NH)>(p, xs, ringB, hw - (NH - rms_nf(NH)), lane, t_aux);      // X1, X2 inside; the LAST four helpers fold (waves 4..7 of 8: four SIMDs)
                 if (late) {                                            // the walker walks now: the issue stall costs nothing here
 #pragma unroll
                     for (int j = 0; j < R; j++) issue_next(buf[j]);
@@ -688,7 +720,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
         TIMED_BARRIER();                                               // B1
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         if (NORM) {
-            const float r = rms_scale_wide<NH>(p, xs, ringB, lane, t_aux);     // X1, X2 inside
+            const float r = rms_scale_wide<rms_nf(NH)>(p, xs, ringB, lane, t_aux);     // X1, X2 inside
             if (lane == 0) xs[kpad] = r;
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             TIMED_BARRIER();                                           // B2
@@ -853,7 +885,7 @@ __global__ __launch_bounds__((gq_ncw(RW) + NH) * 64) void gemv_quad_kernel(GemvP
         TIMED_BARRIER();                                               // B1: xs (or the squares) are in LDS
         if (NORM) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-            rms_fold<NH>(p, xs, ringB, hw, lane, t_aux);               // X1, X2 inside
+            rms_fold<rms_nf(NH)>(p, xs, ringB, hw < rms_nf(NH) ? hw : -1, lane, t_aux);      // X1, X2 inside; the first four helpers fold (four consecutive waves: four SIMDs)
             if (late) {                                                // the walker walks now: the issue stall costs nothing here
 #pragma unroll
                 for (int j = 0; j < R; j++) issue_next(buf[j]);
@@ -923,7 +955,7 @@ __global__ __launch_bounds__((gq_ncw(RW) + NH) * 64) void gemv_quad_kernel(GemvP
         if (NORM) {
             float r;
             if (wave == 0) {
-                r = rms_scale_wide<NH>(p, xs, ringB, lane, t_aux);     // X1, X2 inside
+                r = rms_scale_wide<rms_nf(NH)>(p, xs, ringB, lane, t_aux);     // X1, X2 inside
                 LNB_STAMP(3);
                 if (lane == 0) xs[kpad] = r;
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -2626,7 +2658,7 @@ static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
     size_t lds = 4 * (size_t)SA + xs_bytes(p->K, SA / (NCH * RW * 2));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (xs_bytes(p->K, SA / (NCH * RW * 2)) / 4 > (size_t)XCh<NORM>::value * (1 + NH) * 512) return hipErrorInvalidValue;   // x staging registers
-    if (NORM && (rms_scratch_bytes(NH) > 4 * (size_t)SA || seq_leaf_size(p->K, NH * 64) > 256)) return hipErrorInvalidValue;   // records live in the idle ring; leaf over-read stays inside the x padding
+    if (NORM && (rms_scratch_bytes(rms_nf(NH)) > 4 * (size_t)SA || seq_leaf_size(p->K, rms_nf(NH) * 64) > 256)) return hipErrorInvalidValue;   // records live in the idle ring; leaf over-read stays inside the x padding
     hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3((1 + NH) * 64), lds, st, *p);
     return hipGetLastError();
 }
@@ -2641,7 +2673,7 @@ static hipError_t launch_quad_t(const GemvParams* p, hipStream_t st) {
     const size_t lds = GQ_SLOTS * SB + xs_bytes(p->K, KS);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
     if (xs_bytes(p->K, KS) / 4 > (size_t)XCh<NORM>::value * NW * 512) return hipErrorInvalidValue;     // x staging registers
-    if (NORM && (rms_scratch_bytes(NH) > GQ_SLOTS * SB || seq_leaf_size(p->K, NH * 64) > 256)) return hipErrorInvalidValue;
+    if (NORM && (rms_scratch_bytes(rms_nf(NH)) > GQ_SLOTS * SB || seq_leaf_size(p->K, rms_nf(NH) * 64) > 256)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3(NW * 64), lds, st, *p);
     return hipGetLastError();
 }
@@ -2749,7 +2781,7 @@ extern "C" hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st) {
 extern "C" hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps, hipStream_t st) {
     static const int wide = getenv("LNB_NORM_ROWS_WIDE") ? atoi(getenv("LNB_NORM_ROWS_WIDE")) : 1;
     const size_t lds_w = bn_scratch() + ((size_t)bn_kpad(K) + 8) * 4;                  // one workgroup of seven waves per row: the exact parallel evaluation of the serial sum
-    if (wide && !(K & 127) && lds_w <= 64 * 1024 && (size_t)bn_kpad(K) <= (size_t)XCh<true>::value * (1 + BN_NH) * 512 && seq_leaf_size(K, BN_NH * 64) <= 256) {
+    if (wide && !(K & 127) && lds_w <= 64 * 1024 && (size_t)bn_kpad(K) <= (size_t)XCh<true>::value * (1 + BN_NH) * 512 && seq_leaf_size(K, rms_nf(BN_NH) * 64) <= 256) {
         hipLaunchKernelGGL(batch_rmsnorm_xt_kernel<false>, dim3((unsigned)S), dim3((1 + BN_NH) * 64), lds_w, st, x, w, eps, out, K);
         return hipGetLastError();
     }
@@ -2909,7 +2941,7 @@ extern "C" hipError_t lnbk_batch_prepare(void) {             // raise the dynami
 }
 extern "C" hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K, int nseq, hipStream_t st) {
     const size_t lds = bn_scratch() + ((size_t)bn_kpad(K) + 8) * 4;
-    if ((K & 127) || lds > 160 * 1024 || (size_t)bn_kpad(K) > (size_t)XCh<true>::value * (1 + BN_NH) * 512 || seq_leaf_size(K, BN_NH * 64) > 256) return hipErrorInvalidValue;
+    if ((K & 127) || lds > 160 * 1024 || (size_t)bn_kpad(K) > (size_t)XCh<true>::value * (1 + BN_NH) * 512 || seq_leaf_size(K, rms_nf(BN_NH) * 64) > 256) return hipErrorInvalidValue;
     hipLaunchKernelGGL(batch_rmsnorm_xt_kernel<true>, dim3((unsigned)nseq), dim3((1 + BN_NH) * 64), lds, st, x, norm_w, eps, xt, K);
     return hipGetLastError();
 }

@@ -167,38 +167,41 @@ SEQ_HD int32_t seq_guess_tight(float lo, float hi) {
     return el;
 }
 // a leaf whose approximate prefix sums say "enters the next binade here": split at the term that takes the approximate running sum across
-// the edge, if that is unambiguous (no approximate sum of the leaf -- the one in front of it included -- within 2e-6 of the edge: several
-// times the error of the approximate prefix).  One pass, no data-dependent branch: the device runs it for a whole wave at once (terms in
+// the edge, if that is unambiguous (no approximate sum of the leaf -- the one in front of it included -- within 2e-6 (relative) of the edge:
+// several times the error of the approximate prefix).  One pass, no data-dependent branch: the device runs it for a whole wave at once (terms in
 // front of the crossing feed the sums of binade el, terms behind it those of el + 1; + 0 leaves a sum unchanged).  p: 16-byte aligned,
 // n a multiple of 4.  A wrong split costs a fallback, never a wrong result -- the walk verifies every item.
 struct SeqSplit { int ok; SeqItem a, b; };
+#define SEQ_FMIN(a, b) __builtin_fminf(a, b)
+#define SEQ_FABS(a) __builtin_fabsf(a)
 SEQ_HD int seq_split_candidate(float lo, float hi) {
     const uint32_t el = (seq_f2u(lo) >> 23) & 0xFFu, eh = (seq_f2u(hi) >> 23) & 0xFFu;
-    return (el >= 1u && eh == el + 1u && eh < 0xFFu) ? 1 : 0;
+    return (el >= 1u && eh > el && eh < 0xFFu) ? 1 : 0;       // (one term may lift the sum several binades: an outlier channel)
 }
 SEQ_HD SeqSplit seq_split_leaf(const float* p, int n, float lo, float hi) {
     SeqSplit r;
     const int cand = seq_split_candidate(lo, hi);
-    const int32_t el = cand ? (int32_t)((seq_f2u(lo) >> 23) & 0xFFu) : 1, eh = el + 1;
-    const float edge = seq_u2f((uint32_t)eh << 23), e_lo = edge * 0.999998f, e_hi = edge * 1.000002f;
+    const int32_t el = cand ? (int32_t)((seq_f2u(lo) >> 23) & 0xFFu) : 1, eh = cand ? (int32_t)((seq_f2u(hi) >> 23) & 0xFFu) : 2;
+    const float edge = seq_u2f((uint32_t)eh << 23);
     float a0, a1, b0, b1; seq_sim_init(el, a0, a1); seq_sim_init(eh, b0, b1);
-    float run = lo, xs = 0.0f;
-    int amb = !(lo <= e_lo);
+    // ten operations per term on the device: add, compare, three selects (one mask operation), subtract, min, two packed adds
+    float run = lo, xs = 0.0f, clear = edge - lo;                    // clear: the smallest |approximate sum - edge| seen (lo < edge: el < eh)
+    bool was = false;
     const float* q = (const float*)__builtin_assume_aligned(p, 16);
     for (int i = 0; i < n; i += 4) {
         const float vv[4] = {q[i], q[i + 1], q[i + 2], q[i + 3]};
         for (int j = 0; j < 4; j++) {
             const float v = vv[j], nx = run + v;
-            const int was = run >= edge, is = nx >= edge;
-            amb |= (nx > e_lo && nx < e_hi) ? 1 : 0;
+            const bool is = nx >= edge;
             const float ta = is ? 0.0f : v, tb = was ? v : 0.0f;
             xs = (is && !was) ? v : xs;
+            clear = SEQ_FMIN(clear, SEQ_FABS(nx - edge));
             a0 = a0 + ta; a1 = a1 + ta; b0 = b0 + tb; b1 = b1 + tb;
-            run = nx;
+            run = nx; was = is;
         }
     }
     const SeqNode na = seq_sim_node(el, a0, a1), nb = seq_sim_node(eh, b0, b1);
-    r.ok = (cand && !amb && run >= edge && (na.a >> 24) != 0u && (nb.a >> 24) != 0u) ? 1 : 0;
+    r.ok = (cand && was && clear > edge * 2e-6f && (na.a >> 24) != 0u && (nb.a >> 24) != 0u) ? 1 : 0;
     r.a = seq_item_of_node(na); r.b = seq_item_of_node(nb); r.b.x = seq_f2u(xs);
     return r;
 }

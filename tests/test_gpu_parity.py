@@ -215,6 +215,26 @@ def test_rmsnorm_exact_parallel_sum_adversarial(lnb, k, rw):
     assert (y == orc_linear(xn, w)).all()
 
 
+@pytest.mark.parametrize("k,rw", [(4096, 24), (4096, 16), (2048, 32)])
+def test_rmsnorm_item_list_walk_many_rows(lnb, k, rw):
+    """Round 4: the norm sum is walked as a list of items (runs of leaves + leaves split at a binade crossing), every check OR-ed, with
+    the old record walk as the fallback (a crossing too close to call: ~2.5 % of gaussian rows).  384 rows of varied scale, with and
+    without outlier channels, hit both paths; the bits must be the oracle's either way."""
+    rng = np.random.default_rng(k * 3 + rw)
+    nw = bf(1 + 0.1 * rng.standard_normal(k))
+    w = bf(rng.standard_normal((48, k)) * 0.05)
+    for chunk in range(48):
+        x = rng.standard_normal((8, k)) * np.exp(rng.uniform(-6, 6, (8, 1)))
+        if chunk % 3 == 1:
+            for r in range(8): x[r, rng.integers(0, k, 1 + r % 4)] *= rng.uniform(50, 3000)
+        if chunk % 3 == 2: x *= (rng.random((8, k)) < 0.3)
+        x = bf(x)
+        y = lnb.op_rmsnorm_linear(x, nw, 1e-5, w, rw=rw)
+        xn = np.zeros_like(x)
+        orc.lib().orc_rmsnorm_bf16(orc._p(x), orc._p(nw), orc._p(xn), 8, k, np.float32(1e-5), None)
+        assert (y == orc_linear(xn, w)).all(), chunk
+
+
 @pytest.mark.parametrize("k,rw,reps", [(4096, 32, 1), (512, 16, 1), (4096, 64, 1), (4096, 32, 2), (4096, 24, 1), (1024, 24, 2)])
 def test_rmsnorm_rows_with_non_finite_and_overflowing_squares(lnb, k, rw, reps):
     """Rows the parity-map evaluation of the norm sum was not designed around: inf / NaN activations, squares that overflow f32

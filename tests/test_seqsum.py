@@ -102,7 +102,7 @@ def test_item_list_walk_is_bit_identical_and_rarely_falls_back(lib):
     fast_gauss, items = [], []
     for trial in range(3200):
         K = [4096, 4096, 8192, 256, 512, 1024, 64, 3072, 5120, 8][trial % 10] if trial >= 1600 else 4096
-        NH = [7, 6, 2][trial % 3]
+        NH = [4, 3, 2][trial % 3]              # the device folds on at most four waves (rms_nf)
         p = _cases(rng, K, trial)
         fast, ni = C.c_int(0), C.c_int(0)
         r = lib.seqsum_ref(p.ctypes.data, K)
@@ -112,3 +112,17 @@ def test_item_list_walk_is_bit_identical_and_rarely_falls_back(lib):
             fast_gauss.append(fast.value); items.append(ni.value)
     print("gaussian rows: list sufficient for %.1f %%, %.1f items per row" % (100 * np.mean(fast_gauss), np.mean(items)))
     assert np.mean(fast_gauss) > 0.95 and np.mean(items) < 40
+    # outlier channels (one term lifts the sum several binades -- the massive activations of trained Llama checkpoints): still the list
+    fast_out = []
+    for trial in range(200):
+        x = rng.standard_normal(4096).astype(np.float32) * np.float32(0.05)
+        for pos in rng.integers(300, 4096, size=1 + trial % 3):
+            x[pos] = np.float32(rng.uniform(20, 400))
+        p = (x * x).astype(np.float32)
+        fast = C.c_int(0)
+        r = lib.seqsum_ref(p.ctypes.data, 4096)
+        s = lib.seqsum_items(p.ctypes.data, 4096, 4, 256, C.byref(fast), None)
+        assert np.float32(r).view(np.uint32) == np.float32(s).view(np.uint32), trial
+        fast_out.append(fast.value)
+    print("rows with outlier channels: list sufficient for %.1f %%" % (100 * np.mean(fast_out)))
+    assert np.mean(fast_out) > 0.9
