@@ -1176,7 +1176,7 @@ static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {
         AttnParams ap{}; ap.q = b->q; ap.out = b->att_xt; ap.out_xt = nullptr; ap.btab = b->tab; ap.bkv = b->kv + (l - m->layer_begin); ap.dbg = nullptr;
         ap.S = n; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = b->lds_T; ap.lds_T = b->lds_T; ap.host_T = 0;
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));
-        ap.force_zseq = 0; ap.zseq_count = b->ctxs[0]->zseq_count;
+        ap.force_zseq = 0; ap.zseq_count = b->ctxs[0]->zseq_count; ap.exp_tab = m->exp_tab;     // (attn_gqa_kernel looks exp up)
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {
         GemmParams g = wide_of(b, L.m_wo, b->att_xt, m->q_dim, dim, 1); g.out = b->h; g.res = b->x;
@@ -1213,7 +1213,7 @@ static int enqueue_batch_kernel(lnb_batch* b, int l, int which) {
         AttnParams ap{}; ap.q = b->q; ap.out_xt = b->att_xt; ap.btab = b->tab; ap.bkv = b->kv + (l - m->layer_begin); ap.dbg = nullptr;
         ap.S = n; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = b->lds_T; ap.lds_T = b->lds_T; ap.host_T = 0;
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));
-        ap.force_zseq = 0; ap.zseq_count = b->ctxs[0]->zseq_count;
+        ap.force_zseq = 0; ap.zseq_count = b->ctxs[0]->zseq_count; ap.exp_tab = m->exp_tab;     // (attn_gqa_kernel looks exp up)
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {
         StreamParams p = stream_of(b, L.m_wo, b->att_xt, m->q_dim, dim, 1); p.out = b->h; p.res = b->x;

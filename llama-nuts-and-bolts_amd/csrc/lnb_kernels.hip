@@ -2114,6 +2114,38 @@ DEVINL float cert_p(double e, const CertZ& c, int& bad) {
     }
     return pj;
 }
+// the reference's serial softmax denominator, walked by ONE wave: rowExpSum += exp(...), j ascending, f64 (impl:492-499).  16 values per half,
+// the other half's LDS reads in flight, one wait per half; branch-free (e is zero-padded to a multiple of 32, and readable 16 values further)
+DEVINL double attn_zseq_wave(const double* e, int T) {
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    const d2* e2 = (const d2*)e;
+    double z = 0.0;
+    d2 a[8], b[8];
+#define ATT_TOUCH8(r) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]))
+#pragma unroll
+    for (int u = 0; u < 8; u++) a[u] = e2[u];
+    ATT_TOUCH8(a);
+    for (int j = 0; j < T; j += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) b[u] = e2[((j + 16) >> 1) + u];
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) { z += a[u].x; z += a[u].y; }
+        __builtin_amdgcn_sched_barrier(0);
+        ATT_TOUCH8(b);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) a[u] = e2[((j + 32) >> 1) + u];      // may run past the row's padding: unused then
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int u = 0; u < 8; u++) { z += b[u].x; z += b[u].y; }
+        __builtin_amdgcn_sched_barrier(0);
+        ATT_TOUCH8(a);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+#undef ATT_TOUCH8
+    return z;
+}
 // DENSE = the batched decode's heads x sequences grids (thousands of workgroups): registers for TWO workgroups per CU (4 waves per SIMD, 128
 // VGPRs) instead of one -- the K rows of the next 512 positions are then NOT kept in flight during a pass's score chains (the ping-pong
 // buffer is 64 of the 178 VGPRs of the single stream's form, which launches 32 workgroups on 256 CUs and wants every register)
@@ -2122,7 +2154,11 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
     constexpr int NK = HD / 8;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int h, i; xcd_head_block(h, i);
+    int h, i;
+    // batched decode (DENSE): sequence-major inside an XCD -- the (H / 8) heads an XCD owns are the query heads of ONE KV head (H = 32, KVH = 8),
+    // so the workgroups of one sequence's four heads are dispatched back to back on the same XCD and the K / V rows the first one pulls are
+    // L2 hits for the other three (head-major order: 128 sequences x 92 KB between two readers of the same rows -- every read went to HBM)
+    if (DENSE && !p.head_major) xcd_head_block_bmajor(h, i); else xcd_head_block(h, i);
     // batched decode: query row i is the one new token of SEQUENCE i of the batch -- its own position, caches and cache length
     const BatchTab* const bt = p.btab;
     const int S = bt ? 1 : p.S, KVH = p.KVH;
@@ -2214,33 +2250,7 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
     __syncthreads();
     if (*zflag) {
         if (wave == 0) {                                     // rowExpSum += exp(...), j ascending, f64 (impl:492-499)
-            typedef double d2 __attribute__((ext_vector_type(2)));
-            const d2* e2 = (const d2*)e;
-            double z = 0.0;
-            d2 a[8], b[8];
-#define ATT_TOUCH8(r) asm volatile("" : "+v"(r[0]), "+v"(r[1]), "+v"(r[2]), "+v"(r[3]), "+v"(r[4]), "+v"(r[5]), "+v"(r[6]), "+v"(r[7]))
-#pragma unroll
-            for (int u = 0; u < 8; u++) a[u] = e2[u];
-            ATT_TOUCH8(a);
-            for (int j = 0; j < T; j += 32) {                // 16 values per half, the other half's reads in flight, one wait per half;
-                                                             // branch-free (e is zero-padded to 32)
-#pragma unroll
-                for (int u = 0; u < 8; u++) b[u] = e2[((j + 16) >> 1) + u];
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 8; u++) { z += a[u].x; z += a[u].y; }
-                __builtin_amdgcn_sched_barrier(0);
-                ATT_TOUCH8(b);
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 8; u++) a[u] = e2[((j + 32) >> 1) + u];      // may run into the p / ring region: unused then
-                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int u = 0; u < 8; u++) { z += b[u].x; z += b[u].y; }
-                __builtin_amdgcn_sched_barrier(0);
-                ATT_TOUCH8(a);
-                __builtin_amdgcn_sched_barrier(0);
-            }
+            const double z = attn_zseq_wave(e, T);
             if (lane == 0) { zb[0] = z; if (p.zseq_count && tid == 0) atomicAdd(p.zseq_count, 1); }
         }
         __syncthreads();
@@ -2277,6 +2287,222 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
             if (bt && p.out_xt) p.out_xt[xt_index(i, h * HD + d)] = bf_trunc(acc);   // batch of up to 16: straight into the B-operand layout of the wo product
             else p.out[((size_t)i * p.H + h) * HD + d] = bf_trunc(acc);        // [S, H*hd] (:508-514)
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// attn_gqa_kernel<HD, G>: the batched decode's attention, one workgroup per (KV head, sequence) serving the G = H / KVH = 4 query heads
+// that share the KV head (round 4).  attn_exact_kernel's grid is (H, sequences): at 128 sequences 4096 workgroups of three dependent
+// memory round trips each (q -> K rows -> V rows), two resident per CU -- 63 us per layer -- and the vector unit does everything one
+// lane-operation at a time (a wave64 instruction occupies its SIMD for four cycles: with two workgroups per CU the kernel is bound by
+// the NUMBER of vector instructions, not by memory: profiles/r04_gqa_stamps.log).  Here:
+//   scores : a thread owns (cached position, head PAIR): its K row feeds both heads' chains through ONE v_pk_fma_f32 per dimension
+//            (q staged in the LDS as (head 2a, head 2a+1) pairs; the same fused multiply-add per lane as mac8); 256 positions per pass;
+//   exp    : one 8-byte load from the model's table of exp(trunc(s / sqrt(hd))) over all 65536 bf16 scores (exp_table_kernel: filled by
+//            the very instruction sequence attn_exact_kernel evaluates inline -- ~130 f64 instructions per score);
+//   Z      : tree estimate + certified p_j per head (cert_p); a head that cannot be certified walks the reference's serial sum on its wave;
+//   PV     : V rows are staged ONCE per workgroup (waves 4..7: raw bf16, 32 positions per chunk, four chunks in flight in registers and a
+//            ring of four LDS buffers, one barrier per chunk); wave g < 4 adds head g, a lane owns two neighbouring dims: one ds_read_b32,
+//            two unpack operations, v_pk_mul_f32 and v_pk_add_f32 per position (multiply, then add: bf16 x bf16 is exact in f32 and the
+//            reference rounds only the sum; j ascending) -- the adders do nothing else, the stagers nothing but copy.
+// Same bits as attn_exact_kernel per head.  dynamic LDS: [G][Tp] f64 e | [G][Tp] f32 p | q pairs | zb | [4][32][HD] bf16 V.
+// grid (KVH, sequences), block 512, two workgroups per CU.
+// ------------------------------------------------------------------------------------------------
+__host__ __device__ inline int gqa_tp(int lds_T) { return ((lds_T + 63) / 64) * 64 + 64; }
+__host__ __device__ inline size_t gqa_lds_bytes(int lds_T, int hd, int G) { return (size_t)G * gqa_tp(lds_T) * 12 + (size_t)G * hd * 4 + 512 + 4 * 32 * (size_t)hd * 2; }
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+// adder side of attn_gqa_kernel: a quarter of a V chunk (8 positions of the lane's bf16 pair, ring buffer (q / 4) & 3) and its 8 p values
+template <int HD> DEVINL void gqa_read_piece(uint32_t (&w)[8], float4 (&pq)[2], const char* vl, const float* pg, int q) {
+    const char* vb = vl + ((q >> 2) & 3) * (32 * HD * 2) + (q & 3) * (8 * HD * 2);
+    pq[0] = *(const float4*)(pg + q * 8); pq[1] = *(const float4*)(pg + q * 8 + 4);           // (wave-uniform addresses: broadcast reads)
+#pragma unroll
+    for (int u = 0; u < 8; u++) w[u] = *(const uint32_t*)(vb + u * (HD * 2));
+}
+DEVINL void gqa_add_piece(f32x2_t& a, const uint32_t (&w)[8], const float4 (&pq)[2]) {      // acc += p_j * v[j][d], j ascending: multiply, then add (:508-514)
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        a += f32x2_t{pq[k].x, pq[k].x} * f32x2_t{bf_lo(w[4 * k]), bf_hi(w[4 * k])};
+        a += f32x2_t{pq[k].y, pq[k].y} * f32x2_t{bf_lo(w[4 * k + 1]), bf_hi(w[4 * k + 1])};
+        a += f32x2_t{pq[k].z, pq[k].z} * f32x2_t{bf_lo(w[4 * k + 2]), bf_hi(w[4 * k + 2])};
+        a += f32x2_t{pq[k].w, pq[k].w} * f32x2_t{bf_lo(w[4 * k + 3]), bf_hi(w[4 * k + 3])};
+    }
+}
+template <int HD, int G> __global__ __launch_bounds__(512, 4) void attn_gqa_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK = HD / 8, NT = 512, NPOS = 256, VC = 32;      // a scores pass: 256 positions x 2 head pairs; V chunks of 32 positions
+    static_assert(G == 4 && HD == 128, "two head pairs; one V unit per thread and chunk; two adder waves");
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int kvh = (int)blockIdx.x, i = (int)blockIdx.y;      // (dispatch order: the eight KV heads of a sequence go to the eight XCDs)
+    const BatchTab* const bt = p.btab;
+    const int seq_len = bt->seq_len[i], T = bt->st[i]->pos + 1, Tp = gqa_tp(p.lds_T);
+    double* e = (double*)smem;                                  // [G][Tp]
+    float* pw = (float*)(smem + (size_t)G * Tp * 8);            // [G][Tp]
+    float* qi = (float*)(smem + (size_t)G * Tp * 12);           // [G / 2][HD][2]: (head 2a, head 2a+1) pairs
+    double* zb = (double*)(smem + (size_t)G * Tp * 12 + (size_t)G * HD * 4);     // per head: 4 wave partials | - | Z | flag
+    uint16_t* vs = (uint16_t*)(smem + (size_t)G * Tp * 12 + (size_t)G * HD * 4 + 512);   // ring [4][VC][HD] bf16
+    const uint32_t row_bytes = (uint32_t)p.KVH * HD * 2;
+    const uint4* kbase = (const uint4*)p.bkv->ck[i] + (size_t)kvh * NK * seq_len;
+    const uint16_t* vbase = p.bkv->cv[i] + (size_t)kvh * HD;
+    const int jl = tid & (NPOS - 1), hp = wave >> 2, pwv = wave & 3;       // position inside a pass, head pair, wave inside the pair
+    const int nch = (T + VC - 1) / VC, Tc = nch * VC;
+#define GQA_STAMP(n) do { if (p.dbg && blockIdx.x == 3 && blockIdx.y == gridDim.y / 2 && lane == 0) p.dbg[wave * 16 + (n)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    GQA_STAMP(0);
+
+    // q of the G heads (contiguous in the row) as head pairs, and this thread's K row of the first pass
+    const uint16_t q16 = p.q[((size_t)i * p.H + (size_t)kvh * G) * HD + tid];
+    uint4 ka[NK];
+    if (pwv * 64 < T) attn_load_k<NK>(ka, kbase, seq_len, jl < T ? jl : T - 1);
+    { const int g = tid >> 7, d = tid & (HD - 1); qi[((g >> 1) * HD + d) * 2 + (g & 1)] = bf_wide(q16); }
+    __syncthreads();
+    GQA_STAMP(1);
+    // ---- scores: one cached position per thread and pass, both heads of the pair over the same K row (llamatransformer.go:456-473)
+    const float* qh = qi + hp * HD * 2;
+    for (int j0 = 0; j0 < T; j0 += NPOS) {
+        const int j = j0 + jl;
+        if (j0 + pwv * 64 >= T) continue;                       // (wave-uniform: a wave past the end of the row leaves the issue slots to the others)
+        if (j0 > 0) attn_load_k<NK>(ka, kbase, seq_len, j < T ? j : T - 1);
+        f32x2_t acc = {0.0f, 0.0f};
+#pragma unroll
+        for (int c = 0; c < NK; c++) {                          // MatMul q.k, d ascending (operations_matmul.go:37-55): acc = fma(q_d, k_d, acc) per head
+            const float4 qa = *(const float4*)(qh + c * 16), qb = *(const float4*)(qh + c * 16 + 4), qc = *(const float4*)(qh + c * 16 + 8), qd = *(const float4*)(qh + c * 16 + 12);
+            const uint4 k = ka[c];
+            float kk;
+            kk = bf_lo(k.x); acc = __builtin_elementwise_fma(f32x2_t{qa.x, qa.y}, f32x2_t{kk, kk}, acc);
+            kk = bf_hi(k.x); acc = __builtin_elementwise_fma(f32x2_t{qa.z, qa.w}, f32x2_t{kk, kk}, acc);
+            kk = bf_lo(k.y); acc = __builtin_elementwise_fma(f32x2_t{qb.x, qb.y}, f32x2_t{kk, kk}, acc);
+            kk = bf_hi(k.y); acc = __builtin_elementwise_fma(f32x2_t{qb.z, qb.w}, f32x2_t{kk, kk}, acc);
+            kk = bf_lo(k.z); acc = __builtin_elementwise_fma(f32x2_t{qc.x, qc.y}, f32x2_t{kk, kk}, acc);
+            kk = bf_hi(k.z); acc = __builtin_elementwise_fma(f32x2_t{qc.z, qc.w}, f32x2_t{kk, kk}, acc);
+            kk = bf_lo(k.w); acc = __builtin_elementwise_fma(f32x2_t{qd.x, qd.y}, f32x2_t{kk, kk}, acc);
+            kk = bf_hi(k.w); acc = __builtin_elementwise_fma(f32x2_t{qd.z, qd.w}, f32x2_t{kk, kk}, acc);
+        }
+        if (j < T) {                                            // / sqrt(hd) :464, exp impl:498: tabulated over the raw bf16 score
+            const double e0 = p.exp_tab[bf_trunc(acc.x)], e1 = p.exp_tab[bf_trunc(acc.y)];
+            e[(hp * 2) * Tp + j] = e0; e[(hp * 2 + 1) * Tp + j] = e1;
+        }
+    }
+    GQA_STAMP(2);
+    // V chunks (32 positions x 256 B, raw bf16): staged by waves 4..7, two 16-byte units per thread and chunk, rows clamped to T-1 (p == +0
+    // there).  Four chunks in flight in registers + a ring of four LDS buffers: the adders (waves 0..3) never wait for memory.  Hand-counted
+    // asm ring (hipcc drains vmcnt(0) around loop-carried register prefetch): RING_LOAD / RING_RETIRE, checked by tools/isa_audit.py.
+    const bool stager = wave >= 4;
+    const int st_t = tid - 256;
+    u32x4 s0[2], s1[2], s2[2], s3[2];
+#define GQA_VLOAD(c, R_) do { int ja_ = (c) * VC + (st_t >> 4), jb_ = ja_ + 16; ja_ = ja_ < T ? ja_ : T - 1; jb_ = jb_ < T ? jb_ : T - 1; \
+        const char* aa_ = (const char*)vbase + ((size_t)(uint32_t)ja_ * row_bytes + (uint32_t)(st_t & 15) * 16u); \
+        const char* ab_ = (const char*)vbase + ((size_t)(uint32_t)jb_ * row_bytes + (uint32_t)(st_t & 15) * 16u); \
+        asm volatile("global_load_dwordx4 %0, %1, off ; RING_LOAD" : "=&v"(R_[0]) : "v"(aa_) : "memory"); \
+        asm volatile("global_load_dwordx4 %0, %1, off ; RING_LOAD" : "=&v"(R_[1]) : "v"(ab_) : "memory"); } while (0)
+#define GQA_VSTORE(c, R_, N_) do { asm volatile("s_waitcnt vmcnt(%2) ; RING_RETIRE %0 %1" : "+v"(R_[0]), "+v"(R_[1]) : "n"(N_) : "memory"); \
+        char* dst_ = (char*)vs + ((c) & 3) * (VC * HD * 2) + (st_t >> 4) * (HD * 2) + (st_t & 15) * 16; \
+        *(u32x4*)dst_ = R_[0]; *(u32x4*)(dst_ + 16 * HD * 2) = R_[1]; } while (0)
+    if (stager) { GQA_VLOAD(0, s0); GQA_VLOAD(1, s1); GQA_VLOAD(2, s2); GQA_VLOAD(3, s3); }     // they land during the denominators
+    for (int j = T + tid; j < ((T + 31) & ~31); j += NT) {      // zero padding: the serial walk runs whole groups of 32
+#pragma unroll
+        for (int g = 0; g < G; g++) e[g * Tp + j] = 0.0;
+    }
+    __syncthreads();
+    GQA_STAMP(3);
+    // ---- softmax denominators: tree estimate + certified p_j per head (header of attn_long_pv_kernel)
+    {
+        double part[2] = {0.0, 0.0};
+        for (int j = jl; j < T; j += NPOS) { part[0] += e[(hp * 2) * Tp + j]; part[1] += e[(hp * 2 + 1) * Tp + j]; }
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) part[g] += __shfl_xor(part[g], o);
+            if (lane == 0) zb[(hp * 2 + g) * 10 + pwv] = part[g];
+        }
+        if (tid < G) *(int*)(zb + tid * 10 + 9) = 0;
+    }
+    __syncthreads();
+    {
+#pragma unroll 1
+        for (int g = hp * 2; g < hp * 2 + 2; g++) {             // (not unrolled: inlined copies of cert_p cost registers)
+            const double* z4 = zb + g * 10;
+            const double zt = (z4[0] + z4[1]) + (z4[2] + z4[3]);
+            const CertZ cz = cert_z(zt, T);
+            int bad = p.force_zseq;
+            for (int j = jl; j < Tc; j += NPOS) pw[g * Tp + j] = j < T ? cert_p(e[g * Tp + j], cz, bad) : 0.0f;   // impl:506 + ToBFloat16 :493; +0 up to the chunk
+            if (bad) *(int*)(zb + g * 10 + 9) = 1;
+        }
+    }
+    GQA_STAMP(4);
+    if (stager) {                                               // chunks 0..2 into the ring, chunks 4..6 in flight
+        GQA_VSTORE(0, s0, 6); GQA_VLOAD(4, s0);
+        GQA_VSTORE(1, s1, 6); GQA_VLOAD(5, s1);
+        GQA_VSTORE(2, s2, 6); GQA_VLOAD(6, s2);
+    }
+    __syncthreads();
+    GQA_STAMP(5);
+    {
+        int flags = 0;
+#pragma unroll
+        for (int g = 0; g < G; g++) flags |= *(const int*)(zb + g * 10 + 9) << g;
+        if (flags) {                                            // (block-uniform) a head that could not be certified: the reference's serial sum, on wave g
+            // (the serial walk wants 64 registers: the stagers' V rows must have LANDED before anything may be spilled around it)
+            if (stager) asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE %0 %1 %2 %3 %4 %5 %6 %7" : "+v"(s0[0]), "+v"(s0[1]), "+v"(s1[0]), "+v"(s1[1]), "+v"(s2[0]), "+v"(s2[1]), "+v"(s3[0]), "+v"(s3[1]) :: "memory");
+            if (wave < G && ((flags >> wave) & 1)) {
+                const double z = attn_zseq_wave(e + wave * Tp, T);
+                if (lane == 0) { zb[wave * 10 + 8] = z; if (p.zseq_count) atomicAdd(p.zseq_count, 1); }
+            }
+            __syncthreads();
+#pragma unroll 1
+            for (int g = 0; g < G; g++) {
+                if (!((flags >> g) & 1)) continue;
+                const double z = zb[g * 10 + 8];
+                for (int j = tid; j < T; j += NT) pw[g * Tp + j] = bf_wide(bf_trunc((float)(e[g * Tp + j] / z)));
+            }
+            __syncthreads();
+        }
+    }
+    // ---- PV: out[g][d] = trunc(sum_{j ascending} p[g][j] * v[j][d]) (:508-514).  Wave g < 4 adds head g, lane l the dims 2l, 2l+1: one
+    // ds_read_b32 (a bf16 pair), two unpack operations, v_pk_mul_f32, v_pk_add_f32 per position.  One barrier per chunk: at step c the adders
+    // read ring buffer c & 3 while the stagers write chunk c+3 (into the buffer read at step c-1) and put chunk c+7 in flight.
+    f32x2_t a0 = {0.0f, 0.0f};
+    if (stager) {
+#define GQA_SSTEP(c, R_) do { if ((c) < nch) { GQA_VSTORE((c) + 3, R_, 6); GQA_VLOAD((c) + 7, R_); __syncthreads(); } } while (0)
+        for (int c = 0; c < nch; c += 4) { GQA_SSTEP(c, s3); GQA_SSTEP(c + 1, s0); GQA_SSTEP(c + 2, s1); GQA_SSTEP(c + 3, s2); }
+#undef GQA_SSTEP
+        asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");    // prefetches past the last chunk
+        GQA_STAMP(6);
+        return;                                                 // (the roles never join again: the ring registers are dead on the adders' path)
+    }
+    {
+        // (a quarter chunk -- 8 positions: 8 V words + 2 x 4 p -- is read from the LDS while the quarter before it is added: left to hipcc, every
+        //  ds_read sat right in front of its use, ~100 cycles of LDS latency per two positions.  The first quarter of chunk c+1 is read during
+        //  step c: chunks up to c+2 are complete then.)
+        const float* pg = pw + wave * Tp;
+        const char* vl = (const char*)vs + lane * 4;
+        uint32_t wA[8], wB[8]; float4 pA[2], pB[2];
+        gqa_read_piece<HD>(wA, pA, vl, pg, 0);
+        for (int q = 0; q < 4 * nch; q += 4) {
+            gqa_read_piece<HD>(wB, pB, vl, pg, q + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            gqa_add_piece(a0, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            gqa_read_piece<HD>(wA, pA, vl, pg, q + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            gqa_add_piece(a0, wB, pB);
+            __builtin_amdgcn_sched_barrier(0);
+            gqa_read_piece<HD>(wB, pB, vl, pg, q + 3);
+            __builtin_amdgcn_sched_barrier(0);
+            gqa_add_piece(a0, wA, pA);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 4 < 4 * nch) gqa_read_piece<HD>(wA, pA, vl, pg, q + 4);
+            __builtin_amdgcn_sched_barrier(0);
+            gqa_add_piece(a0, wB, pB);
+            __syncthreads();
+        }
+    }
+    GQA_STAMP(6);
+#undef GQA_VLOAD
+#undef GQA_VSTORE
+    {
+        const int h = kvh * G + wave, d = 2 * lane;
+        if (p.out_xt) { p.out_xt[xt_index(i, h * HD + d)] = bf_trunc(a0.x); p.out_xt[xt_index(i, h * HD + d + 1)] = bf_trunc(a0.y); }     // batch of up to 16: the B-operand layout of the wo product
+        else *(uint32_t*)(p.out + ((size_t)i * p.H + h) * HD + d) = (uint32_t)bf_trunc(a0.x) | ((uint32_t)bf_trunc(a0.y) << 16);       // [S, H*hd]
     }
 }
 
@@ -2798,6 +3024,7 @@ extern "C" int lnbk_attn_short_max_T(int hd) {
     while (lo < hi) { const int mid = (lo + hi + 1) / 2; if (attn_lds_bytes(mid, hd) <= 160 * 1024) lo = mid; else hi = mid - 1; }
     return lo;
 }
+static long long* g_gqa_dbg = nullptr;                       // LNB_ATTN_GQA_DBG: phase stamps of one attn_gqa_kernel workgroup
 extern "C" hipError_t lnbk_init(void) {
     static bool done = false;
     if (done) return hipSuccess;
@@ -2823,11 +3050,13 @@ extern "C" hipError_t lnbk_init(void) {
     hipError_t e;
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_gqa_kernel<128, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_exact_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if (getenv("LNB_ATTN_GQA_DBG") && !g_gqa_dbg) { if (hipMalloc(&g_gqa_dbg, 8 * 16 * 8) != hipSuccess) return hipErrorOutOfMemory; (void)hipMemset(g_gqa_dbg, 0, 8 * 16 * 8); }
     done = true;
     return hipSuccess;
 }
@@ -2847,6 +3076,16 @@ static hipError_t launch_attn_long(const AttnParams* p, hipStream_t st) {
 extern "C" size_t lnbk_attn_long_lds(int seq_len) { return alp_lds_bytes(seq_len); }
 extern "C" size_t lnbk_attn_short_lds(int seq_len, int hd);
 
+extern "C" void lnbk_attn_gqa_dbg_dump(void) {
+    if (!g_gqa_dbg) return;
+    (void)hipDeviceSynchronize();
+    long long h[128];
+    if (hipMemcpy(h, g_gqa_dbg, sizeof h, hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (int w = 0; w < 8; w++) {
+        fprintf(stderr, "[gqa] wave %d: q+K %lld scores %lld pad+barrier %lld Z+cert %lld V0 store+barrier %lld PV %lld  (start %+lld)\n", w,
+                h[w * 16 + 1] - h[w * 16], h[w * 16 + 2] - h[w * 16 + 1], h[w * 16 + 3] - h[w * 16 + 2], h[w * 16 + 4] - h[w * 16 + 3], h[w * 16 + 5] - h[w * 16 + 4], h[w * 16 + 6] - h[w * 16 + 5], h[w * 16] - h[0]);
+    }
+}
 static bool attn_batch_dense() { const char* e = getenv("LNB_ATTN_BATCH_DENSE"); return !(e && *e && atoi(e) == 0); }   // (read per launch: a test switches it inside one process)
 extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     if (p->longctx && p->S == 1) return launch_attn_long(p, st);
@@ -2858,10 +3097,27 @@ extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     size_t lds = attn_lds_bytes(p->lds_T, p->hd);
     if (lds > 160 * 1024 || p->lds_T <= 0 || p->lds_T > p->seq_len) return hipErrorInvalidValue;
     if (p->host_T > p->lds_T) return hipErrorInvalidValue;      // e[] / pw[] are sized for lds_T positions: never launch past them (lnb_api.cpp check_call refuses first)
+    if (p->btab && p->hd == 128 && p->H == 4 * p->KVH) {        // batched decode: one workgroup per (KV head, sequence) when that fills the chip
+        const char* e = getenv("LNB_ATTN_GQA");                 // 0: never, 1: always, default: from LNB_ATTN_GQA_MIN_WG workgroups on
+        const int mode = (e && *e) ? atoi(e) : -1;
+        const size_t gl = gqa_lds_bytes(p->lds_T, 128, 4);
+        if (mode != 0 && p->exp_tab && gl <= 160 * 1024 && (mode == 1 || (long)p->KVH * p->S >= 256)) {
+            AttnParams q = *p;
+            { const char* f = getenv("LNB_ATTN_GQA_FORCE_ZSEQ"); if (f && *f && atoi(f) != 0) q.force_zseq = 1; }      // (tests: every head walks the serial denominator)
+            if (getenv("LNB_ATTN_GQA_DBG")) {                   // phase stamps of one workgroup (lnbk_attn_gqa_dbg_dump prints them)
+                q.dbg = g_gqa_dbg;                              // (allocated by lnbk_init: no allocation inside a stream capture)
+            }
+            hipLaunchKernelGGL((attn_gqa_kernel<128, 4>), dim3(p->KVH, p->S), dim3(512), gl, st, q);
+            return hipGetLastError();
+        }
+    }
     switch (p->hd) {
     case 128:
-        if (p->btab && (long)p->H * p->S > 256 && attn_batch_dense())   // more workgroups than CUs
-            hipLaunchKernelGGL((attn_exact_kernel<128, true>), dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p);
+        if (p->btab && (long)p->H * p->S > 256 && attn_batch_dense()) { // more workgroups than CUs
+            AttnParams q = *p;
+            { const char* e = getenv("LNB_ATTN_BATCH_HEADMAJOR"); q.head_major = (e && *e && atoi(e) != 0) ? 1 : 0; }     // (A/B of the dispatch order)
+            hipLaunchKernelGGL((attn_exact_kernel<128, true>), dim3(p->H, p->S), dim3(ATT_NT), lds, st, q);
+        }
         else hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p);
         break;
     case 64: hipLaunchKernelGGL(attn_exact_kernel<64>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;

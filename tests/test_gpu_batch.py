@@ -302,6 +302,42 @@ def test_dense_batch_attention_beyond_one_pass_of_512_positions(lnb, monkeypatch
     om.close(); gm.close()
 
 
+@pytest.mark.parametrize("heads,kvh,force_z", [(4, 1, "0"), (8, 2, "0"), (4, 1, "1")])
+def test_gqa_aware_batch_attention_equals_the_oracle_per_sequence(lnb, monkeypatch, heads, kvh, force_z):
+    """Round 4: attn_gqa_kernel -- one workgroup per (KV head, sequence) serves the four query heads that share the KV head (K row loaded
+    once for four score chains, V staged once, one PV chain per thread).  Forced on (LNB_ATTN_GQA=1; by default it takes over from
+    KV heads x sequences >= 256) for narrow (<= 16) and wide batches, prompts that cross one 512-position scores pass and several 64-position
+    PV chunks, and with the serial softmax denominator forced; every sequence against its own CPU-oracle run, KV caches included."""
+    cfg = dict(orc.TINY, dim=128 * heads, n_heads=heads, n_kv_heads=kvh)
+    monkeypatch.setenv("LNB_ATTN_GQA", "1")
+    monkeypatch.setenv("LNB_ATTN_GQA_FORCE_ZSEQ", force_z)
+    steps = 6
+    om = orc.Model(**cfg).fill_synthetic(707).finalize()
+    for n in ((3, 17) if force_z == "0" else (5,)):
+        plens = [5 + 61 * s for s in range(n)]
+        plens[0] = 509                                                              # crosses 512 inside the decode window
+        if n > 4: plens[4] = 63                                                     # crosses a PV chunk edge
+        seqmax = max(plens) + steps + 6
+        gm = lnb.LlamaTransformer(**cfg).fill_synthetic(707).finalize(rope_rows=seqmax + 8).enable_batch()
+        prompts = [orc.synth_tokens(31 * n + s, plens[s], cfg["vocab_size"]) for s in range(n)]
+        ctxs = [lnb.InferenceContext(gm, seqmax) for _ in range(n)]
+        firsts = [ctxs[s].Forward(prompts[s], 0, want_logits=False)[1] for s in range(n)]
+        b = lnb.Batch(ctxs)
+        got, _ = b.decode(firsts, plens, steps)
+        for s in range(n):
+            oc = orc.Context(om, seqmax)
+            r, _ = oc.generate(prompts[s], steps + 1)
+            assert [firsts[s]] + [int(t) for t in got[s]] == [int(t) for t in r][:steps + 1], (n, s)
+            T = plens[s] + steps
+            assert (oc.cache(1, 1)[:T] == ctxs[s].CacheV(1)[:T]).all(), (n, s)
+            oc.close()
+        b.close()
+        for c in ctxs:
+            c.close()
+        gm.close()
+    om.close()
+
+
 def test_a_member_context_cannot_be_destroyed_under_a_live_batch(lnb):
     """a batch bakes its members' device pointers into its tables and graphs -- lnb_ctx_destroy on a member must fail until the
     batch is gone (then succeed); the context and the batch stay usable after the refused call"""
