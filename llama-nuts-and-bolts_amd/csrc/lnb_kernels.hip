@@ -1995,6 +1995,8 @@ template <int HD> __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(Att
 // dynamic LDS: [T f64 e (+ zero pad)][T f32 p (+ zero pad)][hd f32 q][16 B][2 x 64 x hd f32 product ring]
 // ------------------------------------------------------------------------------------------------
 constexpr int ATT_JC = 64;                                  // cached positions per PV chunk
+constexpr int ATT_RP = ATT_JC + 4;                          // product ring: [dim][position] f32, rows padded to 68 floats -- the adders read FOUR positions of their dim per
+                                                            // ds_read_b128 (16 reads + 64 adds per chunk instead of 64 + 64: they were issue-bound), lanes 272 B apart: no conflict
 __host__ __device__ inline size_t attn_off_pw(int seq_len) { return (((size_t)seq_len + 32) * 8 + 15) & ~(size_t)15; }
 __host__ __device__ inline size_t attn_off_q(int seq_len) { return attn_off_pw(seq_len) + ((((size_t)seq_len + ATT_JC) * 4 + 15) & ~(size_t)15); }
 __host__ __device__ inline size_t attn_off_z(int seq_len, int hd) { return attn_off_q(seq_len) + (((size_t)hd * 4 + 15) & ~(size_t)15); }
@@ -2005,8 +2007,9 @@ constexpr int ATT_NPROD = 4;                                // PV: waves 0,1 add
                                                             // stay idle there (two issue-hungry waves on one SIMD halve each other)
 constexpr int ATT_VU = ATT_JC / 4 / ATT_NPROD;              // 4-row units per producer per chunk
 
-// V rows of PV chunk c for producer pwv.  One 16 B load covers 8 dims of one position: 16 lanes per row, 4 rows per instruction,
-// units u -> positions c*64 + (ATT_NPROD*u + pwv)*4 + lane/16.  A PV step (~64 dependent adds) is several times shorter
+// V rows of PV chunk c for producer pwv.  One 16 B load covers 8 dims of one position: 16 lanes per row, 4 rows per instruction;
+// a lane's four units are FOUR CONSECUTIVE positions c*64 + 4 (4 pwv + lane/16) + u of the same 8 dims (so that it can write its
+// products as float4 runs along the position axis of the ring).  A PV step (~64 dependent adds) is several times shorter
 // than a load round trip, so three chunks are kept in flight; hipcc drains vmcnt(0) around loop-carried register prefetch,
 // hence the same hand-counted asm ring as the GEMV (RING_LOAD / RING_RETIRE, checked by tools/isa_audit.py).
 // Always issued (rows clamped to T-1, whose p is +0 beyond the row) so that the count is the same on every path.
@@ -2014,7 +2017,7 @@ DEVINL void attn_load_v(u32x4 (&v)[ATT_VU], const uint16_t* vbase, uint32_t row_
     const uint32_t dq = (uint32_t)(lane & 15) * 16u;                      // byte offset of this lane's 8 dims
 #pragma unroll
     for (int u = 0; u < ATT_VU; u++) {
-        int j = c * ATT_JC + (ATT_NPROD * u + pwv) * 4 + (lane >> 4);
+        int j = c * ATT_JC + (pwv * 4 + (lane >> 4)) * 4 + u;
         j = j < T ? j : T - 1;
         const char* a = (const char*)vbase + ((size_t)(uint32_t)j * row_bytes + dq);
         asm volatile("global_load_dwordx4 %0, %1, off ; RING_LOAD" : "=&v"(v[u]) : "v"(a) : "memory");
@@ -2033,7 +2036,7 @@ template <int NK> DEVINL void attn_load_k(uint4 (&k)[NK], const uint4* kbase, in
 }
 
 // score + exp of one cached position (llamatransformer.go:456-473, Softmax impl:498)
-template <int NK> DEVINL void attn_score(const uint4 (&k)[NK], const float* qf, int j, int T, int S, int i, float divisor, double* e) {
+template <int NK> DEVINL void attn_score(const uint4 (&k)[NK], const float* qf, int j, int T, int S, int i, float divisor, double* e, const double* exp_tab = nullptr) {
     if (j >= T) return;
     const bool masked = (S > 1) && ((j % S) > i);            // triu(-inf,1) broadcast by modulo (tensoriterators.go:47-55)
     double ev = 0.0;                                         // exp(-inf) == 0
@@ -2045,9 +2048,13 @@ template <int NK> DEVINL void attn_score(const uint4 (&k)[NK], const float* qf, 
             acc = mac8(acc, xa, xb, k[c]);
         }
         uint16_t s = bf_trunc(acc);
-        s = bf_trunc(__fdiv_rn(bf_wide(s), divisor));       // DivToScalar :464
-        if (S > 1) s = bf_trunc(bf_wide(s) + 0.0f);          // Add(scores, mask) with mask==0 :469-473
-        ev = exp((double)bf_wide(s));
+        if (exp_tab) ev = exp_tab[s];                        // the model's table of the three lines below over all 65536 raw scores (exp_table_kernel): the batched grids, where
+                                                             // the vector unit is the bound (one stream alone: the ~130 inline instructions are faster than the load's round trip, measured)
+        else {
+            s = bf_trunc(__fdiv_rn(bf_wide(s), divisor));   // DivToScalar :464
+            if (S > 1) s = bf_trunc(bf_wide(s) + 0.0f);      // Add(scores, mask) with mask==0 :469-473
+            ev = exp((double)bf_wide(s));
+        }
     }
     e[j] = ev;
 }
@@ -2056,35 +2063,41 @@ template <int NK> DEVINL void attn_score(const uint4 (&k)[NK], const float* qf, 
 // in ring slot c&1 ([position][dim] f32) after putting chunk c+3's rows in flight (vn); the adders add chunk c-1.
 // The roles are split ONCE (three loops with the same barrier count) so that the ring's load/retire pairing is a property of
 // straight-line code that tools/isa_audit.py can check.
-template <int HD> DEVINL void attn_pv_produce(int c, int nchunks, int pwv, int lane, int T, const uint16_t* vbase, uint32_t row_bytes,
+template <int HD> DEVINL int attn_row_dim(int r) { return (r % (HD / 8)) * 8 + r / (HD / 8); }      // ring row r holds dim (r % (hd/8)) * 8 + r / (hd/8)
+template <int HD, int D = 3> DEVINL void attn_pv_produce(int c, int nchunks, int pwv, int lane, int T, const uint16_t* vbase, uint32_t row_bytes,
                                               const float* pw, char* ring, u32x4 (&vc)[ATT_VU], u32x4 (&vn)[ATT_VU]) {
-    constexpr int SLOT = ATT_JC * HD * 4;
-    attn_load_v(vn, vbase, row_bytes, c + 3, pwv, lane, T);
-    attn_retire_v<3 * ATT_VU>(vc);                           // chunks c+1, c+2, c+3 stay in flight
+    constexpr int SLOT = ATT_RP * HD * 4;
+    attn_load_v(vn, vbase, row_bytes, c + D, pwv, lane, T);
+    attn_retire_v<D * ATT_VU>(vc);                           // chunks c+1 .. c+D stay in flight
     if (c < nchunks && (lane & 15) * 8 < HD) {
-        const int jl0 = pwv * 4 + (lane >> 4);
-        char* dst = ring + (c & 1) * SLOT + (lane & 15) * 32 + jl0 * (HD * 4);
-        const float* pp = pw + c * ATT_JC + jl0;
-#pragma unroll
-        for (int u = 0; u < ATT_VU; u++) {                   // position jl0 + 4*ATT_NPROD*u of the chunk
-            const float pj = pp[4 * ATT_NPROD * u];
-            const u32x4 v = vc[u];                           // exact products: 8-bit x 8-bit significands
-            *(float4*)(dst + u * 4 * ATT_NPROD * HD * 4) = make_float4(pj * bf_lo(v.x), pj * bf_hi(v.x), pj * bf_lo(v.y), pj * bf_hi(v.y));
-            *(float4*)(dst + u * 4 * ATT_NPROD * HD * 4 + 16) = make_float4(pj * bf_lo(v.z), pj * bf_hi(v.z), pj * bf_lo(v.w), pj * bf_hi(v.w));
-        }
+        const int pg = pwv * 4 + (lane >> 4);                // positions 4 pg .. 4 pg + 3 of the chunk
+        // ring row of dim d: (d % 8) * (HD / 8) + d / 8 -- the 16 lanes of a write (same k, dim groups 0..15) hit 16 consecutive rows, 272 B
+        // apart: 16 different 16-byte bank groups (row-major by dim: 8 rows apart, all in two bank groups -- measured 3x the whole kernel)
+        float* dst = (float*)(ring + (c & 1) * SLOT) + (lane & 15) * ATT_RP + 4 * pg;
+        const float4 pj = *(const float4*)(pw + c * ATT_JC + 4 * pg);
+        const u32x4 a = vc[0], b4 = vc[1], c4 = vc[2], d4 = vc[3];    // exact products: 8-bit x 8-bit significands
+        constexpr int KR = (HD / 8) * ATT_RP;                // row distance between k and k + 1
+        *(float4*)(dst + 0 * KR) = make_float4(pj.x * bf_lo(a.x), pj.y * bf_lo(b4.x), pj.z * bf_lo(c4.x), pj.w * bf_lo(d4.x));
+        *(float4*)(dst + 1 * KR) = make_float4(pj.x * bf_hi(a.x), pj.y * bf_hi(b4.x), pj.z * bf_hi(c4.x), pj.w * bf_hi(d4.x));
+        *(float4*)(dst + 2 * KR) = make_float4(pj.x * bf_lo(a.y), pj.y * bf_lo(b4.y), pj.z * bf_lo(c4.y), pj.w * bf_lo(d4.y));
+        *(float4*)(dst + 3 * KR) = make_float4(pj.x * bf_hi(a.y), pj.y * bf_hi(b4.y), pj.z * bf_hi(c4.y), pj.w * bf_hi(d4.y));
+        *(float4*)(dst + 4 * KR) = make_float4(pj.x * bf_lo(a.z), pj.y * bf_lo(b4.z), pj.z * bf_lo(c4.z), pj.w * bf_lo(d4.z));
+        *(float4*)(dst + 5 * KR) = make_float4(pj.x * bf_hi(a.z), pj.y * bf_hi(b4.z), pj.z * bf_hi(c4.z), pj.w * bf_hi(d4.z));
+        *(float4*)(dst + 6 * KR) = make_float4(pj.x * bf_lo(a.w), pj.y * bf_lo(b4.w), pj.z * bf_lo(c4.w), pj.w * bf_lo(d4.w));
+        *(float4*)(dst + 7 * KR) = make_float4(pj.x * bf_hi(a.w), pj.y * bf_hi(b4.w), pj.z * bf_hi(c4.w), pj.w * bf_hi(d4.w));
     }
     __syncthreads();
 }
-template <int HD> DEVINL void attn_pv_add(int c, int nchunks, int d, const char* ring, float& acc) {
-    constexpr int SLOT = ATT_JC * HD * 4;
-    if (c > 0 && c <= nchunks && d < HD) {
+template <int HD> DEVINL void attn_pv_add(int c, int nchunks, int r, const char* ring, float& acc) {      // r: the lane's ring ROW (its dim: attn_row_dim)
+    constexpr int SLOT = ATT_RP * HD * 4;
+    if (c > 0 && c <= nchunks && r < HD) {
         // positions past the end of the row carry p == +0: their products are +-0 and acc is never -0, so whole chunks are added
-        const float* src = (const float*)(ring + ((c - 1) & 1) * SLOT) + d;
-        float a[ATT_JC];
+        const float* src = (const float*)(ring + ((c - 1) & 1) * SLOT) + r * ATT_RP;
+        float4 a[ATT_JC / 4];
 #pragma unroll
-        for (int j = 0; j < ATT_JC; j++) a[j] = src[j * HD];              // whole chunk in flight at once
+        for (int j = 0; j < ATT_JC / 4; j++) a[j] = *(const float4*)(src + 4 * j);     // whole chunk in flight at once
 #pragma unroll
-        for (int j = 0; j < ATT_JC; j++) acc += a[j];
+        for (int j = 0; j < ATT_JC / 4; j++) acc = add4(acc, a[j]);
     }
     __syncthreads();
 }
@@ -2193,14 +2206,14 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
         for (int j0 = 0; j0 < T; j0 += ATT_NT) {
             const int j = j0 + tid;
             if (j0 > 0) attn_load_k<NK>(ka, kbase, seq_len, j < T ? j : T - 1);
-            attn_score<NK>(ka, qf, j, T, S, i, p.divisor, e);
+            attn_score<NK>(ka, qf, j, T, S, i, p.divisor, e, DENSE ? p.exp_tab : nullptr);
         }
     } else
     for (int j0 = 0; j0 < T; j0 += 2 * ATT_NT) {
         const int j = j0 + tid;
         const bool more = j0 + ATT_NT < T, more2 = j0 + 2 * ATT_NT < T;       // block-uniform
         if (more) attn_load_k<NK>(kb, kbase, seq_len, j + ATT_NT < T ? j + ATT_NT : T - 1);
-        attn_score<NK>(ka, qf, j, T, S, i, p.divisor, e);
+        attn_score<NK>(ka, qf, j, T, S, i, p.divisor, e, DENSE ? p.exp_tab : nullptr);
         if (more) {
             if (more2) attn_load_k<NK>(ka, kbase, seq_len, j + 2 * ATT_NT < T ? j + 2 * ATT_NT : T - 1);
             attn_score<NK>(kb, qf, j + ATT_NT, T, S, i, p.divisor, e);
@@ -2215,11 +2228,19 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
     // producers: the first three PV chunks of V go in flight now and land during the Z chain
     const bool producer = (wave & 3) >= 2;
     const int pwv = (wave & 3) - 2 + ((wave >> 2) << 1);                   // waves 2,3,6,7 -> producers 0..3
-    u32x4 v0[ATT_VU], v1[ATT_VU], v2[ATT_VU], v3[ATT_VU];
+    // (single stream: SEVEN chunks -- 448 positions, the whole row at the bench's contexts -- go in flight here, behind the scores: their K
+    //  registers are free now, and with three chunks the producers waited for memory in every PV step: 7.4 k cycles of PV at T = 272,
+    //  of which the adders' chains are 2.4 k.  The batched DENSE form has 128 registers: three chunks.)
+    constexpr int VD = DENSE ? 3 : 7;
+    u32x4 v0[ATT_VU], v1[ATT_VU], v2[ATT_VU], v3[ATT_VU], v4[ATT_VU], v5[ATT_VU], v6[ATT_VU], v7[ATT_VU];
     if (producer) {
         attn_load_v(v0, vbase, row_bytes, 0, pwv, lane, T);
         attn_load_v(v1, vbase, row_bytes, 1, pwv, lane, T);
         attn_load_v(v2, vbase, row_bytes, 2, pwv, lane, T);
+        if constexpr (VD == 7) {
+            attn_load_v(v3, vbase, row_bytes, 3, pwv, lane, T); attn_load_v(v4, vbase, row_bytes, 4, pwv, lane, T);
+            attn_load_v(v5, vbase, row_bytes, 5, pwv, lane, T); attn_load_v(v6, vbase, row_bytes, 6, pwv, lane, T);
+        }
     }
     ATT_STAMP(2);
     __syncthreads();
@@ -2264,6 +2285,18 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
     // standard causal layout (pos0 == 0) the chain can stop at the chunk that holds the diagonal (Tend).
     float acc = 0.0f;
     if (producer) {
+        if constexpr (VD == 7) {
+            for (int c = 0; c <= nchunks; c += 8) {          // eight steps per trip: the V register sets rotate without copies
+                attn_pv_produce<HD, 7>(c, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v0, v7);
+                attn_pv_produce<HD, 7>(c + 1, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v1, v0);
+                attn_pv_produce<HD, 7>(c + 2, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v2, v1);
+                attn_pv_produce<HD, 7>(c + 3, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v3, v2);
+                attn_pv_produce<HD, 7>(c + 4, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v4, v3);
+                attn_pv_produce<HD, 7>(c + 5, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v5, v4);
+                attn_pv_produce<HD, 7>(c + 6, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v6, v5);
+                attn_pv_produce<HD, 7>(c + 7, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v7, v6);
+            }
+        } else
         for (int c = 0; c <= nchunks; c += 4) {              // four steps per trip: the V register sets rotate without copies
             attn_pv_produce<HD>(c, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v0, v3);
             attn_pv_produce<HD>(c + 1, nchunks, pwv, lane, T, vbase, row_bytes, pw, ring, v1, v0);
@@ -2272,18 +2305,26 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
         }
     } else if (wave < 2) {
         const int d = wave * 64 + lane;
-        for (int c = 0; c <= nchunks; c += 4) {
+        for (int c = 0; c <= nchunks; c += (VD + 1)) {       // (the same number of barriers as the producers' trips)
             attn_pv_add<HD>(c, nchunks, d, ring, acc); attn_pv_add<HD>(c + 1, nchunks, d, ring, acc);
             attn_pv_add<HD>(c + 2, nchunks, d, ring, acc); attn_pv_add<HD>(c + 3, nchunks, d, ring, acc);
+            if constexpr (VD == 7) {
+                attn_pv_add<HD>(c + 4, nchunks, d, ring, acc); attn_pv_add<HD>(c + 5, nchunks, d, ring, acc);
+                attn_pv_add<HD>(c + 6, nchunks, d, ring, acc); attn_pv_add<HD>(c + 7, nchunks, d, ring, acc);
+            }
         }
     } else {
-        for (int c = 0; c <= nchunks; c += 4) { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
+        for (int c = 0; c <= nchunks; c += (VD + 1)) {
+            __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads();
+            if constexpr (VD == 7) { __syncthreads(); __syncthreads(); __syncthreads(); __syncthreads(); }
+        }
     }
     asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");   // prefetches past the last chunk
     ATT_STAMP(6);
     if (wave < 2) {
-        const int d = wave * 64 + lane;
-        if (d < HD) {
+        const int r = wave * 64 + lane;
+        if (r < HD) {
+            const int d = attn_row_dim<HD>(r);
             if (bt && p.out_xt) p.out_xt[xt_index(i, h * HD + d)] = bf_trunc(acc);   // batch of up to 16: straight into the B-operand layout of the wo product
             else p.out[((size_t)i * p.H + h) * HD + d] = bf_trunc(acc);        // [S, H*hd] (:508-514)
         }
@@ -3016,7 +3057,7 @@ extern "C" hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, ui
     return hipGetLastError();
 }
 
-static size_t attn_lds_bytes(int seq_len, int hd) { return attn_off_ring(seq_len, hd) + 2 * (size_t)ATT_JC * hd * 4; }
+static size_t attn_lds_bytes(int seq_len, int hd) { return attn_off_ring(seq_len, hd) + 2 * (size_t)ATT_RP * hd * 4; }
 extern "C" size_t lnbk_attn_short_lds(int seq_len, int hd) { return attn_lds_bytes(seq_len, hd); }
 // the longest context the one-workgroup-per-head kernel can stage in 160 KB of LDS (e f64 + p f32 per position + q + the product ring)
 extern "C" int lnbk_attn_short_max_T(int hd) {
