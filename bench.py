@@ -255,8 +255,9 @@ CHAIN_NS = {"row_newbcast": 2.372,     # v_add_f32_dpp row_newbcast, products fe
 HBM_ACHIEVABLE_GBS = 6700.0            # the best streaming READ rate on record for this chip (MI355X_MICROARCH.md price list: 6.5-6.8 TB/s for an nt weight stream; the float4 COPY figure is 6.29)
 BOUNDARY_US = 1.4                      # dependent kernel boundary inside the captured graph (MI355X_MICROARCH.md price list: 1.2-1.45 us)
 X_PROLOGUE_US = 1.2                    # x row: global load + LDS staging + first weights (2.9 k cycles measured, rowcast_lds_kernel)
-NORM_PROLOGUE_US = 3.9                 # norm-fused kernels: x 1.2 k + fold 2.0 k (two waves per SIMD) + walk 2.5 k (15 items at the measured vector<->scalar
-                                       # hand-off costs, tools/chainbench4.hip) + f64 rsqrt 1.2 k + normalise 1.2 k + five barriers = 9 k cycles at 2.3 GHz
+NORM_PROLOGUE_US = 3.5                 # norm-fused kernels: x 1.2 k + fold 3.0 k (~450 instructions incl. the split pass, two waves per SIMD) + the branch-free
+                                       # item walk 0.7 k (18 items x ~31 cycles + list fetch; round 4, second half: was 2.5 k of scalar hand-offs) + f64 rsqrt 1.2 k +
+                                       # normalise 1.2 k + five barriers = 8 k cycles at 2.3 GHz
 
 
 def practical_floor(a, ffn_hidden, Tbar, kernels):
