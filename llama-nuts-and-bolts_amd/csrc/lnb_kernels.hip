@@ -139,6 +139,19 @@ __host__ __device__ inline size_t rms_scratch_bytes(int NH) { return (size_t)NH 
 // Folding waves: every helper (-DLNB_RMS_NF_MAX=4 restricts the fold to four waves on four different SIMDs -- waves w and w+4 of a workgroup
 // share one: HW_ID read per wave, round 4 -- with leaves of 16 terms instead of 12: measured SLOWER, wq|wk|wv 21.2 vs 20.1 us; the fold's time
 // follows its instruction count per wave, not the number of waves on a SIMD).  Helpers past the limit only pass the fold's two barriers.
+// ring stages a norm-fused kernel's helper issues IN FRONT of the fold (the rest behind it): wq|wk|wv, w1|w3 (two chains), output.
+// All R in front stalls the folding waves ~3 k cycles in the issue queue (round 4, first half: everything behind the fold); FOUR of w1|w3's
+// eight do not, and the HBM pipe is already streaming when the prologue ends: w1|w3 44.1 -> 43.0 us, block 127.4 -> 126.1 (0 / 2 / 4 / 6 stages:
+// 44.1 / 43.6 / 43.0 / 43.8); wq|wk|wv (20.2 -> 20.6 at four) and the output product (159.0 -> 159.9) want none.
+#ifndef LNB_EARLY_QUAD
+#define LNB_EARLY_QUAD 0
+#endif
+#ifndef LNB_EARLY_W13
+#define LNB_EARLY_W13 4
+#endif
+#ifndef LNB_EARLY_HEAD
+#define LNB_EARLY_HEAD 0
+#endif
 #ifndef LNB_RMS_NF_MAX
 #define LNB_RMS_NF_MAX 8
 #endif
@@ -631,19 +644,19 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
             // pipeline stalls the issuing waves ~3 k cycles -- the waves that fold; behind the fold they only wait for the walker anyway
             // (measured: wq|wk|wv -1.0 us, w1|w3 -2.3 us, output -1 us)
             constexpr bool late = NORM;
-            if (!late) {
+            constexpr int EARLY_ = NCH == 2 ? LNB_EARLY_W13 : LNB_EARLY_HEAD;
+            constexpr int EARLY = late ? (EARLY_ < R ? EARLY_ : R) : R;      // stages issued in front of the fold
 #pragma unroll
-                for (int j = 0; j < R; j++) issue_next(buf[j]);
-            }
+            for (int j = 0; j < EARLY; j++) issue_next(buf[j]);
             x_store<NORM, NS>(p, xs, kpad, 1 + hw, lane, xv);
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
             TIMED_BARRIER();                                           // B1: xs (or the squares) are in LDS
             if (NORM) {
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
                 rms_fold<rms_nf(NH)>(p, xs, ringB, hw - (NH - rms_nf(NH)), lane, t_aux);      // X1, X2 inside; the LAST four helpers fold (waves 4..7 of 8: four SIMDs)
-                if (late) {                                            // the walker walks now: the issue stall costs nothing here
+                {                                                      // the walker walks now: the issue stall costs nothing here
 #pragma unroll
-                    for (int j = 0; j < R; j++) issue_next(buf[j]);
+                    for (int j = EARLY; j < R; j++) issue_next(buf[j]);
                 }
                 TIMED_BARRIER();                                       // B2: r published
                 __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -876,19 +889,18 @@ __global__ __launch_bounds__((gq_ncw(RW) + NH) * 64) void gemv_quad_kernel(GemvP
             if (issued + 1 < T) { issued++; if (++is == nstages) { is = 0; ib += p.n_wg; } }
         };
         constexpr bool late = NORM;                                    // the weight stream starts behind the norm's fold (see gemv_chain_kernel)
-        if (!late) {
+        constexpr int EARLY = late ? (LNB_EARLY_QUAD < R ? LNB_EARLY_QUAD : R) : R;
 #pragma unroll
-            for (int j = 0; j < R; j++) issue_next(buf[j]);
-        }
+        for (int j = 0; j < EARLY; j++) issue_next(buf[j]);
         x_store<NORM, NS>(p, xs, kpad, wave, lane, xv);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         TIMED_BARRIER();                                               // B1: xs (or the squares) are in LDS
         if (NORM) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
             rms_fold<rms_nf(NH)>(p, xs, ringB, hw < rms_nf(NH) ? hw : -1, lane, t_aux);      // X1, X2 inside; the first four helpers fold (four consecutive waves: four SIMDs)
-            if (late) {                                                // the walker walks now: the issue stall costs nothing here
+            {                                                          // the walker walks now: the issue stall costs nothing here
 #pragma unroll
-                for (int j = 0; j < R; j++) issue_next(buf[j]);
+                for (int j = EARLY; j < R; j++) issue_next(buf[j]);
             }
             TIMED_BARRIER();                                           // B2: r published
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
