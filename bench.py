@@ -458,6 +458,9 @@ def main():
         if reps[-1][2] != reps[0][2]:
             sys.stderr.write("PARITY FAILURE: repeat %d of the timed region produced different tokens\n" % rep)
             sys.exit(3)
+    # fused-RMSNorm rows of the decode steps so far (2 per block + 1 per token) whose sum left the branch-free item walk (same bits, slower walk)
+    n_norm_rows = (W + K * len(reps)) * (2 * cfg["n_layers"] + 1)
+    norm_walk = {"rows": n_norm_rows, "fallback_rows": ctx.norm_fallbacks(), "note": "rows summed by the record walk instead of the item list (a binade crossing too close to call)"} if args.mode == "exact" else None
     order = sorted(range(len(reps)), key=lambda i: reps[i][0])
     med = order[len(order) // 2]
     t0, t1, ev_ms, out = 0.0, reps[med][0], reps[med][1], np.array(reps[med][2], dtype=np.int32)
@@ -524,7 +527,7 @@ def main():
                       "mode": "exact-order (token-id identical to the CPU reference path)" if args.mode == "exact" else
                               "fast (opt-in tolerance mode: split-K f32 sums, same bf16 truncation points; NOT token-identical, see NOTES.md 6.2)",
                       "tokens_vs_oracle_golden": golden_ok, "device_self_check": self_check,
-                      "hip_event_ms_per_step": round(ev_ms / K, 4),
+                      "hip_event_ms_per_step": round(ev_ms / K, 4), "norm_item_walk": norm_walk,
                       "timed_region_repeats_ms_per_step": [round(1e3 * r[0] / K, 4) for r in reps], "reported_repeat": "median",
                       "weight_bytes_resident": model.weight_bytes(), "model_build_s": round(t_load, 1)},
            "roofline": roofline, "kernels": kernels, "last_tokens": [int(t) for t in out[-4:]], "long_run": long_run,

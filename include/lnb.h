@@ -106,6 +106,9 @@ int lnb_ctx_get_mode(const lnb_ctx* c);
  * always walk the serial sum (test hook).  lnb_ctx_zseq_count: rows that could not be certified and walked it. */
 int lnb_ctx_set_attention(lnb_ctx* c, int long_threshold, int force_zseq);
 int lnb_ctx_zseq_count(lnb_ctx* c, int* out);
+/* Diagnostics of the fused RMSNorm (llamatransformer.go:222, :237, :166: RMSNorm in front of wq|wk|wv, w1|w3, output): rows of one-token calls
+ * whose sum of squares left the branch-free item walk for the slower record walk (same bits either way; ~2.5 % of gaussian rows). */
+int lnb_ctx_norm_fallbacks(lnb_ctx* c, int* out);
 /* optional per-layer progress hook = infContext.Logf("Transformer block layer %d / %d was run, took %.4f sec(s)")
  * (llamatransformer.go:157-163); forces a per-layer stream sync, so it is off by default */
 typedef void (*lnb_layer_cb)(int layer_1based, int n_layers, double secs, void* user);

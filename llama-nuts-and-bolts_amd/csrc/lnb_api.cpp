@@ -595,6 +595,15 @@ extern "C" int lnb_ctx_zseq_count(lnb_ctx* c, int* out) {
     *out = c->h_io[0];
     return 0;
 }
+// how many fused-RMSNorm rows (one per norm-fused GEMV launch and row) could not be summed by the branch-free item walk and took the record walk
+extern "C" int lnb_ctx_norm_fallbacks(lnb_ctx* c, int* out) {
+    if (!c || !out) return fail("null argument");
+    HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(hipMemcpyAsync(c->h_io, c->zseq_count + 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    *out = c->h_io[0];
+    return 0;
+}
 extern "C" int lnb_ctx_set_layer_callback(lnb_ctx* c, lnb_layer_cb cb, void* user) { if (!c) return fail("null argument"); c->cb = cb; c->cb_user = user; return 0; }
 extern "C" void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which) { return !c ? nullptr : which == 2 ? (void*)c->ffn : (void*)c->x; }
 extern "C" void* lnb_ctx_stream(lnb_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -651,7 +660,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
     }
     switch (which) {
     case K_QKV: {   // attn_norm + wq|wk|wv + RoPE + KV append  (llamatransformer.go:222, :297-403)
-        GemvParams g{}; g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
+        GemvParams g{}; g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.norm_fb = c->zseq_count + 1; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
         g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.seq_len = c->seq_len; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
         set_grid(g, L.wqkv); HIPCHK(gemv_dispatch(c, &g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, st)); return 0; }
     case K_ATTN: {  // scores / softmax / PV  (:409-514)
@@ -671,7 +680,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x;
         set_grid(o, L.wo); HIPCHK(gemv_dispatch(c, &o, L.wo.rw, 1, EPI_RESID, 0, st)); return 0; }
     case K_W13: {   // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
-        GemvParams f{}; f.w = L.w13.w; f.x = hbuf; f.norm_w = L.ffn_norm; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
+        GemvParams f{}; f.w = L.w13.w; f.x = hbuf; f.norm_w = L.ffn_norm; f.norm_fb = c->zseq_count + 1; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
         f.out = c->ffn; f.silu = m->silu;
         set_grid(f, L.w13); HIPCHK(gemv_dispatch(c, &f, L.w13.rw, 2, EPI_SILU_MUL, 1, st)); return 0; }
     case K_W2: {    // w2 + residual  (:619, :248)
@@ -705,7 +714,7 @@ static int enqueue_head(lnb_ctx* c, int first, int rows) {
         HIPCHK(gemm_dispatch(c->mode, &gm, EPI_STORE, c->stream));
         return 0;
     }
-    GemvParams g{}; g.w = m->output.w; g.x = c->x + (size_t)first * m->a.dim; g.norm_w = m->norm; g.eps = m->a.norm_eps; g.K = m->a.dim;
+    GemvParams g{}; g.w = m->output.w; g.x = c->x + (size_t)first * m->a.dim; g.norm_w = m->norm; g.norm_fb = c->zseq_count + 1; g.eps = m->a.norm_eps; g.K = m->a.dim;
     g.n_rows = m->a.vocab_size; g.S = rows; g.st = c->st; g.out = c->logits;
     set_grid(g, m->output);
     HIPCHK(gemv_dispatch(c, &g, m->output.rw, 1, EPI_STORE, 1, c->stream));

@@ -95,6 +95,7 @@ struct GemvParams {
     int seq_len;
     int q_dim, kv_dim, head_dim;
     long long* dbg;             // optional per-wave timing dump (nullptr in production)
+    int* norm_fb;               // optional counter: rows whose norm sum left the branch-free item walk for the record walk (counted by workgroup 0)
     int lds_pad;                // host side only: extra dynamic LDS requested for the launch (co-residency experiments: forces one workgroup per CU)
 };
 

@@ -437,6 +437,7 @@ template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* 
             } else why |= 4 << 28;
         }
     }
+    if (!done && p.norm_fb && blockIdx.x == 0 && lane == 0) atomicAdd(p.norm_fb, 1);       // (diagnostics: every workgroup walks the same row, one counts)
     if (!done) {
         // ---- the old walk (every record's binade verified item by item, crossing leaves replayed term by term): rows with a leaf that is
         // neither a run member nor cleanly split (non-finite terms, jumps of several binades, a crossing too close to call), with a guess

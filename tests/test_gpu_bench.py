@@ -42,6 +42,8 @@ def test_single_gpu_bench_prints_one_json_line_with_the_contract_keys(mode):
     rp = d["config"]["timed_region_repeats_ms_per_step"]   # three repeats of the same K steps, the median one reported
     assert len(rp) == 3 and sorted(rp)[1] == pytest.approx(d["ms_per_step"], rel=1e-3)
     if mode == "exact":                                    # batched exact decode: n prompts per pass over the weights, sequence 0 = the single run's prompt
+        nw = d["config"]["norm_item_walk"]                 # rows of the fused RMSNorm that needed the record walk: a minority
+        assert nw["rows"] > 0 and 0 <= nw["fallback_rows"] <= nw["rows"] // 2
         sb = d["sequences_in_flight_batched"]
         assert [r["n"] for r in sb["runs"]] == [2, 4, 8, 16, 32, 64, 128] and sb["weights_second_copy_bytes"] > 0
         for r in sb["runs"]:
