@@ -30,14 +30,14 @@ PY
     ;;
   profile)  # the round's record: 8-layer configs[2] oracle golden (host cores, in the background), rocprofv3 trace + FETCH_SIZE pass of the bench, bench lines
     O=$PWD/gpurun_out/prof_r04; mkdir -p $O
-    ( timeout 2400 python tests/golden/make_configs2_cut_tokens.py 8 72 $O > $O/golden8.log 2>&1 ) &
-    GP=$!
+    GP=""
+    if [ "${LNB_REGEN_GOLDEN:-0}" = 1 ]; then ( timeout 2400 python tests/golden/make_configs2_cut_tokens.py 8 72 $O > $O/golden8.log 2>&1 ) & GP=$!; fi
     ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 4 --repeats 1 --cpu-steps 0 --profile-iters 8 --concurrent 0 --batch-sizes "" --no-traffic-probe > $O/trace_bench.json 2> $O/trace.err; echo "trace rc=$?" )
     ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --repeats 1 --cpu-steps 0 --profile-iters 4 --concurrent 0 --batch-sizes "" --no-traffic-probe > $O/pmc_fetch_bench.json 2> $O/pmc_fetch.err; echo "pmc rc=$?" )
     LNB_GEMV_TIMING=1 timeout 300 python tools/kernel_ab.py 50 > $O/stamps.log 2>&1
     timeout 120 tools/chainbench3 > $O/chainbench3.log 2>&1; timeout 60 tools/chainbench4 > $O/chainbench4.log 2>&1
-    wait $GP; cat $O/golden8.log | tail -2
-    [ -f $O/configs2_8layer_tokens.json ] && cp $O/configs2_8layer_tokens.json tests/golden/
+    if [ -n "$GP" ]; then wait $GP; tail -2 $O/golden8.log; [ -f $O/configs2_8layer_tokens.json ] && cp $O/configs2_8layer_tokens.json tests/golden/; fi
+    LNB_ATTN_GQA_DBG=1 timeout 300 python tools/gqa_stamps.py > $O/gqa_stamps.log 2>&1
     ( time timeout 900 python bench.py ) > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"; tail -3 $O/bench_default.err
     timeout 600 python bench.py --steps 20 --warmup 5 > $O/bench_driver_args.json 2> $O/bench_driver_args.err; echo "bench(20) rc=$?"
     timeout 900 python bench.py --prompt-len 4096 --steps 64 --warmup 8 --concurrent 0 --batch-sizes "" > $O/bench_configs2.json 2> $O/bench_configs2.err; echo "cfg2 rc=$?"; head -c 700 $O/bench_configs2.json; echo
