@@ -118,7 +118,9 @@ def one(label):
     json.dump({"source": "rocprofv3 --pmc FETCH_SIZE pass of bench.py (tools/gpu_profile_r02.sh), KB x 2 x 1024: gfx950 correction of MI355X_MICROARCH.md",
                "git_head": git_head(), "classes": {k: v for k, v in classes.items() if "hbm_read_bytes_per_launch" in v}},
               open(os.path.join(DST, label + "_traffic.json"), "w"), indent=1)
-    open(os.path.join(DST, label + "_summary.md"), "w").write("\n".join(lines) + "\n")
+    extra = os.path.join(DST, label + "_before_after.md")      # hand-kept before/after table of the round: appended to the generated summary
+    tail = open(extra).read() if os.path.exists(extra) else ""
+    open(os.path.join(DST, label + "_summary.md"), "w").write("\n".join(lines) + "\n" + tail)
     print("\n".join(lines[:30]))
 
 
