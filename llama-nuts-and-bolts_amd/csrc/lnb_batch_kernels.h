@@ -188,6 +188,103 @@ __global__ __launch_bounds__(256) void mfma_stream_kernel(StreamParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// mfma_pair_kernel<EPI> (round 4): the thin matrices of a batch of up to 16 sequences (wq|wk|wv, wo, w2: one 16-row tile per SIMD, ONE
+// k-ordered chain of K / 4 dependent matrix instructions each).  In mfma_stream_kernel the wave that owns the chain also unpacks its
+// operands (64 vector ops per 128 k-steps) and issues its loads (8 x 1 KiB): 1554 cycles per chunk of which the 32 matrix instructions are
+// 1037 -- 12.1 cycles per k-step.  Here the role split of the single stream's GEMVs: wave w (0, 1) only issues matrix instructions; wave
+// w + 2 -- another SIMD -- streams the weights and activations through the hand-counted ring, unpacks them and leaves the f32
+// operands in the LDS in consumption order ([read r][lane][A 2r, A 2r+1, B 2r, B 2r+1]: sixteen ds_read_b128 per chunk, each feeding two
+// matrix instructions as it lands); two LDS buffers per pair, one workgroup barrier per chunk.
+// Two tiles per CU (the thin matrices have 256-384 tiles: 128-192 of the 256 CUs).  grid.x = min(ceil(n_jobs / 2), CUs), block 256, dynamic LDS 64 KB.  Same chains, same epilogues, same bits as mfma_stream_kernel<1, EPI>.
+// ------------------------------------------------------------------------------------------------
+constexpr int MP_BUF = 16 * 64 * 16;                        // one chunk's operands of one pair: 16 KB
+template <int EPI>
+__global__ __launch_bounds__(256) void mfma_pair_kernel(StreamParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int R = 4, L = 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const int pr = wave & 1;                                 // the pair: its chain wave is wave pr, its helper wave pr + 2 -- on ANOTHER SIMD (waves 0..3 of a
+                                                             // workgroup sit on four different SIMDs): a vector op of the helper between two matrix instructions of the
+                                                             // chain costs the accumulator forwarding just like one of its own (measured: same-SIMD pairs, w2 132 us)
+    const int gw = blockIdx.x * 2 + pr, TW = gridDim.x * 2;
+    const int nchunks = p.K >> 7;
+    // every wave of the workgroup runs the SAME number of chunks (one barrier per chunk): that of its first pair; a pair without a job left
+    // streams a valid chain and drops the result
+    const int T = ((p.n_jobs - (int)blockIdx.x * 2 + TW - 1) / TW) * nchunks;
+    const size_t chain_bytes = (size_t)nchunks * 4096;
+    const int last_chain = p.n_chains - 1;
+    char* const lds = smem + (size_t)pr * 2 * MP_BUF + (size_t)lane * 16;      // this lane's 16 bytes of read r: + r * 1024 (+ MP_BUF: the other buffer)
+    if (wave >= 2) {
+        // ================================ helper: HBM -> registers -> unpack -> LDS ================================
+        const unsigned aoff = (unsigned)(((lane & 15) * 4 + (lane >> 4)) * 16), boff = (unsigned)lane * 16u;
+        u32x4 buf[R][L];
+        int ij = gw, ic = 0, issued = 0;
+        auto issue_next = [&](u32x4 (&dst)[L]) {
+            const char* xb = (const char*)p.xt + (size_t)ic * 4096;
+            int tc = ij; tc = tc < last_chain ? tc : last_chain;
+            const char* wb = (const char*)p.w + (size_t)tc * chain_bytes + (size_t)ic * 4096;
+            ld_unit_nt<0>(dst[0], aoff, wb); ld_unit_nt<1>(dst[1], aoff, wb); ld_unit_nt<2>(dst[2], aoff, wb); ld_unit_nt<3>(dst[3], aoff, wb);
+            ld_unit<0>(dst[4], boff, xb); ld_unit<1>(dst[5], boff, xb); ld_unit<2>(dst[6], boff, xb); ld_unit<3>(dst[7], boff, xb);
+            if (issued + 1 < T) { issued++; if (++ic == nchunks) { ic = 0; ij += TW; } }
+        };
+#pragma unroll
+        for (int j = 0; j < R; j++) issue_next(buf[j]);
+        // chunk t -> LDS buffer t & 1, k-groups g = 4 e + m in order: read r holds groups 2r, 2r + 1
+        for (int t0 = 0; t0 < T + 1; t0 += R) {              // (T chunks; the helper runs one barrier ahead of the chain wave's first chunk)
+#pragma unroll
+            for (int j = 0; j < R; j++) {
+                const int t = t0 + j;
+                if (t < T) {
+                    wait_chunk<(R - 1) * L, L>(buf[j]);
+                    float4 op[16];
+#pragma unroll
+                    for (int r = 0; r < 16; r++) {
+                        const int g0 = 2 * r, g1 = 2 * r + 1;
+                        op[r] = make_float4(unit_elem(buf[j][g0 & 3], g0 >> 2), unit_elem(buf[j][g1 & 3], g1 >> 2),
+                                            unit_elem(buf[j][4 + (g0 & 3)], g0 >> 2), unit_elem(buf[j][4 + (g1 & 3)], g1 >> 2));
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; r++) asm volatile("" : "+v"(op[r].x), "+v"(op[r].y), "+v"(op[r].z), "+v"(op[r].w));      // pinned in front of the refill (see mfma_stream_kernel)
+                    issue_next(buf[j]);
+                    char* dst = lds + (size_t)(t & 1) * MP_BUF;
+#pragma unroll
+                    for (int r = 0; r < 16; r++) *(float4*)(dst + r * 1024) = op[r];
+                }
+                if (t <= T) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_s_barrier(); }   // barrier t: chunk t is in the LDS (t == T: the last chunk is being consumed)
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
+        return;
+    }
+    // ==================================== chain wave: matrix instructions only ====================================
+    __builtin_amdgcn_s_setprio(3);
+    f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+    int c = 0, job = gw;
+    for (int t = 0; t < T; t++) {
+        __builtin_amdgcn_s_barrier();                         // barrier t: chunk t is in buffer t & 1 (and everybody is done reading chunk t-1's buffer... of the step before)
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        const char* src = lds + (size_t)(t & 1) * MP_BUF;
+        float4 op[16];
+#pragma unroll
+        for (int r = 0; r < 16; r++) op[r] = *(const float4*)(src + r * 1024);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {                        // k-groups ascending: the reference's k order (operations_lineartransform.go:46-65)
+            if (r == 0 && c == 0) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(op[r].x, op[r].z, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);     // (C = 0 inside the instruction: see mfma_stream_kernel)
+            else acc = __builtin_amdgcn_mfma_f32_16x16x4f32(op[r].x, op[r].z, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_16x16x4f32(op[r].y, op[r].w, acc, 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (++c == nchunks) {                                 // end of this job's chain: D layout = column lane & 15, rows (lane >> 4) * 4 + r
+            if (job <= last_chain) stream_epilogue<EPI>(p, acc, acc, lane & 15, job * 16 + (lane >> 4) * 4);
+            c = 0; job += TW;
+        }
+    }
+    __builtin_amdgcn_s_barrier();                             // barrier T (pairs with the helper's last one)
+}
+
+// ------------------------------------------------------------------------------------------------
 // batch_rmsnorm_xt_kernel: RMSNorm (llamatransformer.go:633-660) of the batch's rows, one workgroup per sequence, with the EXACT parallel
 // evaluation of the reference's serial sum of squares -- the prologue of the norm-fused GEMVs (rms_fold / rms_scale_wide, lnb_seqsum.h) --
 // written out in the B-operand layout of the following product.  grid = nseq, block = (1 + NH) * 64, dynamic LDS = scratch + (kpad + 8) f32.

@@ -3232,6 +3232,17 @@ extern "C" hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int 
     const int ACC = acc2 ? 2 : 1;
     q.n_jobs = (p->n_chains + ACC - 1) / ACC;
     unsigned grid = (unsigned)((q.n_jobs + 3) / 4); if (grid > (unsigned)num_cus) grid = (unsigned)num_cus;
+    {   // thin matrices: chain wave + helper wave per tile (mfma_pair_kernel); LNB_STREAM_PAIR=0: the one-wave form
+        const char* e = getenv("LNB_STREAM_PAIR");
+        if (!acc2 && !(e && *e && atoi(e) == 0) && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_QKV_ROPE)) {
+            const size_t lds = (size_t)2 * 2 * MP_BUF;
+            unsigned gp = (unsigned)((q.n_jobs + 1) / 2); if (gp > (unsigned)num_cus) gp = (unsigned)num_cus;
+            if (epi == EPI_STORE) hipLaunchKernelGGL((mfma_pair_kernel<EPI_STORE>), dim3(gp), dim3(256), lds, st, q);
+            else if (epi == EPI_RESID) hipLaunchKernelGGL((mfma_pair_kernel<EPI_RESID>), dim3(gp), dim3(256), lds, st, q);
+            else hipLaunchKernelGGL((mfma_pair_kernel<EPI_QKV_ROPE>), dim3(gp), dim3(256), lds, st, q);
+            return hipGetLastError();
+        }
+    }
 #define LNB_STREAM(A, E) hipLaunchKernelGGL((mfma_stream_kernel<A, E>), dim3(grid), dim3(256), 0, st, q)
     switch (epi) {
     case EPI_STORE: if (acc2) LNB_STREAM(2, EPI_STORE); else LNB_STREAM(1, EPI_STORE); break;
@@ -3246,6 +3257,9 @@ extern "C" hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int 
 extern "C" hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream_t st);
 extern "C" hipError_t lnbk_batch_prepare(void) {             // raise the dynamic-LDS limits once, outside any stream capture
     hipError_t e = hipFuncSetAttribute((const void*)batch_rmsnorm_xt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mfma_pair_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mfma_pair_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mfma_pair_kernel<EPI_QKV_ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int ep = EPI_STORE; ep <= EPI_SILU_MUL && e == hipSuccess; ep++) e = lnbk_gemm_stream(nullptr, ep, 0, nullptr);
     return e;
 }

@@ -152,7 +152,7 @@ def main(asm_path=None):
         txt = open(asm).read().split("\n")
     funcs, cur = {}, None
     for i, ln in enumerate(txt):
-        m = re.match(r"^(_Z1[45678](?:gemv_chain|gemv_quad|attn_exact|attn_gqa|rowcast|rowcast_lds|mfma_stream|gemm_stream)_kernel\S*):", ln)
+        m = re.match(r"^(_Z1[45678](?:gemv_chain|gemv_quad|attn_exact|attn_gqa|rowcast|rowcast_lds|mfma_stream|mfma_pair|gemm_stream)_kernel\S*):", ln)
         if m:
             cur = []; funcs[m.group(1)] = cur
             continue
@@ -175,7 +175,7 @@ def main(asm_path=None):
         for no, t, bad in v[:6]:
             print("    line %d: %s   <- in-flight v%s" % (no, t, bad))
         # (mfma_stream_kernel's accumulators LIVE in AGPRs -- the matrix cores write them there: accvgpr moves are its epilogue, not a spill)
-        total += len(v) + (0 if ("mfma_stream" in name or "gemm_stream" in name) else accv)
+        total += len(v) + (0 if ("mfma_stream" in name or "mfma_pair" in name or "gemm_stream" in name) else accv)
     # scratch memory and VGPR spills: never.  SGPR spills into VGPR lanes (v_writelane, no memory): tolerated for the kernels listed here only --
     # attn_gqa_kernel inlines the f64 exp (two dozen SGPRs of polynomial constants) and saves 18 scalars in one VGPR around it
     SGPR_SPILL_OK = ("attn_gqa_kernel",)
