@@ -45,6 +45,14 @@ PY
     head -c 600 $O/bench_default.json; echo
     find $O -name "*.csv" | head; du -sh gpurun_out
     ;;
+  batchprof)  # rocprofv3 kernel stats of the batched step at 16 and 128 sequences (8 layers of the 8B shape: the prompts' prefill dominates a full-depth trace)
+    for n in 16 128; do
+      O=$PWD/gpurun_out/prof_r04_batch_n$n; mkdir -p $O
+      ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O -o t -- python $GRAFT_REPO_ROOT/tools/batch_bench.py --n $n --steps 16 --layers 8 > $O/out.json 2> $O/err.log; echo "n=$n rc=$?" )
+      f=$(find $O -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && cp $f gpurun_out/r04_batch_kernel_stats_n$n.csv
+      tail -1 $O/out.json | cut -c1-300
+    done
+    ;;
   suite)    # whole GPU suite
     ( timeout 3000 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -5
     ;;
