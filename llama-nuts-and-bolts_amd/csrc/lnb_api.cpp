@@ -1114,7 +1114,7 @@ static int batch_alloc(lnb_batch* b) {
     HIPCHK(hipMalloc((void**)&b->kv, kv.size() * sizeof(BatchKV)));
     HIPCHK(hipMemcpyAsync(b->kv, kv.data(), kv.size() * sizeof(BatchKV), hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));                 // (the host copies above are stack / vector memory)
-    const size_t N = std::max(n, LNB_STREAM_COLS), dim = m->a.dim;
+    const size_t N = (size_t)((std::max(n, LNB_STREAM_COLS) + 15) / 16) * 16, dim = m->a.dim;      // (whole column groups of 16: the 17..32-sequence form keeps B-operand layouts per group)
     auto zalloc = [&](uint16_t** p, size_t elems) -> int { HIPCHK(hipMalloc((void**)p, elems * 2)); HIPCHK(hipMemsetAsync(*p, 0, elems * 2, b->stream)); return 0; };
     // 1..16 sequences: activations in the B-operand layout [K][16 sequences], the columns past n stay zero for ever; 17..128: plain rows [n][K]
     if (zalloc(&b->x, N * dim) || zalloc(&b->h, N * dim) || zalloc(&b->xt, N * dim) || zalloc(&b->q, N * m->q_dim) || zalloc(&b->att_xt, N * m->q_dim) ||
@@ -1165,9 +1165,49 @@ static GemmParams wide_of(const lnb_batch* b, const uint16_t* w16, const uint16_
     GemmParams g{}; g.w16 = w16; g.nch = nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = b->n;
     return g;
 }
+// 17 .. 32 sequences (LNB_BATCH_GROUPS=0: off): the thin matrices -- one k-ordered chain per 16-row tile and 16 columns -- as TWO column groups of
+// mfma_pair_kernel on disjoint CUs (256-384 tiles x 2 groups: every CU carries two chains) instead of rows of gemm_stream_kernel (one chain per
+// wave, its operands unpacked by the same wave); the fat matrices stay rows.  The activations between them change layout at their producers:
+// norm -> xt groups (batch_rmsnorm_xt_kernel), attention -> out_xt groups, SiLU*up epilogue -> out_xt groups.
+static bool batch_groups(const lnb_batch* b) {
+    static const int on = env_int("LNB_BATCH_GROUPS", 1);
+    return on && b->n > LNB_STREAM_COLS && b->n <= 2 * LNB_STREAM_COLS;
+}
 static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {
     lnb_model* m = b->m; const lnb_model_args& a = m->a; hipStream_t st = b->stream;
     const int n = b->n, dim = a.dim, F = m->ffn_hidden;
+    if (batch_groups(b) && which != K_HEAD) {
+        LayerW& L = m->layers[l - m->layer_begin];
+        const int G = (n + LNB_STREAM_COLS - 1) / LNB_STREAM_COLS;
+        auto pair_of = [&](const uint16_t* w, const uint16_t* xt, int K, int n_rows) {
+            StreamParams p{}; p.w = w; p.xt = xt; p.K = K; p.n_rows = n_rows; p.nch = 1; p.n_chains = (n_rows + 15) / 16; p.nseq = n; p.n_groups = G; p.dbg = nullptr;
+            return p;
+        };
+        switch (which) {
+        case K_QKV: {
+            HIPCHK(lnbk_batch_rmsnorm(b->x, L.attn_norm, a.norm_eps, b->xt, dim, n, st));
+            StreamParams p = pair_of(L.m_wqkv, b->xt, dim, L.wqkv.n_rows);
+            p.cis = m->cis; p.q_out = b->q; p.tab = b->tab; p.kv = b->kv + (l - m->layer_begin); p.q_dim = m->q_dim; p.kv_dim = m->kv_dim; p.head_dim = m->head_dim;
+            HIPCHK(lnbk_stream(&p, EPI_QKV_ROPE, 0, g_num_cus, st)); return 0; }
+        case K_ATTN: {
+            AttnParams ap{}; ap.q = b->q; ap.out_xt = b->att_xt; ap.btab = b->tab; ap.bkv = b->kv + (l - m->layer_begin); ap.dbg = nullptr;
+            ap.S = n; ap.H = a.n_heads; ap.KVH = a.n_kv_heads; ap.hd = m->head_dim; ap.seq_len = b->lds_T; ap.lds_T = b->lds_T; ap.host_T = 0;
+            ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));
+            ap.force_zseq = 0; ap.zseq_count = b->ctxs[0]->zseq_count; ap.exp_tab = m->exp_tab;
+            HIPCHK(lnbk_attn(&ap, st)); return 0; }
+        case K_WO: {
+            StreamParams p = pair_of(L.m_wo, b->att_xt, m->q_dim, dim); p.out = b->h; p.res = b->x;
+            HIPCHK(lnbk_stream(&p, EPI_RESID, 0, g_num_cus, st)); return 0; }
+        case K_W13: {
+            HIPCHK(lnbk_rmsnorm_rows(b->h, L.ffn_norm, b->xt, n, dim, a.norm_eps, st));
+            GemmParams g = wide_of(b, L.m_w13, b->xt, dim, F, 2); g.out = nullptr; g.out_xt = b->ffn_xt; g.silu = m->silu;
+            HIPCHK(lnbk_gemm_stream(&g, EPI_SILU_MUL, g_num_cus, st)); return 0; }
+        case K_W2: {
+            StreamParams p = pair_of(L.m_w2, b->ffn_xt, F, dim); p.out = b->x; p.res = b->h;
+            HIPCHK(lnbk_stream(&p, EPI_RESID, 0, g_num_cus, st)); return 0; }
+        }
+        return fail("bad kernel id");
+    }
     if (which == K_HEAD) {
         HIPCHK(lnbk_rmsnorm_rows(b->x, m->norm, b->xt, n, dim, a.norm_eps, st));
         GemmParams g = wide_of(b, m->m_output, b->xt, dim, a.vocab_size, 1); g.out = b->logits;

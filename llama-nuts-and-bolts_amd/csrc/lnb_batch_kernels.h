@@ -211,7 +211,8 @@ __global__ __launch_bounds__(256) void mfma_pair_kernel(StreamParams p) {
     const int nchunks = p.K >> 7;
     // every wave of the workgroup runs the SAME number of chunks (one barrier per chunk): that of its first pair; a pair without a job left
     // streams a valid chain and drops the result
-    const int T = ((p.n_jobs - (int)blockIdx.x * 2 + TW - 1) / TW) * nchunks;
+    const int G = p.n_groups > 1 ? p.n_groups : 1, n_units = p.n_jobs * G;       // unit u = (column group u / n_jobs, tile u % n_jobs): the groups of a tile run on different CUs at the same time
+    const int T = ((n_units - (int)blockIdx.x * 2 + TW - 1) / TW) * nchunks;
     const size_t chain_bytes = (size_t)nchunks * 4096;
     const int last_chain = p.n_chains - 1;
     char* const lds = smem + (size_t)pr * 2 * MP_BUF + (size_t)lane * 16;      // this lane's 16 bytes of read r: + r * 1024 (+ MP_BUF: the other buffer)
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(256) void mfma_pair_kernel(StreamParams p) {
         u32x4 buf[R][L];
         int ij = gw, ic = 0, issued = 0;
         auto issue_next = [&](u32x4 (&dst)[L]) {
-            const char* xb = (const char*)p.xt + (size_t)ic * 4096;
-            int tc = ij; tc = tc < last_chain ? tc : last_chain;
+            const int uj = ij < n_units ? ij : n_units - 1;                         // (a pair without a unit left streams a valid one and drops the result)
+            const char* xb = (const char*)p.xt + ((size_t)(uj / p.n_jobs) * 16 * (size_t)p.K) * 2 + (size_t)ic * 4096;
+            int tc = uj % p.n_jobs; tc = tc < last_chain ? tc : last_chain;
             const char* wb = (const char*)p.w + (size_t)tc * chain_bytes + (size_t)ic * 4096;
             ld_unit_nt<0>(dst[0], aoff, wb); ld_unit_nt<1>(dst[1], aoff, wb); ld_unit_nt<2>(dst[2], aoff, wb); ld_unit_nt<3>(dst[3], aoff, wb);
             ld_unit<0>(dst[4], boff, xb); ld_unit<1>(dst[5], boff, xb); ld_unit<2>(dst[6], boff, xb); ld_unit<3>(dst[7], boff, xb);
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256) void mfma_pair_kernel(StreamParams p) {
         }
         __builtin_amdgcn_sched_barrier(0);
         if (++c == nchunks) {                                 // end of this job's chain: D layout = column lane & 15, rows (lane >> 4) * 4 + r
-            if (job <= last_chain) stream_epilogue<EPI>(p, acc, acc, lane & 15, job * 16 + (lane >> 4) * 4);
+            if (job < n_units && job % p.n_jobs <= last_chain) stream_epilogue<EPI>(p, acc, acc, (job / p.n_jobs) * 16 + (lane & 15), (job % p.n_jobs) * 16 + (lane >> 4) * 4);
             c = 0; job += TW;
         }
     }
@@ -345,7 +347,7 @@ __global__ __launch_bounds__((1 + BN_NH) * 64) void batch_rmsnorm_xt_kernel(cons
         uint32_t w4[4];
 #pragma unroll
         for (int e = 0; e < 8; e += 2) w4[e >> 1] = (uint32_t)bf_trunc(xs[kb + 16 * e]) | ((uint32_t)bf_trunc(xs[kb + 16 * (e + 1)]) << 16);
-        *(uint4*)(xt + xt_index(s, kb)) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+        *(uint4*)(xt + xt_group(s, K) + xt_index(s & 15, kb)) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
     }
 }
 

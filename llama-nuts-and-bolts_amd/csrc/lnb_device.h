@@ -113,6 +113,7 @@ struct GemmParams {
     // rows = the one new token of each SEQUENCE of a batch (lnb_batch_*, more than 16 sequences): EPI_QKV_ROPE takes row m's position, caches
     // and cache length from the batch tables instead of st / cache_k / cache_v / seq_len
     const struct BatchTab* btab; const struct BatchKV* bkv;
+    uint16_t* out_xt;           // EPI_SILU_MUL of a 17..32-sequence batch: the result in the B-operand layout, column groups of 16 (xt_group), for mfma_pair_kernel; else nullptr
     int rows_fastest;           // dispatch order of gemm_stream_kernel's workgroups: 1 = row groups fastest (set by the launcher for many row groups), 0 = weight-tile groups fastest
 };
 
@@ -157,6 +158,8 @@ LNB_HD size_t m16_index(int n, int k, int c, int K, int NCH) {
     return ((((((size_t)t * NCH + c) * (size_t)(K >> 7) + C) * 4 + m) * 16 + i) * 4 + kk) * 8 + e;
 }
 LNB_HD size_t m16_elems(int n_rows, int K, int NCH) { return (size_t)((n_rows + 15) / 16) * 16 * (size_t)NCH * (size_t)K; }
+// more than 16 sequences in the B-operand layout: group s / 16 is a layout of its own, 16 * K elements further (xt_group)
+LNB_HD size_t xt_group(int s, int K) { return (size_t)(s >> 4) * 16 * (size_t)K; }
 LNB_HD size_t xt_index(int s, int k) {
     const int C = k >> 7, e = (k >> 4) & 7, m = (k >> 2) & 3, kk = k & 3;
     return ((((size_t)C * 4 + m) * 4 + kk) * 16 + s) * 8 + e;
@@ -178,6 +181,7 @@ struct StreamParams {              // mfma_stream_kernel: Y[s][n] = trunc(sum_k 
     int n_chains;                  // tile-chains = ceil(n_rows / 16) * nch
     int n_jobs;                    // jobs of ACC tile-chains each
     int nseq;
+    int n_groups;                  // mfma_pair_kernel: column groups of 16 sequences (0 / 1: one); group g reads xt + g * 16 * K and writes columns 16 g ..
     uint16_t* out; const uint16_t* res;            // EPI_STORE / EPI_RESID: [nseq][n_rows] bf16
     uint16_t* out_xt; const float* silu;           // EPI_SILU_MUL: gate*up activations in the B-operand layout of the next product (K' = n_rows)
     const float* cis; uint16_t* q_out; const BatchTab* tab; const BatchKV* kv; int q_dim, kv_dim, head_dim;   // EPI_QKV_ROPE

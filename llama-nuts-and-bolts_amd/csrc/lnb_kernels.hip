@@ -1548,7 +1548,9 @@ template <int EPI> DEVINL void gemm_epilogue4(const GemmParams& p, const f32x4& 
         else if (EPI == EPI_RESID) p.out[o] = bf_trunc(bf_wide(p.res[o]) + bf_wide(bf_trunc(g[r])));            // ml.Add, impl:320-332
         else if (EPI == EPI_SILU_MUL) {                                                                           // activations.go:36-39, :614
             const uint16_t gs = bf_trunc(p.silu[bf_trunc(g[r])]);
-            p.out[o] = bf_trunc(bf_wide(gs) * bf_wide(bf_trunc(u[r])));
+            const uint16_t y = bf_trunc(bf_wide(gs) * bf_wide(bf_trunc(u[r])));
+            if (p.out_xt) p.out_xt[xt_group(m, p.n_rows) + xt_index(m & 15, n)] = y;       // the next product reads column groups (mfma_pair_kernel)
+            else p.out[o] = y;
         } else if (EPI == EPI_QKV_ROPE) {                                                                         // llamatransformer.go:297-403
             // rows of one sequence: consecutive positions of its cache; rows of a batch (btab): row m is sequence m's one new token
             const int pos = p.btab ? p.btab->st[m]->pos : p.st->pos + m;
@@ -2338,7 +2340,7 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
         const int r = wave * 64 + lane;
         if (r < HD) {
             const int d = attn_row_dim<HD>(r);
-            if (bt && p.out_xt) p.out_xt[xt_index(i, h * HD + d)] = bf_trunc(acc);   // batch of up to 16: straight into the B-operand layout of the wo product
+            if (bt && p.out_xt) p.out_xt[xt_group(i, p.H * HD) + xt_index(i & 15, h * HD + d)] = bf_trunc(acc);   // column batches: straight into the B-operand layout of the wo product
             else p.out[((size_t)i * p.H + h) * HD + d] = bf_trunc(acc);        // [S, H*hd] (:508-514)
         }
     }
@@ -2555,7 +2557,7 @@ template <int HD, int G> __global__ __launch_bounds__(512, 4) void attn_gqa_kern
 #undef GQA_VSTORE
     {
         const int h = kvh * G + wave, d = 2 * lane;
-        if (p.out_xt) { p.out_xt[xt_index(i, h * HD + d)] = bf_trunc(a0.x); p.out_xt[xt_index(i, h * HD + d + 1)] = bf_trunc(a0.y); }     // batch of up to 16: the B-operand layout of the wo product
+        if (p.out_xt) { uint16_t* o = p.out_xt + xt_group(i, p.H * HD); o[xt_index(i & 15, h * HD + d)] = bf_trunc(a0.x); o[xt_index(i & 15, h * HD + d + 1)] = bf_trunc(a0.y); }     // column batches: the B-operand layout of the wo product
         else *(uint32_t*)(p.out + ((size_t)i * p.H + h) * HD + d) = (uint32_t)bf_trunc(a0.x) | ((uint32_t)bf_trunc(a0.y) << 16);       // [S, H*hd]
     }
 }
@@ -3227,16 +3229,17 @@ extern "C" hipError_t lnbk_m16_from_tiled(const uint16_t* src, uint16_t* dst, in
 }
 // acc2: two tile-chains per wave (fat matrices and the gate|up pairs); else one (thin matrices: every tile on its own SIMD)
 extern "C" hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int num_cus, hipStream_t st) {
-    if ((p->K & 127) || p->nseq < 1 || p->nseq > LNB_STREAM_COLS || p->n_chains < 1) return hipErrorInvalidValue;
+    const int G = p->n_groups > 1 ? p->n_groups : 1;
+    if ((p->K & 127) || p->nseq < 1 || p->nseq > G * LNB_STREAM_COLS || p->n_chains < 1 || (G > 1 && acc2)) return hipErrorInvalidValue;
     StreamParams q = *p;
     const int ACC = acc2 ? 2 : 1;
     q.n_jobs = (p->n_chains + ACC - 1) / ACC;
     unsigned grid = (unsigned)((q.n_jobs + 3) / 4); if (grid > (unsigned)num_cus) grid = (unsigned)num_cus;
     {   // thin matrices: chain wave + helper wave per tile (mfma_pair_kernel); LNB_STREAM_PAIR=0: the one-wave form
         const char* e = getenv("LNB_STREAM_PAIR");
-        if (!acc2 && !(e && *e && atoi(e) == 0) && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_QKV_ROPE)) {
+        if (!acc2 && (G > 1 || !(e && *e && atoi(e) == 0)) && (epi == EPI_STORE || epi == EPI_RESID || epi == EPI_QKV_ROPE)) {
             const size_t lds = (size_t)2 * 2 * MP_BUF;
-            unsigned gp = (unsigned)((q.n_jobs + 1) / 2); if (gp > (unsigned)num_cus) gp = (unsigned)num_cus;
+            unsigned gp = (unsigned)((q.n_jobs * G + 1) / 2); if (gp > (unsigned)num_cus) gp = (unsigned)num_cus;
             if (epi == EPI_STORE) hipLaunchKernelGGL((mfma_pair_kernel<EPI_STORE>), dim3(gp), dim3(256), lds, st, q);
             else if (epi == EPI_RESID) hipLaunchKernelGGL((mfma_pair_kernel<EPI_RESID>), dim3(gp), dim3(256), lds, st, q);
             else hipLaunchKernelGGL((mfma_pair_kernel<EPI_QKV_ROPE>), dim3(gp), dim3(256), lds, st, q);

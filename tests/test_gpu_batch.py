@@ -134,6 +134,38 @@ def test_wide_batch_decode_at_the_8b_shape_equals_single_sequence_runs_and_the_g
     gm.close()
 
 
+def test_column_group_batch_of_17_to_32_sequences_at_the_8b_shape(lnb):
+    """Round 4: 17 .. 32 sequences run the thin matrices (wq|wk|wv, wo, w2) as two column groups of mfma_pair_kernel, the fat ones as rows of
+    gemm_stream_kernel; the activations change layout at their producers (norm, attention, SiLU*up epilogue).  25 sequences (a ragged
+    second group) of different prompt lengths at the 8B shape: sequence 0 the configs[1] golden, sequences 1, 15, 16, 24 their own
+    single-sequence runs, KV caches included."""
+    cfg = dict(lnb.LLAMA_8B)
+    steps, n = 10, 25
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1234).finalize().enable_batch()
+    plens = [128 if s == 0 else 20 + (s * 11) % 60 for s in range(n)]
+    prompts = [lnb.synth_tokens(99 + s, plens[s], cfg["vocab_size"]) for s in range(n)]
+    ctxs = [lnb.InferenceContext(gm, plens[s] + steps + 8) for s in range(n)]
+    firsts = [ctxs[s].Forward(prompts[s], 0, want_logits=False)[1] for s in range(n)]
+    b = lnb.Batch(ctxs)
+    got, ms = b.decode(firsts, plens, steps)
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "configs1_tokens.json")))["tokens"]
+    assert [firsts[0]] + [int(t) for t in got[0]] == gold[:steps + 1]
+    for s in (1, 15, 16, 24):
+        solo = lnb.InferenceContext(gm, plens[s] + steps + 8)
+        _, f = solo.Forward(prompts[s], 0, want_logits=False)
+        assert f == firsts[s]
+        ref, _ = solo.decode_greedy(f, plens[s], steps)
+        assert [int(t) for t in got[s]] == [int(t) for t in ref], s
+        T = plens[s] + steps
+        for layer in (0, 31):
+            assert (solo.CacheK(layer)[:T] == ctxs[s].CacheK(layer)[:T]).all() and (solo.CacheV(layer)[:T] == ctxs[s].CacheV(layer)[:T]).all()
+        solo.close()
+    b.close()
+    for c in ctxs:
+        c.close()
+    gm.close()
+
+
 def test_batch_argument_checks(lnb):
     cfg = dict(orc.TINY)
     gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1).finalize()
