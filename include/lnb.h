@@ -145,7 +145,8 @@ int lnb_decode_greedy_until(lnb_ctx* c, int32_t token, int start_pos, int max_st
  * call (src/ml/operations_lineartransform.go:173-193).  A batch groups 1..128 contexts of ONE whole-model handle; per step, every
  * sequence's one-token Forward + Argmax (inference.go:194-252) is evaluated in a single pass over the weights: up to 16 sequences are the 16
  * columns of the f32 matrix-core instruction, which computes each column's k-ordered chain exactly; 17..128 sequences are the rows of the
- * prefill's streaming product (1 / 2 / 4 tiles of 16 sequences per wave, same instruction, same chains).  Per-sequence position, RoPE row, KV
+ * prefill's streaming product (1 / 2 / 4 tiles of 16 sequences per wave, same instruction, same chains) -- except that 17..32 sequences keep
+ * the column form, as two groups of 16, for the matrices with few output rows (wq|wk|wv, wo, w2).  Per-sequence position, RoPE row, KV
  * append and attention; every sequence's tokens, logits and caches are bit-identical to its single-sequence run (and the CPU reference).
  * lnb_model_enable_batch: builds the weights' second, matrix-core friendly copy on the device (once, after lnb_model_finalize; it costs the
  *   model's matrix bytes again -- 15 GB for the 8B shape; fails cleanly when that does not fit, the other entry points stay usable).  Works
