@@ -2553,6 +2553,7 @@ template <int HD, int G> __global__ __launch_bounds__(512, 4) void attn_gqa_kern
         }
     }
     GQA_STAMP(6);
+#undef GQA_STAMP
 #undef GQA_VLOAD
 #undef GQA_VSTORE
     {

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Phase stamps (s_memtime ticks, 100 MHz) of one workgroup of attn_gqa_kernel at 128 sequences of the 8B shape: LNB_ATTN_GQA_DBG=1 python tools/gqa_stamps.py"""
+"""Phase stamps (s_memtime ticks = shader clock cycles, as in the GEMV stamps) of one workgroup of attn_gqa_kernel at 128 sequences of the 8B shape: LNB_ATTN_GQA_DBG=1 python tools/gqa_stamps.py"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "llama-nuts-and-bolts_amd"))
