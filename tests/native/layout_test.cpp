@@ -55,6 +55,17 @@ int main() {
                         for (int e = 0; e < 8; e++)
                             CHECK(xt_index(s, 128 * C + 16 * e + 4 * m + kk) == ((((size_t)C * 4 + m) * 4 + kk) * 16 + s) * 8 + e, "xt unit layout");
     }
+    // ---- xt for more than 16 sequences (round 4, 17 .. 32 sequences): group s / 16 is a whole layout of its own, 16 * K elements further --------
+    for (int K : {128, 4096}) {
+        std::vector<char> seen((size_t)32 * K, 0);
+        for (int s = 0; s < 32; s++)
+            for (int k = 0; k < K; k++) {
+                const size_t ix = xt_group(s, K) + xt_index(s & 15, k);
+                CHECK(ix < (size_t)32 * K, "grouped xt index out of range");
+                CHECK((ix >= (size_t)16 * K) == (s >= 16), "group 1 lives behind group 0");
+                if (ix < (size_t)32 * K) { CHECK(!seen[ix], "grouped xt index not injective"); seen[ix] = 1; }
+            }
+    }
     // ---- tiled GEMV layout [N/RW][K/8][NCH][RW][8] (RW 4: the row-broadcast layout [N/4][K/128][row%4][k%16][(k%128)/16], one chain): a
     // bijection into tiled_elems for every row-block width the library uses; a lane's 16-byte piece = eight k of its own row ---------------
     for (int RW : {4, 16, 28, 32, 56, 64})
