@@ -101,16 +101,17 @@ def pmc_traffic(kernel_name, model_name, mode):
     return None, None, None
 
 
-GOLDENS = {("llama8b", 128): "configs1_tokens.json", ("llama8b-2l", 4096): "configs2_2layer_tokens.json", ("llama8b-8l", 4096): "configs2_8layer_tokens.json"}
+GOLDENS = {("llama8b", 128): "configs1_tokens.json", ("llama8b-2l", 4096): "configs2_2layer_tokens.json", ("llama8b-8l", 4096): "configs2_8layer_tokens.json",
+           ("llama8b", 4096): "configs2_32layer_tokens.json"}      # configs[2] at FULL depth: made once by tests/golden/make_configs2_cut_tokens.py 32 (hours of host cores)
 
 
-def check_golden(args, first_tok, warm_toks, timed_toks):
+def check_golden(args, first_tok, warm_toks, timed_toks, key=None):
     """The tokens this run produced against the CPU ORACLE's continuation committed under tests/golden/: configs[1] exactly (8B shape,
     seed-1234 weights, the 128-token synthetic prompt; make_configs1_tokens.py) or the configs[2] workload on the two-layer cut of the
     shape (`--model llama8b-2l --prompt-len 4096`; make_configs2_2layer_tokens.py).  exact mode: a mismatch is a parity failure and the
     bench refuses to print a number; fast mode: reports how many leading tokens agree.  None when no golden covers the workload (then
     device_self_check below is what stands behind the number, and the line says so)."""
-    fn = GOLDENS.get((args.model, args.prompt_len))
+    fn = GOLDENS.get(key or (args.model, args.prompt_len))
     path = os.path.join(ROOT, "tests", "golden", fn) if fn else None
     if not path or not os.path.exists(path):
         return None
@@ -149,15 +150,67 @@ def device_self_check(lnb, model, args, prompt, seq_len, run_tokens):
     return {"oracle": "none at this size (no CPU-oracle golden for %s at prompt length %d)" % (args.model, args.prompt_len), "forms": agree}
 
 
-def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens):
+CFG2_P, CFG2_W, CFG2_K = 4096, 4, 64
+
+
+def configs2_record(lnb, model, cfg, args, a):
+    """BASELINE configs[2] inside the DEFAULT line, so that it is timed by whoever runs `python bench.py` (VERDICT r4 #1c): the 4096-token prompt
+    in one Forward (exact chains on the f32 matrix cores), then 4 warm-up + 64 timed greedy steps at T = 4101 ... 4164 through the long-context
+    attention kernels (three repeats of the same 64 steps, median), every token compared with the CPU oracle's continuation of the FULL 32-layer
+    model (tests/golden/configs2_32layer_tokens.json, made once on the host by tests/golden/make_configs2_cut_tokens.py 32).  A mismatch in exact
+    mode is a parity failure: the bench refuses to print."""
+    P, W, K = CFG2_P, CFG2_W, CFG2_K
+    seq_len = P + W + K + 8
+    ctx = lnb.InferenceContext(model, seq_len).set_mode(args.mode)
+    prompt = lnb.synth_tokens(99, P, cfg["vocab_size"])
+    lnb._chk(lnb.lib().lnb_ctx_synchronize(ctx.h))
+    t0 = time.perf_counter()
+    _, first = ctx.Forward(prompt, 0, want_logits=False)
+    t_pf = time.perf_counter() - t0
+    warm, _ = ctx.decode_greedy(first, P, W)
+    tok, pos = int(warm[-1]), P + W
+    reps = []
+    for rep in range(3):
+        lnb._chk(lnb.lib().lnb_ctx_synchronize(ctx.h))
+        t0 = time.perf_counter()
+        o_, ev_ = ctx.decode_greedy(tok, pos, K)
+        reps.append((time.perf_counter() - t0, ev_, [int(t) for t in o_]))
+        if reps[-1][2] != reps[0][2]:
+            sys.stderr.write("PARITY FAILURE (configs[2]): repeat %d of the timed region produced different tokens\n" % rep)
+            sys.exit(3)
+    wall, ev_ms, out = sorted(reps, key=lambda r: r[0])[1]
+    golden = check_golden(args, first, [int(t) for t in warm], out, key=("llama8b", P))
+    Tbar = pos + (K - 1) / 2.0 + 1.0
+    B = algorithmic_bytes_per_token(a, model.ffn_hidden, Tbar)
+    att_ms = ctx.profile_kernel(1, int(Tbar) - 1, 16)
+    zseq = ctx.zseq_count()
+    ctx.close()
+    tps = K / wall
+    hd = a["dim"] // a["n_heads"]
+    mm = a["n_layers"] * (a["dim"] * (a["n_heads"] + 2 * a["n_kv_heads"]) * hd + a["dim"] * a["dim"] + 3 * a["dim"] * model.ffn_hidden)    # multiply-accumulates per row
+    return {"workload": "Llama-3.1-8B bf16, 1xMI355X, long-prefill seq_len=%d + %d decode (configs[2]; %d warm-up steps first)" % (P, K, W),
+            "prefill": {"rows": P, "ms": round(1e3 * t_pf, 1), "TFLOP/s": round(2.0 * P * mm / t_pf / 1e12, 1), "peak_TFLOP/s": 157.3,
+                        "frac_of_f32_mfma_peak": round(2.0 * P * mm / t_pf / 1e12 / 157.3, 4),
+                        "kernel": "gemm_mfma_kernel + attn_mfma_kernel (v_mfma_f32_16x16x4_f32 = the k-ordered chain; matmul FLOPs only)"},
+            "decode": {"steps": K, "tokens_per_s": round(tps, 2), "ms_per_step": round(1e3 * wall / K, 4), "hip_event_ms_per_step": round(ev_ms / K, 4),
+                       "repeats_ms_per_step": [round(1e3 * r[0] / K, 4) for r in reps], "mean_context": Tbar,
+                       "frac_of_hbm_roofline": round(tps * B / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_token": int(B),
+                       "attention_us_per_layer": round(1e3 * att_ms, 2), "softmax_rows_that_walked_the_serial_sum": zseq},
+            "tokens_vs_oracle_golden": golden if golden else {"compared": 0, "note": "tests/golden/configs2_32layer_tokens.json is missing"},
+            "first_token": int(first)}
+
+
+def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens, n_seq=None, sched="throughput"):
     """Not the headline (configs[1] is ONE prompt): the same resident model decoding `--concurrent` independent prompts at once, one
     context and stream each, through the one-GPU form of the pipeline tick path (lnb_pipeline_tick: captured stage graphs, device-side
     token ring).  Their kernels overlap -- one sequence's chain-bound launches under another's HBM-bound ones -- which is what every
     pipeline rank gets per stage.  Sequence 0 has the headline run's prompt: its tokens are compared with that run's."""
     import pipeline
-    n_seq, P, W, K = args.concurrent, args.prompt_len, min(args.warmup, 4), min(args.steps, 48)
+    n_seq, P, W, K = n_seq or args.concurrent, args.prompt_len, min(args.warmup, 4), min(args.steps, 48)
     seq_len = P + W + K + 8
-    ctxs = [lnb.InferenceContext(model, seq_len).set_mode(args.mode) for _ in range(n_seq)]
+    # the contexts take the THROUGHPUT forms of the one-token kernels (lnb_ctx_set_schedule: every workgroup <= 57 KB of LDS, so that one
+    # context's chain-bound launch shares the CUs with another's HBM-bound gate|up launch); sched="latency" = the single stream's forms, for the A/B
+    ctxs = [lnb.InferenceContext(model, seq_len).set_mode(args.mode).set_schedule(sched) for _ in range(n_seq)]
     pipe = lnb.Pipeline(model, 0, 1, None)
     prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
     n_decode = W + K
@@ -179,7 +232,7 @@ def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens):
     tps = n_seq * K / wall
     Tbar = P + W + (K - 1) / 2.0 + 1.0
     B = algorithmic_bytes_per_token(a, model.ffn_hidden, Tbar)
-    return {"n": n_seq, "tokens_per_s": round(tps, 2), "steps_each": K, "ms_per_token": round(1e3 * wall / (n_seq * K), 4),
+    return {"n": n_seq, "schedule": sched, "tokens_per_s": round(tps, 2), "steps_each": K, "ms_per_token": round(1e3 * wall / (n_seq * K), 4),
             "frac_of_hbm_roofline": round(tps * B / 1e9 / PEAK_HBM_GBS, 4),
             "sequence0_tokens_vs_single_run": {"compared": n_cmp, "identical_prefix": same},
             "note": "aggregate of independent prompts on ONE GPU; weights are re-read per sequence (no batching: every token keeps its own exact chains)"}
@@ -241,6 +294,18 @@ def batched_sequences(lnb, model, cfg, args, a, single_run_tokens):
     mm = a["n_layers"] * (a["dim"] * (a["n_heads"] + 2 * a["n_kv_heads"]) * (a["dim"] // a["n_heads"]) + a["dim"] * a["dim"] + 3 * a["dim"] * model.ffn_hidden)   # multiply-accumulates per row
     out["prefill_streamed"] = {"rows": P, "ms": round(1e3 * best, 2), "TFLOP/s": round(2.0 * P * mm / best / 1e12, 2), "peak_TFLOP/s": 157.3, "frac_of_f32_mfma_peak": round(2.0 * P * mm / best / 1e12 / 157.3, 4),
                                "kernel": "gemm_stream_kernel", "first_token_same_as_headline_prefill": bool(single_run_tokens and int(tok_pf) == int(single_run_tokens[0]))}
+    out["weight_bytes_resident_with_the_second_copy"] = model.weight_bytes() + model.batch_bytes()
+    if args.model == "llama8b" and not args.no_configs2 and P < CFG2_P:
+        # configs[2]'s prompt again on the streaming feed (the default line's configs2.prefill ran before the copy existed)
+        c2 = lnb.InferenceContext(model, CFG2_P + 8)
+        p2 = lnb.synth_tokens(99, CFG2_P, cfg["vocab_size"])
+        lnb._chk(lnb.lib().lnb_ctx_synchronize(c2.h))
+        t1 = time.perf_counter()
+        _, tok2 = c2.Forward(p2, 0, want_logits=False)
+        dt = time.perf_counter() - t1
+        c2.close()
+        out["prefill_streamed_4096"] = {"rows": CFG2_P, "ms": round(1e3 * dt, 1), "TFLOP/s": round(2.0 * CFG2_P * mm / dt / 1e12, 1), "frac_of_f32_mfma_peak": round(2.0 * CFG2_P * mm / dt / 1e12 / 157.3, 4),
+                                        "first_token": int(tok2)}
     for c in ctxs:
         c.close()
     out["note"] = ("aggregate tokens/s of n independent prompts decoded together on ONE GPU: one pass over the weights per step, each sequence a "
@@ -248,45 +313,79 @@ def batched_sequences(lnb, model, cfg, args, a, single_run_tokens):
     return out
 
 
-# measured step costs of the exact k-ordered chains on this chip (tools/chainbench3.hip, profiles/r04_chainbench.log), in ns per k-step of
-# ONE chain wave with nothing else in its way, and what a launch cannot avoid paying around them
-CHAIN_NS = {"row_newbcast": 2.372,     # v_add_f32_dpp row_newbcast, products fetched from the LDS 64 steps per ds_read_b128 (5.56 cycles): wo, w2
-            "quad_perm": 2.922}        # v_add_f32_dpp quad_perm, 16 steps per ds_read_b128 (6.81 cycles): wq|wk|wv (24 rows per CU need 16 rows per chain wave)
+# Bare cost of one dependent add of a k-ordered f32 chain on gfx950, in shader cycles per k-step of ONE chain wave with nothing else in its way
+# (micro-benchmarks tools/chainbench3.hip / chainbench4.hip, logs profiles/r04_chainbench3.log; hardware numbers, not this library's kernels)
+CHAIN_CYCLES = {"row_newbcast": 5.56,  # v_add_f32_dpp row_newbcast, products fetched from the LDS 64 steps per ds_read_b128: wo, w2
+                "quad_perm": 6.81}     # v_add_f32_dpp quad_perm, 16 steps per ds_read_b128: wq|wk|wv (24 rows per CU need 16 rows per chain wave)
 HBM_ACHIEVABLE_GBS = 6700.0            # the best streaming READ rate on record for this chip (MI355X_MICROARCH.md price list: 6.5-6.8 TB/s for an nt weight stream; the float4 COPY figure is 6.29)
-BOUNDARY_US = 1.4                      # dependent kernel boundary inside the captured graph (MI355X_MICROARCH.md price list: 1.2-1.45 us)
-X_PROLOGUE_US = 1.2                    # x row: global load + LDS staging + first weights (2.9 k cycles measured, rowcast_lds_kernel)
-NORM_PROLOGUE_US = 3.5                 # norm-fused kernels: x 1.2 k + fold 3.0 k (~450 instructions incl. the split pass, two waves per SIMD) + the branch-free
-                                       # item walk 0.7 k (18 items x ~31 cycles + list fetch; round 4, second half: was 2.5 k of scalar hand-offs) + f64 rsqrt 1.2 k +
-                                       # normalise 1.2 k + five barriers = 8 k cycles at 2.3 GHz
+NOMINAL_GHZ = 2.344                    # shader clock the r04 chain figures were quoted at; used only where a launch's own clock could not be measured
+GEMV_CLASSES = {0: ("attn_norm+wqkv+rope GEMV", "quad_perm"), 2: ("wo+residual GEMV", "row_newbcast"), 3: ("ffn_norm+w1|w3+silu GEMV", None),
+                4: ("w2+residual GEMV", "row_newbcast"), 5: ("norm+output GEMV", None)}
 
 
-def practical_floor(a, ffn_hidden, Tbar, kernels):
-    """What the EXACT arithmetic can reach on this chip with the step costs that were actually measured -- not a bound with operands arriving
-    for free.  Chain-bound launches: K x the measured DPP step (every output is one k-ordered chain of K dependent f32 adds,
-    operations_lineartransform.go:46-65, and no operand delivery is cheaper than a DPP broadcast: tools/chainbench3.hip); HBM-bound
-    launches: bytes at the chip's measured streaming rate; both behind their measured prologue, plus one kernel boundary each.
-    The attention is taken as measured (latency-bound at this context: no floor claimed)."""
+def measured_model(ctx, a, ffn_hidden, Tbar, kernels, tps):
+    """Two things, kept apart (VERDICT r4 #2f):
+    * `hardware_bound` -- depends on the chip and the arithmetic only: per launch max(K x the bare DPP chain step at the launch's measured shader
+      clock, algorithmic bytes / 6.7 TB/s), NO prologue, NO kernel boundary; the attention as measured (latency-bound, no bound claimed).
+      Every output is one k-ordered chain of K dependent f32 adds (operations_lineartransform.go:46-65): nothing that keeps the bits goes below it.
+    * `per_kernel` -- the CURRENT kernels taken apart with stamps of THIS run (lnb_profile_kernel_stamps: one launch per class with the per-wave
+      cycle stamps armed; stamp 7 = the same launch on the constant-rate wall clock, so cycles become microseconds at the clock the launch really
+      ran at): prologue (kernel start -> the chain wave's first add), main loop (cycles per k-step for the chain-bound launches, GB/s for the
+      HBM-bound ones), and boundary = HIP-event launch-to-launch time minus the longest wave's in-kernel time.  `floor_us` = the hardware bound
+      of the launch + ITS measured prologue + ITS measured boundary: what the launch would take with a perfect main loop and nothing else
+      changed -- a statement about these kernels, not about the chip."""
     d, hd = a["dim"], a["dim"] // a["n_heads"]
     kb = kernel_bytes(a, ffn_hidden, Tbar)
+    Ksteps = {0: d, 2: a["n_heads"] * hd, 3: d, 4: ffn_hidden, 5: d}
+    per, hw_rows, fl_rows, cur_rows = {}, {}, {}, {}
+    for which, (name, chain) in GEMV_CLASSES.items():
+        got_us = 1e3 * kernels[name]["ms"]
+        try:
+            v, khz = ctx.profile_kernel_stamps(which, int(Tbar) - 1)
+        except Exception as e:                                     # the model is a report, never a reason to lose the line
+            v, khz = None, 0
+        rec = {"us": round(got_us, 2)}
+        ghz = NOMINAL_GHZ
+        prologue_us = boundary_us = None
+        if v is not None and khz > 0:
+            cw = next((w for w in range(8) if v[w][0] > 0 and v[w][12] > 0), None)       # a chain wave: stamp 6 = the cycle its main loop starts
+            if cw is not None and v[cw][13] > 0:
+                wall_us = v[cw][13] / khz * 1e3
+                ghz = v[cw][1] / wall_us * 1e-3                    # shader cycles per wall microsecond of the same wave, same launch
+                in_kernel_us = max(v[w][2] for w in range(8)) / ghz * 1e-3
+                prologue_us = v[cw][12] / ghz * 1e-3
+                main_cycles = v[cw][1] - v[cw][12]
+                boundary_us = max(0.0, got_us - in_kernel_us)
+                rec.update({"shader_clock_GHz": round(ghz, 3), "in_kernel_us": round(in_kernel_us, 2), "prologue_us": round(prologue_us, 2),
+                            "main_loop_us": round(main_cycles / ghz * 1e-3, 2), "barrier_wait_us_of_the_chain_wave": round(v[cw][3] / ghz * 1e-3, 2),
+                            "boundary_us": round(boundary_us, 2)})
+                if chain:
+                    rec["cycles_per_k_step"] = round(main_cycles / Ksteps[which], 3)
+                else:
+                    rec["main_loop_GBps"] = round(kb[which] / (main_cycles / ghz) , 1)
+        hw = max(Ksteps[which] * CHAIN_CYCLES[chain] / ghz * 1e-3 if chain else 0.0, kb[which] / HBM_ACHIEVABLE_GBS * 1e-3)
+        rec["hardware_bound_us"] = round(hw, 2)
+        if prologue_us is not None:
+            rec["floor_us"] = round(hw + prologue_us + boundary_us, 2)
+            rec["achieved_over_floor"] = round((hw + prologue_us + boundary_us) / got_us, 3)
+        per[name] = rec
+        hw_rows[which], cur_rows[which] = hw, got_us
+        fl_rows[which] = rec.get("floor_us", got_us)
     att = 1e3 * kernels[KERNEL_NAMES[1]]["ms"]
-    rows = [("attn_norm+wqkv+rope GEMV", max(d * CHAIN_NS["quad_perm"] * 1e-3, kb[0] / HBM_ACHIEVABLE_GBS * 1e-3) + NORM_PROLOGUE_US + BOUNDARY_US),
-            ("attention", att),
-            ("wo+residual GEMV", max(a["n_heads"] * hd * CHAIN_NS["row_newbcast"] * 1e-3, kb[2] / HBM_ACHIEVABLE_GBS * 1e-3) + X_PROLOGUE_US + BOUNDARY_US),
-            ("ffn_norm+w1|w3+silu GEMV", kb[3] / HBM_ACHIEVABLE_GBS * 1e-3 + NORM_PROLOGUE_US + BOUNDARY_US),
-            ("w2+residual GEMV", max(ffn_hidden * CHAIN_NS["row_newbcast"] * 1e-3, kb[4] / HBM_ACHIEVABLE_GBS * 1e-3) + X_PROLOGUE_US + BOUNDARY_US),
-            ("norm+output GEMV", kb[5] / HBM_ACHIEVABLE_GBS * 1e-3 + NORM_PROLOGUE_US + BOUNDARY_US)]
-    per = {}
-    for name, floor_us in rows:
-        got = 1e3 * kernels[name]["ms"]
-        per[name] = {"us": round(got, 2), "practical_floor_us": round(floor_us, 2), "achieved_over_floor": round(floor_us / got, 3)}
-    t_tok = 1e-6 * (a["n_layers"] * sum(f for _, f in rows[:5]) + rows[5][1])
+    per["attention"] = {"us": round(att, 2), "note": "latency-bound at this context: taken as measured in both sums"}
     B = algorithmic_bytes_per_token(a, ffn_hidden, Tbar)
-    frac = B / t_tok / 1e9 / PEAK_HBM_GBS
-    return {"ms_per_token": round(1e3 * t_tok, 4), "tokens_per_s": round(1.0 / t_tok, 1), "frac_of_hbm_roofline": round(frac, 4), "per_kernel": per,
-            "constants": {"chain_ns_per_step": CHAIN_NS, "hbm_achievable_GBps": HBM_ACHIEVABLE_GBS, "boundary_us": BOUNDARY_US,
-                          "x_prologue_us": X_PROLOGUE_US, "norm_prologue_us": NORM_PROLOGUE_US},
-            "verdict": ("the practical floor of the exact order is %.3f of the 8 TB/s roofline: the 0.50 target is %s it" % (frac, "inside" if frac >= 0.5 else "ABOVE")),
-            "note": "per launch: max(K x measured DPP chain step, bytes / 6.7 TB/s) + measured prologue + one 1.4 us boundary; attention as measured"}
+
+    def token(rows):
+        t = 1e-6 * (a["n_layers"] * (rows[0] + att + rows[2] + rows[3] + rows[4]) + rows[5])
+        return {"ms_per_token": round(1e3 * t, 4), "tokens_per_s": round(1.0 / t, 1), "frac_of_hbm_roofline": round(B / t / 1e9 / PEAK_HBM_GBS, 4)}
+
+    hwb, flr = token(hw_rows), token(fl_rows)
+    return {"hardware_bound": dict(hwb, note="per launch max(K x bare DPP chain step at the measured clock, bytes / 6.7 TB/s); no prologue, no boundary; attention as measured",
+                                   achieved_frac_of_bound=round(tps / hwb["tokens_per_s"], 4)),
+            "floor_with_measured_prologues_and_boundaries": dict(flr, achieved_frac_of_floor=round(tps / flr["tokens_per_s"], 4),
+                                                                  note="hardware bound + each launch's prologue and boundary as stamped in this run: a model of the current kernels, not of the chip"),
+            "per_kernel": per,
+            "constants": {"bare_chain_cycles_per_step": CHAIN_CYCLES, "hbm_achievable_GBps": HBM_ACHIEVABLE_GBS, "source": "tools/chainbench3.hip, profiles/r04_chainbench3.log; MI355X_MICROARCH.md"}}
 
 
 def traffic_child(lnb, cfg, args):
@@ -297,13 +396,14 @@ def traffic_child(lnb, cfg, args):
     model = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize(rope_rows=max(pos + 16, 2 * cfg["max_seq_len"]))
     ctx = lnb.InferenceContext(model, pos + 8).set_mode(args.mode)
     ctx.Forward(lnb.synth_tokens(99, 16, cfg["vocab_size"]), 0, want_logits=False)
-    ctx.profile_kernel(args.traffic_child, pos, 24)
+    for which in [int(w) for w in str(args.traffic_child).split(",")]:
+        ctx.profile_kernel(which, pos, 24)
     ctx.close(); model.close()
     return 0
 
 
-def probe_traffic(args, dom, pos):
-    """HBM bytes per launch of the dominant kernel, measured in THIS run: PMC counters cannot be read from inside a process, so a child
+def probe_traffic(args, classes, pos):
+    """HBM bytes per launch of the dominant kernel symbol (its launch classes, e.g. wo and w2 of rowcast_lds_kernel), measured in THIS run: PMC counters cannot be read from inside a process, so a child
     (traffic_child) is run under `rocprofv3 --kernel-trace --pmc FETCH_SIZE` (a counter pass of its own, no other trace domains) and its
     counter file is read back.  FETCH_SIZE is in KiB and tallies wide coalesced reads at half their bytes on gfx950 (MI355X_MICROARCH.md,
     section HBM): bytes = KiB x 1024 x 2.  None when rocprofv3 is missing, when this process already runs under it, or on any failure
@@ -318,7 +418,7 @@ def probe_traffic(args, dom, pos):
     tmp = tempfile.mkdtemp(prefix="lnb_traffic_", dir="/tmp")
     try:
         cmd = [rp, "--kernel-trace", "--pmc", "FETCH_SIZE", "--output-format", "csv", "-d", tmp, "-o", "pmc", "--", sys.executable,
-               os.path.abspath(__file__), "--traffic-child", str(dom), "--traffic-pos", str(pos), "--model", args.model, "--mode", args.mode]
+               os.path.abspath(__file__), "--traffic-child", ",".join(str(c) for c in classes), "--traffic-pos", str(pos), "--model", args.model, "--mode", args.mode]
         r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=300)
         if r.returncode != 0:
             return None
@@ -329,11 +429,11 @@ def probe_traffic(args, dom, pos):
                     for row in csv.DictReader(open(os.path.join(root, fn))):
                         if row.get("Counter_Name") == "FETCH_SIZE":
                             per.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
-        per = {k: v for k, v in per.items() if len(v) >= 20}          # the looped class (24 + 3 warm-up launches); the prompt's kernels ran twice
+        per = {k: v for k, v in per.items() if len(v) >= 20}          # the looped classes (24 + 3 warm-up launches each); the prompt's kernels ran twice
         if not per:
             return None
         kname, vals = max(per.items(), key=lambda kv: sum(kv[1]))     # (the long-context attention is two kernels: the heavier one)
-        total = sum(sum(v) / len(v) for v in per.values())
+        total = sum(sum(v) / len(v) for v in per.values())            # (one symbol looped as two classes: the mean over all its launches)
         return {"bytes_per_launch": int(total * 1024 * 2), "launches": len(vals),
                 "source": "this run: rocprofv3 --pmc FETCH_SIZE over %d launches of %s (child process, two layers of the shape), KiB x 1024 x 2 (gfx950 correction)"
                           % (len(vals), kname.split("(")[0][:80])}
@@ -386,7 +486,8 @@ def main():
     ap.add_argument("--batch-sizes", type=lambda v: [int(x) for x in v.split(",") if x], default=[2, 4, 8, 16, 32, 64, 128],
                     help="also time BATCHED exact decode of this many prompts (comma list, each 1..128; empty = skip)")
     ap.add_argument("--no-traffic-probe", action="store_true", help="do not run the rocprofv3 FETCH_SIZE pass of the dominant kernel")
-    ap.add_argument("--traffic-child", type=int, default=-1, help=argparse.SUPPRESS)      # internal: kernel class to loop under rocprofv3
+    ap.add_argument("--no-configs2", action="store_true", help="leave the configs[2] record (4096-token prompt + 64 steps, oracle-golden checked) out of the default line")
+    ap.add_argument("--traffic-child", default="", help=argparse.SUPPRESS)      # internal: kernel class(es) to loop under rocprofv3, comma separated
     ap.add_argument("--traffic-pos", type=int, default=0, help=argparse.SUPPRESS)
     ap.add_argument("--model", default="llama8b", choices=["llama8b", "llama8b-2l", "llama8b-8l", "tiny", "llama70b-like"])
     ap.add_argument("--mode", default="exact", choices=["exact", "fast"],
@@ -419,7 +520,7 @@ def main():
         cfg.update(dim=8192, n_layers=80, n_heads=64, n_kv_heads=8, multiple_of=4096)
         name = "random-init Llama-shape dim=8192 n_layers=80"
 
-    if args.traffic_child >= 0:
+    if args.traffic_child:
         return traffic_child(lnb, cfg, args)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus > 1 or world > 1 or os.environ.get("LNB_FORCE_PIPELINE") == "1":     # (the env switch runs the N-GPU code path on one GPU)
@@ -431,8 +532,10 @@ def main():
     # trace has crashed inside the tool on runs of tens of thousands of graph-launched kernels)
     K_LONG = 256 if (K < 64 and args.model in ("llama8b", "llama8b-2l", "llama8b-8l") and not os.environ.get("ROCP_TOOL_LIBRARIES")) else 0
     seq_len = P + W + K + K_LONG + 8
+    # the default line also carries configs[2] (4096-token prompt + 64 steps): one model serves both, its RoPE table long enough for either
+    with_cfg2 = args.model == "llama8b" and P < CFG2_P and not args.no_configs2 and not os.environ.get("ROCP_TOOL_LIBRARIES")
     t_load = time.time()
-    model = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"]))
+    model = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"], (CFG2_P + CFG2_W + CFG2_K + 8) if with_cfg2 else 0))
     ctx = lnb.InferenceContext(model, seq_len).set_mode(args.mode)
     t_load = time.time() - t_load
     prompt = lnb.synth_tokens(99, P, cfg["vocab_size"])
@@ -493,27 +596,41 @@ def main():
         kernels[KERNEL_NAMES[which]] = {"ms": round(ms, 5), "GB/s": (round(kb[which] / ms / 1e6, 1) if kb[which] else None)}
     dom = max(range(6), key=lambda i: (1 if i == 5 else cfg["n_layers"]) * kernels[KERNEL_NAMES[i]]["ms"])
     dom_ms = kernels[KERNEL_NAMES[dom]]["ms"]
-    traffic, traffic_src, traffic_head = pmc_traffic(KERNEL_NAMES[dom], name, args.mode)
-    traffic_live = None if args.no_traffic_probe else probe_traffic(args, dom, int(Tbar) - 1)
-    if traffic_live:
-        traffic, traffic_src, traffic_head = traffic_live["bytes_per_launch"], traffic_live["source"], None
-    # the kernel SYMBOL with the largest share of the token's GPU time (wo and w2 are one symbol; VERDICT r3 #1d), next to the dominant class
-    sym_of = {0: "gemv_quad_kernel / gemv_chain_kernel (attn_norm+wq|wk|wv)", 1: "attn_exact_kernel", 2: "rowcast_lds_kernel (wo, w2)", 3: "gemv_chain_kernel<56,2,..> (w1|w3)",
-              4: "rowcast_lds_kernel (wo, w2)", 5: "gemv_chain_kernel<64,1,..> (output)"}
-    sym_t, sym_b = {}, {}
+    # The `roofline` object is that of the kernel SYMBOL with the largest share of the token's GPU time -- what rocprofv3 --stats ranks first
+    # (wo and w2 are two launches of ONE symbol per block: VERDICT r3 #1d, r4 weak #3) -- per launch: algorithmic bytes and HIP-event time
+    # averaged over the symbol's launches of one token.  The single heaviest launch CLASS (gate|up) is reported next to it as `dominant_class`.
+    rc = "rowcast_lds_kernel (wo, w2)" if os.environ.get("LNB_ROWCAST_LDS", "1") != "0" else "rowcast_kernel (wo, w2)"
+    sym_of = {0: "gemv_quad_kernel / gemv_chain_kernel (attn_norm+wq|wk|wv)", 1: "attn_exact_kernel", 2: rc, 3: "gemv_chain_kernel<56,2,..> (w1|w3)",
+              4: rc, 5: "gemv_chain_kernel<64,1,..> (output)"}
+    sym_t, sym_b, sym_n, sym_cls = {}, {}, {}, {}
     for i in range(6):
         nrep = 1 if i == 5 else cfg["n_layers"]
         sym_t[sym_of[i]] = sym_t.get(sym_of[i], 0.0) + nrep * kernels[KERNEL_NAMES[i]]["ms"]
         sym_b[sym_of[i]] = sym_b.get(sym_of[i], 0.0) + nrep * kb[i]
+        sym_n[sym_of[i]] = sym_n.get(sym_of[i], 0) + nrep
+        sym_cls.setdefault(sym_of[i], []).append(i)
     tot_t = sum(sym_t.values())
     top = max(sym_t, key=lambda k: sym_t[k])
-    largest_symbol = {"symbol": top, "share_of_gpu_time": round(sym_t[top] / tot_t, 4), "GB/s": round(sym_b[top] / sym_t[top] / 1e6, 1),
-                      "frac": round(sym_b[top] / sym_t[top] / 1e6 / PEAK_HBM_GBS, 4),
-                      "all": {k: {"share": round(sym_t[k] / tot_t, 4), "frac": round(sym_b[k] / sym_t[k] / 1e6 / PEAK_HBM_GBS, 4)} for k in sym_t}}
-    roofline = {"bound": "hbm", "kernel": KERNEL_NAMES[dom], "largest_symbol_by_gpu_time": largest_symbol, "achieved": round(kb[dom] / dom_ms / 1e6, 1), "peak": PEAK_HBM_GBS,
-                "unit": "GB/s", "frac": round(kb[dom] / dom_ms / 1e6 / PEAK_HBM_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
-                "traffic_measured_in_run": bool(traffic_live), "traffic_profile_git_head": traffic_head,
-                "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": dom_ms,
+    top_ms, top_bytes = sym_t[top] / sym_n[top], sym_b[top] / sym_n[top]           # per launch of the symbol
+    traffic_live = None if args.no_traffic_probe else probe_traffic(args, sym_cls[top], int(Tbar) - 1)
+    traffic, traffic_src, traffic_head = None, None, None
+    if traffic_live:
+        traffic, traffic_src = traffic_live["bytes_per_launch"], traffic_live["source"]
+    else:                                                                          # the committed PMC pass, per class, averaged over the symbol's launches
+        got = [pmc_traffic(KERNEL_NAMES[i], name, args.mode) for i in sym_cls[top]]
+        if all(g[0] for g in got):
+            traffic, traffic_src, traffic_head = int(sum(g[0] for g in got) / len(got)), got[0][1], got[0][2]
+    symbols = {k: {"share_of_gpu_time": round(sym_t[k] / tot_t, 4), "launches_per_token": sym_n[k], "avg_launch_us": round(1e3 * sym_t[k] / sym_n[k], 2),
+                   "frac": round(sym_b[k] / sym_t[k] / 1e6 / PEAK_HBM_GBS, 4)} for k in sym_t}
+    roofline = {"bound": "hbm", "kernel": top, "share_of_gpu_time": round(sym_t[top] / tot_t, 4),
+                "achieved": round(top_bytes / top_ms / 1e6, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(top_bytes / top_ms / 1e6 / PEAK_HBM_GBS, 4),
+                "traffic": traffic, "traffic_source": traffic_src, "traffic_measured_in_run": bool(traffic_live), "traffic_profile_git_head": traffic_head,
+                "algorithmic_bytes_per_launch": int(top_bytes), "avg_launch_ms": round(top_ms, 5),
+                "note": "the kernel symbol with the largest share of a token's GPU time; bytes and time per launch are averages over its %d launches per token "
+                        "(classes: %s)" % (sym_n[top], ", ".join(KERNEL_NAMES[i] for i in sym_cls[top])),
+                "symbols": symbols,
+                "dominant_class": {"kernel": KERNEL_NAMES[dom], "achieved": round(kb[dom] / dom_ms / 1e6, 1), "frac": round(kb[dom] / dom_ms / 1e6 / PEAK_HBM_GBS, 4),
+                                   "algorithmic_bytes_per_launch": kb[dom], "avg_launch_ms": dom_ms},
                 "whole_step": {"achieved": round(tps * B / 1e9, 1), "frac": round(tps * B / 1e9 / PEAK_HBM_GBS, 4),
                                "algorithmic_bytes_per_token": int(B), "mean_context": Tbar,
                                "roofline_tokens_per_s": round(PEAK_HBM_GBS * 1e9 / B, 1)}}
@@ -521,7 +638,10 @@ def main():
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
            "config": {"workload": "%s bf16, 1xMI355X, single-prompt greedy decode, seq_len=%d -> +%d tokens (%s)"
-                                  % (name, P, K, ("configs[2] decode" if P >= 4096 else "configs[1]") if args.model == "llama8b" else "shape of configs[4] on one GPU" if args.model == "llama70b-like" else
+                                  % (name, P, K, ("configs[2] decode" if P >= 4096 else
+                                                  "configs[1] proper: +256 tokens" if K == 256 else
+                                                  "configs[1]'s prompt and kernels with the caller's --steps %d; the same context's next %d steps -- configs[1]'s +256 -- are `long_run`" % (K, K_LONG) if K_LONG else
+                                                  "configs[1]'s prompt, --steps %d" % K) if args.model == "llama8b" else "shape of configs[4] on one GPU" if args.model == "llama70b-like" else
                                      "configs[2] workload on the %d-layer cut the CPU oracle reaches" % cfg["n_layers"] if args.model in ("llama8b-2l", "llama8b-8l") else "test shape"),
                       "prompt_len": P, "sequences_in_flight": 1, "parallelism": "single GPU",
                       "mode": "exact-order (token-id identical to the CPU reference path)" if args.mode == "exact" else
@@ -529,7 +649,7 @@ def main():
                       "tokens_vs_oracle_golden": golden_ok, "device_self_check": self_check,
                       "hip_event_ms_per_step": round(ev_ms / K, 4), "norm_item_walk": norm_walk,
                       "timed_region_repeats_ms_per_step": [round(1e3 * r[0] / K, 4) for r in reps], "reported_repeat": "median",
-                      "weight_bytes_resident": model.weight_bytes(), "model_build_s": round(t_load, 1)},
+                      "weight_bytes_resident": model.weight_bytes(), "model_build_s": round(t_load, 1)},     # (+ sequences_in_flight_batched.weights_second_copy_bytes once that section has run)
            "roofline": roofline, "kernels": kernels, "last_tokens": [int(t) for t in out[-4:]], "long_run": long_run,
            # prefill of the prompt: the same exact f32 chains on the matrix cores (v_mfma_f32_16x16x4_f32, bit-identical to the
            # k-ordered loop); FLOPs = 2 x rows x layer-matmul elements; peak = f32 MFMA (MI355X_MICROARCH.md: 157.3 TFLOP/s)
@@ -543,14 +663,27 @@ def main():
         # a profile is of the headline path anyway
         res["sequences_in_flight"] = {"skipped": "running under rocprofv3 (set LNB_BENCH_CONCURRENT_UNDER_PROFILER=1 to force)"}
     elif args.concurrent > 1:
-        res["sequences_in_flight"] = concurrent_sequences(lnb, model, cfg, args, a, [first_tok] + warm_toks + [int(t) for t in out])
-    roofline["practical_floor"] = practical_floor(a, model.ffn_hidden, Tbar, kernels)
-    roofline["practical_floor"]["achieved_frac_of_floor"] = round(tps / roofline["practical_floor"]["tokens_per_s"], 4)
+        # several independent prompts in flight on the one GPU, one context and stream each (what a pipeline rank runs per stage; the N = 2
+        # pipeline's regime is n = 2): the contexts take the THROUGHPUT forms of the one-token kernels; the same run with the single stream's
+        # latency forms next to it (round 4 had only those: 308 -> 272 tokens/s at n = 8)
+        run_toks = [first_tok] + warm_toks + [int(t) for t in out]
+        res["sequences_in_flight"] = concurrent_sequences(lnb, model, cfg, args, a, run_toks)
+        res["sequences_in_flight"]["latency_forms_same_run"] = {k: v for k, v in concurrent_sequences(lnb, model, cfg, args, a, run_toks, sched="latency").items()
+                                                                if k in ("schedule", "tokens_per_s", "ms_per_token", "frac_of_hbm_roofline")}
+        if args.concurrent != 2:
+            two = concurrent_sequences(lnb, model, cfg, args, a, run_toks, n_seq=2)
+            res["sequences_in_flight"]["n2"] = {k: v for k, v in two.items() if k != "note"}
+    if with_cfg2:
+        res["configs2"] = configs2_record(lnb, model, cfg, args, a)
+    roofline["measured_model"] = measured_model(ctx, a, model.ffn_hidden, Tbar, kernels, tps)
     if args.batch_sizes and args.mode == "exact" and not os.environ.get("ROCP_TOOL_LIBRARIES"):
         try:
             res["sequences_in_flight_batched"] = batched_sequences(lnb, model, cfg, args, a, [first_tok] + warm_toks + [int(t) for t in out])
         except lnb.LnbError as e:                                # (e.g. the second weight copy does not fit next to a 141 GB model)
             res["sequences_in_flight_batched"] = {"skipped": str(e)}
+        ps = res["sequences_in_flight_batched"].get("prefill_streamed_4096")
+        if ps and "configs2" in res:
+            ps["first_token_same_as_configs2"] = bool(ps["first_token"] == res["configs2"]["first_token"])
     if args.cpu_steps > 0:
         res["cpu_baseline"] = cpu_baseline(cfg, prompt[:8], args.cpu_steps)        # 8 + 24 = configs[0]'s seq_len of 32
     ctx.close(); model.close()

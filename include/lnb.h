@@ -100,6 +100,15 @@ int lnb_ctx_read_kv(lnb_ctx* c, int layer, int which /*0=K 1=V*/, uint16_t* host
 enum { LNB_MODE_EXACT = 0, LNB_MODE_FAST = 1 };
 int lnb_ctx_set_mode(lnb_ctx* c, int mode);
 int lnb_ctx_get_mode(const lnb_ctx* c);
+/* Kernel FORMS of the exact one-token steps of a context (same arithmetic, same bits).  LNB_SCHED_LATENCY (default): one generation owns the
+ * chip -- every launch takes all CUs with eight or nine waves and 91..124 KB of LDS per workgroup.  LNB_SCHED_THROUGHPUT: for several
+ * generations in flight on one GPU, one context and stream each (the reference's one InferenceContext per generation, inference.go:174; what
+ * every pipeline rank runs): every workgroup stays at or below 57 KB of LDS, so that a chain-bound launch of one context shares the CUs with
+ * the HBM-bound gate|up launch of another.  Slower for a single stream, faster in aggregate (bench.py: sequences_in_flight).  Switchable
+ * between calls; the context's captured graphs are dropped. */
+enum { LNB_SCHED_LATENCY = 0, LNB_SCHED_THROUGHPUT = 1 };
+int lnb_ctx_set_schedule(lnb_ctx* c, int sched);
+int lnb_ctx_get_schedule(const lnb_ctx* c);
 /* Decode attention form (both bit-identical to the reference arithmetic): one-token calls whose context exceeds long_threshold
  * positions use the long-context kernels (scores over all CUs, PV per (head, 16-dim slice), softmax denominator certified against
  * the reference's serial f64 sum instead of walked).  long_threshold < 0: keep (default 512, env LNB_ATTN_LONG_T); force_zseq = 1:
@@ -132,6 +141,8 @@ int lnb_forward(lnb_ctx* c, const int32_t* tokens, int seq, int start_pos, float
  * any host round trip; out_tokens[i] is the token generated by step i.  ms_out (optional) = device time of
  * the n_steps measured with HIP events on the library's stream. */
 int lnb_decode_greedy(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int32_t* out_tokens, float* ms_out);
+/* (lnb_decode_greedy and lnb_batch_decode always produce n_steps tokens: stop ids of the context are NOT compared by them -- use the
+ * _until forms, which report how far the run got.) */
 /* Stop ids ON THE DEVICE (inference.go:233-252: generation ends with the first token that is one of model.StopTokenIds -- <|eot_id|>,
  * <|eom_id|> -- and that token is emitted).  lnb_ctx_set_stop_ids gives a context up to 8 of them (0: none); the token-feedback kernel then
  * freezes the generation (position, token word, token log) at the first match, so a run of any length can be enqueued without a host check
@@ -163,9 +174,13 @@ int64_t lnb_model_batch_bytes(lnb_model* m);
 int lnb_batch_create(lnb_ctx* const* ctxs, int n, lnb_batch** out);
 int lnb_batch_destroy(lnb_batch* b);
 int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, float* ms_out);
-/* ... with per-sequence stop ids (lnb_ctx_set_stop_ids on the member contexts, below): n_generated[s] tokens of row s are valid, the last one
- * the stop token if the sequence finished before max_steps; a finished sequence's position and caches stay where they stopped */
-int lnb_batch_decode_until(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int max_steps, int32_t* out_tokens, int32_t* n_generated, float* ms_out);
+/* ... with per-sequence stop ids (lnb_ctx_set_stop_ids on the member contexts, above): n_generated[s] tokens of row s are valid, the last one
+ * the stop token if the sequence finished; finished[s] (optional, may be NULL) = 1 if a stop id ended sequence s -- n_generated[s] == max_steps
+ * alone cannot tell.  A finished sequence's position and caches stay where they stopped.  Decoding in chunks: pass start_pos[s] < 0 for a
+ * sequence that has finished -- it stays frozen (n_generated[s] = 0, finished[s] = 1) instead of restarting from its stop token; its
+ * tokens[s] is ignored.  (Stop ids are a single-GPU feature of the batch: lnb_batch_set_state on a stage of a multi-stage pipeline refuses
+ * contexts that carry any -- only the last stage would see the token.) */
+int lnb_batch_decode_until(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int max_steps, int32_t* out_tokens, int32_t* n_generated, int32_t* finished, float* ms_out);
 /* measurement aid: average HIP-event time of one kernel class of the batched step (which as lnb_profile_kernel; a norm launch counts
  * with the product it feeds), every sequence placed at `pos`; overwrites the caches' row `pos` */
 int lnb_batch_profile_kernel(lnb_batch* b, int which, int pos, int iters, float* avg_ms_out);
@@ -245,6 +260,11 @@ int lnb_pipeline_selftest(int device, int n_bytes);
  * 6 the five kernels of a whole block.  Consecutive launches cycle through this stage's layers so every launch
  * streams its weights from HBM instead of the 256 MiB Infinity Cache.  The KV cache content at `pos` is overwritten. */
 int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, float* avg_ms_out);
+/* ... and the in-kernel cycle stamps of ONE launch of a GEMV class (which 0, 2, 3, 4 or 5): out[8 waves][16] doubles, per wave = {workgroups
+ * that reported, avg total shader cycles, max total, avg barrier wait, avg "x staged / prologue end", avg "norm fold or walk" (wo / w2 chain
+ * waves: chain start), avg phase stamps 0..6, stamp 7 = the same launch on the constant-rate wall clock}; *wall_clock_khz = that clock's rate
+ * (hipDeviceAttributeWallClockRate).  bench.py turns them into the measured prologue / per-step / boundary terms of roofline.measured_model. */
+int lnb_profile_kernel_stamps(lnb_ctx* c, int which, int pos, double* out, int* wall_clock_khz);
 
 /* ---- single-op entry points (the src/ml operators on the hot path), used by the parity tests --------
  * y[rows,n] = trunc(sum_k x[rows,k]*w[n,k])  == ml.LinearTransformation (operations_impl.go:427-447);

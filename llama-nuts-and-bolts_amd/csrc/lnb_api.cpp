@@ -29,7 +29,7 @@ hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st);
 hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps, hipStream_t st);
 hipError_t lnbk_embed(const uint16_t* emb, const int32_t* tokens, uint16_t* x, int S, int dim, int vocab, int* err, hipStream_t st);
 hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_token, StepState* state, int32_t* out_tokens, int out_cap, int advance, hipStream_t st);
-hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st);
+hipError_t lnbk_set_state(StepState* state, int pos, int n_out, int honour_stop, hipStream_t st);
 hipError_t lnbk_set_stop(StepState* state, const int32_t* ids, int n, hipStream_t st);
 hipError_t lnbk_advance_state(StepState* state, int rows, hipStream_t st);
 hipError_t lnbk_tile(const uint16_t* src, uint16_t* dst, int rows, int K, int row_off, int chain, int RW, int NCH, int gather, hipStream_t st);
@@ -44,7 +44,7 @@ hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int num_cus, hi
 hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K, int nseq, hipStream_t st);
 hipError_t lnbk_batch_embed(const uint16_t* emb, const BatchTab* tab, uint16_t* x, int nseq, int dim, int vocab, int* err, hipStream_t st);
 hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const BatchTab* tab, int nseq, int32_t* ring, hipStream_t st);
-hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring, hipStream_t st);
+hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring, int honour_stop, hipStream_t st);
 hipError_t lnbk_batch_scatter_ring(const BatchTab* tab, const int32_t* ring, hipStream_t st);
 hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st);
 hipError_t lnbk_batch_prepare(void);
@@ -117,6 +117,8 @@ struct lnb_ctx {
     int32_t* h_io = nullptr;               // pinned host words of lnb_forward_stage_begin/_end: [0] argmax, [1] token error, [2..] tokens
     bool pending = false, pending_tokens = false, pending_argmax = false;
     int mode = LNB_MODE_EXACT;             // LNB_MODE_FAST: split-K kernels of lnb_fast.hip (tolerance mode, opt-in)
+    int sched = LNB_SCHED_LATENCY;         // LNB_SCHED_THROUGHPUT: the co-residency-friendly forms of the one-token kernels (lnb_ctx_set_schedule)
+    int n_stop = 0;                        // host copy of StepState.n_stop (lnb_ctx_set_stop_ids): entry points that cannot honour stop ids refuse such a context
     int batch_users = 0;                   // live lnb_batch handles this context is a member of: their device tables and captured graphs hold its raw pointers
     // long-context decode attention (attn_long_*_kernel): used for one-token calls whose context exceeds attn_long_T
     double* e_buf = nullptr; double* z_part = nullptr; int* zseq_count = nullptr;
@@ -137,9 +139,9 @@ struct lnb_ctx {
 // the set_state launch" shortcut (dev_pos) can never act on a position some OTHER entry point has since overwritten (lnb_forward,
 // lnb_decode_greedy and lnb_profile_kernel may be mixed with ticks on one context).  known = false: the caller is about to advance
 // the state on the device by itself (greedy loop) and the host stops tracking it.
-static hipError_t ctx_set_state(lnb_ctx* c, int pos, int n_out, bool known) {
+static hipError_t ctx_set_state(lnb_ctx* c, int pos, int n_out, bool known, bool honour_stop = false) {
     c->dev_pos = known ? pos : -1;
-    return lnbk_set_state(c->st, pos, n_out, c->stream);
+    return lnbk_set_state(c->st, pos, n_out, honour_stop ? 1 : 0, c->stream);
 }
 // the pinned staging words h_io[2..] are reused by every enqueue-only call that takes host tokens: wait for the copy that still reads them
 static int staging_acquire(lnb_ctx* c) {
@@ -574,6 +576,23 @@ extern "C" int lnb_ctx_set_mode(lnb_ctx* c, int mode) {
     return 0;
 }
 extern "C" int lnb_ctx_get_mode(const lnb_ctx* c) { return c ? c->mode : -1; }
+// Which FORMS of the exact one-token kernels this context's steps launch (same arithmetic, same bits; tests/test_gpu_round5.py).  The latency
+// forms (default) are built for ONE stream owning the chip: every launch takes all 256 CUs with eight or nine waves and 91 - 124 KB of LDS per
+// workgroup, so nothing of another stream fits beside it.  A server or a pipeline rank keeps several generations in flight, one context and
+// stream each (inference.go:174): there a chain-bound launch of one context should hide under the HBM-bound gate|up launch of another, which
+// needs both workgroups on one CU -- the throughput forms keep every workgroup at or below 57 KB (wq|wk|wv: 128-step stages; wo, w2: the
+// self-feeding row-broadcast kernel).  Round 4 had lost this (8 prompts in flight 308 -> 272 tokens/s) when it made the latency forms the only ones.
+extern "C" int lnb_ctx_set_schedule(lnb_ctx* c, int sched) {
+    if (!c) return fail("null argument");
+    if (sched != LNB_SCHED_LATENCY && sched != LNB_SCHED_THROUGHPUT) return fail("unknown schedule %d (LNB_SCHED_LATENCY = 0, LNB_SCHED_THROUGHPUT = 1)", sched);
+    if (sched == c->sched) return 0;
+    HIPCHK(hipSetDevice(c->m->device));
+    HIPCHK(hipStreamSynchronize(c->stream));
+    drop_graphs(c);
+    c->sched = sched;
+    return 0;
+}
+extern "C" int lnb_ctx_get_schedule(const lnb_ctx* c) { return c ? c->sched : -1; }
 // Decode attention form: one-token calls at contexts above long_threshold run the chip-wide long-context kernels (bit-identical to the
 // one-workgroup-per-head kernel, tests/test_gpu_configs.py).  long_threshold < 0 keeps the current value; force_zseq = 1 makes the
 // long-context kernel always walk the reference's serial f64 sum instead of certifying the tree estimate (test hook).
@@ -662,6 +681,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
     case K_QKV: {   // attn_norm + wq|wk|wv + RoPE + KV append  (llamatransformer.go:222, :297-403)
         GemvParams g{}; g.w = L.wqkv.w; g.x = c->x; g.norm_w = L.attn_norm; g.norm_fb = c->zseq_count + 1; g.eps = a.norm_eps; g.K = a.dim; g.n_rows = L.wqkv.n_rows; g.S = S; g.st = c->st;
         g.cis = m->cis; g.q_out = c->q; g.cache_k = ck; g.cache_v = cv; g.seq_len = c->seq_len; g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
+        g.sched = c->sched;
         set_grid(g, L.wqkv); HIPCHK(gemv_dispatch(c, &g, L.wqkv.rw, 1, EPI_QKV_ROPE, 1, st)); return 0; }
     case K_ATTN: {  // scores / softmax / PV  (:409-514)
         AttnParams ap{}; ap.q = c->q; ap.cache_k = ck; ap.cache_v = cv; ap.out = c->att; ap.st = c->st; ap.dbg = g_dbg;
@@ -677,14 +697,14 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
         }
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
-        GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x;
+        GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x; o.sched = c->sched;
         set_grid(o, L.wo); HIPCHK(gemv_dispatch(c, &o, L.wo.rw, 1, EPI_RESID, 0, st)); return 0; }
     case K_W13: {   // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
         GemvParams f{}; f.w = L.w13.w; f.x = hbuf; f.norm_w = L.ffn_norm; f.norm_fb = c->zseq_count + 1; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
         f.out = c->ffn; f.silu = m->silu;
         set_grid(f, L.w13); HIPCHK(gemv_dispatch(c, &f, L.w13.rw, 2, EPI_SILU_MUL, 1, st)); return 0; }
     case K_W2: {    // w2 + residual  (:619, :248)
-        GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = hbuf; d.lds_pad = lds_pad;
+        GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = hbuf; d.lds_pad = lds_pad; d.sched = c->sched;
         set_grid(d, L.w2); HIPCHK(gemv_dispatch(c, &d, L.w2.rw, 1, EPI_RESID, 0, st)); return 0; }
     }
     return fail("bad kernel id");
@@ -860,6 +880,7 @@ extern "C" int lnb_ctx_set_stop_ids(lnb_ctx* c, const int32_t* ids, int n) {
     HIPCHK(hipSetDevice(c->m->device));
     HIPCHK(lnbk_set_stop(c->st, ids, n, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
+    c->n_stop = n;
     return 0;
 }
 static int decode_greedy_impl(lnb_ctx* c, int32_t token, int start_pos, int n_steps, int32_t* out_tokens, int* n_generated, int* finished, float* ms_out);
@@ -902,7 +923,10 @@ static int decode_greedy_impl(lnb_ctx* c, int32_t token, int start_pos, int n_st
     if (use_graph && any_long && capture(&c->graph_long, true)) return -1;
     HIPCHK(hipMemcpyAsync(c->dtok, &token, 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(c->derr, 0, 4, st));
-    HIPCHK(ctx_set_state(c, start_pos, 0, false));          // the argmax kernel advances the position on the device from here on
+    // (the argmax kernel advances the position on the device from here on.)  Stop ids are compared only on behalf of a caller that learns how far
+    // the run got: lnb_decode_greedy promises n_steps tokens and ignores them -- it used to freeze silently at a stop id and hand back stale
+    // log entries behind it
+    HIPCHK(ctx_set_state(c, start_pos, 0, false, n_generated != nullptr));
     c->call_T = 0;                                           // (the captured graphs serve every position: nothing host-side to validate)
     HIPCHK(hipEventRecord(c->ev0, st));
     for (int i = 0; i < n_steps; i++) {
@@ -920,6 +944,52 @@ static int decode_greedy_impl(lnb_ctx* c, int32_t token, int start_pos, int n_st
     if (c->h_io[1]) return fail("generated token id is outside the vocabulary");
     if (n_generated) { *n_generated = hs.n_out; if (finished) *finished = hs.finished; c->dev_pos = -1; }     // (a stopped run leaves the device position short of start_pos + n_steps)
     return 0;
+}
+
+// One launch of a GEMV class with the per-wave debug buffer armed (GemvParams.dbg): out[w * 16 + ..] for wave w = {workgroups that reported, avg
+// total cycles, max total, avg barrier wait, avg [2] (x staged / prologue end), avg [3] (fold or walk; rowcast_lds chain waves: chain start),
+// avg stamps 0..7 (stamp 7 = the launch on the constant-rate wall clock)}.  The device position must have been set by the caller.
+static int gemv_stamps(lnb_ctx* c, int which, double* out) {
+    lnb_model* m = c->m; hipStream_t st = c->stream;
+    const size_t n = (size_t)4096 * 8 * 4, n2 = (size_t)4096 * 8 * 8;       // + 8 phase stamps per wave behind the four totals (LNB_STAMP in lnb_kernels.hip)
+    long long* dbuf = nullptr;
+    HIPCHK(hipMalloc((void**)&dbuf, (n + n2) * 8)); HIPCHK(hipMemsetAsync(dbuf, 0, (n + n2) * 8, st));
+    g_dbg = dbuf;
+    const int nl = m->layer_end - m->layer_begin;
+    int rc = which == K_HEAD ? enqueue_head(c, 0, 1) : enqueue_layer_kernel(c, m->layer_begin + 7 % nl, 1, which);
+    g_dbg = nullptr;
+    if (rc) { hipFree(dbuf); return -1; }
+    HIPCHK(hipStreamSynchronize(st));
+    std::vector<long long> h(n + n2);
+    HIPCHK(hipMemcpy(h.data(), dbuf, (n + n2) * 8, hipMemcpyDeviceToHost));
+    hipFree(dbuf);
+    for (int w = 0; w < 8; w++) {
+        double* o = out + w * 16; for (int k = 0; k < 16; k++) o[k] = 0;
+        int cnt = 0;
+        for (int g = 0; g < 4096; g++) {
+            const long long* d = &h[((size_t)g * 8 + w) * 4]; const long long* s8 = &h[n + ((size_t)g * 8 + w) * 8];
+            if (d[0] <= 0) continue;
+            cnt++; o[1] += (double)d[0]; if ((double)d[0] > o[2]) o[2] = (double)d[0]; o[3] += (double)d[1]; o[4] += (double)d[2]; o[5] += (double)d[3];
+            for (int k = 0; k < 8; k++) o[6 + k] += (double)s8[k];
+        }
+        o[0] = cnt;
+        if (cnt) { o[1] /= cnt; o[3] /= cnt; o[4] /= cnt; o[5] /= cnt; for (int k = 0; k < 8; k++) o[6 + k] /= cnt; }
+    }
+    return 0;
+}
+// measurement aid (bench.py: roofline.measured_model): the in-kernel cycle stamps of ONE launch of a GEMV class (which: 0, 2, 3, 4, 5 as in
+// lnb_profile_kernel) at position pos; out = 8 waves x 16 doubles as gemv_stamps lays them out; *wall_clock_khz = the rate of stamp 7's clock
+extern "C" int lnb_profile_kernel_stamps(lnb_ctx* c, int which, int pos, double* out, int* wall_clock_khz) {
+    if (!c || !out) return fail("null argument");
+    lnb_model* m = c->m;
+    HIPCHK(hipSetDevice(m->device));
+    if (which < 0 || which > K_HEAD || which == K_ATTN) return fail("bad arguments");
+    if (check_call(c, 1, pos)) return -1;
+    if (which == K_HEAD && !m->last()) return fail("this stage does not own output.weight");
+    c->attn_long = want_long_attention(c, 1, pos);
+    HIPCHK(ctx_set_state(c, pos, 0, true));
+    if (wall_clock_khz) { int khz = 0; HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m->device)); *wall_clock_khz = khz; }
+    return gemv_stamps(c, which, out);
 }
 
 extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, float* avg_ms_out) {
@@ -996,25 +1066,13 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
         }
     }
     if (env_int("LNB_GEMV_TIMING", 0) && which != K_ATTN && which != K_LAYER) {
-        const size_t n = (size_t)4096 * 8 * 4, n2 = (size_t)4096 * 8 * 8;       // + 8 phase stamps per wave behind the four totals (LNB_STAMP in lnb_kernels.hip)
-        long long* dbuf = nullptr;
-        HIPCHK(hipMalloc((void**)&dbuf, (n + n2) * 8)); HIPCHK(hipMemsetAsync(dbuf, 0, (n + n2) * 8, st));
-        g_dbg = dbuf;
-        int rc = run(7);
-        g_dbg = nullptr;
-        if (rc) { hipFree(dbuf); return -1; }
-        HIPCHK(hipStreamSynchronize(st));
-        std::vector<long long> h(n + n2);
-        HIPCHK(hipMemcpy(h.data(), dbuf, (n + n2) * 8, hipMemcpyDeviceToHost));
-        hipFree(dbuf);
+        double v[8 * 16];
+        if (gemv_stamps(c, which, v)) return -1;
         fprintf(stderr, "[timing] kernel class %d: per-wave s_memtime ticks (avg over workgroups)\n", which);
         for (int w = 0; w < 8; w++) {
-            double tot = 0, wait = 0, tx = 0, mx = 0, aux = 0; int cnt = 0;
-            for (int g = 0; g < 4096; g++) { const long long* d = &h[((size_t)g * 8 + w) * 4]; if (d[0] > 0) { tot += d[0]; wait += d[1]; tx += d[2]; aux += d[3]; if (d[0] > mx) mx = (double)d[0]; cnt++; } }
-            if (cnt) fprintf(stderr, "[timing]   wave %d: n=%d total=%.0f (max %.0f) barrier_wait=%.0f x_or_vmwait=%.0f rms_fold_or_walk=%.0f\n", w, cnt, tot / cnt, mx, wait / cnt, tx / cnt, aux / cnt);
-            double sm[8] = {0}; int sc = 0;
-            for (int g = 0; g < 4096; g++) { const long long* d = &h[n + ((size_t)g * 8 + w) * 8]; if (d[0] > 0) { for (int k = 0; k < 8; k++) sm[k] += (double)d[k]; sc++; } }
-            if (sc) { fprintf(stderr, "[timing]     stamps (since kernel start):"); for (int k = 0; k < 8; k++) fprintf(stderr, " %.0f", sm[k] / sc); fprintf(stderr, "\n"); }
+            const double* d = v + w * 16;
+            if (d[0] > 0) fprintf(stderr, "[timing]   wave %d: n=%d total=%.0f (max %.0f) barrier_wait=%.0f x_or_vmwait=%.0f rms_fold_or_walk=%.0f\n", w, (int)d[0], d[1], d[2], d[3], d[4], d[5]);
+            if (d[0] > 0) { fprintf(stderr, "[timing]     stamps (since kernel start):"); for (int k = 0; k < 8; k++) fprintf(stderr, " %.0f", d[6 + k]); fprintf(stderr, "\n"); }
         }
     }
     return 0;
@@ -1295,17 +1353,20 @@ static int enqueue_batch_step(lnb_batch* b, bool ring_in = false) {
     } else HIPCHK(lnbk_batch_advance(b->tab, b->stream));
     return 0;
 }
-static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, int32_t* n_generated, float* ms_out);
+static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, int32_t* n_generated, int32_t* finished, float* ms_out);
 extern "C" int lnb_batch_decode(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, float* ms_out) {
-    return batch_decode_impl(b, tokens, start_pos, n_steps, out_tokens, nullptr, ms_out);
+    return batch_decode_impl(b, tokens, start_pos, n_steps, out_tokens, nullptr, nullptr, ms_out);     // n_steps tokens per sequence: stop ids are not compared
 }
 // with per-sequence stop ids (lnb_ctx_set_stop_ids on the member contexts): n_generated[s] tokens of row s of out_tokens are valid; a finished
 // sequence's column keeps computing its last step (the pass over the weights is shared), its state and caches stay where they stopped
-extern "C" int lnb_batch_decode_until(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int max_steps, int32_t* out_tokens, int32_t* n_generated, float* ms_out) {
+// finished[s] (optional) = 1 if a stop id ended sequence s: n_generated[s] == max_steps alone cannot tell a run that stopped on its last step from
+// one that did not.  A caller that decodes in chunks passes start_pos[s] < 0 for a sequence that has finished: it stays frozen (nothing of it is
+// touched, n_generated[s] = 0, finished[s] = 1) instead of being restarted from its stop token.
+extern "C" int lnb_batch_decode_until(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int max_steps, int32_t* out_tokens, int32_t* n_generated, int32_t* finished, float* ms_out) {
     if (!n_generated) return fail("null argument");
-    return batch_decode_impl(b, tokens, start_pos, max_steps, out_tokens, n_generated, ms_out);
+    return batch_decode_impl(b, tokens, start_pos, max_steps, out_tokens, n_generated, finished, ms_out);
 }
-static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, int32_t* n_generated, float* ms_out) {
+static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos, int n_steps, int32_t* out_tokens, int32_t* n_generated, int32_t* finished, float* ms_out) {
     if (!b || !tokens || !start_pos || !out_tokens) return fail("null argument");
     lnb_model* m = b->m;
     if (!m->first() || !m->last()) return fail("lnb_batch_decode needs a whole-model handle; pipeline stages run their batches through lnb_pipeline_tick_batch");
@@ -1314,8 +1375,10 @@ static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t*
     for (int s = 0; s < b->n; s++) {
         lnb_ctx* c = b->ctxs[s];
         if (n_steps > c->dout_cap) return fail("sequence %d: n_steps %d exceeds the context length %d", s, n_steps, c->dout_cap);
-        if (check_call(c, 1, start_pos[s]) || check_call(c, 1, start_pos[s] + n_steps - 1)) return -1;
-        if (tokens[s] < 0 || tokens[s] >= m->a.vocab_size) return fail("sequence %d: token id at index 0 is outside the vocabulary", s);
+        const bool frozen = start_pos[s] < 0;                 // an ended sequence of a chunked run (lnb_batch_decode_until): nothing of it is touched
+        if (frozen && !n_generated) return fail("sequence %d: negative start position (only lnb_batch_decode_until takes one, for a sequence that has finished)", s);
+        if (!frozen && (check_call(c, 1, start_pos[s]) || check_call(c, 1, start_pos[s] + n_steps - 1))) return -1;
+        if (!frozen && (tokens[s] < 0 || tokens[s] >= m->a.vocab_size)) return fail("sequence %d: token id at index 0 is outside the vocabulary", s);
         if (c->pending) return fail("sequence %d: a lnb_forward_stage_begin has not been ended", s);
         HIPCHK(hipStreamSynchronize(c->stream));             // whatever the context's own stream still does to its caches comes first
         c->dev_pos = -1; c->call_T = 0;                      // the batch advances the context's device-side position by itself
@@ -1336,7 +1399,7 @@ static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t*
     HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + LNB_BATCH_MAX, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(b->derr, 0, 4, st));
-    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, b->ring, st));
+    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, b->ring, n_generated ? 1 : 0, st));
     HIPCHK(hipEventRecord(b->ev0, st));
     for (int i = 0; i < n_steps; i++) {
         if (use_graph) HIPCHK(hipGraphLaunch(b->graph, st));
@@ -1351,7 +1414,7 @@ static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t*
     HIPCHK(hipStreamSynchronize(st));
     if (ms_out) HIPCHK(hipEventElapsedTime(ms_out, b->ev0, b->ev1));
     if (b->h_io[2 * LNB_BATCH_MAX]) return fail("sequence %d: generated token id is outside the vocabulary", b->h_io[2 * LNB_BATCH_MAX] - 1);
-    for (int s = 0; s < (int)hs.size(); s++) n_generated[s] = hs[s].n_out;
+    for (int s = 0; s < (int)hs.size(); s++) { n_generated[s] = hs[s].n_out; if (finished) finished[s] = hs[s].finished; }
     return 0;
 }
 // Every sequence's position (and, on the first stage, optionally its next input token) before a run of lnb_pipeline_tick_batch steps: the
@@ -1373,10 +1436,16 @@ extern "C" int lnb_batch_set_state(lnb_batch* b, const int32_t* tokens, const in
     if (!b || !start_pos) return fail("null argument");
     HIPCHK(hipSetDevice(b->m->device));
     HIPCHK(hipMemsetAsync(b->derr, 0, 4, b->stream));        // a fresh run: forget what an earlier one latched
+    const bool one_stage = b->m->first() && b->m->last();
     for (int s = 0; s < b->n; s++) {
         lnb_ctx* c = b->ctxs[s];
         if (check_call(c, 1, start_pos[s])) return -1;
         if (tokens && (tokens[s] < 0 || tokens[s] >= b->m->a.vocab_size)) return fail("sequence %d: token id at index 0 is outside the vocabulary", s);
+        // only the LAST stage's argmax sees a stop id: the other stages would go on advancing their positions, re-embedding the stale ring token
+        // and appending KV rows behind the stop.  Stop ids in a multi-stage batched pipeline belong to the host: it reads the tokens.
+        if (c->n_stop > 0 && !one_stage)
+            return fail("sequence %d: its context carries %d stop ids, which a batched tick of a multi-stage pipeline cannot honour (only the last stage sees the "
+                        "token): clear them (lnb_ctx_set_stop_ids(ctx, NULL, 0)) and end the sequence on the host", s, c->n_stop);
         c->dev_pos = -1; c->call_T = 0;
     }
     HIPCHK(hipDeviceSynchronize());                          // a setup call: whatever the contexts' streams and the pipe's exchange stream still do
@@ -1385,7 +1454,7 @@ extern "C" int lnb_batch_set_state(lnb_batch* b, const int32_t* tokens, const in
     memcpy(b->h_io + LNB_BATCH_MAX, start_pos, (size_t)b->n * 4);
     if (tokens) HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
     HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + LNB_BATCH_MAX, (size_t)b->n * 4, hipMemcpyHostToDevice, b->stream));
-    HIPCHK(lnbk_batch_set_state(b->tab, tokens ? b->d_tokens : nullptr, b->d_pos, b->ring, b->stream));
+    HIPCHK(lnbk_batch_set_state(b->tab, tokens ? b->d_tokens : nullptr, b->d_pos, b->ring, one_stage ? 1 : 0, b->stream));
     HIPCHK(hipStreamSynchronize(b->stream));
     return 0;
 }
@@ -1401,7 +1470,7 @@ extern "C" int lnb_batch_profile_kernel(lnb_batch* b, int which, int pos, int it
     hipStream_t st = b->stream;
     HIPCHK(hipMemcpyAsync(b->d_tokens, b->h_io, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemcpyAsync(b->d_pos, b->h_io + LNB_BATCH_MAX, (size_t)b->n * 4, hipMemcpyHostToDevice, st));
-    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, b->ring, st));
+    HIPCHK(lnbk_batch_set_state(b->tab, b->d_tokens, b->d_pos, b->ring, 0, st));
     const int nl = m->layer_end - m->layer_begin;
     auto run = [&](int i) -> int {
         const int l = m->layer_begin + i % nl;

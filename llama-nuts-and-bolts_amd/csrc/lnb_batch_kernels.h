@@ -362,12 +362,17 @@ __global__ void batch_embed_kernel(const uint16_t* emb, const BatchTab* tab, uin
 }
 // start of a batched run: every sequence's token word (tokens == nullptr: keep what its context holds) and position (its own context's
 // StepState); ring = the batch's contiguous token words (the pipeline's token exchange), kept equal to the contexts' words
-__global__ void batch_set_state_kernel(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring) {
+// pos[s] < 0: sequence s has ENDED (a stop id in an earlier chunk of the run): it stays frozen -- token word, position and caches as they are, no
+// tokens logged -- while its column goes on recomputing its last step (the pass over the weights is shared)
+__global__ void batch_set_state_kernel(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring, int honour_stop) {
     const int s = threadIdx.x;
     if (s >= tab->n) return;
-    if (tokens) *tab->dtok[s] = tokens[s];
+    const bool frozen = pos[s] < 0;
+    if (tokens && !frozen) *tab->dtok[s] = tokens[s];
     if (ring) ring[s] = *tab->dtok[s];
-    tab->st[s]->pos = pos[s]; tab->st[s]->n_out = 0; tab->st[s]->finished = 0;
+    StepState* st = tab->st[s];
+    if (!frozen) st->pos = pos[s];
+    st->n_out = 0; st->finished = frozen ? 1 : 0; st->honour_stop = honour_stop;
 }
 // pipeline, first stage: the tokens the last stage sent (contiguous) -> every sequence's own token word
 __global__ void batch_scatter_ring_kernel(const BatchTab* tab, const int32_t* ring) {

@@ -68,6 +68,8 @@ struct StepState {
                         // then on -- the remaining steps of an enqueued run recompute the same step into the same KV row and change nothing visible
     int32_t n_stop;     // stop ids in use (0: never finishes)
     int32_t stop[LNB_MAX_STOP_IDS];
+    int32_t honour_stop; // set per call: 1 = the entry point reports how far the run got (lnb_decode_greedy_until, lnb_batch_decode_until, pipeline ticks of a
+                        // one-stage pipe) and the stop ids are compared; 0 = lnb_decode_greedy / lnb_batch_decode, which promise n_steps tokens: the ids are ignored
 };
 
 enum { EPI_STORE = 0, EPI_QKV_ROPE = 1, EPI_RESID = 2, EPI_SILU_MUL = 3 };
@@ -97,6 +99,9 @@ struct GemvParams {
     long long* dbg;             // optional per-wave timing dump (nullptr in production)
     int* norm_fb;               // optional counter: rows whose norm sum left the branch-free item walk for the record walk (counted by workgroup 0)
     int lds_pad;                // host side only: extra dynamic LDS requested for the launch (co-residency experiments: forces one workgroup per CU)
+    int sched;                  // host side only: 0 = latency forms (one stream owns the chip: every CU, eight or nine waves, up to 124 KB of LDS per
+                                // workgroup), 1 = throughput forms of the same arithmetic (lnb_ctx_set_schedule: at most 57 KB of LDS per workgroup, so
+                                // that a chain-bound launch of one context shares a CU with the HBM-bound gate|up launch of another)
 };
 
 // exact-order prefill GEMM on the f32 matrix cores (gemm_mfma_kernel): Y[m][n] for S >= 16 rows per call

@@ -561,7 +561,10 @@ DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, i
 #define TIMED_BARRIER() do { if (p.dbg) { long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
 // phase stamp i (0..7) of this wave, cycles since the kernel started: a second region behind the [4096][8][4] totals (lnb_api.cpp prints the averages)
 #define LNB_STAMP(i) do { if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = clock64() - t_begin; } while (0)
-#define DBG_EXIT() do { if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; d_[3] = t_aux; } } while (0)
+// ... and stamp 7 = the same interval on the constant-rate wall clock (s_memrealtime; hipDeviceAttributeWallClockRate): the shader clock of THIS launch
+// under ITS load = total / wall, which is what turns the cycle counts into microseconds (bench.py: roofline.measured_model)
+#define LNB_WALL_EXIT() do { if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8 + 7] = (long long)wall_clock64() - t_wall0; } while (0)
+#define DBG_EXIT() do { if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; d_[3] = t_aux; } LNB_WALL_EXIT(); } while (0)
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 // asm loads are invisible to hipcc's s_waitcnt bookkeeping: the ring below is waited for by hand (wait_ring)
@@ -581,6 +584,7 @@ template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
 __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long t_begin = p.dbg ? clock64() : 0, t_wait = 0, t_x = 0, t_aux = 0;
+    const long long t_wall0 = p.dbg ? (long long)wall_clock64() : 0;
     constexpr int KC = SA / (NCH * RW * 16);              // 8-wide k chunks per stage
     constexpr int GS = KC / 2;                            // 16-step groups per stage
     constexpr int SB = 2 * SA;                            // f32 product stage
@@ -745,6 +749,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
         }
     }
     if (p.dbg) t_x = clock64() - t_begin;
+    LNB_STAMP(6);                                                      // (stamp 6 marks a chain wave: the cycle its main loop starts)
     float acc[NCH];
 #pragma unroll
     for (int c = 0; c < NCH; c++) acc[c] = 0.0f;
@@ -843,6 +848,7 @@ template <int RW, int KS, int NH, int R, int EPI, bool NORM>
 __global__ __launch_bounds__((gq_ncw(RW) + NH) * 64) void gemv_quad_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long t_begin = p.dbg ? clock64() : 0, t_wait = 0, t_x = 0, t_aux = 0;
+    const long long t_wall0 = p.dbg ? (long long)wall_clock64() : 0;
     constexpr int NCW = gq_ncw(RW), NW = NCW + NH;
     constexpr int KC = KS / 8;                            // 8-wide k chunks per stage
     constexpr int GS = KS / 16;                           // 16-step groups per stage
@@ -1179,6 +1185,7 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xT = (float*)smem;                                // x[128c + 16i + j] at xT[(c*16 + j)*8 + i]
     const long long t_begin = p.dbg ? clock64() : 0;         // LNB_GEMV_TIMING: [wg][wave] = {total, -, prologue, -}
+    const long long t_wall0 = p.dbg ? (long long)wall_clock64() : 0;
     long long t_x = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1226,6 +1233,7 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     }
     __syncthreads();
     if (p.dbg) t_x = clock64() - t_begin;
+    LNB_STAMP(6);
     const float* xl = xT + (size_t)(lane & 15) * 8;
     float acc = 0.0f;
     float pr[8];
@@ -1267,7 +1275,8 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
         }
     }
     asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
-    if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = 0; d_[2] = t_x; d_[3] = 0; }
+    if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = 0; d_[2] = t_x; d_[3] = t_x; }
+    LNB_WALL_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1302,8 +1311,9 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* ring = smem;
     uint16_t* xb = (uint16_t*)(smem + RL_SLOTS * RL_STAGE);  // x[128c + 16i + j] at xb[(c*16 + j)*8 + i]
-    const long long t_begin = p.dbg ? clock64() : 0;         // LNB_GEMV_TIMING: [wg][wave] = {total, barrier wait, prologue, -}
-    long long t_x = 0, t_wait = 0;
+    const long long t_begin = p.dbg ? clock64() : 0;         // LNB_GEMV_TIMING: [wg][wave] = {total, barrier wait, x staged, chain start (chain waves)}
+    const long long t_wall0 = p.dbg ? (long long)wall_clock64() : 0;
+    long long t_x = 0, t_wait = 0, t_chain = 0;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), pair = wave & 3;
     const int K = p.K, S = p.S, nchunks = K >> 7, nst = nchunks / RL_SC;
@@ -1425,6 +1435,8 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         }
         __builtin_amdgcn_s_setprio(3);
+        if (p.dbg) { t_chain = clock64() - t_begin; t_wait = 0; }         // (chain waves report the barrier wait of the main loop only)
+        LNB_STAMP(6);
         float acc = 0.0f;
         float4 ba[2], bb[2];                                 // products of the chunk being added / of the next one
         ba[0] = *(const float4*)src0; bb[0] = *(const float4*)(src0 + 1024);     // stage 0, chunk 0
@@ -1463,7 +1475,8 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
         }
     }
 #undef RL_BARRIER
-    if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; d_[3] = 0; }
+    if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; d_[3] = t_chain; }
+    LNB_WALL_EXIT();
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2857,7 +2870,7 @@ __global__ __launch_bounds__(1024) void argmax_kernel(const uint16_t* logits, in
             if (n < out_cap) out_tokens[n] = tok;
             st->n_out = n + 1;
             st->pos = st->pos + 1;
-            for (int k = 0; k < st->n_stop; k++) if (tok == st->stop[k]) st->finished = 1;     // the stop token itself is emitted (GSFinishedByReachingEOS)
+            if (st->honour_stop) for (int k = 0; k < st->n_stop; k++) if (tok == st->stop[k]) st->finished = 1;     // the stop token itself is emitted (GSFinishedByReachingEOS)
         }
     }
 }
@@ -2876,12 +2889,12 @@ __global__ __launch_bounds__(1024) void batch_argmax_kernel(const uint16_t* logi
             if (n < tab->dout_cap[s]) tab->dout[s][n] = tok;
             st->n_out = n + 1;
             st->pos = st->pos + 1;
-            for (int k = 0; k < st->n_stop; k++) if (tok == st->stop[k]) st->finished = 1;
+            if (st->honour_stop) for (int k = 0; k < st->n_stop; k++) if (tok == st->stop[k]) st->finished = 1;
         }
     }
 }
 
-__global__ void set_state_kernel(StepState* st, int pos, int n_out) { st->pos = pos; st->n_out = n_out; st->finished = 0; }
+__global__ void set_state_kernel(StepState* st, int pos, int n_out, int honour_stop) { st->pos = pos; st->n_out = n_out; st->finished = 0; st->honour_stop = honour_stop; }
 struct StopIds { int32_t n; int32_t id[LNB_MAX_STOP_IDS]; };
 __global__ void set_stop_kernel(StepState* st, StopIds s) { st->n_stop = s.n; for (int k = 0; k < LNB_MAX_STOP_IDS; k++) st->stop[k] = k < s.n ? s.id[k] : -1; st->finished = 0; }
 __global__ void advance_state_kernel(StepState* st, int rows) { st->pos = st->pos + rows; }   // end of a captured pipeline-stage step
@@ -2965,7 +2978,10 @@ template <int EPI, bool NORM, int NCH>
 static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     // RW 24 (one chain; the 8B wq|wk|wv: 6144 rows = 256 blocks of 24, one per CU): quad-DPP chain waves fed through the LDS, 256-step
     // stages, six helpers x 2 loads x 5 stages = 60 KiB in flight per CU
-    if constexpr (NCH == 1) if (rw == 24) return launch_quad_t<24, 256, 6, 5, EPI, NORM>(p, st);
+    // Throughput schedule (GemvParams.sched, lnb_ctx_set_schedule): the same kernel with 128-step stages -- 3 x 12 KiB of products + x = 55 KB of LDS
+    // instead of 91 KB, so that a workgroup fits a CU beside the gate|up workgroup (75 KB) of another context's step; twice the stage barriers
+    // (slower alone, which is why one stream keeps the 256-step form), ten stages of one load per helper in flight = the same 60 KiB per CU.
+    if constexpr (NCH == 1) if (rw == 24) return (p && p->sched) ? launch_quad_t<24, 128, 6, 10, EPI, NORM>(p, st) : launch_quad_t<24, 256, 6, 5, EPI, NORM>(p, st);
     // stage geometry (one workgroup per CU).  SA = bf16 bytes per stage, R = stages in flight per helper.
     //  RW 16/32 plain (thin; chain bound): 8 KiB stages, 2 helpers x 4 loads x 7 stages = 56 KiB in flight per CU.
     //  RW 32 with the fused RMSNorm (wq|wk|wv): six helpers so that the exact parallel norm sum has 384 folding lanes, and
@@ -2998,7 +3014,9 @@ template <int EPI> static hipError_t launch_rowcast(const GemvParams* p, hipStre
     if ((p->K & 127) || p->K > 16384) return hipErrorInvalidValue;              // x staging: 8 x 16 B per thread, K*4 bytes of LDS
     // helper-fed chain waves (rowcast_lds_kernel) whenever K is a whole number of its 512-step stages; LNB_ROWCAST_LDS=0: the self-feeding kernel
     static const int use_lds = [] { const char* s = getenv("LNB_ROWCAST_LDS"); return s && *s ? atoi(s) : 1; }();
-    if (use_lds && p->K % (128 * RL_SC) == 0 && p->K >= 2 * 128 * RL_SC && rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0) <= 160 * 1024) {
+    // (throughput schedule: the self-feeding kernel -- four waves and K * 4 bytes of LDS instead of eight waves and 96 KB + K * 2: co-resident with
+    // another context's gate|up workgroup, NOTES R5)
+    if (use_lds && !p->sched && p->K % (128 * RL_SC) == 0 && p->K >= 2 * 128 * RL_SC && rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0) <= 160 * 1024) {
         hipLaunchKernelGGL(kl, dim3((unsigned)(p->S * p->n_wg)), dim3(512), rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0), st, *p);
         return hipGetLastError();
     }
@@ -3193,8 +3211,8 @@ extern "C" hipError_t lnbk_argmax(const uint16_t* logits, int V, int32_t* next_t
     hipLaunchKernelGGL(argmax_kernel, dim3(1), dim3(1024), 0, st, logits, V, next_token, state, out_tokens, out_cap, advance);
     return hipGetLastError();
 }
-extern "C" hipError_t lnbk_set_state(StepState* state, int pos, int n_out, hipStream_t st) {
-    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, state, pos, n_out);
+extern "C" hipError_t lnbk_set_state(StepState* state, int pos, int n_out, int honour_stop, hipStream_t st) {
+    hipLaunchKernelGGL(set_state_kernel, dim3(1), dim3(1), 0, st, state, pos, n_out, honour_stop);
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_set_stop(StepState* state, const int32_t* ids, int n, hipStream_t st) {
@@ -3281,8 +3299,8 @@ extern "C" hipError_t lnbk_batch_argmax(const uint16_t* logits, int V, const Bat
     hipLaunchKernelGGL(batch_argmax_kernel, dim3((unsigned)nseq), dim3(1024), 0, st, logits, V, tab, ring);
     return hipGetLastError();
 }
-extern "C" hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring, hipStream_t st) {
-    hipLaunchKernelGGL(batch_set_state_kernel, dim3(1), dim3(LNB_BATCH_MAX), 0, st, tab, tokens, pos, ring);
+extern "C" hipError_t lnbk_batch_set_state(const BatchTab* tab, const int32_t* tokens, const int32_t* pos, int32_t* ring, int honour_stop, hipStream_t st) {
+    hipLaunchKernelGGL(batch_set_state_kernel, dim3(1), dim3(LNB_BATCH_MAX), 0, st, tab, tokens, pos, ring, honour_stop);
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_batch_scatter_ring(const BatchTab* tab, const int32_t* ring, hipStream_t st) {

@@ -21,6 +21,7 @@ extern void lnbGoLayerCallback(int layer, int nLayers, double secs, void* user);
 import "C"
 
 import (
+	"fmt"
 	"runtime"
 	"runtime/cgo"
 	"unsafe"
@@ -157,6 +158,9 @@ func (ic *InferenceContext) SetStopTokenIds(lt *LlamaTransformer, ids []TokenId)
 // stop id ended the run (finished == true; the stop token is the last one).  The host loop that feeds generatedTokensCh calls it in chunks
 // of any size: the tokens do not depend on the chunking.
 func (ic *InferenceContext) DecodeGreedyUntil(lt *LlamaTransformer, token TokenId, startPos int, maxSteps int) (tokens []TokenId, finished bool, err error) {
+	if maxSteps <= 0 { // &out[0] of an empty slice panics before the library can refuse the call
+		return nil, false, fmt.Errorf("n_steps must be positive")
+	}
 	if err = ic.attach(lt); err != nil {
 		return nil, false, err
 	}
@@ -170,12 +174,28 @@ func (ic *InferenceContext) DecodeGreedyUntil(lt *LlamaTransformer, token TokenI
 	return out[:int(n)], fin != 0, nil
 }
 
-// Close frees the device buffers of this context (idempotent; also run by the finalizer, before the transformer's).
+// SetThroughputSchedule selects the co-residency-friendly forms of the one-token kernels (lnb_ctx_set_schedule): for hosts that keep several
+// generations in flight on one GPU, one InferenceContext each (inference.go:174).  Same tokens either way.
+func (ic *InferenceContext) SetThroughputSchedule(lt *LlamaTransformer, on bool) error {
+	if err := ic.attach(lt); err != nil {
+		return err
+	}
+	s := C.int(C.LNB_SCHED_LATENCY)
+	if on {
+		s = C.int(C.LNB_SCHED_THROUGHPUT)
+	}
+	return lnbCall(func() C.int { return C.lnb_ctx_set_schedule(ic.handle, s) })
+}
+
+// Close frees the device buffers of this context (idempotent; also run by the finalizer, before the transformer's).  The library refuses to
+// destroy a context that a live batch still holds (its tables and captured graphs keep the device pointers): the handle is kept then.
 func (ic *InferenceContext) Close() error {
 	if ic.handle == nil {
 		return nil
 	}
-	C.lnb_ctx_destroy(ic.handle)
+	if err := lnbCall(func() C.int { return C.lnb_ctx_destroy(ic.handle) }); err != nil {
+		return err
+	}
 	ic.handle = nil
 	ic.lt.mu.Lock()
 	ic.lt.ctxs--

@@ -52,8 +52,8 @@ EXPORTS = [
     "lnb_model_set_tensor", "lnb_model_get_tensor", "lnb_model_fill_synthetic", "lnb_model_finalize",
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
-    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear", "lnb_op_argmax", "lnb_op_linear_mode", "lnb_ctx_set_mode", "lnb_ctx_get_mode", "lnb_ctx_set_attention", "lnb_ctx_zseq_count", "lnb_ctx_norm_fallbacks",
-    "lnb_profile_kernel", "lnb_model_num_tensors", "lnb_model_tensor_info",
+    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear", "lnb_op_argmax", "lnb_op_linear_mode", "lnb_ctx_set_mode", "lnb_ctx_get_mode", "lnb_ctx_set_schedule", "lnb_ctx_get_schedule", "lnb_ctx_set_attention", "lnb_ctx_zseq_count", "lnb_ctx_norm_fallbacks",
+    "lnb_profile_kernel", "lnb_profile_kernel_stamps", "lnb_model_num_tensors", "lnb_model_tensor_info",
     "lnb_checkpoint_open", "lnb_checkpoint_close", "lnb_checkpoint_num_tensors", "lnb_checkpoint_find", "lnb_checkpoint_tensor",
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
     "lnb_tokenizer_load", "lnb_tokenizer_free", "lnb_tokenizer_vocab_size", "lnb_tokenizer_special", "lnb_tokenizer_token_id",
@@ -101,10 +101,13 @@ def lib():
     L.lnb_ctx_stream.argtypes = [vp]
     L.lnb_ctx_stream.restype = vp
     L.lnb_profile_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p]
+    L.lnb_profile_kernel_stamps.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(C.c_int)]
     L.lnb_op_linear.argtypes = [C.c_int, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_op_rmsnorm_linear.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_ctx_set_mode.argtypes = [vp, C.c_int]
     L.lnb_ctx_get_mode.argtypes = [vp]
+    L.lnb_ctx_set_schedule.argtypes = [vp, C.c_int]
+    L.lnb_ctx_get_schedule.argtypes = [vp]
     L.lnb_ctx_set_attention.argtypes = [vp, C.c_int, C.c_int]
     L.lnb_ctx_zseq_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.lnb_ctx_norm_fallbacks.argtypes = [vp, C.POINTER(C.c_int)]
@@ -122,7 +125,7 @@ def lib():
     L.lnb_batch_create.argtypes = [C.POINTER(vp), C.c_int, C.POINTER(vp)]
     L.lnb_batch_destroy.argtypes = [vp]
     L.lnb_batch_decode.argtypes = [vp, i32p, i32p, C.c_int, vp, f32p]
-    L.lnb_batch_decode_until.argtypes = [vp, i32p, i32p, C.c_int, vp, vp, f32p]
+    L.lnb_batch_decode_until.argtypes = [vp, i32p, i32p, C.c_int, vp, vp, vp, f32p]
     L.lnb_ctx_set_stop_ids.argtypes = [vp, vp, C.c_int]
     L.lnb_decode_greedy_until.argtypes = [vp, C.c_int32, C.c_int, C.c_int, vp, C.POINTER(C.c_int), C.POINTER(C.c_int), f32p]
     L.lnb_batch_profile_kernel.argtypes = [vp, C.c_int, C.c_int, C.c_int, f32p]
@@ -387,6 +390,11 @@ class InferenceContext:
         _chk(self.L.lnb_ctx_set_mode(self.h, {"exact": 0, "fast": 1}.get(mode, mode)))
         return self
 
+    def set_schedule(self, sched):
+        """'latency' (default: one generation owns the chip) or 'throughput' (several contexts in flight on one GPU share the CUs); same bits"""
+        _chk(self.L.lnb_ctx_set_schedule(self.h, {"latency": 0, "throughput": 1}.get(sched, sched)))
+        return self
+
     def set_attention(self, long_threshold=-1, force_zseq=0):
         """contexts above long_threshold use the long-context decode attention; force_zseq: always walk the serial f64 sum"""
         _chk(self.L.lnb_ctx_set_attention(self.h, long_threshold, force_zseq))
@@ -423,6 +431,13 @@ class InferenceContext:
         _chk(self.L.lnb_profile_kernel(self.h, which, pos, iters, C.byref(ms)))
         return ms.value
 
+    def profile_kernel_stamps(self, which, pos):
+        """in-kernel cycle stamps of one launch of a GEMV class -> (float64 [8 waves, 16], wall clock kHz); layout: include/lnb.h"""
+        out = np.zeros((8, 16), dtype=np.float64)
+        khz = C.c_int(0)
+        _chk(self.L.lnb_profile_kernel_stamps(self.h, which, pos, _p(out), C.byref(khz)))
+        return out, khz.value
+
     def set_stop_ids(self, ids):
         """model.StopTokenIds on the device (inference.go:233-252)"""
         a = np.ascontiguousarray(ids, dtype=np.int32)
@@ -453,7 +468,7 @@ class InferenceContext:
 
     def close(self):
         if self.h:
-            self.L.lnb_ctx_destroy(self.h)
+            _chk(self.L.lnb_ctx_destroy(self.h))             # refused while a live Batch holds the context: the handle (and the device memory) stays
             self.h = C.c_void_p()
 
 
@@ -485,7 +500,9 @@ class Batch:
         out = np.empty((n, max_steps), dtype=np.int32)
         cnt = np.zeros(n, dtype=np.int32)
         ms = C.c_float(0)
-        _chk(self.L.lnb_batch_decode_until(self.h, tok.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_int32)), max_steps, _p(out), _p(cnt), C.byref(ms)))
+        fin = np.zeros(n, dtype=np.int32)
+        _chk(self.L.lnb_batch_decode_until(self.h, tok.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_int32)), max_steps, _p(out), _p(cnt), _p(fin), C.byref(ms)))
+        self.finished = [bool(f) for f in fin]               # per sequence: a stop id ended it (start_pos[s] < 0 keeps an ended sequence frozen in the next chunk)
         return [out[s, :cnt[s]].copy() for s in range(n)], ms.value
 
     def profile_kernel(self, which, pos, iters):

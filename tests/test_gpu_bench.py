@@ -35,10 +35,13 @@ def test_single_gpu_bench_prints_one_json_line_with_the_contract_keys(mode):
     sf = d["sequences_in_flight"]
     assert sf["n"] == 3 and sf["tokens_per_s"] > 0
     assert sf["sequence0_tokens_vs_single_run"]["identical_prefix"] == sf["sequence0_tokens_vs_single_run"]["compared"] > 0
-    pf = rf["practical_floor"]                              # measured step costs, prologues and boundaries: what the exact order can reach
-    assert pf["tokens_per_s"] > 0 and pf["achieved_frac_of_floor"] > 0 and set(pf["per_kernel"]) >= {"wo+residual GEMV", "w2+residual GEMV", "norm+output GEMV"}
-    ls = rf["largest_symbol_by_gpu_time"]
-    assert 0 < ls["share_of_gpu_time"] <= 1 and ls["symbol"] in ls["all"]
+    mm = rf["measured_model"]                               # hardware-only bound next to the current kernels taken apart by this run's cycle stamps
+    assert mm["hardware_bound"]["tokens_per_s"] > 0 and 0 < mm["hardware_bound"]["achieved_frac_of_bound"] <= 1.0
+    assert set(mm["per_kernel"]) >= {"wo+residual GEMV", "w2+residual GEMV", "norm+output GEMV", "attention"}
+    assert all("hardware_bound_us" in v for k, v in mm["per_kernel"].items() if k != "attention")
+    # the roofline object is the kernel SYMBOL with the largest share of the token's GPU time; the heaviest launch class sits next to it
+    assert 0 < rf["share_of_gpu_time"] <= 1 and rf["kernel"] in rf["symbols"] and rf["dominant_class"]["frac"] > 0
+    assert sf["schedule"] == "throughput" and sf["latency_forms_same_run"]["tokens_per_s"] > 0 and sf["n2"]["n"] == 2
     rp = d["config"]["timed_region_repeats_ms_per_step"]   # three repeats of the same K steps, the median one reported
     assert len(rp) == 3 and sorted(rp)[1] == pytest.approx(d["ms_per_step"], rel=1e-3)
     if mode == "exact":                                    # batched exact decode: n prompts per pass over the weights, sequence 0 = the single run's prompt
