@@ -637,6 +637,7 @@ def main():
     res = {"metric": "decode tokens/s Llama-3.1-8B bf16 @1/2/4/8 MI355X; % HBM roofline", "value": round(tps, 2), "unit": "tokens/s",
            "n_gpus": 1, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+           "schema": "lnb-bench/5 (roofline = the kernel symbol with the largest share of GPU time; configs2 = configs[2] in the same line; sequences_in_flight = throughput forms)",
            "config": {"workload": "%s bf16, 1xMI355X, single-prompt greedy decode, seq_len=%d -> +%d tokens (%s)"
                                   % (name, P, K, ("configs[2] decode" if P >= 4096 else
                                                   "configs[1] proper: +256 tokens" if K == 256 else

@@ -42,6 +42,10 @@ typedef struct lnb_model_args {
 
 const char* lnb_last_error(void);
 int lnb_device_count(int* out_count);
+/* preflight of a multi-GPU host (bench.py --gpus N prints it per rank before any timing): the device behind an index (any out pointer may be
+ * NULL) and whether `device` can map `peer`'s memory -- the peer-to-peer path RCCL's ncclSend / ncclRecv ride on (xGMI inside a node) */
+int lnb_device_info(int device, char* name, int name_cap, int64_t* hbm_bytes, int* n_cus, char* arch, int arch_cap);
+int lnb_device_can_access_peer(int device, int peer, int* out);
 
 /* ---- model: replaces model.NewLlamaTransformer (src/model/llamatransformer.go:64-113) --------------
  * A model handle owns the device copy of one pipeline STAGE: transformer blocks [layer_begin,layer_end),

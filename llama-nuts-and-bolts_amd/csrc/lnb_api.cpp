@@ -189,6 +189,27 @@ static int alloc_linear(uint16_t** p, size_t elems, int64_t& bytes) {
 }
 
 extern "C" int lnb_device_count(int* out) { int n = 0; HIPCHK(hipGetDeviceCount(&n)); *out = n; return 0; }
+// what a multi-GPU host prints before it trusts a run (bench.py --gpus N: the per-rank preflight record): the device behind an index, and
+// whether `device` can map `peer`'s memory (hipDeviceCanAccessPeer: xGMI / PCIe peer-to-peer, what RCCL's point-to-point path rides on)
+extern "C" int lnb_device_info(int device, char* name, int name_cap, int64_t* hbm_bytes, int* n_cus, char* arch, int arch_cap) {
+    int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("device %d out of range (%d devices)", device, ndev);
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device));
+    if (name && name_cap > 0) snprintf(name, (size_t)name_cap, "%s", prop.name);
+    if (arch && arch_cap > 0) snprintf(arch, (size_t)arch_cap, "%s", prop.gcnArchName);
+    if (hbm_bytes) *hbm_bytes = (int64_t)prop.totalGlobalMem;
+    if (n_cus) *n_cus = prop.multiProcessorCount;
+    return 0;
+}
+extern "C" int lnb_device_can_access_peer(int device, int peer, int* out) {
+    if (!out) return fail("null argument");
+    int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev || peer < 0 || peer >= ndev) return fail("device pair (%d, %d) out of range (%d devices)", device, peer, ndev);
+    if (device == peer) { *out = 1; return 0; }
+    int can = 0; HIPCHK(hipDeviceCanAccessPeer(&can, device, peer));
+    *out = can;
+    return 0;
+}
 
 extern "C" int lnb_model_ffn_hidden_dim(const lnb_model_args* a) {   // llamatransformer.go:569-577
     int h = 4 * a->dim;
@@ -654,6 +675,16 @@ static hipError_t gemm_dispatch(int mode, const GemmParams* g, int epi, hipStrea
     if (stream_on && g->w16 && (g->K & 127) == 0) return lnbk_gemm_stream(g, epi, g_num_cus, st);
     return lnbk_gemm(g, epi, st);
 }
+// Infinity-Cache warm-up of a block's gate|up weights (235 MB of the 8B shape, the one HBM-bound launch of the block) while the launches in
+// front of it leave the HBM idle: the attention's spare CUs and wo's chain waves touch one line in every LNB_MALL_EVERY-th 8 KB unit (default
+// policy: the lines stay in the 256 MiB memory-side cache; the gate|up kernel's nt stream then finds a share of its bytes there and the
+// HBM channels carry the rest).  0 = off.  Units [0, attn_units) belong to the attention launch, the next wo_units to wo.
+struct MallPlan { int every, attn_units, wo_units, rows, wo_step; };
+static const MallPlan& mall_plan() {
+    static const MallPlan pl = { env_int("LNB_MALL_EVERY", 0), env_int("LNB_MALL_ATTN_UNITS", 1 << 30), env_int("LNB_MALL_WO_UNITS", 1 << 30),
+                                 env_int("LNB_MALL_ROWS", 7), env_int("LNB_MALL_WO_STEP", 1) };
+    return pl;
+}
 static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t st_other = nullptr, int lds_pad = 0) {
     lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = st_other ? st_other : c->stream;
     LayerW& L = m->layers[l - m->layer_begin];
@@ -691,6 +722,11 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
         ap.mfma = use_mfma(S) ? 1 : 0; ap.exp_tab = m->exp_tab;
         ap.longctx = (S == 1 && c->attn_long) ? 1 : 0; ap.force_zseq = c->force_zseq; ap.e_buf = c->e_buf; ap.z_part = c->z_part; ap.zseq_count = c->zseq_count;
+        if (S == 1 && c->mode == LNB_MODE_EXACT && c->sched == LNB_SCHED_LATENCY && mall_plan().every > 0 && m->has_w13(l)) {
+            const MallPlan& pl = mall_plan();
+            const long long units = (long long)(tiled_elems(L.w13.n_rows, L.w13.k, L.w13.rw, L.w13.nch) * 2 / ((size_t)pl.every * 8192));
+            ap.pf_ptr = (const char*)L.w13.w; ap.pf_every = (unsigned)pl.every; ap.pf_first = 0; ap.pf_count = (unsigned)std::min<long long>(units, pl.attn_units); ap.pf_rows = pl.rows;
+        }
         if (c->mode == LNB_MODE_FAST && ap.mfma) {           // tolerance mode prefill: flash form on the bf16 matrix cores
             hipError_t e = lnbk_fast_attn(&ap, st);
             if (e != hipErrorNotSupported) { HIPCHK(e); return 0; }
@@ -698,6 +734,14 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x; o.sched = c->sched;
+        if (S == 1 && c->mode == LNB_MODE_EXACT && c->sched == LNB_SCHED_LATENCY && mall_plan().every > 0 && m->has_w13(l)) {
+            const MallPlan& pl = mall_plan();
+            const long long units = (long long)(tiled_elems(L.w13.n_rows, L.w13.k, L.w13.rw, L.w13.nch) * 2 / ((size_t)pl.every * 8192));
+            const long long first = std::min<long long>(units, pl.attn_units);
+            o.pf_ptr = (const char*)L.w13.w; o.pf_every = (unsigned)pl.every; o.pf_first = (unsigned)first; o.pf_count = (unsigned)std::min<long long>(units - first, pl.wo_units);
+            o.pf_chunk_step = (unsigned)std::max(1, pl.wo_step);
+            if (o.pf_count == 0) o.pf_ptr = nullptr;
+        }
         set_grid(o, L.wo); HIPCHK(gemv_dispatch(c, &o, L.wo.rw, 1, EPI_RESID, 0, st)); return 0; }
     case K_W13: {   // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
         GemvParams f{}; f.w = L.w13.w; f.x = hbuf; f.norm_w = L.ffn_norm; f.norm_fb = c->zseq_count + 1; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;

@@ -580,6 +580,14 @@ template <int N, int NP> DEVINL void wait_ring(u32x4 (&b)[NP]) {
     if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(%8) ; RING_RETIRE %0 %1 %2 %3 %4 %5 %6 %7" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "n"(N) : "memory");
 }
 
+// Infinity-Cache warm-up: one 8 KB unit (64 lines of 128 B) of a weight stream, one dword per line, default cache policy (`nt` touches leave
+// nothing behind, profiles/r03_mall_prefetch.log); unit u of the touch list is the pf_every-th 8 KB unit of the matrix.  The loaded dword is never
+// used, but its destination IS a register with a load in flight: `sink` lives for the whole kernel and the statement is tagged like the ring
+// loads, so that tools/isa_audit.py proves hipcc never touches it (a dead destination would be handed to the next address computation).
+DEVINL void mall_touch_unit(const char* base, unsigned every, unsigned u, int lane, unsigned& sink) {
+    const char* a = base + (size_t)u * every * 8192u + (size_t)lane * 128u;
+    asm volatile("global_load_dword %0, %1, off ; RING_LOAD" : "+v"(sink) : "v"(a) : "memory");
+}
 template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
 __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1440,6 +1448,11 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
         float acc = 0.0f;
         float4 ba[2], bb[2];                                 // products of the chunk being added / of the next one
         ba[0] = *(const float4*)src0; bb[0] = *(const float4*)(src0 + 1024);     // stage 0, chunk 0
+        // warm-up share of this chain wave: units pf_first + wid, + n_waves, ... while any are left (GemvParams.pf_*)
+        const unsigned pf_stride = (unsigned)(p.S * p.n_wg) * 4u, pf_wid = (unsigned)blockIdx.x * 4u + (unsigned)pair;
+        unsigned pf_unit = p.pf_first + pf_wid;
+        int pf_left = (p.pf_ptr && pf_wid < p.pf_count) ? (int)((p.pf_count - pf_wid + pf_stride - 1) / pf_stride) : 0, pf_wait = 1;
+        unsigned pf_sink = 0;
         int sdone = 0, blk = wg;
         for (int it0 = 0; it0 <= NS; it0 += RL_SLOTS) {
 #pragma unroll
@@ -1453,6 +1466,9 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
                     for (int cc = 0; cc < RL_SC; cc++) {
                         const char* q = cc + 1 < RL_SC ? cur + (cc + 1) * 2048 : nxt;      // past the last stage: stale bytes, never added
                         ba[(cc + 1) & 1] = *(const float4*)q; bb[(cc + 1) & 1] = *(const float4*)(q + 1024);
+                        if (pf_left) {                             // (scalar condition) Infinity-Cache warm-up of the next launch's weights, one 8 KB unit per pf_step chunks
+                            if (--pf_wait == 0) { mall_touch_unit(p.pf_ptr, p.pf_every, pf_unit, lane, pf_sink); pf_unit += pf_stride; pf_left--; pf_wait = (int)p.pf_chunk_step; }
+                        }
                         __builtin_amdgcn_sched_barrier(0);         // the reads are issued HERE, in front of the chunk's 128 adds
                         const float4 a = ba[cc & 1], b = bb[cc & 1];
                         const float pr[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -1473,6 +1489,7 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
                 }
             }
         }
+        asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" : "+v"(pf_sink) :: "memory");     // (the warm-up touches; nothing else is outstanding)
     }
 #undef RL_BARRIER
     if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; d_[3] = t_chain; }
@@ -1849,8 +1866,8 @@ extern "C" hipError_t lnbk_exp_table(double* tab, float divisor, hipStream_t st)
 // xcd_head_block: inside an XCD head-major (a head's sub-blocks follow each other: the decode kernels, equal-cost sub-blocks; measured
 // 191.0 against 189.5 tokens/s at configs[2] for the other order).  xcd_head_block_bmajor: sub-block-major (all of the XCD's heads for
 // sub-block 0, then sub-block 1, ...), so a caller whose sub-blocks differ in cost can hand out the longest ones first (prefill).
-DEVINL void xcd_head_block(int& h, int& b) {
-    const unsigned H = gridDim.x, nb = gridDim.y, lin = blockIdx.y * H + blockIdx.x;
+DEVINL void xcd_head_block(int& h, int& b, unsigned nb = gridDim.y) {
+    const unsigned H = gridDim.x, lin = blockIdx.y * H + blockIdx.x;
     if ((H & 7u) == 0) {
         const unsigned v = (lin & 7u) * ((H >> 3) * nb) + (lin >> 3);     // consecutive virtual ids stay on one XCD
         h = (int)(v / nb); b = (int)(v % nb);
@@ -2199,7 +2216,19 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
     // batched decode (DENSE): sequence-major inside an XCD -- the (H / 8) heads an XCD owns are the query heads of ONE KV head (H = 32, KVH = 8),
     // so the workgroups of one sequence's four heads are dispatched back to back on the same XCD and the K / V rows the first one pulls are
     // L2 hits for the other three (head-major order: 128 sequences x 92 KB between two readers of the same rows -- every read went to HBM)
-    if (DENSE && !p.head_major) xcd_head_block_bmajor(h, i); else xcd_head_block(h, i);
+    if constexpr (!DENSE) {
+        // grid rows past the query rows (one-token decode of ONE sequence only): Infinity-Cache warm-up of the gate|up weights on the CUs the H
+        // attention workgroups leave idle; wave w of the pf_rows x H x 8 touches units w, w + n_waves, ... of its share of the touch list
+        if (p.pf_ptr && (int)blockIdx.y >= (int)gridDim.y - p.pf_rows) {
+            const unsigned nw = (unsigned)p.pf_rows * gridDim.x * (ATT_NT / 64);
+            const unsigned w0 = (((unsigned)blockIdx.y - (gridDim.y - (unsigned)p.pf_rows)) * gridDim.x + blockIdx.x) * (ATT_NT / 64) + (unsigned)wave;
+            unsigned sink = 0;
+            for (unsigned g = w0; g < p.pf_count; g += nw) mall_touch_unit(p.pf_ptr, p.pf_every, p.pf_first + g, lane, sink);
+            asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" : "+v"(sink) :: "memory");
+            return;
+        }
+    }
+    if (DENSE && !p.head_major) xcd_head_block_bmajor(h, i); else xcd_head_block(h, i, DENSE ? gridDim.y : gridDim.y - (unsigned)(p.pf_ptr ? p.pf_rows : 0));
     // batched decode: query row i is the one new token of SEQUENCE i of the batch -- its own position, caches and cache length
     const BatchTab* const bt = p.btab;
     const int S = bt ? 1 : p.S, KVH = p.KVH;
@@ -3162,7 +3191,11 @@ extern "C" void lnbk_attn_gqa_dbg_dump(void) {
     }
 }
 static bool attn_batch_dense() { const char* e = getenv("LNB_ATTN_BATCH_DENSE"); return !(e && *e && atoi(e) == 0); }   // (read per launch: a test switches it inside one process)
-extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
+extern "C" hipError_t lnbk_attn(const AttnParams* p_in, hipStream_t st) {
+    // the Infinity-Cache warm-up rows exist in ONE form only: the one-token decode of one sequence on attn_exact_kernel<128> (H workgroups on 256 CUs)
+    AttnParams pc = *p_in;
+    if (!(pc.pf_ptr && pc.pf_rows > 0 && pc.pf_count > 0 && pc.hd == 128 && pc.S == 1 && !pc.btab && !pc.longctx)) { pc.pf_ptr = nullptr; pc.pf_rows = 0; }
+    const AttnParams* p = &pc;
     if (p->longctx && p->S == 1) return launch_attn_long(p, st);
     if (p->mfma && p->S >= 16 && (p->hd == 128 || p->hd == 64)) {       // prefill: 16 query rows per wave on the matrix cores
         if (p->hd == 128) hipLaunchKernelGGL(attn_mfma_kernel<128>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
@@ -3193,7 +3226,7 @@ extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
             { const char* e = getenv("LNB_ATTN_BATCH_HEADMAJOR"); q.head_major = (e && *e && atoi(e) != 0) ? 1 : 0; }     // (A/B of the dispatch order)
             hipLaunchKernelGGL((attn_exact_kernel<128, true>), dim3(p->H, p->S), dim3(ATT_NT), lds, st, q);
         }
-        else hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p);
+        else hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S + (p->pf_ptr ? p->pf_rows : 0)), dim3(ATT_NT), lds, st, *p);
         break;
     case 64: hipLaunchKernelGGL(attn_exact_kernel<64>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
     case 32: hipLaunchKernelGGL(attn_exact_kernel<32>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;

@@ -263,6 +263,11 @@ class TcpGroup:
     def barrier(self):
         self.all_reduce(0, max)
 
+    def set_timeout(self, seconds):
+        """patience of every later collective (the rendezvous itself is bounded by the constructor's timeout)"""
+        for c in self.peers:
+            c.settimeout(seconds)
+
     def close(self):
         for c in self.peers:
             c.close()
@@ -556,7 +561,7 @@ def _golden_check(tokens, prompt_len, model_name):
     return {"compared": n, "identical_prefix": agree, "golden": "tests/golden/configs1_tokens.json (CPU oracle)"}
 
 
-def one_gpu_anchor(lnb, grp, rank, world, cfg, local, mode, P, W, K, n_seq, seq_len, batched):
+def one_gpu_anchor(lnb, grp, rank, world, cfg, local, mode, P, W, K, n_seq, seq_len, batched, sched="throughput"):
     """The same workloads on ONE GPU holding the whole model, measured in this run on rank 0's GPU while the other ranks wait: the anchor
     of the line's efficiency figures (value_N / (N x anchor)).  Unbatched: n_seq sequences in flight through the one-GPU form of the tick
     path.  Batched (if the pipeline ran it): G groups of nb sequences.  Short timed windows (the anchor needs no more than a few percent)."""
@@ -565,7 +570,7 @@ def one_gpu_anchor(lnb, grp, rank, world, cfg, local, mode, P, W, K, n_seq, seq_
         try:
             Ka, Wa = min(K, 24), min(W, 2)
             m = lnb.LlamaTransformer(device=local, **cfg).fill_synthetic(1234).finalize(rope_rows=max(seq_len, 2 * cfg["max_seq_len"]))
-            ctxs = [lnb.InferenceContext(m, seq_len).set_mode(mode) for _ in range(n_seq)]
+            ctxs = [lnb.InferenceContext(m, seq_len).set_mode(mode).set_schedule(sched) for _ in range(n_seq)]
             pp = lnb.Pipeline(m, 0, 1, None)
             prm = [lnb.synth_tokens(99 + q, P, cfg["vocab_size"]) for q in range(n_seq)]
             n_dec = Wa + Ka
@@ -607,6 +612,38 @@ def one_gpu_anchor(lnb, grp, rank, world, cfg, local, mode, P, W, K, n_seq, seq_
     return grp.broadcast(out if rank == 0 else None)
 
 
+def preflight(lnb, grp, rank, world, local):
+    """First contact of a multi-GPU run, BEFORE anything is built or timed: every rank reports the device it sits on, what that device can
+    reach peer-to-peer, and whether RCCL works on it at all (lnb_pipeline_selftest: a one-rank communicator running exactly a tick's grouped
+    ncclSend + ncclRecv).  The records of all ranks come back to every rank; an error on ANY rank ends ALL of them with one message."""
+    rec = {"rank": rank, "device": local, "pid": os.getpid(), "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY")}
+    try:
+        n_dev = lnb.device_count()
+        rec["visible_devices"] = n_dev
+        rec.update(lnb.device_info(local))
+        rec["peer_access"] = [lnb.can_access_peer(local, j) for j in range(n_dev)]
+        t0 = time.perf_counter()
+        lnb.rccl_selftest(local, 1 << 16)
+        rec["rccl_selftest"] = "ok (%.1f s incl. loading librccl)" % (time.perf_counter() - t0)
+    except Exception as e:
+        rec["error"] = "%s: %s" % (type(e).__name__, e)
+    recs = grp.all_reduce([rec], lambda vs: sorted(sum(vs, []), key=lambda r: r["rank"]))
+    devs = [r["device"] for r in recs]
+    bad = ["rank %d: %s" % (r["rank"], r["error"]) for r in recs if "error" in r]
+    if world > 1 and len(set(devs)) != len(devs) and os.environ.get("LNB_PIPELINE_BACKEND", "nccl") == "nccl":
+        bad.append("ranks share a GPU (devices %s): RCCL wants one GPU per rank" % devs)
+    return recs, bad
+
+
+def abort_all(rank, what, details):
+    """one clear message (rank 0 prints it), every rank exits non-zero: bench.py's launcher then stops whatever is left"""
+    import sys
+    if rank == 0:
+        sys.stderr.write("bench.py --gpus N ABORTED %s:\n  %s\n" % (what, "\n  ".join(details)))
+        sys.stderr.flush()
+    os._exit(4)
+
+
 def bench_main(args, cfg, name):
     """bench.py --gpus N under torchrun: weak scaling, 2N sequences in flight, one rank per GPU.
 
@@ -634,12 +671,27 @@ def bench_main(args, cfg, name):
     P, W, K = args.prompt_len, args.warmup, args.steps
     seq_len = P + W + K + 8
     mode = getattr(args, "mode", "exact")
+    # sequences in flight on every rank: the throughput forms of the one-token kernels (lnb_ctx_set_schedule); LNB_PIPELINE_SCHED=latency for the A/B
+    sched = os.environ.get("LNB_PIPELINE_SCHED", "throughput")
+    preflight_rec = None
     stage, dist, torch = None, None, None
     if exchange == "native":
         n_dev = lnb.device_count()
         local %= max(1, n_dev)
         # the torchrun agent's own store listens on MASTER_PORT: the control star takes a port next to it
-        grp = TcpGroup(rank, world, os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + int(os.environ.get("LNB_CONTROL_PORT_OFFSET", "23")))
+        # first contact is bounded: a rank that never shows up, a device without peer access or an RCCL that cannot start ends ALL ranks with one
+        # message inside LNB_PREFLIGHT_TIMEOUT seconds (default 60) instead of a hang somewhere inside the first exchange
+        t_first = float(os.environ.get("LNB_PREFLIGHT_TIMEOUT", "60"))
+        try:
+            grp = TcpGroup(rank, world, os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + int(os.environ.get("LNB_CONTROL_PORT_OFFSET", "23")), timeout=t_first)
+        except Exception as e:
+            sys.stderr.write("bench.py --gpus %d ABORTED at the rendezvous: rank %d saw %s: %s after %.0f s (are all %d ranks running?)\n" % (world, rank, type(e).__name__, e, t_first, world))
+            os._exit(4)
+        pre, bad = preflight(lnb, grp, rank, world, local) if world > 1 or os.environ.get("LNB_FORCE_PREFLIGHT") == "1" else ([], [])
+        if rank == 0 and pre:
+            sys.stderr.write("[preflight] %s\n" % json.dumps(pre))
+        if bad:
+            abort_all(rank, "in the preflight (before anything was built or timed)", bad)
         n_seq = 2 * world if world > 1 else int(os.environ.get("LNB_PIPELINE_SEQS", "2"))
         costs = None
         if world > 1 and os.environ.get("LNB_PIPELINE_PROBE", "1") != "0":
@@ -647,20 +699,38 @@ def bench_main(args, cfg, name):
             costs = grp.broadcast([float(v) for v in probe_costs(lnb, cfg, local, P + W + K // 2)] if rank == 0 else None)
         stage = LnbStage(lnb, None, cfg, rank, world, n_seq, seq_len, local, costs=costs)
         for c in stage.ctx:
-            c.set_mode(mode)
-        ok, pipe = 1, None
+            c.set_mode(mode).set_schedule(sched)             # several sequences in flight per rank: the co-residency-friendly kernel forms
+        ok, pipe, why = 1, None, None
+        import threading
+        # ncclCommInitRank blocks until all N ranks have joined: a watchdog ends this rank (and, through the launcher, the others) if it does not return
+        dog = threading.Timer(t_first, lambda: (sys.stderr.write("bench.py --gpus %d ABORTED: rank %d's ncclCommInitRank did not return within %.0f s "
+                                                                  "(a peer missing, or no peer-to-peer path between the GPUs)\n" % (world, rank, t_first)), os._exit(4)))
+        dog.daemon = True
         try:
             uid = grp.broadcast(lnb.Pipeline.unique_id() if (rank == 0 and world > 1) else None)
+            if world > 1:
+                dog.start()
             pipe = lnb.Pipeline(stage.model, rank, world, uid)
         except Exception as e:                                # (every rank must take the same path: agree below)
-            sys.stderr.write("[rank %d] native RCCL exchange unavailable: %s\n" % (rank, e))
+            why = "%s: %s" % (type(e).__name__, e)
+            ok = 0
+        dog.cancel()
+        counts = grp.all_reduce([(rank, pipe.comm_count() if pipe is not None else 0, why)], lambda vs: sorted(sum(vs, [])))
+        if world > 1 and any(c != world for _, c, _ in counts):
             ok = 0
         if grp.all_reduce(ok, min) == 0:
+            details = ["rank %d: communicator of %d ranks (wanted %d)%s" % (r, c, world, "" if not w else " -- " + w) for r, c, w in counts]
+            if os.environ.get("LNB_PIPELINE_FALLBACK") != "torch":
+                abort_all(rank, "while forming the %d-rank RCCL communicator (LNB_PIPELINE_FALLBACK=torch retries through torch.distributed)" % world, details)
+            sys.stderr.write("[rank %d] native RCCL exchange unavailable (%s): falling back to torch.distributed\n" % (rank, "; ".join(details)))
             if pipe is not None:
                 pipe.close()
             stage.close(); stage = None
             grp.close()
             exchange = "torch (native RCCL init failed on some rank)"
+        else:
+            grp.set_timeout(300.0)
+            preflight_rec = {"ranks": pre, "rccl_comm_count_per_rank": [c for _, c, _ in counts]} if pre else None
     if exchange == "native":
         prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
         n_decode = W + K
@@ -683,6 +753,7 @@ def bench_main(args, cfg, name):
             # single stream: sequence 0 again on its (reset) context, W_s warm-up + K_s timed steps
             Ks, Ws = min(K, int(os.environ.get("LNB_SINGLE_STREAM_STEPS", "32"))), min(W, 4)
             c0 = stage.ctx[0]; c0.reset()
+            c0.set_schedule("latency")                       # ONE sequence in the pipe: nothing to share the CUs with, the single stream's forms
             ss = run_single_stream_native(rank, world, pipe, c0, prompts[0], Ws + Ks, 0, 1 + Ws)
             pipe.sync(); grp.barrier()
             t1 = time.perf_counter()
@@ -690,6 +761,7 @@ def bench_main(args, cfg, name):
             pipe.sync(); grp.barrier()
             wall_s = grp.all_reduce(time.perf_counter() - t1, max)
             toks_s = slots_tokens(ss["slots"]) if rank == world - 1 else None
+            c0.set_schedule(sched)
             info = grp.all_reduce([(rank, pipe.comm_count(), toks0, toks_s)], lambda vs: sorted(sum(vs, [])))
             toks0 = info[-1][2]; toks_s = info[-1][3]
             return {"wall": wall, "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * n_seq), 1),
@@ -763,7 +835,7 @@ def bench_main(args, cfg, name):
             stage.close()
             stage = LnbStage(lnb, None, cfg, rank, world, n_seq, seq_len, local, parts=blocks_split(rank, world, cfg["n_layers"]), costs=costs)
             for c in stage.ctx:
-                c.set_mode(mode)
+                c.set_mode(mode).set_schedule(sched)
             uid = grp.broadcast(lnb.Pipeline.unique_id() if rank == 0 else None)
             pipe = lnb.Pipeline(stage.model, rank, world, uid)
             m_lit = measure()
@@ -779,7 +851,10 @@ def bench_main(args, cfg, name):
         # The line's `value` is the UNBATCHED figure -- 2N independent sequences in flight, one-token ticks, the kernels of the N = 1 line --
         # so that the 1 -> 8 curve compares like with like; the batched pipeline (a serving workload: one pass over a stage's weights per
         # group of sequences) is reported next to it, each with a same-workload ONE-GPU anchor measured in this run on rank 0's GPU.
-        extra["value_definition"] = "%d independent sequences in flight, one-token ticks through the %d stages (exact single-sequence kernels, as the N = 1 line)" % (n_seq, world)
+        extra["value_definition"] = ("%d independent sequences in flight, one-token ticks through the %d stages (exact single-sequence kernels in their %s forms: "
+                                     "lnb_ctx_set_schedule; the N = 1 line's sequences_in_flight section is the same regime on one GPU)" % (n_seq, world, sched))
+        extra["schedule"] = sched
+        extra["preflight"] = preflight_rec
         extra["value_single_stream"] = m_bal["single_stream"]["tokens_per_s"]
         extra["value_batched"] = mb.get("tokens_per_s") if isinstance(mb, dict) else None
         tick_us = 1e6 * wall / max(1, K * n_seq)
@@ -792,7 +867,7 @@ def bench_main(args, cfg, name):
                                   "note": "a tick = one sequence's one-token step on one stage; with 2N sequences in flight the pipeline's period is the slowest stage"}
         if os.environ.get("LNB_PIPELINE_ANCHOR", "1") != "0":
             extra["one_gpu_anchor"] = one_gpu_anchor(lnb, grp, rank, world, cfg, local, mode, P, W, K, n_seq, seq_len,
-                                                     (mb["groups"], mb["batch"]) if isinstance(mb, dict) and "groups" in mb else None)
+                                                     (mb["groups"], mb["batch"]) if isinstance(mb, dict) and "groups" in mb else None, sched)
             an = extra["one_gpu_anchor"]
             if an.get("unbatched_tokens_per_s"):
                 extra["efficiency_vs_one_gpu"] = {"unbatched": round((K * n_seq / wall) / (world * an["unbatched_tokens_per_s"]), 4)}
@@ -829,7 +904,7 @@ def bench_main(args, cfg, name):
         costs = probe(device if backend == "nccl" else "cpu")
         stage = LnbStage(lnb, torch, cfg, rank, world, n_seq, seq_len, local, costs=costs)
         for c in stage.ctx:
-            c.set_mode(mode)
+            c.set_mode(mode).set_schedule(sched)
         prompts = [lnb.synth_tokens(99 + s, P, cfg["vocab_size"]) for s in range(n_seq)]
         n_decode = W + K
         t_split = n_seq * (1 + W)              # prefill phase + W warm-up decode rounds
@@ -855,6 +930,9 @@ def bench_main(args, cfg, name):
         res = {"metric": "decode tokens/s Llama-3.1-8B bf16 @1/2/4/8 MI355X; % HBM roofline", "value": round(tps, 2), "unit": "tokens/s",
                "n_gpus": world, "steps": K, "warmup": W, "ms_per_step": round(1000.0 * wall / K, 4), "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               # `value` changed meaning between rounds (r03: the batched pipeline; r04: unbatched ticks, latency forms; r05: unbatched ticks, throughput forms):
+               # files of different schema versions are not like for like
+               "schema": "lnb-bench-multigpu/3 (value = unbatched one-token ticks, throughput kernel forms; batched and single-stream figures under config)",
                "config": dict({"workload": "%s bf16, %dxMI355X layer pipeline (blocks per GPU %s), RCCL p2p hidden-state hand-off, %d sequences in flight, "
                                            "prompt %d -> +%d tokens each" % (name, world, ",".join("%.3g" % ((stage_parts(r, world, cfg["n_layers"], *stage.costs)[1]
                                                                                                                 - stage_parts(r, world, cfg["n_layers"], *stage.costs)[0]) / 3.0)

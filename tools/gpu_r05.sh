@@ -1,0 +1,37 @@
+#!/bin/bash
+# round 5 GPU runner (one parametrised script; every mode writes under gpurun_out/r05_*).
+#   tools/gpu_r05.sh <mode> [args]
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+export TMPDIR=/tmp PYTHONPATH=$PWD:$PWD/llama-nuts-and-bolts_amd
+mkdir -p gpurun_out
+mode=$1; shift
+ab() {   # per-kernel decode timings of the 8B block shape (tools/kernel_ab.py); env passes through; label = $1
+  local label=$1; shift
+  echo "== $label"; timeout 300 python tools/kernel_ab.py ${AB_ITERS:-200} 2>&1 | tail -1
+}
+case "$mode" in
+  first)    # first contact of the round: the new tests, the Infinity-Cache warm-up A/B, the default bench line
+    ( timeout 900 python -m pytest tests/test_gpu_round5.py tests/test_gpu_bench.py -x -q ) 2>&1 | tail -15
+    {
+      ab "default (no warm-up)"
+      LNB_MALL_EVERY=4 LNB_MALL_WO_UNITS=0 ab "every 4, attention rows only (58 MB)"
+      LNB_MALL_EVERY=4 LNB_MALL_ATTN_UNITS=3584 ab "every 4, half attention / half wo"
+      LNB_MALL_EVERY=4 LNB_MALL_ATTN_UNITS=0 ab "every 4, wo chain waves only"
+      LNB_MALL_EVERY=2 LNB_MALL_ATTN_UNITS=5000 ab "every 2 (117 MB), 5000 units attention / rest wo"
+      LNB_MALL_EVERY=8 LNB_MALL_WO_UNITS=0 ab "every 8, attention only (29 MB)"
+      LNB_MALL_EVERY=1 LNB_MALL_ATTN_UNITS=6000 LNB_MALL_WO_UNITS=12000 ab "every 1, 47 MB attention + 94 MB wo (prefix of the matrix)"
+    } 2>&1 | tee gpurun_out/r05_mall_ab.log
+    ( time timeout 900 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err; echo "bench rc=$?"; tail -3 gpurun_out/r05_bench_default.err
+    head -c 1500 gpurun_out/r05_bench_default.json; echo
+    ;;
+  ab)       # env passes through
+    ab "${1:-custom}"
+    ;;
+  suite)    # whole GPU suite
+    ( timeout 3000 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r05_gpu_suite.log
+    ;;
+  bench)
+    timeout 900 python bench.py "$@" 2>gpurun_out/r05_bench_last.err | tail -1 | tee gpurun_out/r05_bench_last.json | head -c 1200; echo; tail -3 gpurun_out/r05_bench_last.err
+    ;;
+  *) echo "unknown mode $mode"; exit 2;;
+esac
