@@ -357,8 +357,7 @@ def measured_model(ctx, a, ffn_hidden, Tbar, kernels, tps):
                 main_cycles = v[cw][1] - v[cw][12]
                 boundary_us = max(0.0, got_us - in_kernel_us)
                 rec.update({"shader_clock_GHz": round(ghz, 3), "in_kernel_us": round(in_kernel_us, 2), "prologue_us": round(prologue_us, 2),
-                            "main_loop_us": round(main_cycles / ghz * 1e-3, 2), "barrier_wait_us_of_the_chain_wave": round(v[cw][3] / ghz * 1e-3, 2),
-                            "boundary_us": round(boundary_us, 2)})
+                            "main_loop_us": round(main_cycles / ghz * 1e-3, 2), "boundary_us": round(boundary_us, 2)})
                 if chain:
                     rec["cycles_per_k_step"] = round(main_cycles / Ksteps[which], 3)
                 else:
@@ -674,6 +673,8 @@ def main():
         if args.concurrent != 2:
             two = concurrent_sequences(lnb, model, cfg, args, a, run_toks, n_seq=2)
             res["sequences_in_flight"]["n2"] = {k: v for k, v in two.items() if k != "note"}
+            res["sequences_in_flight"]["n2"]["latency_forms_same_run"] = {k: v for k, v in concurrent_sequences(lnb, model, cfg, args, a, run_toks, n_seq=2, sched="latency").items()
+                                                                          if k in ("schedule", "tokens_per_s", "ms_per_token", "frac_of_hbm_roofline")}
     if with_cfg2:
         res["configs2"] = configs2_record(lnb, model, cfg, args, a)
     roofline["measured_model"] = measured_model(ctx, a, model.ffn_hidden, Tbar, kernels, tps)

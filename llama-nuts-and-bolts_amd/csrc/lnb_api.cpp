@@ -174,8 +174,9 @@ static int auto_rw(int lane_rows, const char* env, int K = 0, bool plain = false
 }
 static int g_num_cus = 256;
 static long long* g_dbg = nullptr;   // LNB_GEMV_TIMING=1: per-wave timing dump of the profiled launch
+static int g_dbg_full = 0;           // ... with every barrier and ring wait timed (perturbs the launch); 0: phase stamps and the exit record only
 // one resident workgroup per CU: a matrix with more row blocks than CUs is walked persistently
-static void set_grid(GemvParams& g, const TiledDesc& t) { g.dbg = g_dbg; g.n_blocks = t.n_blocks; g.n_wg = t.n_blocks < g_num_cus ? t.n_blocks : g_num_cus; }
+static void set_grid(GemvParams& g, const TiledDesc& t) { g.dbg = g_dbg; g.dbg_full = g_dbg ? g_dbg_full : 0; g.n_blocks = t.n_blocks; g.n_wg = t.n_blocks < g_num_cus ? t.n_blocks : g_num_cus; }
 static int alloc_tiled(TiledDesc& t, int n_rows, int K, int rw, int nch, int64_t& bytes) {
     t.n_rows = n_rows; t.k = K; t.rw = rw; t.nch = nch; t.n_blocks = rw == 4 ? (n_rows + 15) / 16 : (n_rows + rw - 1) / rw;   // rw 4: 16-row workgroups
     size_t n = tiled_elems(n_rows, K, rw, nch) * 2;
@@ -675,16 +676,6 @@ static hipError_t gemm_dispatch(int mode, const GemmParams* g, int epi, hipStrea
     if (stream_on && g->w16 && (g->K & 127) == 0) return lnbk_gemm_stream(g, epi, g_num_cus, st);
     return lnbk_gemm(g, epi, st);
 }
-// Infinity-Cache warm-up of a block's gate|up weights (235 MB of the 8B shape, the one HBM-bound launch of the block) while the launches in
-// front of it leave the HBM idle: the attention's spare CUs and wo's chain waves touch one line in every LNB_MALL_EVERY-th 8 KB unit (default
-// policy: the lines stay in the 256 MiB memory-side cache; the gate|up kernel's nt stream then finds a share of its bytes there and the
-// HBM channels carry the rest).  0 = off.  Units [0, attn_units) belong to the attention launch, the next wo_units to wo.
-struct MallPlan { int every, attn_units, wo_units, rows, wo_step; };
-static const MallPlan& mall_plan() {
-    static const MallPlan pl = { env_int("LNB_MALL_EVERY", 0), env_int("LNB_MALL_ATTN_UNITS", 1 << 30), env_int("LNB_MALL_WO_UNITS", 1 << 30),
-                                 env_int("LNB_MALL_ROWS", 7), env_int("LNB_MALL_WO_STEP", 1) };
-    return pl;
-}
 static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t st_other = nullptr, int lds_pad = 0) {
     lnb_model* m = c->m; const lnb_model_args& a = m->a; hipStream_t st = st_other ? st_other : c->stream;
     LayerW& L = m->layers[l - m->layer_begin];
@@ -722,11 +713,6 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
         ap.mfma = use_mfma(S) ? 1 : 0; ap.exp_tab = m->exp_tab;
         ap.longctx = (S == 1 && c->attn_long) ? 1 : 0; ap.force_zseq = c->force_zseq; ap.e_buf = c->e_buf; ap.z_part = c->z_part; ap.zseq_count = c->zseq_count;
-        if (S == 1 && c->mode == LNB_MODE_EXACT && c->sched == LNB_SCHED_LATENCY && mall_plan().every > 0 && m->has_w13(l)) {
-            const MallPlan& pl = mall_plan();
-            const long long units = (long long)(tiled_elems(L.w13.n_rows, L.w13.k, L.w13.rw, L.w13.nch) * 2 / ((size_t)pl.every * 8192));
-            ap.pf_ptr = (const char*)L.w13.w; ap.pf_every = (unsigned)pl.every; ap.pf_first = 0; ap.pf_count = (unsigned)std::min<long long>(units, pl.attn_units); ap.pf_rows = pl.rows;
-        }
         if (c->mode == LNB_MODE_FAST && ap.mfma) {           // tolerance mode prefill: flash form on the bf16 matrix cores
             hipError_t e = lnbk_fast_attn(&ap, st);
             if (e != hipErrorNotSupported) { HIPCHK(e); return 0; }
@@ -734,18 +720,10 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {    // wo + residual  (:522, :232)
         GemvParams o{}; o.w = L.wo.w; o.x = c->att; o.K = m->q_dim; o.n_rows = a.dim; o.S = S; o.st = c->st; o.out = hbuf; o.res = c->x; o.sched = c->sched;
-        if (S == 1 && c->mode == LNB_MODE_EXACT && c->sched == LNB_SCHED_LATENCY && mall_plan().every > 0 && m->has_w13(l)) {
-            const MallPlan& pl = mall_plan();
-            const long long units = (long long)(tiled_elems(L.w13.n_rows, L.w13.k, L.w13.rw, L.w13.nch) * 2 / ((size_t)pl.every * 8192));
-            const long long first = std::min<long long>(units, pl.attn_units);
-            o.pf_ptr = (const char*)L.w13.w; o.pf_every = (unsigned)pl.every; o.pf_first = (unsigned)first; o.pf_count = (unsigned)std::min<long long>(units - first, pl.wo_units);
-            o.pf_chunk_step = (unsigned)std::max(1, pl.wo_step);
-            if (o.pf_count == 0) o.pf_ptr = nullptr;
-        }
         set_grid(o, L.wo); HIPCHK(gemv_dispatch(c, &o, L.wo.rw, 1, EPI_RESID, 0, st)); return 0; }
     case K_W13: {   // ffn_norm + w1|w3 + SiLU*up  (:237, :601-617)
         GemvParams f{}; f.w = L.w13.w; f.x = hbuf; f.norm_w = L.ffn_norm; f.norm_fb = c->zseq_count + 1; f.eps = a.norm_eps; f.K = a.dim; f.n_rows = m->ffn_hidden; f.S = S; f.st = c->st;
-        f.out = c->ffn; f.silu = m->silu;
+        f.out = c->ffn; f.silu = m->silu; f.sched = c->sched;
         set_grid(f, L.w13); HIPCHK(gemv_dispatch(c, &f, L.w13.rw, 2, EPI_SILU_MUL, 1, st)); return 0; }
     case K_W2: {    // w2 + residual  (:619, :248)
         GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = hbuf; d.lds_pad = lds_pad; d.sched = c->sched;
@@ -993,15 +971,15 @@ static int decode_greedy_impl(lnb_ctx* c, int32_t token, int start_pos, int n_st
 // One launch of a GEMV class with the per-wave debug buffer armed (GemvParams.dbg): out[w * 16 + ..] for wave w = {workgroups that reported, avg
 // total cycles, max total, avg barrier wait, avg [2] (x staged / prologue end), avg [3] (fold or walk; rowcast_lds chain waves: chain start),
 // avg stamps 0..7 (stamp 7 = the launch on the constant-rate wall clock)}.  The device position must have been set by the caller.
-static int gemv_stamps(lnb_ctx* c, int which, double* out) {
+static int gemv_stamps(lnb_ctx* c, int which, double* out, int full) {
     lnb_model* m = c->m; hipStream_t st = c->stream;
     const size_t n = (size_t)4096 * 8 * 4, n2 = (size_t)4096 * 8 * 8;       // + 8 phase stamps per wave behind the four totals (LNB_STAMP in lnb_kernels.hip)
     long long* dbuf = nullptr;
     HIPCHK(hipMalloc((void**)&dbuf, (n + n2) * 8)); HIPCHK(hipMemsetAsync(dbuf, 0, (n + n2) * 8, st));
-    g_dbg = dbuf;
+    g_dbg = dbuf; g_dbg_full = full;
     const int nl = m->layer_end - m->layer_begin;
     int rc = which == K_HEAD ? enqueue_head(c, 0, 1) : enqueue_layer_kernel(c, m->layer_begin + 7 % nl, 1, which);
-    g_dbg = nullptr;
+    g_dbg = nullptr; g_dbg_full = 0;
     if (rc) { hipFree(dbuf); return -1; }
     HIPCHK(hipStreamSynchronize(st));
     std::vector<long long> h(n + n2);
@@ -1033,7 +1011,7 @@ extern "C" int lnb_profile_kernel_stamps(lnb_ctx* c, int which, int pos, double*
     c->attn_long = want_long_attention(c, 1, pos);
     HIPCHK(ctx_set_state(c, pos, 0, true));
     if (wall_clock_khz) { int khz = 0; HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m->device)); *wall_clock_khz = khz; }
-    return gemv_stamps(c, which, out);
+    return gemv_stamps(c, which, out, 0);                    // light: the launch runs as it does in production
 }
 
 extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, float* avg_ms_out) {
@@ -1111,7 +1089,7 @@ extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, flo
     }
     if (env_int("LNB_GEMV_TIMING", 0) && which != K_ATTN && which != K_LAYER) {
         double v[8 * 16];
-        if (gemv_stamps(c, which, v)) return -1;
+        if (gemv_stamps(c, which, v, 1)) return -1;
         fprintf(stderr, "[timing] kernel class %d: per-wave s_memtime ticks (avg over workgroups)\n", which);
         for (int w = 0; w < 8; w++) {
             const double* d = v + w * 16;

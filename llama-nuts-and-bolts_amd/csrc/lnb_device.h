@@ -97,12 +97,10 @@ struct GemvParams {
     int seq_len;
     int q_dim, kv_dim, head_dim;
     long long* dbg;             // optional per-wave timing dump (nullptr in production)
+    int dbg_full;               // with dbg: 1 = also time every barrier and ring wait (two s_memtime reads + an lgkmcnt(0) each: the launch runs ~15 % slower,
+                                // LNB_GEMV_TIMING=1), 0 = only the phase stamps and the exit record (bench.py's measured model: the launch runs as in production)
     int* norm_fb;               // optional counter: rows whose norm sum left the branch-free item walk for the record walk (counted by workgroup 0)
     int lds_pad;                // host side only: extra dynamic LDS requested for the launch (co-residency experiments: forces one workgroup per CU)
-    // Infinity-Cache warm-up of the NEXT launch's weight stream (gate|up behind wo; lnb_api.cpp: mall_plan): the chain waves of rowcast_lds_kernel touch
-    // one line in pf_every-th 8 KB units while they add (default cache policy: the lines land in the 256 MiB memory-side cache, where the nt stream of
-    // the gate|up launch finds them); wave instruction g (one 8 KB unit = 64 lines) is unit pf_first + g; nullptr = off
-    const char* pf_ptr; unsigned pf_every, pf_first, pf_count, pf_chunk_step;
     int sched;                  // host side only: 0 = latency forms (one stream owns the chip: every CU, eight or nine waves, up to 124 KB of LDS per
                                 // workgroup), 1 = throughput forms of the same arithmetic (lnb_ctx_set_schedule: at most 57 KB of LDS per workgroup, so
                                 // that a chain-bound launch of one context shares a CU with the HBM-bound gate|up launch of another)
@@ -149,9 +147,6 @@ struct AttnParams {
     // cache length come from the tables; the output goes to out_xt in the B-operand layout of the wo product (lnb_batch_kernels.h)
     const struct BatchTab* btab; const struct BatchKV* bkv; uint16_t* out_xt;
     int head_major;             // batched dense grid: 1 = head-major dispatch order inside an XCD (the round-3 order), 0 = sequence-major (the heads of a KV head back to back)
-    // one-token decode, one sequence: the launch has H workgroups for 256 CUs and moves almost no bytes -- pf_rows extra grid rows of workgroups
-    // (blockIdx.y >= S) touch units [pf_first, pf_first + pf_count) of the coming gate|up weight stream into the Infinity Cache (see GemvParams)
-    const char* pf_ptr; unsigned pf_every, pf_first, pf_count; int pf_rows;
 };
 
 // ---- batched exact decode: up to 16 independent sequences per pass over the weights (lnb_batch_kernels.h) --------------------------

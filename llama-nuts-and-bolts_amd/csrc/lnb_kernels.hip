@@ -558,7 +558,7 @@ DEVINL void gemv_epilogue(const GemvParams& p, const float (&acc)[NCH], int m, i
 // dynamic LDS: [2 * 2*SA product ring][kpad f32 x + 16 B]
 // ------------------------------------------------------------------------------------------------
 // optional per-wave timing (GemvParams.dbg != nullptr): [wg][wave][4] = {total, barrier wait, x staging / vm wait, -} in s_memtime ticks
-#define TIMED_BARRIER() do { if (p.dbg) { long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
+#define TIMED_BARRIER() do { if (p.dbg_full) { long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
 // phase stamp i (0..7) of this wave, cycles since the kernel started: a second region behind the [4096][8][4] totals (lnb_api.cpp prints the averages)
 #define LNB_STAMP(i) do { if (p.dbg && lane == 0) p.dbg[(size_t)4096 * 8 * 4 + ((size_t)blockIdx.x * 8 + wave) * 8 + (i)] = clock64() - t_begin; } while (0)
 // ... and stamp 7 = the same interval on the constant-rate wall clock (s_memrealtime; hipDeviceAttributeWallClockRate): the shader clock of THIS launch
@@ -580,14 +580,6 @@ template <int N, int NP> DEVINL void wait_ring(u32x4 (&b)[NP]) {
     if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(%8) ; RING_RETIRE %0 %1 %2 %3 %4 %5 %6 %7" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "n"(N) : "memory");
 }
 
-// Infinity-Cache warm-up: one 8 KB unit (64 lines of 128 B) of a weight stream, one dword per line, default cache policy (`nt` touches leave
-// nothing behind, profiles/r03_mall_prefetch.log); unit u of the touch list is the pf_every-th 8 KB unit of the matrix.  The loaded dword is never
-// used, but its destination IS a register with a load in flight: `sink` lives for the whole kernel and the statement is tagged like the ring
-// loads, so that tools/isa_audit.py proves hipcc never touches it (a dead destination would be handed to the next address computation).
-DEVINL void mall_touch_unit(const char* base, unsigned every, unsigned u, int lane, unsigned& sink) {
-    const char* a = base + (size_t)u * every * 8192u + (size_t)lane * 128u;
-    asm volatile("global_load_dword %0, %1, off ; RING_LOAD" : "+v"(sink) : "v"(a) : "memory");
-}
 template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
 __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -685,9 +677,9 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
                 const int t = it0 + j;
                 if (t <= T) {
                     if (t < T) {
-                        const long long tb_ = p.dbg ? clock64() : 0;
+                        const long long tb_ = p.dbg_full ? clock64() : 0;
                         wait_ring<(R - 1) * NP, NP>(buf[j]);           // stage t landed; R-1 younger stages stay in flight
-                        if (p.dbg) t_x += clock64() - tb_;
+                        if (p.dbg_full) t_x += clock64() - tb_;
                         char* dst = ringB + (t & 1) * SB;
                         const float* xst = xs + (size_t)st * (KC * 8);
                         if constexpr (NCH == 2) {
@@ -940,9 +932,9 @@ __global__ __launch_bounds__((gq_ncw(RW) + NH) * 64) void gemv_quad_kernel(GemvP
                 const int t = it0 + j;
                 if (t <= T + 1) {
                     if (t < T) {
-                        const long long tb_ = p.dbg ? clock64() : 0;
+                        const long long tb_ = p.dbg_full ? clock64() : 0;
                         wait_ring<(R - 1) * NP, NP>(buf[j]);           // stage t landed; R-1 younger stages stay in flight
-                        if (p.dbg) t_x += clock64() - tb_;
+                        if (p.dbg_full) t_x += clock64() - tb_;
                         char* dst = ringB + (size_t)(t % GQ_SLOTS) * SB;
                         const float* xst = xs + (size_t)st * KS;
                         float4 xa[NP], xb[NP];
@@ -1361,7 +1353,7 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
         __syncthreads();
         if (p.dbg) t_x = clock64() - t_begin;
     };
-#define RL_BARRIER() do { if (p.dbg) { const long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
+#define RL_BARRIER() do { if (p.dbg_full) { const long long tb_ = clock64(); __builtin_amdgcn_s_barrier(); t_wait += clock64() - tb_; } else __builtin_amdgcn_s_barrier(); } while (0)
     // Schedule (iterations it = 0 .. NS, one s_barrier each).  Iteration 0 fills the ring from BOTH sides: the helper makes stage 0, the
     // chain wave -- idle until there is something to add -- makes stage 1 from four weight loads of its own (otherwise it sits through
     // two helper stages, ~4 k cycles per launch measured).  From then on: iteration it, the helper writes stage it+1 (slot (it+1) % 3),
@@ -1448,11 +1440,6 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
         float acc = 0.0f;
         float4 ba[2], bb[2];                                 // products of the chunk being added / of the next one
         ba[0] = *(const float4*)src0; bb[0] = *(const float4*)(src0 + 1024);     // stage 0, chunk 0
-        // warm-up share of this chain wave: units pf_first + wid, + n_waves, ... while any are left (GemvParams.pf_*)
-        const unsigned pf_stride = (unsigned)(p.S * p.n_wg) * 4u, pf_wid = (unsigned)blockIdx.x * 4u + (unsigned)pair;
-        unsigned pf_unit = p.pf_first + pf_wid;
-        int pf_left = (p.pf_ptr && pf_wid < p.pf_count) ? (int)((p.pf_count - pf_wid + pf_stride - 1) / pf_stride) : 0, pf_wait = 1;
-        unsigned pf_sink = 0;
         int sdone = 0, blk = wg;
         for (int it0 = 0; it0 <= NS; it0 += RL_SLOTS) {
 #pragma unroll
@@ -1466,9 +1453,6 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
                     for (int cc = 0; cc < RL_SC; cc++) {
                         const char* q = cc + 1 < RL_SC ? cur + (cc + 1) * 2048 : nxt;      // past the last stage: stale bytes, never added
                         ba[(cc + 1) & 1] = *(const float4*)q; bb[(cc + 1) & 1] = *(const float4*)(q + 1024);
-                        if (pf_left) {                             // (scalar condition) Infinity-Cache warm-up of the next launch's weights, one 8 KB unit per pf_step chunks
-                            if (--pf_wait == 0) { mall_touch_unit(p.pf_ptr, p.pf_every, pf_unit, lane, pf_sink); pf_unit += pf_stride; pf_left--; pf_wait = (int)p.pf_chunk_step; }
-                        }
                         __builtin_amdgcn_sched_barrier(0);         // the reads are issued HERE, in front of the chunk's 128 adds
                         const float4 a = ba[cc & 1], b = bb[cc & 1];
                         const float pr[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
@@ -1489,7 +1473,6 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
                 }
             }
         }
-        asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" : "+v"(pf_sink) :: "memory");     // (the warm-up touches; nothing else is outstanding)
     }
 #undef RL_BARRIER
     if (p.dbg && lane == 0) { long long* d_ = p.dbg + ((size_t)blockIdx.x * 8 + wave) * 4; d_[0] = clock64() - t_begin; d_[1] = t_wait; d_[2] = t_x; d_[3] = t_chain; }
@@ -1866,8 +1849,8 @@ extern "C" hipError_t lnbk_exp_table(double* tab, float divisor, hipStream_t st)
 // xcd_head_block: inside an XCD head-major (a head's sub-blocks follow each other: the decode kernels, equal-cost sub-blocks; measured
 // 191.0 against 189.5 tokens/s at configs[2] for the other order).  xcd_head_block_bmajor: sub-block-major (all of the XCD's heads for
 // sub-block 0, then sub-block 1, ...), so a caller whose sub-blocks differ in cost can hand out the longest ones first (prefill).
-DEVINL void xcd_head_block(int& h, int& b, unsigned nb = gridDim.y) {
-    const unsigned H = gridDim.x, lin = blockIdx.y * H + blockIdx.x;
+DEVINL void xcd_head_block(int& h, int& b) {
+    const unsigned H = gridDim.x, nb = gridDim.y, lin = blockIdx.y * H + blockIdx.x;
     if ((H & 7u) == 0) {
         const unsigned v = (lin & 7u) * ((H >> 3) * nb) + (lin >> 3);     // consecutive virtual ids stay on one XCD
         h = (int)(v / nb); b = (int)(v % nb);
@@ -2216,19 +2199,7 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
     // batched decode (DENSE): sequence-major inside an XCD -- the (H / 8) heads an XCD owns are the query heads of ONE KV head (H = 32, KVH = 8),
     // so the workgroups of one sequence's four heads are dispatched back to back on the same XCD and the K / V rows the first one pulls are
     // L2 hits for the other three (head-major order: 128 sequences x 92 KB between two readers of the same rows -- every read went to HBM)
-    if constexpr (!DENSE) {
-        // grid rows past the query rows (one-token decode of ONE sequence only): Infinity-Cache warm-up of the gate|up weights on the CUs the H
-        // attention workgroups leave idle; wave w of the pf_rows x H x 8 touches units w, w + n_waves, ... of its share of the touch list
-        if (p.pf_ptr && (int)blockIdx.y >= (int)gridDim.y - p.pf_rows) {
-            const unsigned nw = (unsigned)p.pf_rows * gridDim.x * (ATT_NT / 64);
-            const unsigned w0 = (((unsigned)blockIdx.y - (gridDim.y - (unsigned)p.pf_rows)) * gridDim.x + blockIdx.x) * (ATT_NT / 64) + (unsigned)wave;
-            unsigned sink = 0;
-            for (unsigned g = w0; g < p.pf_count; g += nw) mall_touch_unit(p.pf_ptr, p.pf_every, p.pf_first + g, lane, sink);
-            asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" : "+v"(sink) :: "memory");
-            return;
-        }
-    }
-    if (DENSE && !p.head_major) xcd_head_block_bmajor(h, i); else xcd_head_block(h, i, DENSE ? gridDim.y : gridDim.y - (unsigned)(p.pf_ptr ? p.pf_rows : 0));
+    if (DENSE && !p.head_major) xcd_head_block_bmajor(h, i); else xcd_head_block(h, i);
     // batched decode: query row i is the one new token of SEQUENCE i of the batch -- its own position, caches and cache length
     const BatchTab* const bt = p.btab;
     const int S = bt ? 1 : p.S, KVH = p.KVH;
@@ -3003,6 +2974,7 @@ static hipError_t launch_quad_t(const GemvParams* p, hipStream_t st) {
     return hipGetLastError();
 }
 
+static bool env_tp_w13() { static const int on = [] { const char* e = getenv("LNB_TP_W13"); return e && *e ? atoi(e) : 1; }(); return on != 0; }   // (A/B switch of the throughput gate|up form)
 template <int EPI, bool NORM, int NCH>
 static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     // RW 24 (one chain; the 8B wq|wk|wv: 6144 rows = 256 blocks of 24, one per CU): quad-DPP chain waves fed through the LDS, 256-step
@@ -3026,7 +2998,9 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     if (rw == 64) return launch_chain_t<64, NCH, 12288, 6, 8, EPI, NORM>(p, st);
     // RW 56 (two chains only): 28672 gate/up rows = 256 blocks of 56 x 2 -- one block per CU on ALL 256 CUs instead of 224 of them;
     // seven helpers (448 lanes = one (k-chunk, row) pair each), 64-step stages
-    if constexpr (NCH == 2) if (rw == 56) return launch_chain_t<56, 2, 14336, 7, 8, EPI, NORM>(p, st);
+    // (throughput schedule: six ring stages instead of eight -- 133 instead of 149 VGPRs, so that two of its waves and two of the 128-step
+    // wq|wk|wv kernel's fit one SIMD's 512 registers: a gate|up workgroup of one context beside a wq|wk|wv workgroup of another)
+    if constexpr (NCH == 2) if (rw == 56) return (p && p->sched && env_tp_w13()) ? launch_chain_t<56, 2, 14336, 7, 6, EPI, NORM>(p, st) : launch_chain_t<56, 2, 14336, 7, 8, EPI, NORM>(p, st);
     // RW 28 (two chains, LNB_RW_W13=28): the same stream cut into 512 half-height blocks, two per workgroup -- rows [0, F/2) are complete
     // after the first block of every workgroup: the row-band order a w1|w3 -> w2 pipeline needs (measurement, NOTES.md 6.1)
     if constexpr (NCH == 2) if (rw == 28) return launch_chain_t<28, 2, 14336, 7, 8, EPI, NORM>(p, st);
@@ -3191,11 +3165,7 @@ extern "C" void lnbk_attn_gqa_dbg_dump(void) {
     }
 }
 static bool attn_batch_dense() { const char* e = getenv("LNB_ATTN_BATCH_DENSE"); return !(e && *e && atoi(e) == 0); }   // (read per launch: a test switches it inside one process)
-extern "C" hipError_t lnbk_attn(const AttnParams* p_in, hipStream_t st) {
-    // the Infinity-Cache warm-up rows exist in ONE form only: the one-token decode of one sequence on attn_exact_kernel<128> (H workgroups on 256 CUs)
-    AttnParams pc = *p_in;
-    if (!(pc.pf_ptr && pc.pf_rows > 0 && pc.pf_count > 0 && pc.hd == 128 && pc.S == 1 && !pc.btab && !pc.longctx)) { pc.pf_ptr = nullptr; pc.pf_rows = 0; }
-    const AttnParams* p = &pc;
+extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     if (p->longctx && p->S == 1) return launch_attn_long(p, st);
     if (p->mfma && p->S >= 16 && (p->hd == 128 || p->hd == 64)) {       // prefill: 16 query rows per wave on the matrix cores
         if (p->hd == 128) hipLaunchKernelGGL(attn_mfma_kernel<128>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
@@ -3226,7 +3196,7 @@ extern "C" hipError_t lnbk_attn(const AttnParams* p_in, hipStream_t st) {
             { const char* e = getenv("LNB_ATTN_BATCH_HEADMAJOR"); q.head_major = (e && *e && atoi(e) != 0) ? 1 : 0; }     // (A/B of the dispatch order)
             hipLaunchKernelGGL((attn_exact_kernel<128, true>), dim3(p->H, p->S), dim3(ATT_NT), lds, st, q);
         }
-        else hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S + (p->pf_ptr ? p->pf_rows : 0)), dim3(ATT_NT), lds, st, *p);
+        else hipLaunchKernelGGL(attn_exact_kernel<128>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p);
         break;
     case 64: hipLaunchKernelGGL(attn_exact_kernel<64>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;
     case 32: hipLaunchKernelGGL(attn_exact_kernel<32>, dim3(p->H, p->S), dim3(ATT_NT), lds, st, *p); break;

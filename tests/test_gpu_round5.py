@@ -50,10 +50,11 @@ def test_committed_configs2_goldens_at_depth_are_reproduced_by_the_device(lnb, n
     got, _ = gc.decode_greedy(first, P, n - 1)
     assert [first] + [int(t) for t in got] == gold["tokens"]
     assert gc.zseq_count() == 0                              # every softmax row certified its denominator (no serial walk)
-    if n_layers == 8:                                        # ... and through the other forms: serial f64 denominator forced; chunked prefill; throughput schedule
+    if n_layers == 8:                                        # ... and through the other forms: serial f64 denominator forced, throughput schedule
+        # (ONE Forward again: the reference's mask is [seq, seq] broadcast over the context, llamatransformer.go:55-64 -- a prompt fed in chunks is a
+        # different computation there, and here)
         g2 = lnb.InferenceContext(gm, P + 12).set_attention(-1, 1).set_schedule("throughput")
-        g2.Forward(prompt[:2048], 0, want_logits=False)
-        _, f2 = g2.Forward(prompt[2048:], 2048, want_logits=False)
+        _, f2 = g2.Forward(prompt, 0, want_logits=False)
         more, _ = g2.decode_greedy(f2, P, 8)
         assert [f2] + [int(t) for t in more] == gold["tokens"][:9]
         g2.close()

@@ -24,6 +24,23 @@ case "$mode" in
     ( time timeout 900 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err; echo "bench rc=$?"; tail -3 gpurun_out/r05_bench_default.err
     head -c 1500 gpurun_out/r05_bench_default.json; echo
     ;;
+  second)   # the full-depth configs[2] golden on the box's host cores (background, ~25 min of 64 threads) while the GPU runs the suite and the A/Bs
+    mkdir -p gpurun_out/gold32
+    ( timeout 3000 python tests/golden/make_configs2_cut_tokens.py 32 100 gpurun_out/gold32 > gpurun_out/gold32/log.txt 2>&1 ) & GP=$!
+    ( timeout 1500 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r05_gpu_suite.log
+    {
+      ab "4 layers"
+      AB_LAYERS=32 ab "32 layers"
+      AB_SCHED=throughput ab "4 layers, throughput forms"
+    } 2>&1 | tee gpurun_out/r05_ab_layers.log
+    Q="--steps 48 --warmup 4 --batch-sizes= --cpu-steps 0 --no-traffic-probe --no-configs2 --repeats 1 --profile-iters 4"
+    for v in "LNB_TP_W13=1" "LNB_TP_W13=0"; do
+      echo "== concurrent, $v"; env $v timeout 300 python bench.py $Q 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read()); print(d['value'], json.dumps(d['sequences_in_flight']))"
+    done 2>&1 | tee gpurun_out/r05_concurrent_ab.log
+    ( time timeout 900 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err; echo "bench rc=$?"; tail -3 gpurun_out/r05_bench_default.err
+    timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_driver_args.json 2> gpurun_out/r05_bench_driver_args.err; echo "bench(20) rc=$?"
+    wait $GP; tail -2 gpurun_out/gold32/log.txt; ls -la gpurun_out/gold32
+    ;;
   ab)       # env passes through
     ab "${1:-custom}"
     ;;

@@ -6,7 +6,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "llama-nuts-and-bolts_amd"))
 import lnb
 
-cfg = dict(lnb.LLAMA_8B); cfg["n_layers"] = 4
+cfg = dict(lnb.LLAMA_8B); cfg["n_layers"] = int(os.environ.get("AB_LAYERS", "4"))     # (AB_LAYERS=32: the launches cycle through the full model's weights, as a decode step does)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
 m = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize()
 c = lnb.InferenceContext(m, 512)
@@ -14,9 +14,12 @@ prompt = lnb.synth_tokens(99, 128, cfg["vocab_size"])
 _, first = c.Forward(prompt, 0, want_logits=False)
 toks, _ = c.decode_greedy(first, 128, 16)
 names = ["qkv", "attn", "wo", "w13", "w2", "head", "block"]
-out = {}
+if os.environ.get("AB_SCHED"):
+    c.set_schedule(os.environ["AB_SCHED"])
+out, reps = {}, {}
 for rep in range(3):
     for w, n in enumerate(names):
         ms = c.profile_kernel(w, 272, iters)
         out[n] = min(out.get(n, 1e9), round(ms * 1e3, 2))
-print(json.dumps({"so": os.path.basename(os.environ.get("LNB_SO", "default")), "us": out, "tok": [int(t) for t in toks[-3:]]}))
+        reps.setdefault(n, []).append(round(ms * 1e3, 2))
+print(json.dumps({"so": os.path.basename(os.environ.get("LNB_SO", "default")), "layers": cfg["n_layers"], "us": out, "reps": reps, "tok": [int(t) for t in toks[-3:]]}))
