@@ -976,9 +976,13 @@ static int gemv_stamps(lnb_ctx* c, int which, double* out, int full) {
     const size_t n = (size_t)4096 * 8 * 4, n2 = (size_t)4096 * 8 * 8;       // + 8 phase stamps per wave behind the four totals (LNB_STAMP in lnb_kernels.hip)
     long long* dbuf = nullptr;
     HIPCHK(hipMalloc((void**)&dbuf, (n + n2) * 8)); HIPCHK(hipMemsetAsync(dbuf, 0, (n + n2) * 8, st));
-    g_dbg = dbuf; g_dbg_full = full;
     const int nl = m->layer_end - m->layer_begin;
-    int rc = which == K_HEAD ? enqueue_head(c, 0, 1) : enqueue_layer_kernel(c, m->layer_begin + 7 % nl, 1, which);
+    // three plain launches of the class on other layers first, back to back with the stamped one: it then runs as a launch inside a decode step does
+    // (instruction cache, clocks and memory pipeline warm) instead of as the first launch after an idle gap
+    int rc = 0;
+    for (int i = 4; i < 7 && !rc; i++) rc = which == K_HEAD ? enqueue_head(c, 0, 1) : enqueue_layer_kernel(c, m->layer_begin + i % nl, 1, which);
+    g_dbg = dbuf; g_dbg_full = full;
+    if (!rc) rc = which == K_HEAD ? enqueue_head(c, 0, 1) : enqueue_layer_kernel(c, m->layer_begin + 7 % nl, 1, which);
     g_dbg = nullptr; g_dbg_full = 0;
     if (rc) { hipFree(dbuf); return -1; }
     HIPCHK(hipStreamSynchronize(st));

@@ -110,7 +110,7 @@ def test_stop_ids_only_count_for_the_until_entry_points(lnb):
     keeps an ended sequence frozen (start_pos < 0) instead of restarting it from its stop token."""
     om = orc.Model(**TINY).fill_synthetic(1234).finalize()
     gm = lnb.LlamaTransformer(**TINY).fill_synthetic(1234).finalize().enable_batch()
-    n, steps = 4, 24
+    n, steps = 4, 25                                          # (five chunks of five below)
     prompts = [orc.synth_tokens(300 + s, 6 + s, TINY["vocab_size"]) for s in range(n)]
     refs = [[int(t) for t in orc.Context(om, 64).generate(prompts[s], steps + 2)[0]] for s in range(n)]
     # single sequence: the stop id is on the context, lnb_decode_greedy runs through it and every token is the oracle's
