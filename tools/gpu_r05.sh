@@ -41,6 +41,15 @@ case "$mode" in
     timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_driver_args.json 2> gpurun_out/r05_bench_driver_args.err; echo "bench(20) rc=$?"
     wait $GP; tail -2 gpurun_out/gold32/log.txt; ls -la gpurun_out/gold32
     ;;
+  third)    # the round's records on an otherwise idle box: new tests, default line, driver arguments, configs[2], 70B-like shape, the N-GPU code path on one GPU
+    ( timeout 900 python -m pytest tests/test_gpu_round5.py -x -q ) 2>&1 | tail -6 | tee gpurun_out/r05_round5_tests.log
+    ( time timeout 900 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err; echo "bench rc=$?"; tail -3 gpurun_out/r05_bench_default.err
+    timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_driver_args.json 2> gpurun_out/r05_bench_driver_args.err; echo "bench(20) rc=$?"
+    timeout 900 python bench.py --prompt-len 4096 --steps 64 --warmup 8 --concurrent 0 --batch-sizes= --cpu-steps 0 > gpurun_out/r05_bench_configs2.json 2> gpurun_out/r05_bench_configs2.err; echo "cfg2 rc=$?"; tail -2 gpurun_out/r05_bench_configs2.err
+    ( time timeout 1200 python bench.py --model llama70b-like --steps 16 --warmup 2 --cpu-steps 0 ) > gpurun_out/r05_bench_70b_like.json 2> gpurun_out/r05_bench_70b_like.err; echo "70b rc=$?"; tail -3 gpurun_out/r05_bench_70b_like.err
+    LNB_FORCE_PIPELINE=1 LNB_FORCE_PREFLIGHT=1 timeout 900 python bench.py --gpus 1 --steps 64 --warmup 8 --cpu-steps 0 > gpurun_out/r05_bench_pipeline_one_gpu.json 2> gpurun_out/r05_bench_pipeline_one_gpu.err; echo "pipe rc=$?"; tail -4 gpurun_out/r05_bench_pipeline_one_gpu.err
+    for f in default driver_args configs2 70b_like pipeline_one_gpu; do echo "--- $f"; head -c 400 gpurun_out/r05_bench_$f.json; echo; done
+    ;;
   ab)       # env passes through
     ab "${1:-custom}"
     ;;
