@@ -50,6 +50,19 @@ case "$mode" in
     LNB_FORCE_PIPELINE=1 LNB_FORCE_PREFLIGHT=1 timeout 900 python bench.py --gpus 1 --steps 64 --warmup 8 --cpu-steps 0 > gpurun_out/r05_bench_pipeline_one_gpu.json 2> gpurun_out/r05_bench_pipeline_one_gpu.err; echo "pipe rc=$?"; tail -4 gpurun_out/r05_bench_pipeline_one_gpu.err
     for f in default driver_args configs2 70b_like pipeline_one_gpu; do echo "--- $f"; head -c 400 gpurun_out/r05_bench_$f.json; echo; done
     ;;
+  queues)   # sequences in flight against the number of hardware queues the HIP runtime spreads the streams over (GPU_MAX_HW_QUEUES, default 4)
+    Q="--steps 48 --warmup 4 --batch-sizes= --cpu-steps 0 --no-traffic-probe --no-configs2 --repeats 1 --profile-iters 4"
+    for q in default 2 8 16; do
+      for n in 2 8 16; do
+        if [ "$q" = default ]; then E="LNB_DUMMY=1"; else E="GPU_MAX_HW_QUEUES=$q"; fi
+        echo "== GPU_MAX_HW_QUEUES=$q, $n sequences in flight"
+        env $E timeout 300 python bench.py $Q --concurrent $n 2>/dev/null | python -c "
+import json,sys
+d=json.loads(sys.stdin.read()); s=d['sequences_in_flight']
+print('single', d['value'], '| n', s['n'], 'throughput', s['tokens_per_s'], 'latency', s['latency_forms_same_run']['tokens_per_s'], '| n2', s.get('n2',{}).get('tokens_per_s'), s.get('n2',{}).get('latency_forms_same_run',{}).get('tokens_per_s'))"
+      done
+    done 2>&1 | tee gpurun_out/r05_hw_queues.log
+    ;;
   ab)       # env passes through
     ab "${1:-custom}"
     ;;
