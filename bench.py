@@ -200,6 +200,16 @@ def configs2_record(lnb, model, cfg, args, a):
             "first_token": int(first)}
 
 
+def _c_getenv(name):
+    """the process environment as the C runtime sees it (liblnb_hip.so sets a default GPU_MAX_HW_QUEUES=16 while it is loaded: os.environ is a
+    snapshot taken at interpreter start and does not show it)"""
+    import ctypes
+    g = ctypes.CDLL(None).getenv
+    g.restype = ctypes.c_char_p
+    v = g(name.encode())
+    return v.decode() if v else None
+
+
 def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens, n_seq=None, sched="throughput"):
     """Not the headline (configs[1] is ONE prompt): the same resident model decoding `--concurrent` independent prompts at once, one
     context and stream each, through the one-GPU form of the pipeline tick path (lnb_pipeline_tick: captured stage graphs, device-side
@@ -232,7 +242,7 @@ def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens, n_seq=None
     tps = n_seq * K / wall
     Tbar = P + W + (K - 1) / 2.0 + 1.0
     B = algorithmic_bytes_per_token(a, model.ffn_hidden, Tbar)
-    return {"n": n_seq, "schedule": sched, "tokens_per_s": round(tps, 2), "steps_each": K, "ms_per_token": round(1e3 * wall / (n_seq * K), 4),
+    return {"n": n_seq, "schedule": sched, "GPU_MAX_HW_QUEUES": _c_getenv("GPU_MAX_HW_QUEUES"), "tokens_per_s": round(tps, 2), "steps_each": K, "ms_per_token": round(1e3 * wall / (n_seq * K), 4),
             "frac_of_hbm_roofline": round(tps * B / 1e9 / PEAK_HBM_GBS, 4),
             "sequence0_tokens_vs_single_run": {"compared": n_cmp, "identical_prefix": same},
             "note": "aggregate of independent prompts on ONE GPU; weights are re-read per sequence (no batching: every token keeps its own exact chains)"}

@@ -51,6 +51,14 @@ hipError_t lnbk_batch_prepare(void);
 hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream_t st);
 }
 
+// The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run one after the
+// other.  This library gives every context its own stream precisely so that several generations overlap on one GPU (one InferenceContext per
+// generation, inference.go:174; 2N contexts per pipeline rank): with the default, two contexts can land on ONE queue (2 in flight: 218 instead of
+// 278 tokens/s) and eight share four (306 instead of 337 tokens/s; profiles/r05_hw_queues.log).  The runtime reads the variable when it initialises
+// -- at the first HIP call of the process -- so a default set while this library is being loaded is in time unless the host has used HIP before;
+// a value the host exported wins.
+__attribute__((constructor)) static void lnb_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+
 static thread_local char g_err[1024] = "";
 static int fail(const char* fmt, ...) {
     va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap);

@@ -52,8 +52,8 @@ case "$mode" in
     ;;
   queues)   # sequences in flight against the number of hardware queues the HIP runtime spreads the streams over (GPU_MAX_HW_QUEUES, default 4)
     Q="--steps 48 --warmup 4 --batch-sizes= --cpu-steps 0 --no-traffic-probe --no-configs2 --repeats 1 --profile-iters 4"
-    for q in default 2 8 16; do
-      for n in 2 8 16; do
+    for q in ${QUEUES:-default 2 8 16}; do
+      for n in ${NSEQ:-2 8 16}; do
         if [ "$q" = default ]; then E="LNB_DUMMY=1"; else E="GPU_MAX_HW_QUEUES=$q"; fi
         echo "== GPU_MAX_HW_QUEUES=$q, $n sequences in flight"
         env $E timeout 300 python bench.py $Q --concurrent $n 2>/dev/null | python -c "
