@@ -187,6 +187,9 @@ public:
     std::vector<uint16_t> CacheK(int layer) const { return kv(layer, 0); }   // exported fields, poked by the reference's tests
     std::vector<uint16_t> CacheV(int layer) const { return kv(layer, 1); }
     lnb_ctx* handle() const { return h_; }
+    // hosts that keep several generations in flight on one GPU (one InferenceContext each, inference.go:174): the co-residency-friendly forms of
+    // the one-token kernels (lnb_ctx_set_schedule); same tokens either way
+    void SetThroughputSchedule(bool on) { check(lnb_ctx_set_schedule(h_, on ? LNB_SCHED_THROUGHPUT : LNB_SCHED_LATENCY)); }
 private:
     static void layer_cb(int layer, int n, double secs, void* user) {      // infContext.Logf(...), llamatransformer.go:163
         auto* self = (InferenceContext*)user;

@@ -63,6 +63,10 @@ print('single', d['value'], '| n', s['n'], 'throughput', s['tokens_per_s'], 'lat
       done
     done 2>&1 | tee gpurun_out/r05_hw_queues.log
     ;;
+  handoff)  # kernel boundary against an in-kernel grid hand-off on the decode kernels' launch shape (tools/handoff_bench.hip)
+    [ -x tools/handoff_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/handoff_bench.hip -o tools/handoff_bench
+    for steps in 2048 4096 8192; do timeout 120 tools/handoff_bench $steps; done 2>&1 | tee gpurun_out/r05_handoff_bench.log
+    ;;
   ab)       # env passes through
     ab "${1:-custom}"
     ;;
