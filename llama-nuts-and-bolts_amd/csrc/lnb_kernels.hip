@@ -155,6 +155,9 @@ __host__ __device__ inline size_t rms_scratch_bytes(int NH) { return (size_t)NH 
 #ifndef LNB_RMS_NF_MAX
 #define LNB_RMS_NF_MAX 8
 #endif
+#ifndef LNB_QUAD_R
+#define LNB_QUAD_R 5                                        // ring stages in flight per helper of gemv_quad_kernel<24, 256, ...> (A/B builds: 4, 6)
+#endif
 __host__ __device__ constexpr int rms_nf(int NH) { return NH > LNB_RMS_NF_MAX ? LNB_RMS_NF_MAX : NH; }
 __host__ __device__ inline size_t rms_list_off(int NH) { return (size_t)NH * 528; }
 __host__ __device__ inline size_t rms_meta_off(int NH) { return (size_t)NH * (528 + 2048); }
@@ -2982,7 +2985,7 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     // Throughput schedule (GemvParams.sched, lnb_ctx_set_schedule): the same kernel with 128-step stages -- 3 x 12 KiB of products + x = 55 KB of LDS
     // instead of 91 KB, so that a workgroup fits a CU beside the gate|up workgroup (75 KB) of another context's step; twice the stage barriers
     // (slower alone, which is why one stream keeps the 256-step form), ten stages of one load per helper in flight = the same 60 KiB per CU.
-    if constexpr (NCH == 1) if (rw == 24) return (p && p->sched) ? launch_quad_t<24, 128, 6, 10, EPI, NORM>(p, st) : launch_quad_t<24, 256, 6, 5, EPI, NORM>(p, st);
+    if constexpr (NCH == 1) if (rw == 24) return (p && p->sched) ? launch_quad_t<24, 128, 6, 10, EPI, NORM>(p, st) : launch_quad_t<24, 256, 6, LNB_QUAD_R, EPI, NORM>(p, st);
     // stage geometry (one workgroup per CU).  SA = bf16 bytes per stage, R = stages in flight per helper.
     //  RW 16/32 plain (thin; chain bound): 8 KiB stages, 2 helpers x 4 loads x 7 stages = 56 KiB in flight per CU.
     //  RW 32 with the fused RMSNorm (wq|wk|wv): six helpers so that the exact parallel norm sum has 384 folding lanes, and

@@ -67,6 +67,11 @@ print('single', d['value'], '| n', s['n'], 'throughput', s['tokens_per_s'], 'lat
     [ -x tools/handoff_bench ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 tools/handoff_bench.hip -o tools/handoff_bench
     for steps in 2048 4096 8192; do timeout 120 tools/handoff_bench $steps; done 2>&1 | tee gpurun_out/r05_handoff_bench.log
     ;;
+  variants) # compile-time variants of the library (ab_variants/*.so, built by hand with -D switches) against the default build, per-kernel timings
+    { ab "default build"
+      for so in ab_variants/*.so; do LNB_SO=$PWD/$so ab "$(basename $so .so)"; done
+      ab "default build again"; } 2>&1 | tee gpurun_out/r05_variants.log
+    ;;
   ab)       # env passes through
     ab "${1:-custom}"
     ;;
