@@ -72,6 +72,17 @@ print('single', d['value'], '| n', s['n'], 'throughput', s['tokens_per_s'], 'lat
       for so in ab_variants/*.so; do LNB_SO=$PWD/$so ab "$(basename $so .so)"; done
       ab "default build again"; } 2>&1 | tee gpurun_out/r05_variants.log
     ;;
+  profile)  # rocprofv3 of the bench command: kernel trace + stats, and the FETCH_SIZE counter pass on its own (tools/summarize_profile.py r05 condenses them)
+    O=$PWD/gpurun_out/prof_r05; mkdir -p $O
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 4 --repeats 1 --cpu-steps 0 --profile-iters 8 --concurrent 0 --batch-sizes= --no-traffic-probe > $O/trace_bench.json 2> $O/trace.err; echo "trace rc=$?" )
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --repeats 1 --cpu-steps 0 --profile-iters 4 --concurrent 0 --batch-sizes= --no-traffic-probe > $O/pmc_fetch_bench.json 2> $O/pmc_fetch.err; echo "pmc rc=$?" )
+    LNB_GEMV_TIMING=1 timeout 300 python tools/kernel_ab.py 50 > gpurun_out/r05_stamps.log 2>&1
+    find $O -name "*.csv" | head; du -sh gpurun_out
+    ;;
+  final)    # the round's closing record on one box: whole GPU suite, then the bench lines
+    ( timeout 1500 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -6 | tee gpurun_out/r05_gpu_suite.log
+    $0 third
+    ;;
   ab)       # env passes through
     ab "${1:-custom}"
     ;;
