@@ -645,6 +645,8 @@ def test_pipeline_stages_on_one_device_equal_whole_model(lnb, tiny_pair):
     hip = C.CDLL("libamdhip64.so")
     hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
     assert hip.hipMemcpy(dst, src, nbytes, 3) == 0                             # hipMemcpyDeviceToDevice
+    assert hip.hipDeviceSynchronize() == 0      # a device-to-device hipMemcpy need not have finished when it returns, and the contexts' streams are NON-blocking ones:
+                                                # nothing else orders the copy in front of the next stage's launches (seen once the library spread the streams over 16 hardware queues)
     logits = np.empty((6, TINY["vocab_size"]), dtype=np.float32)
     am = C.c_int32(-2)
     lnb._chk(L.lnb_forward_stage(c1.h, None, 6, 0, lnb._p(logits), C.byref(am)))
@@ -682,6 +684,7 @@ def test_pipeline_stages_cut_inside_a_block(lnb, tiny_pair, cuts, rows):
                 assert hip.hipMemcpy(L.lnb_ctx_hidden_ptr(ctxs[q + 1].h, 0), L.lnb_ctx_hidden_ptr(c.h, 1), len(t) * TINY["dim"] * 2, 3) == 0
                 if cuts[q + 1] % 3 == 2:                       # cut between gate/up and down: the activations travel too
                     assert hip.hipMemcpy(L.lnb_ctx_hidden_ptr(ctxs[q + 1].h, 2), L.lnb_ctx_hidden_ptr(c.h, 2), len(t) * F * 2, 3) == 0
+                assert hip.hipDeviceSynchronize() == 0         # (a D2D hipMemcpy may return before it has run; the contexts' streams do not wait for the null stream)
         return logits, am.value
 
     for lo_, hi_ in ((0, rows), (rows, rows + 1), (rows + 1, rows + 2)):
