@@ -81,9 +81,11 @@ DEVINL float4 mul4(const float4& x, float w0, float w1, float w2, float w3) {   
 // 512-element chunks per stager wave held in registers: 12 for the plain kernels (K up to 18k with 3 stagers), 6 for the
 // RMSNorm kernels (K = dim <= 8192; they also hold the norm weights and must stay clear of the 256-VGPR budget)
 template <bool NORM> struct XCh { static constexpr int value = NORM ? 6 : 12; };
-template <bool NORM, int NS>
-DEVINL void x_issue(const GemvParams& p, const uint16_t* xrow, int sidx, int lane, uint4 (&xv)[XCh<NORM>::value], uint4 (&nv)[XCh<NORM>::value]) {
-    constexpr int X_CH = XCh<NORM>::value;
+// X_CH (deduced from the register arrays) is a compile-time property of the kernel instance: the launchers pick the smallest count that covers the
+// row (2 for K = 4096 -- round 5: the norm-fused kernels used to carry 6 chunks' worth of clamped loads, lane-varying compares and registers
+// through x_issue / x_store / x_normalize; of the 2 k cycles x_normalize took, ~1.7 k were control flow around five empty rounds)
+template <bool NORM, int NS, int X_CH>
+DEVINL void x_issue(const GemvParams& p, const uint16_t* xrow, int sidx, int lane, uint4 (&xv)[X_CH], uint4 (&nv)[X_CH]) {
 #pragma unroll
     for (int i = 0; i < X_CH; i++) {
         // UNCONDITIONAL loads (address clamped, value zeroed afterwards): a predicated load would make hipcc
@@ -99,9 +101,8 @@ DEVINL void x_issue(const GemvParams& p, const uint16_t* xrow, int sidx, int lan
     }
 }
 // squares (NORM: Pow(x,2), exact in f32, operations_impl.go:197-217) or plain values; zeros in [K, kpad)
-template <bool NORM, int NS>
-DEVINL void x_store(const GemvParams& p, float* xs, int kpad, int sidx, int lane, const uint4 (&xv)[XCh<NORM>::value]) {
-    constexpr int X_CH = XCh<NORM>::value;
+template <bool NORM, int NS, int X_CH>
+DEVINL void x_store(const GemvParams& p, float* xs, int kpad, int sidx, int lane, const uint4 (&xv)[X_CH]) {
 #pragma unroll
     for (int i = 0; i < X_CH; i++) {
         const int k = ((i * NS + sidx) * 64 + lane) * 8;
@@ -470,9 +471,8 @@ template <int NH> DEVINL float rms_scale_wide(const GemvParams& p, const float* 
     return (float)(1.0 / sqrt((double)mean));
 }
 // trunc(x*r) then trunc(.*w): two truncations (llamatransformer.go:656,638), from the registers loaded by x_issue
-template <int NS>
-DEVINL void x_normalize(const GemvParams& p, float* xs, int kpad, float r, int sidx, int lane, const uint4 (&xv)[XCh<true>::value], const uint4 (&nv)[XCh<true>::value]) {
-    constexpr int X_CH = XCh<true>::value;
+template <int NS, int X_CH>
+DEVINL void x_normalize(const GemvParams& p, float* xs, int kpad, float r, int sidx, int lane, const uint4 (&xv)[X_CH], const uint4 (&nv)[X_CH]) {
 #pragma unroll
     for (int i = 0; i < X_CH; i++) {
         const int k = ((i * NS + sidx) * 64 + lane) * 8;
@@ -583,7 +583,7 @@ template <int N, int NP> DEVINL void wait_ring(u32x4 (&b)[NP]) {
     if constexpr (NP == 8) asm volatile("s_waitcnt vmcnt(%8) ; RING_RETIRE %0 %1 %2 %3 %4 %5 %6 %7" : "+v"(b[0]), "+v"(b[1]), "+v"(b[2]), "+v"(b[3]), "+v"(b[4]), "+v"(b[5]), "+v"(b[6]), "+v"(b[7]) : "n"(N) : "memory");
 }
 
-template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
+template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM, int XC = XCh<NORM>::value>
 __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long t_begin = p.dbg ? clock64() : 0, t_wait = 0, t_x = 0, t_aux = 0;
@@ -620,7 +620,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
         const int hw = wave < CW ? wave : wave - 1;
         u32x4 buf[R][NP];
         {
-            uint4 xv[XCh<NORM>::value], nv[XCh<NORM>::value];
+            uint4 xv[XC], nv[XC];
             x_issue<NORM, NS>(p, xrow, 1 + hw, lane, xv, nv);
             __builtin_amdgcn_s_waitcnt(0x0F70);                        // vmcnt(0): x (and the norm weights) have landed; hipcc needs no
                                                                        // wait of its own in x_store, which would drain the ring below too
@@ -734,7 +734,7 @@ __global__ __launch_bounds__((1 + NH) * 64) void gemv_chain_kernel(GemvParams p)
     }
     // ==================================== chain wave ==================================================
     {
-        uint4 xv[XCh<NORM>::value], nv[XCh<NORM>::value];
+        uint4 xv[XC], nv[XC];
         x_issue<NORM, NS>(p, xrow, 0, lane, xv, nv);
         x_store<NORM, NS>(p, xs, kpad, 0, lane, xv);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -847,7 +847,7 @@ DEVINL void chain16q(float& acc, const float4& q) {
 }
 constexpr int GQ_SLOTS = 3;
 __host__ __device__ constexpr int gq_ncw(int RW) { return (RW + 15) / 16; }
-template <int RW, int KS, int NH, int R, int EPI, bool NORM>
+template <int RW, int KS, int NH, int R, int EPI, bool NORM, int XC = XCh<NORM>::value>
 __global__ __launch_bounds__((gq_ncw(RW) + NH) * 64) void gemv_quad_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     long long t_begin = p.dbg ? clock64() : 0, t_wait = 0, t_x = 0, t_aux = 0;
@@ -882,7 +882,7 @@ __global__ __launch_bounds__((gq_ncw(RW) + NH) * 64) void gemv_quad_kernel(GemvP
         // ================================ helper waves ============================================
         const int hw = wave - NCW;
         u32x4 buf[R][NP];
-        uint4 xv[XCh<NORM>::value], nv[XCh<NORM>::value];
+        uint4 xv[XC], nv[XC];
         x_issue<NORM, NS>(p, xrow, wave, lane, xv, nv);
         __builtin_amdgcn_s_waitcnt(0x0F70);                            // vmcnt(0): x (and the norm weights) have landed (see gemv_chain_kernel)
         const size_t last16 = stream_bytes - 16;
@@ -965,7 +965,7 @@ __global__ __launch_bounds__((gq_ncw(RW) + NH) * 64) void gemv_quad_kernel(GemvP
     }
     // ==================================== chain waves ==================================================
     {
-        uint4 xv[XCh<NORM>::value], nv[XCh<NORM>::value];
+        uint4 xv[XC], nv[XC];
         x_issue<NORM, NS>(p, xrow, wave, lane, xv, nv);
         LNB_STAMP(0);
         x_store<NORM, NS>(p, xs, kpad, wave, lane, xv);
@@ -2949,32 +2949,59 @@ __global__ void synth_fill_kernel(uint16_t* dst, int rows, int K, int row_off, i
 // x staging: a whole number of stages (steps per stage = stage_bytes / (nch*rw*2)) + 64 floats of slack
 static size_t xs_bytes(int K, int steps_per_stage) { return ((size_t)((K + steps_per_stage - 1) / steps_per_stage) * steps_per_stage + 320) * 4 + 16; }
 
-template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
-static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
-    auto kfn = gemv_chain_kernel<RW, NCH, SA, NH, R, EPI, NORM>;
+template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM, int XC>
+static hipError_t launch_chain_x(const GemvParams* p, hipStream_t st) {
+    auto kfn = gemv_chain_kernel<RW, NCH, SA, NH, R, EPI, NORM, XC>;
     if (!p)   // prepare: raise the dynamic-LDS limit once, outside any stream capture
         return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     size_t lds = 4 * (size_t)SA + xs_bytes(p->K, SA / (NCH * RW * 2));
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (xs_bytes(p->K, SA / (NCH * RW * 2)) / 4 > (size_t)XCh<NORM>::value * (1 + NH) * 512) return hipErrorInvalidValue;   // x staging registers
+    if (xs_bytes(p->K, SA / (NCH * RW * 2)) / 4 > (size_t)XC * (1 + NH) * 512) return hipErrorInvalidValue;   // x staging registers
     if (NORM && (rms_scratch_bytes(rms_nf(NH)) > 4 * (size_t)SA || seq_leaf_size(p->K, rms_nf(NH) * 64) > 256)) return hipErrorInvalidValue;   // records live in the idle ring; leaf over-read stays inside the x padding
     hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3((1 + NH) * 64), lds, st, *p);
     return hipGetLastError();
 }
+// x staging chunks per stager wave: the norm-fused kernels are instantiated for 2, 3 and 6 chunks of 512 elements per wave (K up to ~4 K, ~6 K / 12 K with
+// the 70B-like shape's 8192 in the middle one, 24 K) and the smallest that holds the padded row is launched; the plain kernels keep their 12
+template <int RW, int NCH, int SA, int NH, int R, int EPI, bool NORM>
+static hipError_t launch_chain_t(const GemvParams* p, hipStream_t st) {
+    if constexpr (NORM) {
+        if (!p) {
+            hipError_t e = launch_chain_x<RW, NCH, SA, NH, R, EPI, NORM, 2>(p, st);
+            if (e == hipSuccess) e = launch_chain_x<RW, NCH, SA, NH, R, EPI, NORM, 3>(p, st);
+            return e != hipSuccess ? e : launch_chain_x<RW, NCH, SA, NH, R, EPI, NORM, XCh<NORM>::value>(p, st);
+        }
+        const size_t need = xs_bytes(p->K, SA / (NCH * RW * 2)) / 4, per = (size_t)(1 + NH) * 512;
+        if (need <= 2 * per) return launch_chain_x<RW, NCH, SA, NH, R, EPI, NORM, 2>(p, st);
+        if (need <= 3 * per) return launch_chain_x<RW, NCH, SA, NH, R, EPI, NORM, 3>(p, st);
+    }
+    return launch_chain_x<RW, NCH, SA, NH, R, EPI, NORM, XCh<NORM>::value>(p, st);
+}
 
-template <int RW, int KS, int NH, int R, int EPI, bool NORM>
-static hipError_t launch_quad_t(const GemvParams* p, hipStream_t st) {
-    auto kfn = gemv_quad_kernel<RW, KS, NH, R, EPI, NORM>;
+template <int RW, int KS, int NH, int R, int EPI, bool NORM, int XC>
+static hipError_t launch_quad_x(const GemvParams* p, hipStream_t st) {
+    auto kfn = gemv_quad_kernel<RW, KS, NH, R, EPI, NORM, XC>;
     if (!p) return hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     constexpr int NW = gq_ncw(RW) + NH;
     constexpr size_t SB = (size_t)RW * KS * 4;
     if (p->K % KS) return hipErrorInvalidValue;                                  // whole stages only (auto_rw in lnb_api.cpp picks this layout accordingly)
     const size_t lds = GQ_SLOTS * SB + xs_bytes(p->K, KS);
     if (lds > 160 * 1024) return hipErrorInvalidValue;
-    if (xs_bytes(p->K, KS) / 4 > (size_t)XCh<NORM>::value * NW * 512) return hipErrorInvalidValue;     // x staging registers
+    if (xs_bytes(p->K, KS) / 4 > (size_t)XC * NW * 512) return hipErrorInvalidValue;     // x staging registers
     if (NORM && (rms_scratch_bytes(rms_nf(NH)) > GQ_SLOTS * SB || seq_leaf_size(p->K, rms_nf(NH) * 64) > 256)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3(NW * 64), lds, st, *p);
     return hipGetLastError();
+}
+template <int RW, int KS, int NH, int R, int EPI, bool NORM>
+static hipError_t launch_quad_t(const GemvParams* p, hipStream_t st) {
+    if constexpr (NORM) {
+        if (!p) {
+            hipError_t e = launch_quad_x<RW, KS, NH, R, EPI, NORM, 2>(p, st);
+            return e != hipSuccess ? e : launch_quad_x<RW, KS, NH, R, EPI, NORM, XCh<NORM>::value>(p, st);
+        }
+        if (xs_bytes(p->K, KS) / 4 <= (size_t)2 * (gq_ncw(RW) + NH) * 512) return launch_quad_x<RW, KS, NH, R, EPI, NORM, 2>(p, st);
+    }
+    return launch_quad_x<RW, KS, NH, R, EPI, NORM, XCh<NORM>::value>(p, st);
 }
 
 static bool env_tp_w13() { static const int on = [] { const char* e = getenv("LNB_TP_W13"); return e && *e ? atoi(e) : 1; }(); return on != 0; }   // (A/B switch of the throughput gate|up form)
