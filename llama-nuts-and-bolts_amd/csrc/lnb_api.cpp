@@ -680,8 +680,11 @@ static hipError_t gemm_dispatch(int mode, const GemmParams* g, int epi, hipStrea
     if (mode == LNB_MODE_FAST && g->S >= min_rows) { hipError_t e = lnbk_fast_gemm(g, epi, st); if (e != hipErrorNotSupported) return e; }
     // exact order with the matrix-core copy of the weights present (lnb_model_enable_batch): the streaming feed -- the same chains, the
     // same bits (tests/test_gpu_batch.py), the weights never staged through the LDS; LNB_PREFILL_STREAM=0 keeps the LDS-tiled kernel
-    static const int stream_on = env_int("LNB_PREFILL_STREAM", 1);
-    if (stream_on && g->w16 && (g->K & 127) == 0) return lnbk_gemm_stream(g, epi, g_num_cus, st);
+    // Round 5: the same kernel also reads the RESIDENT layouts (no copy needed: the row-broadcast units are M16 units in another order, the chain
+    // layouts' units are transposed inside the lane quads); LNB_PREFILL_NATIVE=0 keeps the LDS-tiled kernel for models without the copy
+    static const int stream_on = env_int("LNB_PREFILL_STREAM", 1), native_on = env_int("LNB_PREFILL_NATIVE", 1);
+    if (stream_on && (g->K & 127) == 0 && (g->w16 || (native_on && g->w && (g->rw == 4 ? g->nch == 1 && (epi == EPI_STORE || epi == EPI_RESID) : g->rw >= 16))))
+        return lnbk_gemm_stream(g, epi, g_num_cus, st);
     return lnbk_gemm(g, epi, st);
 }
 static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t st_other = nullptr, int lds_pad = 0) {

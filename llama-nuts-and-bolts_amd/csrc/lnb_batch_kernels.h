@@ -425,11 +425,42 @@ DEVINL void ld_plain(u32x4& d, const void* a) { asm volatile("global_load_dwordx
 #define GS_OCC1 2                                            // waves per SIMD the register budget is set for at NTW = 1 / NTW = 2 (tools/gemmstream_bench.hip sweeps them)
 #define GS_OCC2 2
 #endif
-template <int EPI, int NCH, int NTW>
+// SRC: where the A operand comes from.  0 = the M16 copy (lnb_model_enable_batch).  Round 5 -- the RESIDENT layouts, no second copy:
+//   1 = the row-broadcast layout of wo / w2 (tag RW 4): its 16-byte units ARE M16 units (the eight k of one row with the same k % 16), only their order
+//       in memory differs -- lane (i, kk) finds unit (m) of chunk C at ((4 tile + i / 4) * K / 128 + C) * 1024 + ((i % 4) * 16 + 4 m + kk) * 16: same loads,
+//       same unpack, different address arithmetic;
+//   2 = the chain layouts [N/RW][K/8][NCH][RW][8] (wq|wk|wv, w1|w3, output): a unit holds EIGHT CONSECUTIVE k of one row, so the four lanes (i, 0..3) of a
+//       quad load the four units of 32 consecutive k (load j of a chunk: k = 128 C + 32 j + 8 kk ...) and every k-group's operand is fetched from the quad
+//       lane that holds it: two v_mov_b32_dpp quad_perm broadcasts (the dword pair with the group's four k) + one v_perm_b32 (element kk) per matrix
+//       instruction and chain instead of one shift -- shared by the NTW batch tiles of the wave, hidden behind the matrix pipe.
+// The k-groups are consumed in the same ascending order in all three, so the chains -- and the bits -- are the same (tests/test_gpu_batch.py).
+template <int G> DEVINL float ct_elem(const u32x4& v, unsigned sel) {      // chain layouts: operand of k-group G (0..7) of a load's 32 k, for this lane's kk (sel)
+    constexpr int q = G >> 1, dw = (G & 1) * 2;
+    const int d0 = __builtin_amdgcn_update_dpp(0, (int)v[dw], q * 0x55, 0xf, 0xf, false);          // quad_perm:[q,q,q,q]
+    const int d1 = __builtin_amdgcn_update_dpp(0, (int)v[dw + 1], q * 0x55, 0xf, 0xf, false);
+    return __uint_as_float(__builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, sel));
+}
+// a byte offset that IS wave-uniform, told to the compiler (its divergence analysis loses track of the issue cursor through the lambdas: the "s" operand
+// of the asm loads would be handed a VGPR pair)
+DEVINL size_t uniform_off(size_t off) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)off), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(off >> 32));
+    return ((size_t)hi << 32) | lo;
+}
+DEVINL void ld_w_plain(u32x4& d, unsigned voff, const char* sb) { asm volatile("global_load_dwordx4 %0, %1, %2 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory"); }
+template <int M> DEVINL void ld_rc_unit(u32x4& d, unsigned voff, const char* sb) {     // row-broadcast layout: unit m of the lane's row and chunk sits 64 m bytes further
+    static_assert(M >= 0 && M < 4, "unit");
+    if constexpr (M == 0) asm volatile("global_load_dwordx4 %0, %1, %2 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:64 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:128 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+    if constexpr (M == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
+}
+template <int EPI, int NCH, int NTW, int SRC = 0>
 __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW == 4 ? 2 : 1) void gemm_stream_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int L = NCH * 4 + NTW;                         // loads per chunk and lane: NCH * 4 weight units + NTW activation units
-    constexpr int R = NCH == 1 ? (NTW == 1 ? GS_R1 : NTW == 2 ? GS_R2 : 3) : 3;   // chunks in flight.  A chunk of one batch tile is 32 matrix instructions = ~1.5k
+    constexpr int R = NCH == 1 ? (NTW == 1 ? GS_R1 : NTW == 2 ? GS_R2 : 3) : (SRC == 2 && NTW == 4) ? 2 : 3;   // chunks in flight (two chains x four batch tiles from a chain
+                                                             // layout: 2 -- a chunk is then 256 matrix instructions = 3.6 us of lookahead each, and the third slot's 48
+                                                             // registers spilled).  A chunk of one batch tile is 32 matrix instructions = ~1.5k
                                                              // cycles of a wave: three of them in flight are less than HBM's latency under load
     static_assert(R * L <= 60, "vmcnt is a 6-bit counter");
     constexpr int D = NTW == 1 ? 3 : NTW == 2 ? 2 : 1;       // B-operand reads run this many steps (of four k-groups) ahead of their matrix instructions
@@ -446,6 +477,12 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
     const int T = rounds * nchunks;
     const size_t chain_bytes = (size_t)nchunks * 4096;
     const unsigned aoff = (unsigned)(((lane & 15) * 4 + (lane >> 4)) * 16);
+    // resident layouts: per-lane byte offsets of this lane's (row i = lane & 15, kk = lane >> 4)
+    const unsigned rc_voff = (unsigned)(((lane & 15) >> 2) * nchunks * 1024 + (((lane & 15) & 3) * 16 + (lane >> 4)) * 16);
+    const int ct_rw = p.rw > 0 ? p.rw : 16;                   // (chain layouts only)
+    const unsigned ct_s8 = (unsigned)(NCH * ct_rw * 16);     // bytes from one 8-wide k chunk of a row block to the next
+    const unsigned ct_sel = 0x0c0cu | ((uint32_t)(2 * (lane >> 4)) << 16) | ((uint32_t)(2 * (lane >> 4) + 1) << 24);       // v_perm_b32: element kk of a four-element dword pair
+    unsigned ct_voff = 0; size_t ct_base = 0; int ct_tile = -1;
     float* Bs = (float*)smem;                                // [2][rows_wg][GS_PITCH]
     constexpr size_t bs_stride = (size_t)rows_wg * GS_PITCH;
     const int srow = lane & 15, scol = wave * 4 + (lane >> 4);                     // staging: row inside a batch tile, 16-byte k-unit of the chunk
@@ -457,8 +494,29 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
     auto tile_of = [&](int round) { int t = (round * (int)gridDim.x + bx) * 4 + wave; return t < n_tiles ? t : n_tiles - 1; };
     auto issue_next = [&](u32x4 (&dst)[L]) {
         const int tile = tile_of(ir);
+        if constexpr (SRC == 2) {
+            if (tile != ct_tile) {                           // (wave-uniform; once per weight tile) the lane's row: block b and row r inside it; b0 = the tile's first block
+                int n = tile * 16 + (lane & 15); n = n < p.n_rows ? n : p.n_rows - 1;
+                const int b0 = (tile * 16) / ct_rw, b = n / ct_rw, r = n - b * ct_rw;
+                ct_voff = (unsigned)(b - b0) * (unsigned)(p.K >> 3) * ct_s8 + (unsigned)r * 16u + (unsigned)(lane >> 4) * ct_s8;
+                ct_base = (size_t)b0 * (size_t)(p.K >> 3) * ct_s8;
+                ct_tile = tile;
+            }
+        }
 #pragma unroll
         for (int c = 0; c < NCH; c++) {
+            if constexpr (SRC == 1) {
+                const char* wb = (const char*)p.w + uniform_off(((size_t)tile * 4 * nchunks + (size_t)ic) * 1024);
+                ld_rc_unit<0>(dst[c * 4 + 0], rc_voff, wb); ld_rc_unit<1>(dst[c * 4 + 1], rc_voff, wb);
+                ld_rc_unit<2>(dst[c * 4 + 2], rc_voff, wb); ld_rc_unit<3>(dst[c * 4 + 3], rc_voff, wb);
+                continue;
+            }
+            if constexpr (SRC == 2) {
+                const size_t o0 = uniform_off(ct_base + (size_t)c * (size_t)(ct_rw * 16) + (size_t)(16 * ic) * ct_s8), oj = uniform_off((size_t)4 * ct_s8);
+#pragma unroll
+                for (int jj = 0; jj < 4; jj++) ld_w_plain(dst[c * 4 + jj], ct_voff, (const char*)p.w + o0 + (size_t)jj * oj);
+                continue;
+            }
             const char* wb = (const char*)p.w16 + (size_t)(tile * NCH + c) * chain_bytes + ((GS_DBG & 16) ? 0 : (size_t)ic * 4096);
             if constexpr (GS_W_NT) {
                 ld_unit_nt<0>(dst[c * 4 + 0], aoff, wb); ld_unit_nt<1>(dst[c * 4 + 1], aoff, wb);
@@ -520,10 +578,15 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                     constexpr int e = decltype(ec)::value;
                     if constexpr (e + D < 8 && !(GS_DBG & 64)) lds_issue(std::integral_constant<int, e + D>{});
                     float av[NCH][4];
+                    static_for<0, 4>([&](auto mc) __attribute__((always_inline)) {
+                        constexpr int m = decltype(mc)::value;
 #pragma unroll
-                    for (int m = 0; m < 4; m++)
-#pragma unroll
-                        for (int cc = 0; cc < NCH; cc++) av[cc][m] = (GS_DBG & 32) ? __uint_as_float(buf[j][cc * 4 + m][e >> 1]) : unit_elem(buf[j][cc * 4 + m], e);
+                        for (int cc = 0; cc < NCH; cc++) {
+                            // chain layouts: k-group g = 4 e + m lives in load g / 8 = e / 2 of the chunk, as group 4 (e % 2) + m of its 32 k
+                            if constexpr (SRC == 2) av[cc][m] = ct_elem<4 * (e & 1) + m>(buf[j][cc * 4 + (e >> 1)], ct_sel);
+                            else av[cc][m] = (GS_DBG & 32) ? __uint_as_float(buf[j][cc * 4 + m][e >> 1]) : unit_elem(buf[j][cc * 4 + m], e);
+                        }
+                    });
                     if constexpr (e == 7) {                  // every weight register of the slot has been read (the x registers were consumed above): refill
 #pragma unroll
                         for (int m = 0; m < 4; m++)

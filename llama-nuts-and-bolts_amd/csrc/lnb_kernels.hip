@@ -3362,7 +3362,10 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
 #undef LNB_GS_PREP
         return e;
     }
-    if (!p->w16 || (p->K & 127) || p->S < 1) return hipErrorInvalidValue;
+    // A operand: the M16 copy when the model carries one, else the RESIDENT layout (round 5: no second copy needed for a prompt) -- the row-broadcast
+    // layout's units are M16 units in another order (src 1), the chain layouts' units hold eight consecutive k and are transposed inside the quad (src 2)
+    const int src = p->w16 ? 0 : (p->w && p->rw == 4 && NCH == 1 && (EPI == EPI_STORE || EPI == EPI_RESID)) ? 1 : (p->w && p->rw >= 16 && p->nch == NCH) ? 2 : -1;
+    if (src < 0 || (p->K & 127) || p->S < 1) return hipErrorInvalidValue;
     const int n_tiles = (p->n_rows + 15) / 16;
     const int ct = (p->S + 15) / 16;                         // batch tiles of 16 rows
     int ntw = lnb_gemm_stream_ntw(n_tiles, ct, NCH, num_cus);
@@ -3380,11 +3383,14 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
     static const int order = getenv("LNB_GS_ORDER") ? atoi(getenv("LNB_GS_ORDER")) : -1;
     q.rows_fastest = order >= 0 ? order : lnb_gemm_stream_rows_fastest((int)grid.y);
     const size_t lds = (size_t)2 * rows_wg * GS_PITCH * 4;
-    switch (ntw) {
-    case 1: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 1>), grid, dim3(256), lds, st, q); break;
-    case 2: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 2>), grid, dim3(256), lds, st, q); break;
-    default: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 4>), grid, dim3(256), lds, st, q); break;
-    }
+#define LNB_GS_LAUNCH(SRC_) switch (ntw) { \
+    case 1: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 1, SRC_>), grid, dim3(256), lds, st, q); break; \
+    case 2: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 2, SRC_>), grid, dim3(256), lds, st, q); break; \
+    default: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 4, SRC_>), grid, dim3(256), lds, st, q); break; }
+    if (src == 0) { LNB_GS_LAUNCH(0) }
+    else if (src == 2) { LNB_GS_LAUNCH(2) }
+    else if constexpr (NCH == 1 && (EPI == EPI_STORE || EPI == EPI_RESID)) { LNB_GS_LAUNCH(1) }
+#undef LNB_GS_LAUNCH
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream_t st) {

@@ -83,6 +83,13 @@ print('single', d['value'], '| n', s['n'], 'throughput', s['tokens_per_s'], 'lat
     ( timeout 1500 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -6 | tee gpurun_out/r05_gpu_suite.log
     $0 third
     ;;
+  prefill)  # exact prefill: the streaming kernel on the RESIDENT layouts (default) against the LDS-tiled kernel and the M16 copy; parity tests first
+    ( timeout 900 python -m pytest tests/test_gpu_batch.py tests/test_gpu_full_8b.py tests/test_gpu_round5.py -x -q -k "prefill or golden or 8b or full" ) 2>&1 | tail -5
+    ( timeout 900 python -m pytest tests/test_gpu_parity.py tests/test_gpu_configs.py -x -q ) 2>&1 | tail -3
+    { echo "== resident layouts (default)"; timeout 600 python tools/prefill_bench.py --modes exact --sizes 16,64,128,256,512,2048,4096
+      echo "== LDS-tiled kernel (LNB_PREFILL_NATIVE=0)"; LNB_PREFILL_NATIVE=0 timeout 600 python tools/prefill_bench.py --modes exact --sizes 16,64,128,256,512,2048,4096
+      echo "== M16 copy (--stream)"; timeout 600 python tools/prefill_bench.py --modes exact --stream --sizes 16,64,128,256,512,2048,4096; } 2>&1 | tee gpurun_out/r05_prefill.log
+    ;;
   ab)       # env passes through
     ab "${1:-custom}"
     ;;
