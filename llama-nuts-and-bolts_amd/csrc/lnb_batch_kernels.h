@@ -429,16 +429,26 @@ DEVINL void ld_plain(u32x4& d, const void* a) { asm volatile("global_load_dwordx
 //   1 = the row-broadcast layout of wo / w2 (tag RW 4): its 16-byte units ARE M16 units (the eight k of one row with the same k % 16), only their order
 //       in memory differs -- lane (i, kk) finds unit (m) of chunk C at ((4 tile + i / 4) * K / 128 + C) * 1024 + ((i % 4) * 16 + 4 m + kk) * 16: same loads,
 //       same unpack, different address arithmetic;
-//   2 = the chain layouts [N/RW][K/8][NCH][RW][8] (wq|wk|wv, w1|w3, output): a unit holds EIGHT CONSECUTIVE k of one row, so the four lanes (i, 0..3) of a
-//       quad load the four units of 32 consecutive k (load j of a chunk: k = 128 C + 32 j + 8 kk ...) and every k-group's operand is fetched from the quad
-//       lane that holds it: two v_mov_b32_dpp quad_perm broadcasts (the dword pair with the group's four k) + one v_perm_b32 (element kk) per matrix
-//       instruction and chain instead of one shift -- shared by the NTW batch tiles of the wave, hidden behind the matrix pipe.
+//   2 = the chain layouts [N/RW][K/8][NCH][RW][8] (wq|wk|wv, w1|w3, output): a unit holds EIGHT CONSECUTIVE k of one row.  The four lanes that feed one
+//       row of the A operand -- (i, kk = 0..3) = lanes i, i + 16, i + 32, i + 48: one in each 16-lane row of the wave -- load the four units of 32
+//       consecutive k (load j of a chunk: k = 128 C + 32 j + 8 kk ...), and a 4 x 4 transpose over the wave's ROWS hands every lane the element it owns of
+//       each of the eight k-groups: v_permlane16_swap_b32 + v_permlane32_swap_b32, the row swaps new in gfx950 (tools/permlane_probe.hip prints what they
+//       do), 12 of them + 8 v_perm_b32 half-selects per 8 matrix instructions and chain instead of 8 shifts -- shared by the NTW batch tiles of the wave,
+//       hidden behind the matrix pipe.  (A DPP quad is four ADJACENT lanes, i.e. four different rows of the operand: quad_perm cannot do this.)
 // The k-groups are consumed in the same ascending order in all three, so the chains -- and the bits -- are the same (tests/test_gpu_batch.py).
-template <int G> DEVINL float ct_elem(const u32x4& v, unsigned sel) {      // chain layouts: operand of k-group G (0..7) of a load's 32 k, for this lane's kk (sel)
-    constexpr int q = G >> 1, dw = (G & 1) * 2;
-    const int d0 = __builtin_amdgcn_update_dpp(0, (int)v[dw], q * 0x55, 0xf, 0xf, false);          // quad_perm:[q,q,q,q]
-    const int d1 = __builtin_amdgcn_update_dpp(0, (int)v[dw + 1], q * 0x55, 0xf, 0xf, false);
-    return __uint_as_float(__builtin_amdgcn_perm((unsigned)d1, (unsigned)d0, sel));
+DEVINL void ct_ops(float (&op)[8], const u32x4& v, unsigned sel) {      // chain layouts: the eight operands (k-groups g' = 0..7 of a load's 32 k) of this lane
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        // source row r (the lane kk = r of the quartet) holds k = 8 r + 4 h + {0, 1} in P and + {2, 3} in Q; k-group g' = 2 r + h wants, in target row t,
+        // element t of those four: rows 0, 1 take P's halves, rows 2, 3 take Q's
+        const unsigned P = v[2 * h], Q = v[2 * h + 1];
+        const auto pp = __builtin_amdgcn_permlane16_swap(P, P, false, false);              // [P0 P0 P2 P2], [P1 P1 P3 P3]   (rows of the wave)
+        const auto qq = __builtin_amdgcn_permlane16_swap(Q, Q, false, false);
+        const auto a = __builtin_amdgcn_permlane32_swap(pp[0], qq[0], false, false);       // [P0 P0 Q0 Q0], [P2 P2 Q2 Q2]
+        const auto b = __builtin_amdgcn_permlane32_swap(pp[1], qq[1], false, false);       // [P1 P1 Q1 Q1], [P3 P3 Q3 Q3]
+        op[0 + h] = __uint_as_float(__builtin_amdgcn_perm(0u, a[0], sel)); op[2 + h] = __uint_as_float(__builtin_amdgcn_perm(0u, b[0], sel));
+        op[4 + h] = __uint_as_float(__builtin_amdgcn_perm(0u, a[1], sel)); op[6 + h] = __uint_as_float(__builtin_amdgcn_perm(0u, b[1], sel));
+    }
 }
 // a byte offset that IS wave-uniform, told to the compiler (its divergence analysis loses track of the issue cursor through the lambdas: the "s" operand
 // of the asm loads would be handed a VGPR pair)
@@ -481,7 +491,7 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
     const unsigned rc_voff = (unsigned)(((lane & 15) >> 2) * nchunks * 1024 + (((lane & 15) & 3) * 16 + (lane >> 4)) * 16);
     const int ct_rw = p.rw > 0 ? p.rw : 16;                   // (chain layouts only)
     const unsigned ct_s8 = (unsigned)(NCH * ct_rw * 16);     // bytes from one 8-wide k chunk of a row block to the next
-    const unsigned ct_sel = 0x0c0cu | ((uint32_t)(2 * (lane >> 4)) << 16) | ((uint32_t)(2 * (lane >> 4) + 1) << 24);       // v_perm_b32: element kk of a four-element dword pair
+    const unsigned ct_sel = ((lane >> 4) & 1) ? 0x03020c0cu : 0x01000c0cu;      // v_perm_b32: the low (kk even) / high (kk odd) half of a dword, widened to f32
     unsigned ct_voff = 0; size_t ct_base = 0; int ct_tile = -1;
     float* Bs = (float*)smem;                                // [2][rows_wg][GS_PITCH]
     constexpr size_t bs_stride = (size_t)rows_wg * GS_PITCH;
@@ -574,19 +584,22 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                         }
                 };
                 if constexpr (!(GS_DBG & 64)) static_for<0, D>(lds_issue);
+                float opq[NCH][8];                           // (chain layouts) the operands of the current load's eight k-groups
                 static_for<0, 8>([&](auto ec) __attribute__((always_inline)) {
                     constexpr int e = decltype(ec)::value;
                     if constexpr (e + D < 8 && !(GS_DBG & 64)) lds_issue(std::integral_constant<int, e + D>{});
                     float av[NCH][4];
-                    static_for<0, 4>([&](auto mc) __attribute__((always_inline)) {
-                        constexpr int m = decltype(mc)::value;
+                    if constexpr (SRC == 2 && (e & 1) == 0) {      // chain layouts: load e / 2 of the chunk carries the k-groups 4 e .. 4 e + 7; all eight operands at once
+#pragma unroll
+                        for (int cc = 0; cc < NCH; cc++) ct_ops(opq[cc], buf[j][cc * 4 + (e >> 1)], ct_sel);
+                    }
+#pragma unroll
+                    for (int m = 0; m < 4; m++)
 #pragma unroll
                         for (int cc = 0; cc < NCH; cc++) {
-                            // chain layouts: k-group g = 4 e + m lives in load g / 8 = e / 2 of the chunk, as group 4 (e % 2) + m of its 32 k
-                            if constexpr (SRC == 2) av[cc][m] = ct_elem<4 * (e & 1) + m>(buf[j][cc * 4 + (e >> 1)], ct_sel);
+                            if constexpr (SRC == 2) av[cc][m] = opq[cc][4 * (e & 1) + m];
                             else av[cc][m] = (GS_DBG & 32) ? __uint_as_float(buf[j][cc * 4 + m][e >> 1]) : unit_elem(buf[j][cc * 4 + m], e);
                         }
-                    });
                     if constexpr (e == 7) {                  // every weight register of the slot has been read (the x registers were consumed above): refill
 #pragma unroll
                         for (int m = 0; m < 4; m++)
