@@ -1231,8 +1231,18 @@ extern "C" int lnb_batch_create(lnb_ctx* const* ctxs, int n, lnb_batch** out) {
         if (ctxs[s]->mode != LNB_MODE_EXACT) return fail("context %d is in the tolerance mode: batched decode is exact-order only", s);
     }
     lnb_model* m = ctxs[0]->m;
-    if (!m->batch_enabled) return fail("lnb_model_enable_batch has not been called on this model");
     HIPCHK(hipSetDevice(m->device));
+    if (!m->batch_enabled) {
+        // Round 5: batches of MORE than 32 sequences are rows of the streaming product, which reads the RESIDENT weight layouts as well (gemm_stream_kernel,
+        // SRC 1 / 2): no second copy.  Only the column forms of up to 32 sequences (mfma_stream_kernel / mfma_pair_kernel) read the M16 copy.
+        if (n <= 2 * LNB_STREAM_COLS)
+            return fail("lnb_model_enable_batch has not been called on this model: batches of up to %d sequences run on the matrix-core copy of the weights "
+                        "(batches of %d..%d sequences do not need it)", 2 * LNB_STREAM_COLS, 2 * LNB_STREAM_COLS + 1, LNB_BATCH_MAX);
+        if (m->part_begin % 3 || m->part_end % 3) return fail("batched decode needs a stage of whole blocks (this one is cut inside a block: parts [%d, %d))", m->part_begin, m->part_end);
+        if (m->a.dim % 128 || m->q_dim % 128 || m->ffn_hidden % 128)
+            return fail("batched decode streams the weights in 128-step chunks: dim (%d), n_heads*head_dim (%d) and the FFN hidden size (%d) must be multiples of 128", m->a.dim, m->q_dim, m->ffn_hidden);
+        HIPCHK(lnbk_batch_prepare());
+    }
     lnb_batch* b = new lnb_batch();
     b->m = m; b->n = n; b->ctxs.assign(ctxs, ctxs + n);
     for (int s = 0; s < n; s++) {
@@ -1256,8 +1266,9 @@ static bool stream_acc2(const StreamParams& p) { return p.nch == 2 || p.n_chains
 // More than 16 sequences: the batch's rows through the prefill's streaming product (gemm_stream_kernel: weights M16 -> A operand, 1 / 2 / 4
 // batch tiles of 16 sequences per wave), plain row-major activations.  Same chains per sequence; EPI_QKV_ROPE and the attention take each
 // row's position and caches from the batch tables.  (xt / att_xt / ffn_xt hold rows here, not the B-operand layout.)
-static GemmParams wide_of(const lnb_batch* b, const uint16_t* w16, const uint16_t* x, int K, int n_rows, int nch) {
-    GemmParams g{}; g.w16 = w16; g.nch = nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = b->n;
+// (w16 == nullptr -- no matrix-core copy: the resident layout t feeds the same kernel, gemm_stream_kernel SRC 1 / 2)
+static GemmParams wide_of(const lnb_batch* b, const TiledDesc& t, const uint16_t* w16, const uint16_t* x, int K, int n_rows, int nch) {
+    GemmParams g{}; g.w16 = w16; g.w = t.w; g.rw = t.rw; g.nch = nch; g.x = x; g.K = K; g.n_rows = n_rows; g.S = b->n;
     return g;
 }
 // 17 .. 32 sequences (LNB_BATCH_GROUPS=0: off): the thin matrices -- one k-ordered chain per 16-row tile and 16 columns -- as TWO column groups of
@@ -1295,7 +1306,7 @@ static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {
             HIPCHK(lnbk_stream(&p, EPI_RESID, 0, g_num_cus, st)); return 0; }
         case K_W13: {
             HIPCHK(lnbk_rmsnorm_rows(b->h, L.ffn_norm, b->xt, n, dim, a.norm_eps, st));
-            GemmParams g = wide_of(b, L.m_w13, b->xt, dim, F, 2); g.out = nullptr; g.out_xt = b->ffn_xt; g.silu = m->silu;
+            GemmParams g = wide_of(b, L.w13, L.m_w13, b->xt, dim, F, 2); g.out = nullptr; g.out_xt = b->ffn_xt; g.silu = m->silu;
             HIPCHK(lnbk_gemm_stream(&g, EPI_SILU_MUL, g_num_cus, st)); return 0; }
         case K_W2: {
             StreamParams p = pair_of(L.m_w2, b->ffn_xt, F, dim); p.out = b->x; p.res = b->h;
@@ -1305,7 +1316,7 @@ static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {
     }
     if (which == K_HEAD) {
         HIPCHK(lnbk_rmsnorm_rows(b->x, m->norm, b->xt, n, dim, a.norm_eps, st));
-        GemmParams g = wide_of(b, m->m_output, b->xt, dim, a.vocab_size, 1); g.out = b->logits;
+        GemmParams g = wide_of(b, m->output, m->m_output, b->xt, dim, a.vocab_size, 1); g.out = b->logits;
         HIPCHK(lnbk_gemm_stream(&g, EPI_STORE, g_num_cus, st));
         return 0;
     }
@@ -1313,7 +1324,7 @@ static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {
     switch (which) {
     case K_QKV: {
         HIPCHK(lnbk_rmsnorm_rows(b->x, L.attn_norm, b->xt, n, dim, a.norm_eps, st));
-        GemmParams g = wide_of(b, L.m_wqkv, b->xt, dim, L.wqkv.n_rows, 1);
+        GemmParams g = wide_of(b, L.wqkv, L.m_wqkv, b->xt, dim, L.wqkv.n_rows, 1);
         g.cis = m->cis; g.q_out = b->q; g.btab = b->tab; g.bkv = b->kv + (l - m->layer_begin); g.q_dim = m->q_dim; g.kv_dim = m->kv_dim; g.head_dim = m->head_dim;
         HIPCHK(lnbk_gemm_stream(&g, EPI_QKV_ROPE, g_num_cus, st)); return 0; }
     case K_ATTN: {
@@ -1323,14 +1334,14 @@ static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {
         ap.force_zseq = 0; ap.zseq_count = b->ctxs[0]->zseq_count; ap.exp_tab = m->exp_tab;     // (attn_gqa_kernel looks exp up)
         HIPCHK(lnbk_attn(&ap, st)); return 0; }
     case K_WO: {
-        GemmParams g = wide_of(b, L.m_wo, b->att_xt, m->q_dim, dim, 1); g.out = b->h; g.res = b->x;
+        GemmParams g = wide_of(b, L.wo, L.m_wo, b->att_xt, m->q_dim, dim, 1); g.out = b->h; g.res = b->x;
         HIPCHK(lnbk_gemm_stream(&g, EPI_RESID, g_num_cus, st)); return 0; }
     case K_W13: {
         HIPCHK(lnbk_rmsnorm_rows(b->h, L.ffn_norm, b->xt, n, dim, a.norm_eps, st));
-        GemmParams g = wide_of(b, L.m_w13, b->xt, dim, F, 2); g.out = b->ffn_xt; g.silu = m->silu;
+        GemmParams g = wide_of(b, L.w13, L.m_w13, b->xt, dim, F, 2); g.out = b->ffn_xt; g.silu = m->silu;
         HIPCHK(lnbk_gemm_stream(&g, EPI_SILU_MUL, g_num_cus, st)); return 0; }
     case K_W2: {
-        GemmParams g = wide_of(b, L.m_w2, b->ffn_xt, F, dim, 1); g.out = b->x; g.res = b->h;
+        GemmParams g = wide_of(b, L.w2, L.m_w2, b->ffn_xt, F, dim, 1); g.out = b->x; g.res = b->h;
         HIPCHK(lnbk_gemm_stream(&g, EPI_RESID, g_num_cus, st)); return 0; }
     }
     return fail("bad kernel id");

@@ -195,3 +195,36 @@ def test_cycle_stamps_of_a_gemv_launch(lnb):
         assert 1.0 < ghz < 2.6, (which, ghz)
         assert 0 < v[cw][12] < v[cw][1] <= v[cw][2]
     gc.close(); gm.close()
+
+
+def test_prefill_and_large_batches_run_from_the_resident_layouts(lnb):
+    """Round 5: gemm_stream_kernel reads the RESIDENT weight layouts (row-broadcast units = M16 units in another order; chain-layout units transposed
+    over the wave's rows with v_permlane16/32_swap), so a prompt and a batch of more than 32 sequences need no second copy of the weights.
+    Tiny model: prefill logits bits = oracle = LDS-tiled kernel; 40 sequences batched WITHOUT lnb_model_enable_batch = their oracle runs; up to 32 are refused."""
+    import subprocess, sys
+    om = orc.Model(**TINY).fill_synthetic(1234).finalize()
+    gm = lnb.LlamaTransformer(**TINY).fill_synthetic(1234).finalize()
+    assert gm.batch_bytes() == 0
+    for rows in (16, 37, 64):
+        toks = orc.synth_tokens(7, rows, TINY["vocab_size"])
+        gc = lnb.InferenceContext(gm, 128)
+        lg, am = gc.Forward(toks, 0)
+        lo, ao = orc.Context(om, 128).forward(toks, 0)
+        assert (_bits(lg) == _bits(lo)).all() and am == ao, rows
+        gc.close()
+    n, steps = 40, 6
+    prompts = [orc.synth_tokens(900 + s, 5 + s % 7, TINY["vocab_size"]) for s in range(n)]
+    ctxs = [lnb.InferenceContext(gm, 32) for _ in range(n)]
+    firsts = [ctxs[s].Forward(prompts[s], 0, want_logits=False)[1] for s in range(n)]
+    with pytest.raises(lnb.LnbError, match="up to 32 sequences"):
+        lnb.Batch(ctxs[:20])
+    b = lnb.Batch(ctxs)
+    assert gm.batch_bytes() == 0
+    got, _ = b.decode(firsts, [len(p) for p in prompts], steps)
+    for s in range(0, n, 3):
+        ref, _ = orc.Context(om, 32).generate(prompts[s], steps + 1)
+        assert [firsts[s]] + [int(t) for t in got[s]] == [int(t) for t in ref], s
+    b.close()
+    for c in ctxs:
+        c.close()
+    gm.close(); om.close()
