@@ -97,7 +97,7 @@ print('single', d['value'], '| n', s['n'], 'throughput', s['tokens_per_s'], 'lat
     ( timeout 3000 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r05_gpu_suite.log
     ;;
   bench)
-    timeout 900 python bench.py "$@" 2>gpurun_out/r05_bench_last.err | tail -1 | tee gpurun_out/r05_bench_last.json | head -c 1200; echo; tail -3 gpurun_out/r05_bench_last.err
+    timeout 900 python bench.py "$@" > gpurun_out/r05_bench_last.json 2> gpurun_out/r05_bench_last.err; echo "rc=$?"; head -c 600 gpurun_out/r05_bench_last.json; echo; tail -3 gpurun_out/r05_bench_last.err
     ;;
   *) echo "unknown mode $mode"; exit 2;;
 esac
