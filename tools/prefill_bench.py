@@ -35,7 +35,8 @@ for mode in a.modes.split(","):
             best = min(best, time.perf_counter() - t0)
         tf = 2.0 * S * MATMUL / best / 1e12
         peak = 157.3 if mode == "exact" else 2500.0
-        r = {"mode": mode, "kernel": ("gemm_stream_kernel (weights M16 -> A operand)" if (a.stream and mode == "exact") else "gemm_mfma_kernel (LDS-tiled)") if mode == "exact" else "fast_gemm_kernel", "rows": S, "ms": round(best * 1e3, 2), "TFLOP/s": round(tf, 1), "peak_TFLOP/s": peak, "frac_of_peak": round(tf / peak, 4),
+        r = {"mode": mode, "kernel": ("gemm_stream_kernel (weights M16 -> A operand)" if a.stream else "gemm_mfma_kernel (LDS-tiled)" if os.environ.get("LNB_PREFILL_NATIVE") == "0" else
+                        "gemm_stream_kernel (resident layouts -> A operand, no second copy)") if mode == "exact" else "fast_gemm_kernel", "rows": S, "ms": round(best * 1e3, 2), "TFLOP/s": round(tf, 1), "peak_TFLOP/s": peak, "frac_of_peak": round(tf / peak, 4),
              "frac_of_bf16_peak_2500": round(tf / 2500.0, 4), "next_token": int(tok)}
         print(json.dumps(r), flush=True)
         res.append(r)
