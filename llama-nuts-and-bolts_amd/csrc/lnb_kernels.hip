@@ -1183,7 +1183,7 @@ DEVINL void chain128(float& acc, const float (&pr)[8]) {
                  "v_add_f32_dpp %0, %8, %0 row_newbcast:15 row_mask:0xf bank_mask:0xf\n\t"
                  : "+v"(acc) : "v"(pr[0]), "v"(pr[1]), "v"(pr[2]), "v"(pr[3]), "v"(pr[4]), "v"(pr[5]), "v"(pr[6]), "v"(pr[7]));
 }
-template <int EPI, int RC_XU = 8>                           // RC_XU: 16 B units of x per thread (K <= 2048 * RC_XU), picked by the launcher like the norm kernels' chunk count
+template <int EPI>
 __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* xT = (float*)smem;                                // x[128c + 16i + j] at xT[(c*16 + j)*8 + i]
@@ -1201,6 +1201,7 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     const unsigned voff = (unsigned)lane * 16u;
     // x first, all of its loads in flight at once, and the weight stream only once x has landed: queued in front of x -- or
     // even right behind it -- the 14 MB burst of first weight loads delays the x rows that every CU reads (measured both ways)
+    constexpr int RC_XU = 8;                                 // 16 B units of x per thread: K <= 16384
     const uint16_t* xrow = p.x + (size_t)m * K;
     uint4 xv[RC_XU];
 #pragma unroll
@@ -1307,7 +1308,7 @@ constexpr int RL_SLOTS = 3;
 constexpr int RL_R = 12;                                    // 1 KiB weight chunks in flight per helper wave (a multiple of RL_SC * RL_SLOTS' unroll)
 constexpr int RL_STAGE = 4 * RL_SC * 2048;                  // bytes of products per stage: 4 pairs x RL_SC chunks x 2 KiB
 __host__ __device__ constexpr size_t rl_lds_bytes(int K) { return (size_t)RL_SLOTS * RL_STAGE + (size_t)K * 2; }
-template <int EPI, int RL_XU = 4>                           // RL_XU: 16 B units of x per thread (K <= 4096 * RL_XU)
+template <int EPI>
 __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
     static_assert(RL_R == RL_SC * RL_SLOTS, "the helper's ring index and the product slot are static inside a three-stage unroll");
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1324,6 +1325,7 @@ __global__ __launch_bounds__(512) void rowcast_lds_kernel(GemvParams p) {
     const int nb_mine = (p.n_blocks - wg + p.n_wg - 1) / p.n_wg;       // 16-row blocks wg, wg+n_wg, ...
     const int NS = nb_mine * nst;                                      // stages this workgroup walks
     // x first, all of its loads in flight at once; the weight stream starts once x has landed (NOTES.md 5.1)
+    constexpr int RL_XU = 4;                                 // 16 B units of x per thread: K <= 16384
     const uint16_t* xrow = p.x + (size_t)m * K;
     uint4 xv[RL_XU];
 #pragma unroll
@@ -3036,31 +3038,22 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
 }
 
 template <int EPI> static hipError_t launch_rowcast(const GemvParams* p, hipStream_t st) {
+    auto kfn = rowcast_kernel<EPI>;
+    auto kl = rowcast_lds_kernel<EPI>;
     if (!p) {
-        hipError_t e = hipSuccess;
-#define LNB_RC_PREP(K_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)K_, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        LNB_RC_PREP((rowcast_lds_kernel<EPI, 1>)); LNB_RC_PREP((rowcast_lds_kernel<EPI, 2>)); LNB_RC_PREP((rowcast_lds_kernel<EPI, 4>));
-        LNB_RC_PREP((rowcast_kernel<EPI, 2>)); LNB_RC_PREP((rowcast_kernel<EPI, 4>)); LNB_RC_PREP((rowcast_kernel<EPI, 8>));
-#undef LNB_RC_PREP
-        return e;
+        hipError_t e = hipFuncSetAttribute((const void*)kl, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e != hipSuccess ? e : hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     }
-    if ((p->K & 127) || p->K > 16384) return hipErrorInvalidValue;              // x staging: up to 8 x 16 B per thread, K*4 bytes of LDS
-    const size_t pad = (size_t)(p->lds_pad > 0 ? p->lds_pad : 0);
-    const dim3 grid((unsigned)(p->S * p->n_wg));
+    if ((p->K & 127) || p->K > 16384) return hipErrorInvalidValue;              // x staging: 8 x 16 B per thread, K*4 bytes of LDS
     // helper-fed chain waves (rowcast_lds_kernel) whenever K is a whole number of its 512-step stages; LNB_ROWCAST_LDS=0: the self-feeding kernel
     static const int use_lds = [] { const char* s = getenv("LNB_ROWCAST_LDS"); return s && *s ? atoi(s) : 1; }();
     // (throughput schedule: the self-feeding kernel -- four waves and K * 4 bytes of LDS instead of eight waves and 96 KB + K * 2: co-resident with
     // another context's gate|up workgroup, NOTES R5)
-    if (use_lds && !p->sched && p->K % (128 * RL_SC) == 0 && p->K >= 2 * 128 * RL_SC && rl_lds_bytes(p->K) + pad <= 160 * 1024) {
-        // x units per thread: the smallest instance that holds the row (wo of the 8B shape: ONE 16 B unit per thread, not four clamped loads and compares)
-        if (p->K <= 4096) hipLaunchKernelGGL((rowcast_lds_kernel<EPI, 1>), grid, dim3(512), rl_lds_bytes(p->K) + pad, st, *p);
-        else if (p->K <= 8192) hipLaunchKernelGGL((rowcast_lds_kernel<EPI, 2>), grid, dim3(512), rl_lds_bytes(p->K) + pad, st, *p);
-        else hipLaunchKernelGGL((rowcast_lds_kernel<EPI, 4>), grid, dim3(512), rl_lds_bytes(p->K) + pad, st, *p);
+    if (use_lds && !p->sched && p->K % (128 * RL_SC) == 0 && p->K >= 2 * 128 * RL_SC && rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0) <= 160 * 1024) {
+        hipLaunchKernelGGL(kl, dim3((unsigned)(p->S * p->n_wg)), dim3(512), rl_lds_bytes(p->K) + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0), st, *p);
         return hipGetLastError();
     }
-    if (p->K <= 4096) hipLaunchKernelGGL((rowcast_kernel<EPI, 2>), grid, dim3(256), (size_t)p->K * 4 + pad, st, *p);
-    else if (p->K <= 8192) hipLaunchKernelGGL((rowcast_kernel<EPI, 4>), grid, dim3(256), (size_t)p->K * 4 + pad, st, *p);
-    else hipLaunchKernelGGL((rowcast_kernel<EPI, 8>), grid, dim3(256), (size_t)p->K * 4 + pad, st, *p);
+    hipLaunchKernelGGL(kfn, dim3((unsigned)(p->S * p->n_wg)), dim3(256), (size_t)p->K * 4 + (size_t)(p->lds_pad > 0 ? p->lds_pad : 0), st, *p);
     return hipGetLastError();
 }
 
