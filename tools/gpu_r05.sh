@@ -90,6 +90,12 @@ print('single', d['value'], '| n', s['n'], 'throughput', s['tokens_per_s'], 'lat
       echo "== LDS-tiled kernel (LNB_PREFILL_NATIVE=0)"; LNB_PREFILL_NATIVE=0 timeout 600 python tools/prefill_bench.py --modes exact --sizes 16,64,128,256,512,2048,4096
       echo "== M16 copy (--stream)"; timeout 600 python tools/prefill_bench.py --modes exact --stream --sizes 16,64,128,256,512,2048,4096; } 2>&1 | tee gpurun_out/r05_prefill.log
     ;;
+  closing)  # after the last kernel change: quick parity, the throughput forms, the default / driver lines, the rocprofv3 record
+    ( timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round5.py -x -q ) 2>&1 | tail -3
+    ( time timeout 900 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err; echo "bench rc=$?"; tail -3 gpurun_out/r05_bench_default.err
+    timeout 600 python bench.py --steps 20 --warmup 5 > gpurun_out/r05_bench_driver_args.json 2> gpurun_out/r05_bench_driver_args.err; echo "bench(20) rc=$?"
+    $0 profile
+    ;;
   ab)       # env passes through
     ab "${1:-custom}"
     ;;
