@@ -1129,6 +1129,7 @@ struct lnb_batch {
     uint16_t *x = nullptr, *h = nullptr, *xt = nullptr, *q = nullptr, *att_xt = nullptr, *ffn_xt = nullptr, *logits = nullptr;
     int* derr = nullptr; int32_t *d_tokens = nullptr, *d_pos = nullptr; int32_t* h_io = nullptr;   // pinned: [0..MAX) tokens, [MAX..2 MAX) positions, [2 MAX] error word (MAX = LNB_BATCH_MAX)
     hipGraphExec_t graph = nullptr; int lds_T = 0; bool counted = false;
+    bool rows_form = false;                // the model carries no matrix-core copy: every product runs as ROWS of gemm_stream_kernel on the resident layouts, whatever n
     // pipeline stage (lnb_pipeline_tick_batch): the contiguous token words exchanged between the last and the first stage, the stage step
     // as a captured graph, events towards / from the exchange stream (as lnb_ctx has them for single-sequence ticks)
     int32_t* ring = nullptr; hipGraphExec_t stage_graph = nullptr;
@@ -1233,18 +1234,16 @@ extern "C" int lnb_batch_create(lnb_ctx* const* ctxs, int n, lnb_batch** out) {
     lnb_model* m = ctxs[0]->m;
     HIPCHK(hipSetDevice(m->device));
     if (!m->batch_enabled) {
-        // Round 5: batches of MORE than 32 sequences are rows of the streaming product, which reads the RESIDENT weight layouts as well (gemm_stream_kernel,
-        // SRC 1 / 2): no second copy.  Only the column forms of up to 32 sequences (mfma_stream_kernel / mfma_pair_kernel) read the M16 copy.
-        if (n <= 2 * LNB_STREAM_COLS)
-            return fail("lnb_model_enable_batch has not been called on this model: batches of up to %d sequences run on the matrix-core copy of the weights "
-                        "(batches of %d..%d sequences do not need it)", 2 * LNB_STREAM_COLS, 2 * LNB_STREAM_COLS + 1, LNB_BATCH_MAX);
+        // Round 5: a batch on a model WITHOUT the matrix-core copy runs every product as rows of the streaming product, which reads the RESIDENT
+        // weight layouts (gemm_stream_kernel, SRC 1 / 2) -- any number of sequences.  The copy (lnb_model_enable_batch) is a pure performance
+        // option: the column forms of up to 32 sequences (mfma_stream_kernel / mfma_pair_kernel) read it and are faster there.
         if (m->part_begin % 3 || m->part_end % 3) return fail("batched decode needs a stage of whole blocks (this one is cut inside a block: parts [%d, %d))", m->part_begin, m->part_end);
         if (m->a.dim % 128 || m->q_dim % 128 || m->ffn_hidden % 128)
             return fail("batched decode streams the weights in 128-step chunks: dim (%d), n_heads*head_dim (%d) and the FFN hidden size (%d) must be multiples of 128", m->a.dim, m->q_dim, m->ffn_hidden);
         HIPCHK(lnbk_batch_prepare());
     }
     lnb_batch* b = new lnb_batch();
-    b->m = m; b->n = n; b->ctxs.assign(ctxs, ctxs + n);
+    b->m = m; b->n = n; b->ctxs.assign(ctxs, ctxs + n); b->rows_form = !m->batch_enabled;
     for (int s = 0; s < n; s++) {
         if (ctxs[s]->seq_len > ctxs[s]->attn_short_cap) {
             const int sl = ctxs[s]->seq_len, cap = ctxs[s]->attn_short_cap; delete b;
@@ -1277,7 +1276,7 @@ static GemmParams wide_of(const lnb_batch* b, const TiledDesc& t, const uint16_t
 // norm -> xt groups (batch_rmsnorm_xt_kernel), attention -> out_xt groups, SiLU*up epilogue -> out_xt groups.
 static bool batch_groups(const lnb_batch* b) {
     static const int on = env_int("LNB_BATCH_GROUPS", 1);
-    return on && b->n > LNB_STREAM_COLS && b->n <= 2 * LNB_STREAM_COLS;
+    return on && !b->rows_form && b->n > LNB_STREAM_COLS && b->n <= 2 * LNB_STREAM_COLS;
 }
 static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {
     lnb_model* m = b->m; const lnb_model_args& a = m->a; hipStream_t st = b->stream;
@@ -1348,7 +1347,7 @@ static int enqueue_batch_kernel_wide(lnb_batch* b, int l, int which) {
 }
 // which: K_QKV (attention norm + wq|wk|wv + RoPE + KV append), K_ATTN, K_WO, K_W13 (ffn norm + w1|w3 + SiLU*up), K_W2, K_HEAD (norm + output)
 static int enqueue_batch_kernel(lnb_batch* b, int l, int which) {
-    if (b->n > LNB_STREAM_COLS) return enqueue_batch_kernel_wide(b, l, which);
+    if (b->n > LNB_STREAM_COLS || b->rows_form) return enqueue_batch_kernel_wide(b, l, which);
     lnb_model* m = b->m; const lnb_model_args& a = m->a; hipStream_t st = b->stream;
     const int n = b->n, dim = a.dim, F = m->ffn_hidden;
     if (which == K_HEAD) {

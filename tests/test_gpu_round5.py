@@ -200,7 +200,8 @@ def test_cycle_stamps_of_a_gemv_launch(lnb):
 def test_prefill_and_large_batches_run_from_the_resident_layouts(lnb):
     """Round 5: gemm_stream_kernel reads the RESIDENT weight layouts (row-broadcast units = M16 units in another order; chain-layout units transposed
     over the wave's rows with v_permlane16/32_swap), so a prompt and a batch of more than 32 sequences need no second copy of the weights.
-    Tiny model: prefill logits bits = oracle = LDS-tiled kernel; 40 sequences batched WITHOUT lnb_model_enable_batch = their oracle runs; up to 32 are refused."""
+    Tiny model: prefill logits bits = oracle; 40 / 20 / 5 sequences batched WITHOUT lnb_model_enable_batch (every product as rows of the streaming kernel) =
+    their oracle runs, and the same contexts go on with the column forms once the copy exists."""
     import subprocess, sys
     om = orc.Model(**TINY).fill_synthetic(1234).finalize()
     gm = lnb.LlamaTransformer(**TINY).fill_synthetic(1234).finalize()
@@ -216,14 +217,23 @@ def test_prefill_and_large_batches_run_from_the_resident_layouts(lnb):
     prompts = [orc.synth_tokens(900 + s, 5 + s % 7, TINY["vocab_size"]) for s in range(n)]
     ctxs = [lnb.InferenceContext(gm, 32) for _ in range(n)]
     firsts = [ctxs[s].Forward(prompts[s], 0, want_logits=False)[1] for s in range(n)]
-    with pytest.raises(lnb.LnbError, match="up to 32 sequences"):
-        lnb.Batch(ctxs[:20])
-    b = lnb.Batch(ctxs)
-    assert gm.batch_bytes() == 0
-    got, _ = b.decode(firsts, [len(p) for p in prompts], steps)
-    for s in range(0, n, 3):
-        ref, _ = orc.Context(om, 32).generate(prompts[s], steps + 1)
-        assert [firsts[s]] + [int(t) for t in got[s]] == [int(t) for t in ref], s
+    refs = {}
+    for cnt in (40, 20, 5):                                          # (more than 32: rows anyway; 17..32 and <= 16: the rows form INSTEAD of the column forms)
+        for c, p in zip(ctxs[:cnt], prompts):
+            c.reset(); c.Forward(p, 0, want_logits=False)
+        b = lnb.Batch(ctxs[:cnt])
+        assert gm.batch_bytes() == 0
+        got, _ = b.decode(firsts[:cnt], [len(p) for p in prompts[:cnt]], steps)
+        for s in range(0, cnt, 3):
+            if s not in refs:
+                refs[s] = [int(t) for t in orc.Context(om, 32).generate(prompts[s], steps + 3)[0]]
+            assert [firsts[s]] + [int(t) for t in got[s]] == refs[s][:steps + 1], (cnt, s)
+        b.close()
+    gm.enable_batch()                                                # ... and the column forms pick the same caches up
+    b = lnb.Batch(ctxs[:5])
+    more, _ = b.decode([int(got[s][-1]) for s in range(5)], [len(prompts[s]) + steps for s in range(5)], 2)      # (got: the five-sequence run just above)
+    for s in (0, 3):
+        assert [int(t) for t in more[s]] == refs[s][steps + 1:steps + 3], s
     b.close()
     for c in ctxs:
         c.close()
