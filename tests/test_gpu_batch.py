@@ -170,8 +170,7 @@ def test_batch_argument_checks(lnb):
     cfg = dict(orc.TINY)
     gm = lnb.LlamaTransformer(**cfg).fill_synthetic(1).finalize()
     c0, c1 = lnb.InferenceContext(gm, 32), lnb.InferenceContext(gm, 32)
-    with pytest.raises(lnb.LnbError, match="enable_batch"):
-        lnb.Batch([c0, c1])
+    lnb.Batch([c0, c1]).close()                              # (round 5: without the second copy a batch runs its products as rows on the resident layouts)
     gm.enable_batch()
     with pytest.raises(lnb.LnbError, match="twice"):
         lnb.Batch([c0, c0])
