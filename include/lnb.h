@@ -235,6 +235,12 @@ int lnb_pipeline_init(lnb_model* stage, int rank, int world, const void* id128, 
  * ONE host thread in lock-step order (a stage on another device is refused; running a sequence whose input has been requested but not
  * yet posted by its sender is an error, not a read of stale data) */
 int lnb_pipeline_init_loopback(lnb_model* stage, int rank, int world, const char* group, lnb_pipe** out);
+/* the same pipe WITHOUT a transport, for a host layer that moves what crosses the stage boundary itself (pipeline.py's torch.distributed
+ * fallback when RCCL cannot form its communicator: staging tensors + batch_isend_irecv between lnb_pipeline_sync calls): ticks take `run`
+ * only (send / recv are refused), everything else -- captured stage steps, positions advancing on the device, the first stage reading the
+ * ring's token words, the last stage's token log -- as above.  The buffers to move: lnb_ctx_hidden_ptr (a sequence), lnb_batch_boundary_ptr
+ * (a batch).  lnb_pipeline_comm_count reports 0. */
+int lnb_pipeline_init_host(lnb_model* stage, int rank, int world, lnb_pipe** out);
 int lnb_pipeline_destroy(lnb_pipe* p);
 int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int run_pos, const int32_t* run_tokens,
                       lnb_ctx* send, int send_rows, lnb_ctx* recv, int recv_rows, int* token_slot_out);
@@ -250,6 +256,9 @@ int lnb_batch_set_state(lnb_batch* b, const int32_t* tokens, const int32_t* star
  * returns an error if the word was set since the last check (or the last lnb_batch_set_state) and clears it.  Call it after
  * lnb_pipeline_sync, before trusting lnb_pipeline_read_tokens.  (lnb_batch_decode checks for itself.) */
 int lnb_batch_check_error(lnb_batch* b);
+/* device pointers of what a batched tick exchanges (owned by the batch).  which: 0 = the hidden states [n, dim] bf16 -- the stage's input
+ * before `run`, its output after; 1 = the n int32 token words the last stage's argmax leaves and the first stage of a multi-stage pipe reads */
+void* lnb_batch_boundary_ptr(lnb_batch* b, int which);
 int lnb_pipeline_tick_batch(lnb_pipe* p, lnb_batch* run, lnb_batch* send, lnb_batch* recv, int* token_slot_out);
 int lnb_pipeline_sync(lnb_pipe* p);
 /* the number of ranks the exchange spans as the TRANSPORT reports it (ncclCommCount of the communicator; pipes joined to an in-process

@@ -1467,6 +1467,14 @@ static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t*
 // Every sequence's position (and, on the first stage, optionally its next input token) before a run of lnb_pipeline_tick_batch steps: the
 // positions then advance on the device with every step.  tokens == NULL keeps what each context's token word holds (what the
 // single-sequence prefill ticks left there).
+// what a batched tick exchanges, for a host layer that moves it itself (lnb_pipeline_init_host)
+extern "C" void* lnb_batch_boundary_ptr(lnb_batch* b, int which) {
+    if (!b) { fail("null argument"); return nullptr; }
+    if (which == 0) return b->x;
+    if (which == 1) return b->ring;
+    fail("lnb_batch_boundary_ptr: which = %d (0: hidden states [n, dim] bf16, 1: the n token words)", which);
+    return nullptr;
+}
 extern "C" int lnb_batch_check_error(lnb_batch* b) {
     if (!b) return fail("null argument");
     HIPCHK(hipSetDevice(b->m->device));
@@ -1561,6 +1569,7 @@ struct lnb_pipe {
     hipStream_t xs = nullptr;              // exchange stream
     int32_t* h_tok = nullptr; int tok_cap = 0, tok_n = 0;   // pinned RING of the tokens the last stage produced, in tick order: slot s lives at s % tok_cap
     bool use_graph = true;
+    bool host = false;                     // no transport: the host layer moves the boundary buffers (lnb_pipeline_init_host)
 };
 static int pipe_log_cap() { const int v = env_int("LNB_PIPELINE_LOG_CAP", 1 << 16); return v < 4 ? 4 : v; }   // (the env knob is for the wrap-around test)
 #define NCCLCHK(p_, expr) do { int r_ = (expr); if (r_ != 0) return fail("%s failed: %s (%s:%d)", #expr, (p_)->api->GetErrorString(r_), __FILE__, __LINE__); } while (0)
@@ -1626,6 +1635,24 @@ extern "C" int lnb_pipeline_init_loopback(lnb_model* m, int rank, int world, con
         g.device = m->device;
         p->loop_tag = group; p->loop = &g; p->loop->users++;
     }
+    *out = p;
+    return 0;
+}
+// The pipe WITHOUT a transport: stage steps, graphs, positions and the token log as in the other two, but what crosses the stage boundary is
+// moved by the host layer (pipeline.py's torch.distributed fallback: staging tensors + batch_isend_irecv) between lnb_pipeline_sync calls.
+extern "C" int lnb_pipeline_init_host(lnb_model* m, int rank, int world, lnb_pipe** out) {
+    if (!m || !out) return fail("null argument");
+    *out = nullptr;
+    if (world < 1 || rank < 0 || rank >= world) return fail("rank %d out of range for %d pipeline stages", rank, world);
+    if (!m->finalized) return fail("model not finalized");
+    if ((rank == 0) != m->first()) return fail("pipeline rank %d: only the first stage owns tok_embeddings (this stage starts at block part %d)", rank, m->part_begin);
+    if ((rank == world - 1) != m->last()) return fail("pipeline rank %d of %d: only the last stage owns norm + output (this stage ends at block part %d)", rank, world, m->part_end);
+    HIPCHK(hipSetDevice(m->device));
+    lnb_pipe* p = new lnb_pipe();
+    p->m = m; p->rank = rank; p->world = world; p->host = true; p->use_graph = env_int("LNB_PIPELINE_GRAPH", 1) != 0;
+    hipError_t e = hipStreamCreateWithFlags(&p->xs, hipStreamNonBlocking);
+    if (e == hipSuccess) { p->tok_cap = pipe_log_cap(); e = hipHostMalloc((void**)&p->h_tok, (size_t)p->tok_cap * 4, hipHostMallocDefault); }
+    if (e != hipSuccess) { fail("pipeline init: %s", hipGetErrorString(e)); if (p->xs) hipStreamDestroy(p->xs); delete p; return -1; }
     *out = p;
     return 0;
 }
@@ -1734,6 +1761,7 @@ extern "C" int lnb_pipeline_tick(lnb_pipe* p, lnb_ctx* run, int run_rows, int ru
     HIPCHK(hipSetDevice(m->device));
     const bool first = p->rank == 0, last = p->rank == p->world - 1;
     for (lnb_ctx* c : {run, send, recv}) if (c) { if (c->m != m) return fail("context of another model stage"); if (pipe_events(c)) return -1; }
+    if (p->host && (send || recv)) return fail("this pipe has no transport (lnb_pipeline_init_host): the host layer moves lnb_ctx_hidden_ptr's buffers itself; send and recv must be NULL");
     if (token_slot_out) *token_slot_out = -1;
     if (run) {
         if (check_call(run, run_rows, run_pos)) return -1;
@@ -1820,6 +1848,7 @@ extern "C" int lnb_pipeline_tick_batch(lnb_pipe* p, lnb_batch* run, lnb_batch* s
     HIPCHK(hipSetDevice(m->device));
     const bool first = p->rank == 0, last = p->rank == p->world - 1;
     for (lnb_batch* b : {run, send, recv}) if (b) { if (b->m != m) return fail("batch of another model stage"); if (batch_events(b)) return -1; }
+    if (p->host && (send || recv)) return fail("this pipe has no transport (lnb_pipeline_init_host): the host layer moves lnb_batch_boundary_ptr's buffers itself; send and recv must be NULL");
     if (token_slot_out) *token_slot_out = -1;
     if (run) {
         hipStream_t st = run->stream;
@@ -1919,6 +1948,7 @@ extern "C" int lnb_pipeline_comm_count(lnb_pipe* p, int* out) {
     if (!p || !out) return fail("null argument");
     *out = 1;
     if (p->world == 1) return 0;
+    if (p->host) { *out = 0; return 0; }                     // no transport of its own
     if (p->loop) { std::lock_guard<std::mutex> lock(g_loops_mu); *out = p->loop->users; return 0; }
     int n = 0;
     NCCLCHK(p, p->api->CommCount(p->comm, &n));

@@ -61,6 +61,7 @@ EXPORTS = [
     "lnb_tokenizer_stream_create", "lnb_tokenizer_stream_free", "lnb_tokenizer_decode_stream", "lnb_tokenizer_stream_pending",
     "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens", "lnb_pipeline_selftest", "lnb_pipeline_comm_count",
     "lnb_model_enable_batch", "lnb_model_batch_bytes", "lnb_batch_create", "lnb_batch_destroy", "lnb_batch_decode", "lnb_batch_decode_until", "lnb_ctx_set_stop_ids", "lnb_decode_greedy_until", "lnb_batch_profile_kernel", "lnb_batch_set_state", "lnb_batch_check_error", "lnb_pipeline_tick_batch",
+    "lnb_pipeline_init_host", "lnb_batch_boundary_ptr",
 ]
 
 
@@ -116,6 +117,9 @@ def lib():
     L.lnb_pipeline_unique_id.argtypes = [vp]
     L.lnb_pipeline_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.lnb_pipeline_init_loopback.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
+    L.lnb_pipeline_init_host.argtypes = [vp, C.c_int, C.c_int, C.POINTER(vp)]
+    L.lnb_batch_boundary_ptr.argtypes = [vp, C.c_int]
+    L.lnb_batch_boundary_ptr.restype = C.c_void_p
     L.lnb_pipeline_selftest.argtypes = [C.c_int, C.c_int]
     L.lnb_pipeline_destroy.argtypes = [vp]
     L.lnb_pipeline_tick.argtypes = [vp, vp, C.c_int, C.c_int, vp, vp, C.c_int, vp, C.c_int, C.POINTER(C.c_int)]
@@ -533,6 +537,13 @@ class Batch:
         _chk(self.L.lnb_batch_set_state(self.h, None if tok is None else tok.ctypes.data_as(C.POINTER(C.c_int32)), pos.ctypes.data_as(C.POINTER(C.c_int32))))
         return self
 
+    def boundary_ptr(self, which):
+        """device address of what a batched tick exchanges: 0 = hidden states [n, dim] bf16 (stage input / output), 1 = the n int32 token words"""
+        ptr = self.L.lnb_batch_boundary_ptr(self.h, which)
+        if not ptr:
+            _chk(-1)
+        return int(ptr)
+
     def check_error(self):
         """after Pipeline.sync(): raises if a pipeline tick of this batch met a token outside the vocabulary / an all-NaN logits row"""
         _chk(self.L.lnb_batch_check_error(self.h))
@@ -548,10 +559,14 @@ class Pipeline:
     """One rank of the layer-sharded pipeline behind the C ABI (lnb_pipeline_*): RCCL send / recv straight from / into the stage's
     device buffers, stage steps as captured graphs, nothing synchronised per tick."""
 
-    def __init__(self, transformer, rank, world, unique_id=None, loopback_group=None):
-        """unique_id: rank 0's 128 RCCL id bytes (world > 1); loopback_group: a name -- the in-process transport instead of RCCL"""
+    def __init__(self, transformer, rank, world, unique_id=None, loopback_group=None, host_transport=False):
+        """unique_id: rank 0's 128 RCCL id bytes (world > 1); loopback_group: a name -- the in-process transport instead of RCCL;
+        host_transport: no transport at all -- ticks only `run`, the caller moves the boundary buffers (pipeline.run_ticks_batched_torch)"""
         self.L, self.rank, self.world = transformer.L, rank, world
         self.h = C.c_void_p()
+        if host_transport:
+            _chk(self.L.lnb_pipeline_init_host(transformer.h, rank, world, C.byref(self.h)))
+            return
         if loopback_group is not None:
             _chk(self.L.lnb_pipeline_init_loopback(transformer.h, rank, world, loopback_group.encode(), C.byref(self.h)))
             return

@@ -544,6 +544,119 @@ def run_ticks_native_batched(rank, world, pipe, batches, n_decode, lo=0, hi=None
     return state
 
 
+def device_view(torch, ptr, shape, typestr, device_index):
+    """zero-copy torch view of a device buffer the library owns (CUDA array interface v2)"""
+    class _Wrap:
+        __cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(_Wrap(), device="cuda:%d" % device_index)
+
+
+def prefill_torch(rank, world, stage, dist, torch, prompts, device):
+    """every sequence's prompt through all stages, one after the other, with torch.distributed moving the hidden state (the fallback's
+    counterpart of prefill_through_pipeline).  -> on rank 0 (and the last rank): the first generated token of every sequence."""
+    P = len(prompts[0])
+    first, last = rank == 0, rank == world - 1
+    comm = "cpu" if (world > 1 and dist.get_backend() == "gloo") else device
+    firsts = []
+    for q, prompt in enumerate(prompts):
+        if not first:
+            for dst in stage.hidden_buffers(q, P, "in"):
+                inn = torch.empty_like(dst, device=comm)
+                dist.recv(inn, rank - 1)
+                dst.copy_(inn)
+            if device != "cpu":
+                torch.cuda.synchronize()
+        stage.launch(q, P, 0, np.ascontiguousarray(prompt, dtype=np.int32) if first else None)
+        tok = stage.collect()
+        if not last:
+            for src in stage.hidden_buffers(q, P, "out"):
+                out = torch.empty_like(src, device=comm)
+                out.copy_(src)
+                dist.send(out, rank + 1)
+        else:
+            firsts.append(int(tok))
+    if world > 1 and (first or last):                         # the token ring of the prefill, all sequences at once
+        t_ = torch.tensor(firsts if last else [0] * len(prompts), dtype=torch.int32, device=comm)
+        if last:
+            dist.send(t_, 0)
+        else:
+            dist.recv(t_, world - 1)
+            firsts = [int(v) for v in t_.tolist()]
+    return firsts
+
+
+def run_ticks_batched_torch(rank, world, pipe, batches, dist, torch, n_decode, device, dim, lo=0, hi=None, state=None):
+    """run_ticks_native_batched with the exchange done HERE (the fallback when RCCL cannot form its communicator, and what two ranks sharing
+    one GPU over gloo run): `pipe` has no transport (lnb.Pipeline(..., host_transport=True)), a tick enqueues the group's stage step
+    (tick_batch(run=...): captured graph, positions advance on the device), and while it runs the result of the previous tick's group goes
+    downstream and the input of the next tick's group arrives through torch staging tensors (batch_isend_irecv: one grouped exchange per
+    tick); then the stage step is waited for (pipe.sync) and the received rows are copied into the group's boundary buffers
+    (lnb_batch_boundary_ptr: hidden states [n, dim], or the n token words on the ring's edge).  Same schedule, same item order, same slots."""
+    G = len(batches)
+    n_items = n_decode * G
+    gap = 2 if world > 1 else 1
+    assert world == 1 or G == 2 * world, "the overlapped schedule keeps 2*world groups in flight"
+    first, last = rank == 0, rank == world - 1
+    nxt_rank, prv_rank = (rank + 1) % world, (rank - 1) % world
+    comm = "cpu" if (world > 1 and dist.get_backend() == "gloo") else device
+    dev_index = int(str(device).split(":")[1]) if ":" in str(device) else 0
+    if state is None:
+        state = {"prev": None, "slots": [[] for _ in range(G)], "views": {}, "staging": {}}
+    if hi is None:
+        hi = n_items + gap * (world - 1)
+
+    def view(g, which):                                       # 0: hidden states [n, dim] (bf16 bits), 1: the n token words
+        key = (g, which)
+        if key not in state["views"] and hasattr(batches[g], "boundary_tensor"):      # (a test's stand-in batch on the CPU)
+            state["views"][key] = batches[g].boundary_tensor(which)
+        if key not in state["views"]:
+            n = len(batches[g].ctxs)
+            state["views"][key] = device_view(torch, batches[g].boundary_ptr(which), (n, dim) if which == 0 else (n,), "<i2" if which == 0 else "<i4", dev_index)
+        return state["views"][key]
+
+    def staging(kind, g, which, like):
+        key = (kind, g, which)
+        if key not in state["staging"]:
+            state["staging"][key] = torch.empty_like(like, device=comm)
+        return state["staging"][key]
+
+    for t, item in schedule(rank, world, n_decode, G, gap):
+        if t < lo:
+            continue
+        if t >= hi:
+            break
+        slot = pipe.tick_batch(run=batches[item % G]) if item is not None else None     # enqueued on the batch's own stream ...
+        ops, landed = [], []
+        prev = state["prev"]
+        if prev is not None and world > 1:                    # ... while the exchange runs on the backend's (the previous tick ended with pipe.sync: prev's result is complete)
+            k, g = divmod(prev, G)
+            if not last or k + 1 < n_decode:                  # the tokens of the final step are not needed by rank 0
+                src = view(g, 1 if last else 0)
+                out = staging("out", g, 1 if last else 0, src)
+                out.copy_(src)
+                ops.append(dist.P2POp(dist.isend, out, nxt_rank))
+        nx = t + 1 - gap * rank
+        if 0 <= nx < n_items and world > 1:
+            k, g = divmod(nx, G)
+            if not first or k > 0:                            # (step 0's tokens: Batch.set_state put them into the ring's words)
+                dst = view(g, 1 if first else 0)
+                inn = staging("in", g, 1 if first else 0, dst)
+                ops.append(dist.P2POp(dist.irecv, inn, prv_rank))
+                landed.append((dst, inn))
+        works = dist.batch_isend_irecv(ops) if ops else []
+        pipe.sync()
+        for req in works:
+            req.wait()
+        for dst, inn in landed:
+            dst.copy_(inn)
+        if works and device != "cpu":
+            torch.cuda.synchronize()                          # the backend and the copies ran on torch's streams; the library has its own
+        if item is not None and last:
+            state["slots"][item % G].append(slot)
+        state["prev"] = item
+    return state
+
+
 def blocks_split(rank, world, n_layers):
     """configs[3] literally: n_layers / world whole blocks per GPU (the head on top of the last stage's share)"""
     return 3 * (rank * n_layers // world), 3 * ((rank + 1) * n_layers // world)
@@ -920,6 +1033,48 @@ def bench_main(args, cfg, name):
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         wall = float(tmax.item())
         extra = {"exchange": "torch.distributed batch_isend_irecv through staging tensors (%s)" % exchange}
+
+        def measure_batched_torch(nb):
+            """the batched pipeline of the native path (measure_batched) with the exchange through torch.distributed: groups of nb sequences,
+            2*world groups in flight, whole-block stages, a pipe without a transport (run_ticks_batched_torch)"""
+            lb, le = stage_layers(rank, world, cfg["n_layers"], head_cost=(costs[3] / max(1e-9, sum(costs[:3])) if costs else 1.2))
+            G = 2 * world
+            st2 = LnbStage(lnb, torch, cfg, rank, world, G * nb, seq_len, local, parts=(3 * lb, 3 * le), costs=costs)
+            copy = True
+            try:
+                st2.model.enable_batch()
+            except lnb.LnbError:
+                copy = False                                 # (no room for the matrix-core copy on this rank: its batches run as rows on the resident layouts)
+            prm = [lnb.synth_tokens(99 + q, P, cfg["vocab_size"]) for q in range(G * nb)]
+            firsts = prefill_torch(rank, world, st2, dist, torch, prm, device)
+            pp = lnb.Pipeline(st2.model, rank, world, host_transport=True)
+            bats = [lnb.Batch(st2.ctx[g * nb:(g + 1) * nb]).set_state(firsts[g * nb:(g + 1) * nb] if rank == 0 else None, [P] * nb) for g in range(G)]
+            sb = run_ticks_batched_torch(rank, world, pp, bats, dist, torch, W + K, device, cfg["dim"], 0, G * W)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run_ticks_batched_torch(rank, world, pp, bats, dist, torch, W + K, device, cfg["dim"], G * W, G * (W + K), sb)
+            torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
+            wb = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device if backend == "nccl" else "cpu")
+            dist.all_reduce(wb, op=dist.ReduceOp.MAX)
+            for b_ in bats:
+                b_.check_error()
+            box = [None]
+            if rank == world - 1:
+                box[0] = [firsts[0]] + [int(pp.read_tokens(q, 1)[0]) for q in sb["slots"][0]]
+            dist.broadcast_object_list(box, src=world - 1)
+            res_b = {"sequences_in_flight": G * nb, "groups": G, "batch": nb, "tokens_per_s": round(K * G * nb / float(wb.item()), 2),
+                     "second_weight_copy_on_this_rank": copy, "cut": "whole blocks (the batched hand-off is [n, dim] only)",
+                     "exchange": "pipe without a transport (lnb_pipeline_init_host) + torch.distributed batch_isend_irecv of lnb_batch_boundary_ptr's buffers",
+                     "tokens_vs_oracle_golden": _golden_check(box[0], P, name) if box[0] else None, "tokens_seq0": box[0][:8] if box[0] else None}
+            for b_ in bats:
+                b_.close()
+            pp.close(); st2.close()
+            return res_b
+
+        nb = int(os.environ.get("LNB_PIPELINE_BATCH", "16" if mode == "exact" else "0"))
+        if world > 1 and nb > 0:
+            extra["batched"] = measure_batched_torch(min(nb, 128))
+            extra["value_batched"] = extra["batched"]["tokens_per_s"]
     if rank == 0:
         import bench as _b
         tokens = K * n_seq

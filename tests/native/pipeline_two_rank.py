@@ -1,6 +1,7 @@
 """Two pipeline ranks (gloo) sharing ONE GPU: each owns half of the tiny model's blocks behind the C ABI (pipeline.LnbStage), the
 hidden state and the token ring go through pipeline.run_ticks exactly as in bench.py --gpus 2 (RCCL there, gloo + host staging
-here).  The last rank checks every generated token against the CPU oracle's greedy loop.  Launched by tests/test_gpu_parity.py."""
+here).  The last rank checks every generated token against the CPU oracle's greedy loop.  LNB_TEST_BATCH=nb: then the same with BATCHES of nb
+sequences as the unit (pipeline.run_ticks_batched_torch).  Launched by tests/test_gpu_parity.py."""
 import os
 import sys
 
@@ -34,4 +35,41 @@ if rank == 0:
     assert all(len(r) == n_decode for r in st["received"])
 dist.barrier()
 stage.close()
+nb = int(os.environ.get("LNB_TEST_BATCH", "0"))
+if nb > 0:
+    # the BATCHED tick of the same fallback: groups of nb sequences move through the two stages, one pass over a stage's weights per group and
+    # step (a pipe without a transport + pipeline.run_ticks_batched_torch); every sequence of every group against the oracle's greedy loop
+    G = 2 * world
+    copy = os.environ.get("LNB_TEST_BATCH_COPY", "1") == "1"
+    stage = pipeline.LnbStage(lnb, torch, cfg, rank, world, G * nb, P + n_decode + 8, 0, (0, 3) if rank == 0 else (3, 6))
+    if copy:
+        stage.model.enable_batch()
+    prompts = [lnb.synth_tokens(199 + q, P, cfg["vocab_size"]) for q in range(G * nb)]
+    firsts = pipeline.prefill_torch(rank, world, stage, dist, torch, prompts, "cuda:0")
+    pipe = lnb.Pipeline(stage.model, rank, world, host_transport=True)
+    assert pipe.comm_count() == 0
+    bats = [lnb.Batch(stage.ctx[g * nb:(g + 1) * nb]).set_state(firsts[g * nb:(g + 1) * nb] if rank == 0 else None, [P] * nb) for g in range(G)]
+    try:
+        pipe.tick_batch(run=None, send=bats[0])
+        raise AssertionError("a pipe without a transport accepted a send")
+    except lnb.LnbError as e:
+        assert "no transport" in str(e)
+    sb = pipeline.run_ticks_batched_torch(rank, world, pipe, bats, dist, torch, n_decode, "cuda:0", cfg["dim"], 0, G * 3)      # in two windows, as bench.py runs it
+    sb = pipeline.run_ticks_batched_torch(rank, world, pipe, bats, dist, torch, n_decode, "cuda:0", cfg["dim"], G * 3, None, sb)
+    pipe.sync()
+    for b in bats:
+        b.check_error()
+    if rank == world - 1:
+        om = orc.Model(**cfg).fill_synthetic(1234).finalize()
+        for q in range(G * nb):
+            g, j = divmod(q, nb)
+            got = [firsts[q]] + [int(pipe.read_tokens(sl + j, 1)[0]) for sl in sb["slots"][g]]
+            ref, _ = orc.Context(om, P + n_decode + 8).generate(prompts[q], 1 + n_decode)
+            assert list(ref) == got, (q, list(ref), got)
+        print("PIPELINE_TWO_RANK_BATCHED_OK", G * nb)
+    dist.barrier()
+    for b in bats:
+        b.close()
+    pipe.close()
+    stage.close()
 dist.destroy_process_group()

@@ -749,6 +749,23 @@ def test_pipeline_two_processes_share_one_gpu(lnb, mult, cut):
     assert r.returncode == 0 and "PIPELINE_TWO_RANK_OK" in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
 
 
+@pytest.mark.parametrize("nb,copy", [(3, "1"), (5, "0")])
+def test_pipeline_two_processes_batched_ticks_through_torch_distributed(lnb, nb, copy):
+    """the torch.distributed fallback's BATCHED tick: groups of nb sequences through two ranks sharing this GPU over gloo -- a pipe
+    without a transport (lnb_pipeline_init_host) runs the stage steps, pipeline.run_ticks_batched_torch moves lnb_batch_boundary_ptr's buffers --
+    with and without the second weight copy; every sequence of every group equals the oracle's greedy continuation."""
+    import socket
+    import subprocess
+    import sys
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0)); port = so.getsockname()[1]
+    script = os.path.join(os.path.dirname(__file__), "native", "pipeline_two_rank.py")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), script], capture_output=True, text=True, timeout=600,
+                       env=dict(os.environ, LNB_TEST_MULT="2", LNB_TEST_CUT="0", LNB_TEST_BATCH=str(nb), LNB_TEST_BATCH_COPY=copy))
+    assert r.returncode == 0 and "PIPELINE_TWO_RANK_BATCHED_OK %d" % (4 * nb) in r.stdout, r.stdout[-2000:] + r.stderr[-4000:]
+
+
 @pytest.mark.parametrize("overlap", ["1", "0"])
 def test_bench_two_ranks_prints_exactly_one_json_line(lnb, overlap):
     """The driver's N > 1 launch line (torch.distributed.run ... bench.py --gpus 2) end to end -- timed windows, barrier, max over
@@ -762,7 +779,7 @@ def test_bench_two_ranks_prints_exactly_one_json_line(lnb, overlap):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                         "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "2",
                         "--model", "tiny", "--prompt-len", "20"], capture_output=True, text=True, timeout=600, cwd=root,
-                       env=dict(os.environ, LNB_PIPELINE_BACKEND="gloo", LNB_PIPELINE_OVERLAP=overlap))
+                       env=dict(os.environ, LNB_PIPELINE_BACKEND="gloo", LNB_PIPELINE_OVERLAP=overlap, LNB_PIPELINE_BATCH="3"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
     assert len(lines) == 1, r.stdout
@@ -770,6 +787,8 @@ def test_bench_two_ranks_prints_exactly_one_json_line(lnb, overlap):
     assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     assert d["config"]["sequences_in_flight"] == (4 if overlap == "1" else 2)
     assert abs(d["value"] - 6 * d["config"]["sequences_in_flight"] / (d["ms_per_step"] * 6 / 1e3)) / d["value"] < 1e-3
+    bt = d["config"]["batched"]                               # the fallback's batched tick, next to the unbatched value as in the native line
+    assert bt["groups"] == 4 and bt["batch"] == 3 and bt["tokens_per_s"] == d["config"]["value_batched"] > 0 and len(bt["tokens_seq0"]) == 8
 
 
 def test_pipeline_stage_hidden_views_are_zero_copy_torch_tensors(lnb, tiny_pair):

@@ -116,6 +116,96 @@ def test_pipeline_schedule_matches_single_process(world, n_decode, split, mult):
         assert log[n_seq:2 * n_seq] == [(s, 1, P) for s in range(n_seq)]
 
 
+class FakeBatch:
+    """a group of sequences of one FakeStage: the boundary buffers a batched tick exchanges (hidden rows [n, DIM], n token words)"""
+
+    def __init__(self, stage, seqs):
+        self.stage, self.seqs = stage, list(seqs)
+        self.x = torch.zeros(len(self.seqs), DIM, dtype=torch.int16)
+        self.ring = torch.zeros(len(self.seqs), dtype=torch.int32)
+        self.pos = {s: P for s in self.seqs}
+
+    def boundary_tensor(self, which):
+        return self.x if which == 0 else self.ring
+
+
+class FakePipe:
+    """a pipe without a transport (lnb_pipeline_init_host): tick_batch runs the group's one-token stage step and logs the last stage's tokens"""
+
+    def __init__(self, rank, world):
+        self.rank, self.world, self.log, self.ran = rank, world, [], []
+
+    def tick_batch(self, run=None, send=None, recv=None):
+        assert send is None and recv is None
+        st, slot = run.stage, len(self.log)
+        for j, s in enumerate(run.seqs):
+            if self.rank > 0:
+                st.buf[s][:1] = run.x[j]
+            tok = st.run(s, 1, run.pos[s], np.array([int(run.ring[j])], dtype=np.int32) if self.rank == 0 else None)
+            run.x[j] = st.buf[s][0]
+            run.pos[s] += 1
+            if self.rank == self.world - 1:
+                run.ring[j] = tok
+                self.log.append(tok)
+        self.ran.append(tuple(run.seqs))
+        return slot if self.rank == self.world - 1 else -1
+
+    def sync(self):
+        pass
+
+
+def _batched_worker(rank, world, port, n_decode, nb, split, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    G = 2 * world
+    prompts = [np.arange(P, dtype=np.int32) * (s + 2) % VOCAB for s in range(G * nb)]
+    stage = FakeStage(rank, world, G * nb)
+    firsts = pipeline.prefill_torch(rank, world, stage, dist, torch, prompts, "cpu")
+    bats = [FakeBatch(stage, range(g * nb, (g + 1) * nb)) for g in range(G)]
+    if rank == 0:
+        for g, b in enumerate(bats):
+            b.ring[:] = torch.tensor(firsts[g * nb:(g + 1) * nb], dtype=torch.int32)     # Batch.set_state(tokens, ...)
+    pipe = FakePipe(rank, world)
+    st = pipeline.run_ticks_batched_torch(rank, world, pipe, bats, dist, torch, n_decode, "cpu", DIM, 0, split or None)
+    if split:
+        dist.barrier()
+        st = pipeline.run_ticks_batched_torch(rank, world, pipe, bats, dist, torch, n_decode, "cpu", DIM, split, None, st)
+    toks = None
+    if rank == world - 1:
+        toks = [[firsts[g * nb + j]] + [pipe.log[sl + j] for sl in st["slots"][g]] for g in range(G) for j in range(nb)]
+    q.put((rank, toks, firsts if rank == 0 else None, pipe.ran))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_decode,nb,split", [(2, 5, 3, 0), (2, 4, 2, 5), (3, 3, 2, 7)])
+def test_batched_ticks_through_torch_distributed_match_single_process(world, n_decode, nb, split):
+    """the torch.distributed fallback's BATCHED tick (pipeline.prefill_torch + run_ticks_batched_torch: groups of nb sequences as the unit,
+    2*world groups in flight, hidden rows downstream and the groups' token words back to rank 0), with stand-ins for the library's pipe and
+    batches: every sequence's tokens equal the single-process evaluation, every rank ran every group's every step once, in item order"""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_batched_worker, args=(r, world, port, n_decode, nb, split, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = {}
+    for _ in range(world):
+        rank, toks, firsts, ran = q.get(timeout=120)
+        res[rank] = (toks, firsts, ran)
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    G = 2 * world
+    prompts = [np.arange(P, dtype=np.int32) * (s + 2) % VOCAB for s in range(G * nb)]
+    ref = reference(world, prompts, n_decode)
+    assert res[world - 1][0] == ref
+    assert res[0][1] == [r[0] for r in ref]                           # the prefill's token ring reached rank 0
+    for r in range(world):
+        assert res[r][2] == [tuple(range(g * nb, (g + 1) * nb)) for _ in range(n_decode) for g in range(G)]
+
+
 def test_single_rank_pipeline_is_the_plain_greedy_loop():
     prompts = [np.arange(P, dtype=np.int32) * 2 % VOCAB]
     st = pipeline.run_ticks(0, 1, FakeStage(0, 1, 1), dist, torch, prompts, 5, "cpu")
