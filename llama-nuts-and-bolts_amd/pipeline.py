@@ -699,7 +699,10 @@ def one_gpu_anchor(lnb, grp, rank, world, cfg, local, mode, P, W, K, n_seq, seq_
                 c.close()
             if batched and mode == "exact":
                 G, nb = batched
-                m.enable_batch()
+                try:
+                    m.enable_batch()
+                except lnb.LnbError:                         # no room for the matrix-core copy: the batches run as rows on the resident layouts
+                    out["batched_without_the_second_copy"] = True
                 cb = [lnb.InferenceContext(m, seq_len) for _ in range(G * nb)]
                 firsts = [c.Forward(lnb.synth_tokens(99 + q, P, cfg["vocab_size"]), 0, want_logits=False)[1] for q, c in enumerate(cb)]
                 bats = [lnb.Batch(cb[g * nb:(g + 1) * nb]) for g in range(G)]
@@ -888,11 +891,14 @@ def bench_main(args, cfg, name):
             lb, le = stage_layers(rank, world, cfg["n_layers"], head_cost=(costs[3] / max(1e-9, sum(costs[:3])) if costs else 1.2))
             G = 2 * world if world > 1 else int(os.environ.get("LNB_PIPELINE_SEQS", "2"))
             # every rank must take the same path through the collectives below: set the stage up, then AGREE that it worked everywhere
-            # (enable_batch can fail on one rank only -- the head rank holds the extra output.weight copy) before anything is exchanged
-            st, err = None, None
+            # (an allocation can fail on one rank only) before anything is exchanged
+            st, err, copy = None, None, True
             try:
                 st = LnbStage(lnb, None, cfg, rank, world, G * nb, seq_len, local, parts=(3 * lb, 3 * le), costs=costs)
-                st.model.enable_batch()
+                try:
+                    st.model.enable_batch()
+                except lnb.LnbError:                         # no room for the matrix-core copy on this rank (the head rank holds the extra output.weight
+                    copy = False                             # copy): its batches run as rows on the resident layouts, the hand-off is the same [n, dim]
             except lnb.LnbError as e:
                 err = str(e)
             if grp.all_reduce(0 if err else 1, min) == 0:
@@ -924,8 +930,9 @@ def bench_main(args, cfg, name):
             if rank == world - 1:
                 toks0 = [int(pp.read_tokens(first_slot0, 1)[0])] + [int(pp.read_tokens(q, 1)[0]) for q in sb["slots"][0]]
             info = grp.all_reduce([(rank, pp.comm_count(), toks0)], lambda vs: sorted(sum(vs, [])))
-            cuts = grp.all_reduce([(rank, lb, le)], lambda vs: sorted(sum(vs, [])))
-            res_b = {"wall": wall_b, "sequences_in_flight": G * nb, "groups": G, "batch": nb, "blocks_per_gpu": [e_ - b_ for _, b_, e_ in cuts],
+            cuts = grp.all_reduce([(rank, lb, le, copy)], lambda vs: sorted(sum(vs, [])))
+            res_b = {"wall": wall_b, "sequences_in_flight": G * nb, "groups": G, "batch": nb, "blocks_per_gpu": [e_ - b_ for _, b_, e_, _ in cuts],
+                     "second_weight_copy_per_rank": [bool(c_) for _, _, _, c_ in cuts],
                      "cut": "whole blocks (lnb_model_enable_batch refuses a stage cut inside a block: the batched hand-off is [n, dim] only)",
                      "tokens_per_s": round(K * G * nb / wall_b, 2), "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * G), 1),
                      "rccl_comm_count_per_rank": [c for _, c, _ in info], "tokens_vs_oracle_golden": _golden_check(info[-1][2], P, name) if info[-1][2] else None}
