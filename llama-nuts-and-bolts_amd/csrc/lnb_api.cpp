@@ -1464,9 +1464,6 @@ static int batch_decode_impl(lnb_batch* b, const int32_t* tokens, const int32_t*
     for (int s = 0; s < (int)hs.size(); s++) { n_generated[s] = hs[s].n_out; if (finished) finished[s] = hs[s].finished; }
     return 0;
 }
-// Every sequence's position (and, on the first stage, optionally its next input token) before a run of lnb_pipeline_tick_batch steps: the
-// positions then advance on the device with every step.  tokens == NULL keeps what each context's token word holds (what the
-// single-sequence prefill ticks left there).
 // what a batched tick exchanges, for a host layer that moves it itself (lnb_pipeline_init_host)
 extern "C" void* lnb_batch_boundary_ptr(lnb_batch* b, int which) {
     if (!b) { fail("null argument"); return nullptr; }
@@ -1487,6 +1484,9 @@ extern "C" int lnb_batch_check_error(lnb_batch* b) {
     }
     return 0;
 }
+// Every sequence's position (and, on the first stage, optionally its next input token) before a run of lnb_pipeline_tick_batch steps: the
+// positions then advance on the device with every step.  tokens == NULL keeps what each context's token word holds (what the
+// single-sequence prefill ticks left there).
 extern "C" int lnb_batch_set_state(lnb_batch* b, const int32_t* tokens, const int32_t* start_pos) {
     if (!b || !start_pos) return fail("null argument");
     HIPCHK(hipSetDevice(b->m->device));
