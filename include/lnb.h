@@ -173,7 +173,8 @@ int lnb_decode_greedy_until(lnb_ctx* c, int32_t token, int start_pos, int max_st
  *   most ~7.8 K positions (head_dim 128).  A context must not be used by another call while a batch call that contains it runs.
  * lnb_batch_decode: sequence s continues from tokens[s] at position start_pos[s] (different positions are fine); n_steps greedy steps for
  *   all of them as replays of one captured hipGraph; out_tokens[s * n_steps + i] = token i of sequence s.  Afterwards every context's
- *   cache holds its new rows: lnb_forward / lnb_decode_greedy / another batch may continue it.  * Lifetime: a batch holds its member contexts' device pointers (tables, captured graphs): lnb_ctx_destroy on a member FAILS while the
+ *   cache holds its new rows: lnb_forward / lnb_decode_greedy / another batch may continue it.
+ * Lifetime: a batch holds its member contexts' device pointers (tables, captured graphs): lnb_ctx_destroy on a member FAILS while the
  * batch is alive -- destroy the batch first (the Go binding's Close does it in that order). */
 typedef struct lnb_batch lnb_batch;
 int lnb_model_enable_batch(lnb_model* m);
