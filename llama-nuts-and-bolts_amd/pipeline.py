@@ -808,6 +808,9 @@ def bench_main(args, cfg, name):
             sys.stderr.write("[preflight] %s\n" % json.dumps(pre))
         if bad:
             abort_all(rank, "in the preflight (before anything was built or timed)", bad)
+        # every rank is there and healthy: from here the control star only has to notice a rank that DIES (its socket closes at once); the
+        # patience covers rank 0's probe and the slowest rank's stage build on a cold box.  Forming the communicator stays bounded by the watchdog below.
+        grp.set_timeout(max(t_first, 180.0))
         n_seq = 2 * world if world > 1 else int(os.environ.get("LNB_PIPELINE_SEQS", "2"))
         costs = None
         if world > 1 and os.environ.get("LNB_PIPELINE_PROBE", "1") != "0":
