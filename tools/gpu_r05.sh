@@ -90,6 +90,17 @@ print('single', d['value'], '| n', s['n'], 'throughput', s['tokens_per_s'], 'lat
       echo "== LDS-tiled kernel (LNB_PREFILL_NATIVE=0)"; LNB_PREFILL_NATIVE=0 timeout 600 python tools/prefill_bench.py --modes exact --sizes 16,64,128,256,512,2048,4096
       echo "== M16 copy (--stream)"; timeout 600 python tools/prefill_bench.py --modes exact --stream --sizes 16,64,128,256,512,2048,4096; } 2>&1 | tee gpurun_out/r05_prefill.log
     ;;
+  mfma)     # matrix-core counters of the exact prefill on the RESIDENT layouts (the round's default prompt path): a trace pass and a counter pass per size, 8-block cut
+    O=$PWD/gpurun_out/prof_r05_mfma; rm -rf $O; mkdir -p $O
+    MD=gpurun_out/r05_prefill_mfma_counters.md; : > $MD
+    for S in 128 4096; do
+      ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$S -o t_$S -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py --modes exact --sizes $S --layers 8 --reps 3 > $O/trace_$S.out 2> $O/trace_$S.err; echo "trace $S rc=$?" )
+      ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_$S -o p_$S -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py --modes exact --sizes $S --layers 8 --reps 3 > $O/pmc_$S.out 2> $O/pmc_$S.err; echo "pmc $S rc=$?" )
+      python tools/mfma_counters.py $O/pmc_$S $O/trace_$S "exact prefill, $S rows, gemm_stream_kernel on the resident weight layouts (no second copy), 8-block cut of the 8B shape" >> $MD
+      tail -1 $O/trace_$S.out
+    done
+    cat $MD; find $O -name "*kernel_stats.csv" -exec cp {} gpurun_out/ \; ; du -sh gpurun_out
+    ;;
   closing)  # after the last kernel change: quick parity, the throughput forms, the default / driver lines, the rocprofv3 record
     ( timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_gpu_round5.py -x -q ) 2>&1 | tail -3
     ( time timeout 900 python bench.py ) > gpurun_out/r05_bench_default.json 2> gpurun_out/r05_bench_default.err; echo "bench rc=$?"; tail -3 gpurun_out/r05_bench_default.err

@@ -13,14 +13,15 @@ ap.add_argument("--sizes", default="128,512,2048,4096")
 ap.add_argument("--modes", default="exact,fast")
 ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--out", default="")
+ap.add_argument("--layers", type=int, default=32, help="blocks of the model (fewer: a cheap run under the profiler -- the launches per block are the same)")
 ap.add_argument("--stream", action="store_true", help="enable the matrix-core copy of the weights first: exact prefill products run on gemm_stream_kernel")
 a = ap.parse_args()
 sizes = [int(s) for s in a.sizes.split(",")]
-m = lnb.LlamaTransformer(device=0, **lnb.LLAMA_8B).fill_synthetic(1234).finalize(rope_rows=max(sizes) + 64)
+m = lnb.LlamaTransformer(device=0, **dict(lnb.LLAMA_8B, n_layers=a.layers)).fill_synthetic(1234).finalize(rope_rows=max(sizes) + 64)
 if a.stream:
     m.enable_batch()
 c = lnb.InferenceContext(m, max(sizes) + 8)
-MATMUL = 6979321856                       # weight elements of the 32 blocks (multiply-accumulates per row)
+MATMUL = 6979321856 // 32 * a.layers      # weight elements of the blocks (multiply-accumulates per row)
 res = []
 for mode in a.modes.split(","):
     c.set_mode(mode)
