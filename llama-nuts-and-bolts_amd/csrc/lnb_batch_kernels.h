@@ -417,6 +417,12 @@ DEVINL void ld_plain(u32x4& d, const void* a) { asm volatile("global_load_dwordx
 #define GS_W_NT 0                                            // weight loads: default cache policy (0) -- the row groups of a launch share every weight tile through the L2:
                                                              // 1-5 % faster than non-temporal loads (1) at 128-4096 rows, 3.6 against 4.7 GB of fabric reads per gate|up launch at 4096
 #endif
+#ifndef GS_X1
+#define GS_X1 1                                              // chain layouts at four batch tiles per wave: the one-k matrix instruction with CBSZ / ABID (no transpose); 0 = the row-swap transpose
+#endif
+#ifndef GS_RX
+#define GS_RX 2                                              // ring depth of the two-chain product on the chain layouts at four batch tiles per wave
+#endif
 #ifndef GS_R1
 #define GS_R1 3                                              // ring depth at NTW = 1 / NTW = 2 (one chain)
 #define GS_R2 3
@@ -468,7 +474,7 @@ template <int EPI, int NCH, int NTW, int SRC = 0>
 __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW == 4 ? 2 : 1) void gemm_stream_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int L = NCH * 4 + NTW;                         // loads per chunk and lane: NCH * 4 weight units + NTW activation units
-    constexpr int R = NCH == 1 ? (NTW == 1 ? GS_R1 : NTW == 2 ? GS_R2 : 3) : (SRC == 2 && NTW == 4) ? 2 : 3;   // chunks in flight (two chains x four batch tiles from a chain
+    constexpr int R = NCH == 1 ? (NTW == 1 ? GS_R1 : NTW == 2 ? GS_R2 : 3) : (SRC == 2 && NTW == 4) ? GS_RX : 3;   // chunks in flight (two chains x four batch tiles from a chain
                                                              // layout: 2 -- a chunk is then 256 matrix instructions = 3.6 us of lookahead each, and the third slot's 48
                                                              // registers spilled).  A chunk of one batch tile is 32 matrix instructions = ~1.5k
                                                              // cycles of a wave: three of them in flight are less than HBM's latency under load
@@ -547,6 +553,17 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
     for (int cc = 0; cc < NCH; cc++)
 #pragma unroll
         for (int t = 0; t < NTW; t++) acc[cc][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // X1 (chain layouts, four batch tiles per wave): the four BLOCKS of v_mfma_f32_16x16x1_f32 are the four batch tiles, one k per instruction, and CBSZ = 2
+    // broadcasts the A operand of block ABID to all of them -- lane (i, r) holds k = 32 j + 8 r + e of weight row i (exactly what the chain-layout loads put
+    // there), so ABID = r walks the k of a load in ascending order with NO transpose: one unpack op per element, shared by the four ABID steps that use the
+    // register.  Bit-identical to the chain and at the 16x16x4 instruction's rate (tools/mfma_x1_probe.hip, profiles/r05_mfma_x1_probe.log).
+    constexpr bool X1 = GS_X1 && SRC == 2 && NTW == 4;
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    f32x16 acc16[NCH];
+#pragma unroll
+    for (int cc = 0; cc < NCH; cc++)
+#pragma unroll
+        for (int q = 0; q < 16; q++) acc16[cc][q] = 0.f;
     int c = 0, round = 0;
     const int bcol = lane & 15, bk = lane >> 4;
     for (int t0 = 0; t0 < T; t0 += R) {
@@ -569,6 +586,62 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                 // instructions that consume them (left to hipcc, a read at NTW = 1 / 2 is issued right in front of its use: ~100 cycles of LDS
                 // latency per two matrix instructions, 55 % of the matrix rate at 128 rows); counted lgkmcnt waits, registers handed back
                 // through the same RING markers tools/isa_audit.py checks
+                if constexpr (X1) {
+                    typedef float f32x2 __attribute__((ext_vector_type(2)));
+                    const unsigned ba1 = (unsigned)(size_t)(bw + (size_t)lane * GS_PITCH);       // LDS byte address of this lane's activation row: batch tile lane >> 4, row lane & 15
+                    f32x2 bq1[2][4];                         // the B operands of a group of eight steps (k = 8 g .. 8 g + 7 of the chunk), read one group ahead
+                    auto lds_issue1 = [&](auto gc) __attribute__((always_inline)) {
+                        constexpr int g = decltype(gc)::value;
+#pragma unroll
+                        for (int h = 0; h < 4; h++) {        // (a local result and an address EXPRESSION: hipcc does not see a captured variable named directly in an asm operand of a generic lambda)
+                            f32x2 v;
+                            asm volatile("ds_read_b64 %0, %1 offset:%2 ; RING_LOAD" : "=v"(v) : "v"(ba1 + 0u), "n"(32 * g + 8 * h) : "memory");
+                            bq1[g & 1][h] = v;
+                        }
+                    };
+                    lds_issue1(std::integral_constant<int, 0>{});
+                    float av1[NCH][8];
+                    static_for<0, 16>([&](auto gc) __attribute__((always_inline)) {
+                        constexpr int g = decltype(gc)::value, jj = g >> 2, r = g & 3;       // load jj of the chunk, lane row r: k = 128 C + 32 jj + 8 r + e
+                        if constexpr (g + 1 < 16) lds_issue1(std::integral_constant<int, g + 1>{});
+                        if constexpr (r == 0) {
+#pragma unroll
+                            for (int cc = 0; cc < NCH; cc++)
+#pragma unroll
+                                for (int e = 0; e < 8; e++) { const unsigned w = buf[j][cc * 4 + jj][e >> 1]; av1[cc][e] = (e & 1) ? bf_hi(w) : bf_lo(w); }
+                            if constexpr (jj == 3) {         // every weight register of the slot has been read (the x registers were consumed above): refill
+#pragma unroll
+                                for (int cc = 0; cc < NCH; cc++)
+#pragma unroll
+                                    for (int e = 0; e < 8; e++) asm volatile("" : "+v"(av1[cc][e]));
+                                issue_next(buf[j]);
+                            }
+                        }
+                        asm volatile("s_waitcnt lgkmcnt(%0)" :: "n"(g + 1 < 16 ? 4 : 0) : "memory");
+#pragma unroll
+                        for (int h = 0; h < 4; h++) asm volatile("; RING_RETIRE %0" : "+v"(bq1[g & 1][h]));
+#pragma unroll
+                        for (int e = 0; e < 8; e++)           // ascending k (operations_lineartransform.go:46-65)
+#pragma unroll
+                            for (int cc = 0; cc < NCH; cc++)
+                                acc16[cc] = __builtin_amdgcn_mfma_f32_16x16x1f32(av1[cc][e], bq1[g & 1][e >> 1][e & 1], acc16[cc], 2, r, 0);
+                    });
+                    if (++c == nchunks) {                    // block t of the result = batch tile t: column lane & 15 of it, rows (lane >> 4) * 4 + q of the weight tile
+                        const int tile = (round * (int)gridDim.x + bx) * 4 + wave;
+#pragma unroll
+                        for (int t = 0; t < NTW; t++) {
+                            const f32x4 a0 = {acc16[0][4 * t], acc16[0][4 * t + 1], acc16[0][4 * t + 2], acc16[0][4 * t + 3]};
+                            const f32x4 a1 = {acc16[NCH - 1][4 * t], acc16[NCH - 1][4 * t + 1], acc16[NCH - 1][4 * t + 2], acc16[NCH - 1][4 * t + 3]};
+                            if (tile < n_tiles) gemm_epilogue4<EPI>(p, a0, a1, m0 + t * 16 + (lane & 15), tile * 16 + (lane >> 4) * 4);
+                        }
+#pragma unroll
+                        for (int cc = 0; cc < NCH; cc++)
+#pragma unroll
+                            for (int q = 0; q < 16; q++) acc16[cc][q] = 0.f;
+                        c = 0; round++;
+                    }
+                    continue;
+                }
                 const unsigned ba = (unsigned)(size_t)(bw + (size_t)bcol * GS_PITCH + bk);       // LDS byte address of this lane's (row, kk) at k-group 0, batch tile 0
                 float bq[D + 1][2 * NTW][2];
                 auto lds_issue = [&](auto ec) __attribute__((always_inline)) {

@@ -3364,6 +3364,8 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
     int ntw = lnb_gemm_stream_ntw(n_tiles, ct, NCH, num_cus);
     static const int force = getenv("LNB_GS_NTW") ? atoi(getenv("LNB_GS_NTW")) : 0;    // (tools / experiments)
     if (force == 1 || force == 2 || force == 4) ntw = force;
+    static const int force_ct = getenv("LNB_GS_NTW_CHAIN") ? atoi(getenv("LNB_GS_NTW_CHAIN")) : 0;    // (experiments: the chain layouts only)
+    if (src == 2 && (force_ct == 1 || force_ct == 2 || force_ct == 4)) ntw = force_ct;
     GemmParams q = *p;
     const int rows_wg = 16 * ntw;
     unsigned gx = (unsigned)((n_tiles + 3) / 4); if (gx > (unsigned)num_cus) gx = (unsigned)num_cus;
