@@ -167,7 +167,7 @@ int lnb_decode_greedy_until(lnb_ctx* c, int32_t token, int start_pos, int max_st
  *   model's matrix bytes again -- 15 GB for the 8B shape; fails cleanly when that does not fit, the other entry points stay usable).  Works
  *   on a whole model and on a pipeline stage of whole blocks.  Since round 5 it is a pure PERFORMANCE option: prompts (lnb_forward with 16 or
  *   more rows) stream the resident weight layouts, and lnb_batch_create on a model without the copy runs every product of the batch as rows of
- *   that streaming kernel, whatever the number of sequences (33..128 sequences: 7-9 % slower than with the copy; up to 32 the column forms,
+ *   that streaming kernel, whatever the number of sequences (64..128 sequences: 3-8 % slower than with the copy; up to 32 the column forms,
  *   which read the copy, are the faster ones by more).  Same bits either way.
  * lnb_batch_create: the contexts keep their own KV caches and positions (prefill each with lnb_forward first); seq_len of each context at
  *   most ~7.8 K positions (head_dim 128).  A context must not be used by another call while a batch call that contains it runs.
