@@ -40,8 +40,35 @@ typedef struct lnb_model_args {
     int32_t max_seq_len;         /* 2048; RoPE table has 2*max_seq_len rows (llamatransformer.go:109) */
 } lnb_model_args;
 
+/* ABI version of this header.  A binding (cgo, ctypes, JNI ...) compares it with lnb_abi_version() of the library it loaded and refuses a mismatch:
+ * round 5 changed lnb_batch_decode_until's signature (`finished` in the middle) -- a stale binding would have passed a float* where the library writes
+ * n int32 values.  Bumped whenever an existing entry point changes its arguments; additions do not bump it.
+ *   6: lnb_batch_decode_until(..., n_generated, finished, ms_out); lnb_runtime_info; lnb_abi_version itself. */
+#define LNB_ABI_VERSION 6
+int lnb_abi_version(void);
+
 const char* lnb_last_error(void);
 int lnb_device_count(int* out_count);
+/* Runtime facts a host needs before it trusts a run with SEVERAL contexts in flight (one InferenceContext per generation, one goroutine each:
+ * src/inference/inference.go:163-174).  The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and
+ * streams that share a queue serialise; while it is being loaded this library exports 16 unless the host set a value or LNB_KEEP_HW_QUEUES=1 --
+ * but the runtime reads the variable at ITS initialisation, so a host that used HIP before loading the library keeps its 4 queues (two
+ * contexts in flight then run slower than one).  hw_queues_measured (probe_queues != 0, ~2 ms): streams that really ran concurrently.
+ * A host warns when contexts in flight > min(hw_queues_expected, hw_queues_measured or expected) (bench.py, go/inferencecontext_hip.go do). */
+typedef struct lnb_runtime_info_t {
+    int32_t abi_version;
+    int32_t device, n_cus;
+    int32_t shader_clock_khz, memory_clock_khz, wall_clock_khz;   /* hipDeviceAttributeClockRate / MemoryClockRate / WallClockRate */
+    int32_t hw_queues_env;                 /* GPU_MAX_HW_QUEUES in the process environment now (0: unset = the runtime's default 4) */
+    int32_t hw_queues_set_by_library;      /* 1: the value is this library's load-time default */
+    int32_t hip_initialised_before_load;   /* 1: /dev/kfd was already open when the library was loaded: the runtime had read the variable before */
+    int32_t hw_queues_expected;            /* what the runtime will have honoured given the three fields above */
+    int32_t hw_queues_measured;            /* probe: 32 spinning one-wave kernels on 32 streams ran in 32 / this many rounds (0: not probed) */
+    float   probe_ms;
+    char    device_name[64];
+    char    arch[32];
+} lnb_runtime_info_t;
+int lnb_runtime_info(int device, int probe_queues, lnb_runtime_info_t* out);
 /* preflight of a multi-GPU host (bench.py --gpus N prints it per rank before any timing): the device behind an index (any out pointer may be
  * NULL) and whether `device` can map `peer`'s memory -- the peer-to-peer path RCCL's ncclSend / ncclRecv ride on (xGMI inside a node) */
 int lnb_device_info(int device, char* name, int name_cap, int64_t* hbm_bytes, int* n_cus, char* arch, int arch_cap);
@@ -277,6 +304,10 @@ int lnb_pipeline_selftest(int device, int n_bytes);
  * 6 the five kernels of a whole block.  Consecutive launches cycle through this stage's layers so every launch
  * streams its weights from HBM instead of the 256 MiB Infinity Cache.  The KV cache content at `pos` is overwritten. */
 int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, float* avg_ms_out);
+/* ... and of the gate|up (w1|w3) and down (w2) kernels of a block launched on TWO streams, w2 `w2_delay_us` behind w1|w3: the time a
+ * w1|w3 -> w2 streaming stage (llamatransformer.go:593-624) would have to beat, measured without building it (w2 reads stale activations:
+ * only the time means anything).  w2_lds_pad: extra dynamic LDS for the w2 launch (forces one workgroup of each kernel per CU). */
+int lnb_profile_ffn_pair(lnb_ctx* c, int pos, int iters, int w2_delay_us, int w2_lds_pad, float* avg_ms_out);
 /* ... and the in-kernel cycle stamps of ONE launch of a GEMV class (which 0, 2, 3, 4 or 5): out[8 waves][16] doubles, per wave = {workgroups
  * that reported, avg total shader cycles, max total, avg barrier wait, avg "x staged / prologue end", avg "norm fold or walk" (wo / w2 chain
  * waves: chain start), avg phase stamps 0..6, stamp 7 = the same launch on the constant-rate wall clock}; *wall_clock_khz = that clock's rate

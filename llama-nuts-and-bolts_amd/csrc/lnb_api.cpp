@@ -10,6 +10,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <chrono>
+#include <dirent.h>
+#include <unistd.h>
 #include <deque>
 #include <map>
 #include <mutex>
@@ -49,6 +51,7 @@ hipError_t lnbk_batch_scatter_ring(const BatchTab* tab, const int32_t* ring, hip
 hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st);
 hipError_t lnbk_batch_prepare(void);
 hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream_t st);
+hipError_t lnbk_spin(int us, hipStream_t st);
 }
 
 // The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and streams that share a queue run one after the
@@ -57,7 +60,35 @@ hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream
 // 278 tokens/s) and eight share four (306 instead of 337 tokens/s; profiles/r05_hw_queues.log).  The runtime reads the variable when it initialises
 // -- at the first HIP call of the process -- so a default set while this library is being loaded is in time unless the host has used HIP before;
 // a value the host exported wins.
-__attribute__((constructor)) static void lnb_default_hw_queues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+// Round 6: the default is opt-out (LNB_KEEP_HW_QUEUES=1 leaves the environment alone), what happened is recorded, and
+// lnb_runtime_info() reports it -- including whether the HIP runtime had ALREADY been initialised when this library was loaded (a host that touched
+// HIP first silently keeps 4 queues: 2 contexts in flight then run SLOWER than one) and, on request, the number of streams that really run
+// concurrently (measured, not read from the environment).
+static int g_hwq_set_by_library = 0;      // 1: this library put "16" into the environment
+static int g_hip_live_at_load = 0;        // 1: /dev/kfd was already open when the library was loaded -> the runtime read the variable before us
+static bool kfd_is_open() {
+    // the ROCm runtime (HSA) opens /dev/kfd when it initialises, never before: an open descriptor on it = HIP has been used in this process
+    DIR* d = opendir("/proc/self/fd");
+    if (!d) return false;
+    bool found = false;
+    char path[64], target[256];
+    while (struct dirent* e = readdir(d)) {
+        if (e->d_name[0] == '.') continue;
+        snprintf(path, sizeof path, "/proc/self/fd/%s", e->d_name);
+        const ssize_t n = readlink(path, target, sizeof target - 1);
+        if (n <= 0) continue;
+        target[n] = 0;
+        if (!strcmp(target, "/dev/kfd")) { found = true; break; }
+    }
+    closedir(d);
+    return found;
+}
+__attribute__((constructor)) static void lnb_default_hw_queues() {
+    g_hip_live_at_load = kfd_is_open() ? 1 : 0;
+    const char* keep = getenv("LNB_KEEP_HW_QUEUES");
+    if (keep && *keep && atoi(keep) != 0) return;
+    if (!getenv("GPU_MAX_HW_QUEUES")) { setenv("GPU_MAX_HW_QUEUES", "16", 0); g_hwq_set_by_library = 1; }
+}
 
 static thread_local char g_err[1024] = "";
 static int fail(const char* fmt, ...) {
@@ -181,8 +212,8 @@ static int auto_rw(int lane_rows, const char* env, int K = 0, bool plain = false
     return 64;
 }
 static int g_num_cus = 256;
-static long long* g_dbg = nullptr;   // LNB_GEMV_TIMING=1: per-wave timing dump of the profiled launch
-static int g_dbg_full = 0;           // ... with every barrier and ring wait timed (perturbs the launch); 0: phase stamps and the exit record only
+static thread_local long long* g_dbg = nullptr;   // (thread-local: arming the stamps on one thread must not reach another thread's launches -- ADVICE r5) LNB_GEMV_TIMING=1: per-wave timing dump of the profiled launch
+static thread_local int g_dbg_full = 0;           // ... with every barrier and ring wait timed (perturbs the launch); 0: phase stamps and the exit record only
 // one resident workgroup per CU: a matrix with more row blocks than CUs is walked persistently
 static void set_grid(GemvParams& g, const TiledDesc& t) { g.dbg = g_dbg; g.dbg_full = g_dbg ? g_dbg_full : 0; g.n_blocks = t.n_blocks; g.n_wg = t.n_blocks < g_num_cus ? t.n_blocks : g_num_cus; }
 static int alloc_tiled(TiledDesc& t, int n_rows, int K, int rw, int nch, int64_t& bytes) {
@@ -198,6 +229,61 @@ static int alloc_linear(uint16_t** p, size_t elems, int64_t& bytes) {
 }
 
 extern "C" int lnb_device_count(int* out) { int n = 0; HIPCHK(hipGetDeviceCount(&n)); *out = n; return 0; }
+extern "C" int lnb_abi_version(void) { return LNB_ABI_VERSION; }
+// What the host should know before it trusts a multi-context run: the hardware queues the HIP runtime was told to use, who told it,
+// whether that was in time, and -- probe_queues != 0 -- how many streams REALLY run concurrently: 32 one-wave kernels that each hold their stream for
+// 200 us of wall clock, one per stream; with Q queues they finish in ceil(32 / Q) rounds (about 1-3 ms including the stream set-up).
+extern "C" int lnb_runtime_info(int device, int probe_queues, lnb_runtime_info_t* out) {
+    if (!out) return fail("null argument");
+    memset(out, 0, sizeof *out);
+    out->abi_version = LNB_ABI_VERSION;
+    int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev == 0) return fail("no HIP device: liblnb_hip.so has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail("device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipSetDevice(device));
+    hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device));
+    out->device = device; out->n_cus = prop.multiProcessorCount;
+    snprintf(out->device_name, sizeof out->device_name, "%s", prop.name);
+    snprintf(out->arch, sizeof out->arch, "%s", prop.gcnArchName);
+    int v = 0;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeClockRate, device) == hipSuccess) out->shader_clock_khz = v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeMemoryClockRate, device) == hipSuccess) out->memory_clock_khz = v;
+    if (hipDeviceGetAttribute(&v, hipDeviceAttributeWallClockRate, device) == hipSuccess) out->wall_clock_khz = v;
+    const char* q = getenv("GPU_MAX_HW_QUEUES");
+    out->hw_queues_env = q && *q ? atoi(q) : 0;
+    out->hw_queues_set_by_library = g_hwq_set_by_library;
+    out->hip_initialised_before_load = g_hip_live_at_load;
+    // what the runtime will have honoured: the environment's value unless HIP was live before this library could set it (then the runtime's default, 4,
+    // unless the HOST had exported a value -- which it read at its own initialisation)
+    out->hw_queues_expected = (g_hip_live_at_load && g_hwq_set_by_library) ? 4 : (out->hw_queues_env > 0 ? out->hw_queues_env : 4);
+    if (probe_queues) {
+        constexpr int NSTREAM = 32, SPIN_US = 200;
+        hipStream_t sts[NSTREAM] = {}; hipEvent_t e0 = nullptr, e1 = nullptr, ej[NSTREAM] = {};
+        hipError_t e = hipSuccess;
+        for (int i = 0; i < NSTREAM && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&sts[i], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&ej[i], hipEventDisableTiming); }
+        if (e == hipSuccess) e = hipEventCreate(&e0);
+        if (e == hipSuccess) e = hipEventCreate(&e1);
+        float ms = 0;
+        for (int rep = 0; rep < 2 && e == hipSuccess; rep++) {      // (the first round warms the streams up)
+            e = hipEventRecord(e0, sts[0]);
+            for (int i = 1; i < NSTREAM && e == hipSuccess; i++) e = hipStreamWaitEvent(sts[i], e0, 0);
+            for (int i = 0; i < NSTREAM && e == hipSuccess; i++) e = lnbk_spin(SPIN_US, sts[i]);
+            for (int i = 1; i < NSTREAM && e == hipSuccess; i++) { e = hipEventRecord(ej[i], sts[i]); if (e == hipSuccess) e = hipStreamWaitEvent(sts[0], ej[i], 0); }
+            if (e == hipSuccess) e = hipEventRecord(e1, sts[0]);
+            if (e == hipSuccess) e = hipEventSynchronize(e1);
+            if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        }
+        for (int i = 0; i < NSTREAM; i++) { if (sts[i]) hipStreamDestroy(sts[i]); if (ej[i]) hipEventDestroy(ej[i]); }
+        if (e0) hipEventDestroy(e0);
+        if (e1) hipEventDestroy(e1);
+        HIPCHK(e);
+        const double rounds = (double)ms * 1000.0 / SPIN_US;     // 32 / Q, plus launch overhead
+        int qm = rounds > 0.5 ? (int)((double)NSTREAM / rounds + 0.5) : NSTREAM;
+        out->hw_queues_measured = qm < 1 ? 1 : (qm > NSTREAM ? NSTREAM : qm);
+        out->probe_ms = ms;
+    }
+    return 0;
+}
 // what a multi-GPU host prints before it trusts a run (bench.py --gpus N: the per-rank preflight record): the device behind an index, and
 // whether `device` can map `peer`'s memory (hipDeviceCanAccessPeer: xGMI / PCIe peer-to-peer, what RCCL's point-to-point path rides on)
 extern "C" int lnb_device_info(int device, char* name, int name_cap, int64_t* hbm_bytes, int* n_cus, char* arch, int arch_cap) {
@@ -266,6 +352,7 @@ extern "C" int lnb_model_create_parts(const lnb_model_args* args, int device, in
     HIPCHK(hipSetDevice(device));
     HIPCHK(lnbk_init());
     HIPCHK(lnbk_fast_init());
+    HIPCHK(lnbk_batch_prepare());                                         // dynamic-LDS limits of the prefill / batch kernels, once, outside any capture (a prompt on a model without enable_batch reaches gemm_stream_kernel too)
     { hipDeviceProp_t prop; HIPCHK(hipGetDeviceProperties(&prop, device)); if (prop.multiProcessorCount > 0) g_num_cus = prop.multiProcessorCount; }
     lnb_model* m = new lnb_model();
     m->a = a; m->device = device; m->layer_begin = layer_begin; m->layer_end = layer_end; m->part_begin = part_begin; m->part_end = part_end;
@@ -986,8 +1073,10 @@ static int gemv_stamps(lnb_ctx* c, int which, double* out, int full) {
     lnb_model* m = c->m; hipStream_t st = c->stream;
     const size_t n = (size_t)4096 * 8 * 4, n2 = (size_t)4096 * 8 * 8;       // + 8 phase stamps per wave behind the four totals (LNB_STAMP in lnb_kernels.hip)
     long long* dbuf = nullptr;
-    HIPCHK(hipMalloc((void**)&dbuf, (n + n2) * 8)); HIPCHK(hipMemsetAsync(dbuf, 0, (n + n2) * 8, st));
+    HIPCHK(hipMalloc((void**)&dbuf, (n + n2) * 8));
+    { hipError_t e = hipMemsetAsync(dbuf, 0, (n + n2) * 8, st); if (e != hipSuccess) { hipFree(dbuf); HIPCHK(e); } }
     const int nl = m->layer_end - m->layer_begin;
+    if (nl <= 0 && which != K_HEAD) { hipFree(dbuf); return fail("this stage holds no transformer block: only kernel class %d (norm + output) can be stamped", K_HEAD); }   // (i % nl below)
     // three plain launches of the class on other layers first, back to back with the stamped one: it then runs as a launch inside a decode step does
     // (instruction cache, clocks and memory pipeline warm) instead of as the first launch after an idle gap
     int rc = 0;
@@ -996,10 +1085,13 @@ static int gemv_stamps(lnb_ctx* c, int which, double* out, int full) {
     if (!rc) rc = which == K_HEAD ? enqueue_head(c, 0, 1) : enqueue_layer_kernel(c, m->layer_begin + 7 % nl, 1, which);
     g_dbg = nullptr; g_dbg_full = 0;
     if (rc) { hipFree(dbuf); return -1; }
-    HIPCHK(hipStreamSynchronize(st));
     std::vector<long long> h(n + n2);
-    HIPCHK(hipMemcpy(h.data(), dbuf, (n + n2) * 8, hipMemcpyDeviceToHost));
-    hipFree(dbuf);
+    {   // (no early return between here and the free: ADVICE r5)
+        hipError_t e = hipStreamSynchronize(st);
+        if (e == hipSuccess) e = hipMemcpy(h.data(), dbuf, (n + n2) * 8, hipMemcpyDeviceToHost);
+        hipFree(dbuf);
+        HIPCHK(e);
+    }
     for (int w = 0; w < 8; w++) {
         double* o = out + w * 16; for (int k = 0; k < 16; k++) o[k] = 0;
         int cnt = 0;
@@ -1027,6 +1119,45 @@ extern "C" int lnb_profile_kernel_stamps(lnb_ctx* c, int which, int pos, double*
     HIPCHK(ctx_set_state(c, pos, 0, true));
     if (wall_clock_khz) { int khz = 0; HIPCHK(hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, m->device)); *wall_clock_khz = khz; }
     return gemv_stamps(c, which, out, 0);                    // light: the launch runs as it does in production
+}
+
+// measurement aid (tools/ffn_overlap.py, profiles/r06_ffn_stream.md): what a w1|w3 -> w2 streaming stage could reach, measured before it is built.  The gate|up
+// kernel and the down kernel of a block are launched on two streams, the down kernel `w2_delay_us` microseconds behind the gate|up kernel (a one-wave
+// spin kernel in front of it holds its stream): delay 0 = plain co-residency, delay ~ "the first row band is complete" = the timeline of a band
+// pipeline, with no dependency stall at all (w2 reads STALE activations -- the results are meaningless, only the time is).  w2_lds_pad pads w2's
+// LDS request (r3's way of forcing exactly one workgroup of each kernel per CU).  Both kernels take the forms of the context's schedule.
+extern "C" int lnb_profile_ffn_pair(lnb_ctx* c, int pos, int iters, int w2_delay_us, int w2_lds_pad, float* avg_ms_out) {
+    if (!c || !avg_ms_out) return fail("null argument");
+    lnb_model* m = c->m;
+    HIPCHK(hipSetDevice(m->device));
+    if (iters <= 0 || w2_delay_us < 0) return fail("bad arguments");
+    if (check_call(c, 1, pos)) return -1;
+    const int nl2 = m->layer_end - m->layer_begin;
+    if (nl2 <= 0) return fail("this stage holds no transformer block");
+    hipStream_t st = c->stream, st2 = nullptr; hipEvent_t ef = nullptr, ej = nullptr;
+    HIPCHK(hipStreamCreateWithFlags(&st2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&ef, hipEventDisableTiming)); HIPCHK(hipEventCreateWithFlags(&ej, hipEventDisableTiming));
+    c->attn_long = false;
+    HIPCHK(ctx_set_state(c, pos, 0, true));
+    auto pair = [&](int i) -> int {
+        const int l = m->layer_begin + i % nl2;
+        HIPCHK(hipEventRecord(ef, st)); HIPCHK(hipStreamWaitEvent(st2, ef, 0));
+        if (enqueue_layer_kernel(c, l, 1, K_W13)) return -1;
+        if (w2_delay_us > 0) HIPCHK(lnbk_spin(w2_delay_us, st2));
+        if (enqueue_layer_kernel(c, l, 1, K_W2, st2, w2_lds_pad)) return -1;
+        HIPCHK(hipEventRecord(ej, st2)); HIPCHK(hipStreamWaitEvent(st, ej, 0));
+        return 0;
+    };
+    int rc = 0;
+    for (int i = 0; i < 3 && !rc; i++) rc = pair(i);
+    if (!rc) { HIPCHK(hipEventRecord(c->ev0, st)); for (int i = 0; i < iters && !rc; i++) rc = pair(i + 3); HIPCHK(hipEventRecord(c->ev1, st)); }
+    hipError_t e = hipDeviceSynchronize();
+    float ms2 = 0; if (!rc && e == hipSuccess) e = hipEventElapsedTime(&ms2, c->ev0, c->ev1);
+    hipEventDestroy(ef); hipEventDestroy(ej); hipStreamDestroy(st2);
+    if (rc) return -1;
+    HIPCHK(e);
+    *avg_ms_out = ms2 / (float)iters;
+    return 0;
 }
 
 extern "C" int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, float* avg_ms_out) {

@@ -3310,12 +3310,24 @@ extern "C" hipError_t lnbk_stream(const StreamParams* p, int epi, int acc2, int 
     return hipGetLastError();
 }
 extern "C" hipError_t lnbk_gemm_stream(const GemmParams* p, int epi, int num_cus, hipStream_t st);
+// a one-wave kernel that occupies its stream for `us` microseconds of the constant-rate wall clock (measurement aid: lnb_runtime_info's count of
+// streams that really run concurrently; the delayed second launch of tools/ffn_overlap.py)
+__global__ void spin_kernel(long long ticks) { const long long t0 = (long long)wall_clock64(); while ((long long)wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8); }
+extern "C" hipError_t lnbk_spin(int us, hipStream_t st) {
+    int khz = 100000, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, dev);
+    hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, st, (long long)us * khz / 1000);
+    return hipGetLastError();
+}
 extern "C" hipError_t lnbk_batch_prepare(void) {             // raise the dynamic-LDS limits once, outside any stream capture
+    static bool done = false;
+    if (done) return hipSuccess;
     hipError_t e = hipFuncSetAttribute((const void*)batch_rmsnorm_xt_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mfma_pair_kernel<EPI_STORE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mfma_pair_kernel<EPI_RESID>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e == hipSuccess) e = hipFuncSetAttribute((const void*)mfma_pair_kernel<EPI_QKV_ROPE>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     for (int ep = EPI_STORE; ep <= EPI_SILU_MUL && e == hipSuccess; ep++) e = lnbk_gemm_stream(nullptr, ep, 0, nullptr);
+    done = e == hipSuccess;
     return e;
 }
 extern "C" hipError_t lnbk_batch_rmsnorm(const uint16_t* x, const uint16_t* norm_w, float eps, uint16_t* xt, int K, int nseq, hipStream_t st) {
@@ -3350,8 +3362,12 @@ extern "C" hipError_t lnbk_batch_advance(const BatchTab* tab, hipStream_t st) {
 template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParams* p, int num_cus, hipStream_t st) {
     if (!p) {
         hipError_t e = hipSuccess;
-#define LNB_GS_PREP(N) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, NCH, N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
-        LNB_GS_PREP(1); LNB_GS_PREP(2); LNB_GS_PREP(4);
+        // every instantiation the launch below can pick (the resident-layout sources SRC 1 / 2 request up to 66,560 B at four batch
+        // tiles per wave -- above the 64 KiB a kernel gets without this attribute)
+#define LNB_GS_PREP(N, SRC_) if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, NCH, N, SRC_>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+        LNB_GS_PREP(1, 0); LNB_GS_PREP(2, 0); LNB_GS_PREP(4, 0);
+        LNB_GS_PREP(1, 2); LNB_GS_PREP(2, 2); LNB_GS_PREP(4, 2);
+        if constexpr (NCH == 1 && (EPI == EPI_STORE || EPI == EPI_RESID)) { LNB_GS_PREP(1, 1); LNB_GS_PREP(2, 1); LNB_GS_PREP(4, 1); }
 #undef LNB_GS_PREP
         return e;
     }

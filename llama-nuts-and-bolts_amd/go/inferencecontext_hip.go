@@ -84,6 +84,34 @@ func lnbGoLayerCallback(layer C.int, nLayers C.int, secs C.double, user unsafe.P
 	ic.Logf("Transformer block layer %d / %d was run, took %.4f sec(s)", int(layer), int(nLayers), float64(secs))
 }
 
+var queueWarned bool // (guarded by lt.mu's critical section order: a benign race at worst prints the line twice)
+
+// RuntimeInfo reports what lnb_runtime_info says about the process: hardware queues the HIP runtime was told to use (and, with probe, how many
+// streams really run concurrently), whether the library's default arrived before HIP initialised, device and clocks.
+type RuntimeInfo struct {
+	ABIVersion, Device, NumCUs                             int
+	ShaderClockKHz, MemoryClockKHz, WallClockKHz           int
+	HWQueuesEnv, HWQueuesExpected, HWQueuesMeasured        int
+	HWQueuesSetByLibrary, HIPInitialisedBeforeLibraryLoad  bool
+	DeviceName, Arch                                       string
+}
+
+func GetRuntimeInfo(device int, probeQueues bool) (RuntimeInfo, error) {
+	var ri C.lnb_runtime_info_t
+	probe := C.int(0)
+	if probeQueues {
+		probe = 1
+	}
+	if err := lnbCall(func() C.int { return C.lnb_runtime_info(C.int(device), probe, &ri) }); err != nil {
+		return RuntimeInfo{}, err
+	}
+	return RuntimeInfo{ABIVersion: int(ri.abi_version), Device: int(ri.device), NumCUs: int(ri.n_cus),
+		ShaderClockKHz: int(ri.shader_clock_khz), MemoryClockKHz: int(ri.memory_clock_khz), WallClockKHz: int(ri.wall_clock_khz),
+		HWQueuesEnv: int(ri.hw_queues_env), HWQueuesExpected: int(ri.hw_queues_expected), HWQueuesMeasured: int(ri.hw_queues_measured),
+		HWQueuesSetByLibrary: ri.hw_queues_set_by_library != 0, HIPInitialisedBeforeLibraryLoad: ri.hip_initialised_before_load != 0,
+		DeviceName: C.GoString(&ri.device_name[0]), Arch: C.GoString(&ri.arch[0])}, nil
+}
+
 // attach creates the device-side context on the first Forward.
 func (ic *InferenceContext) attach(lt *LlamaTransformer) error {
 	if ic.handle != nil {
@@ -94,8 +122,22 @@ func (ic *InferenceContext) attach(lt *LlamaTransformer) error {
 	}
 	lt.mu.Lock()
 	lt.ctxs++
+	nctx := lt.ctxs
 	lt.mu.Unlock()
 	ic.lt = lt
+	// One InferenceContext per generation, one goroutine each (inference.go:163-174): every context owns a HIP stream, and streams that
+	// share a hardware queue run one after the other.  Say so ONCE when more contexts are alive than the runtime has queues.
+	if nctx > 1 {
+		var ri C.lnb_runtime_info_t
+		if C.lnb_runtime_info(0, 0, &ri) == 0 && nctx > int(ri.hw_queues_expected) && !queueWarned {
+			queueWarned = true
+			why := ""
+			if ri.hip_initialised_before_load != 0 && ri.hw_queues_set_by_library != 0 {
+				why = " (HIP was initialised before liblnb_hip.so was loaded: export GPU_MAX_HW_QUEUES=16 before the process starts)"
+			}
+			common.GLogger.ConsolePrintf("warning: %d inference contexts on %d hardware queues: their steps will serialise%s", nctx, int(ri.hw_queues_expected), why)
+		}
+	}
 	// Nothing pins the Go object: the reference creates one context per generation and never closes it (inference.go:174), so the
 	// finalizer is what returns the device KV cache.  (A cgo.Handle held for the life of the context would keep it reachable for ever.)
 	runtime.SetFinalizer(ic, func(c *InferenceContext) { c.Close() })

@@ -97,6 +97,11 @@ func boolToC(b bool) C.int32_t {
 // NewLlamaTransformer binds every checkpoint tensor by its Meta key (the names and shapes getTensor / getLayerTensor check,
 // src/model/loader.go:183-192) and builds the RoPE table; same signature and error behaviour as src/model/llamatransformer.go:64-113.
 func NewLlamaTransformer(model *Model) (*LlamaTransformer, error) {
+	// the binding was generated against include/lnb.h's LNB_ABI_VERSION: a stale liblnb_hip.so on the library path must fail here, not write
+	// through a mistyped pointer later
+	if v := int(C.lnb_abi_version()); v != int(C.LNB_ABI_VERSION) {
+		return nil, fmt.Errorf("liblnb_hip.so reports ABI version %d, this binding was built against %d", v, int(C.LNB_ABI_VERSION))
+	}
 	a := model.ModelArgs
 	cargs := C.lnb_model_args{
 		dim: C.int32_t(a.Dim), n_layers: C.int32_t(a.N_Layers), n_heads: C.int32_t(a.N_Heads), n_kv_heads: C.int32_t(a.N_KVHeads),

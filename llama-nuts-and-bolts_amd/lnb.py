@@ -62,7 +62,19 @@ EXPORTS = [
     "lnb_pipeline_unique_id", "lnb_pipeline_init", "lnb_pipeline_init_loopback", "lnb_pipeline_destroy", "lnb_pipeline_tick", "lnb_pipeline_sync", "lnb_pipeline_read_tokens", "lnb_pipeline_selftest", "lnb_pipeline_comm_count",
     "lnb_model_enable_batch", "lnb_model_batch_bytes", "lnb_batch_create", "lnb_batch_destroy", "lnb_batch_decode", "lnb_batch_decode_until", "lnb_ctx_set_stop_ids", "lnb_decode_greedy_until", "lnb_batch_profile_kernel", "lnb_batch_set_state", "lnb_batch_check_error", "lnb_pipeline_tick_batch",
     "lnb_pipeline_init_host", "lnb_batch_boundary_ptr",
+    "lnb_abi_version", "lnb_runtime_info", "lnb_profile_ffn_pair",
 ]
+ABI_VERSION = 6          # LNB_ABI_VERSION of include/lnb.h this binding was written against (tests/test_cabi.py compares it with the header's)
+
+
+class RuntimeInfo(C.Structure):
+    """lnb_runtime_info_t (include/lnb.h)"""
+    _fields_ = [("abi_version", C.c_int32), ("device", C.c_int32), ("n_cus", C.c_int32),
+                ("shader_clock_khz", C.c_int32), ("memory_clock_khz", C.c_int32), ("wall_clock_khz", C.c_int32),
+                ("hw_queues_env", C.c_int32), ("hw_queues_set_by_library", C.c_int32), ("hip_initialised_before_load", C.c_int32),
+                ("hw_queues_expected", C.c_int32), ("hw_queues_measured", C.c_int32), ("probe_ms", C.c_float),
+                ("device_name", C.c_char * 64), ("arch", C.c_char * 32)]
+
 
 
 def lib():
@@ -73,6 +85,12 @@ def lib():
         raise LnbError("liblnb_hip.so is not built (run __graft_entry__.build()); there is no fallback path")
     L = C.CDLL(_SO)
     vp, i32p, f32p = C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_float)
+    # a stale library behind a newer binding (or the reverse) must fail HERE, not write through a mistyped pointer later
+    if not hasattr(L, "lnb_abi_version") or L.lnb_abi_version() != ABI_VERSION:
+        raise LnbError("liblnb_hip.so reports ABI version %s, this binding is written against %d: rebuild the library (make -C csrc)"
+                       % (L.lnb_abi_version() if hasattr(L, "lnb_abi_version") else "none", ABI_VERSION))
+    L.lnb_runtime_info.argtypes = [C.c_int, C.c_int, C.POINTER(RuntimeInfo)]
+    L.lnb_profile_ffn_pair.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, f32p]
     L.lnb_last_error.restype = C.c_char_p
     L.lnb_device_count.argtypes = [C.POINTER(C.c_int)]
     L.lnb_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_char_p, C.c_int]
@@ -191,6 +209,26 @@ def device_info(device=0):
     hbm, cus = C.c_int64(0), C.c_int(0)
     _chk(lib().lnb_device_info(device, name, 256, C.byref(hbm), C.byref(cus), arch, 256))
     return {"name": name.value.decode(), "arch": arch.value.decode(), "hbm_bytes": hbm.value, "n_cus": cus.value}
+
+
+def runtime_info(device=0, probe_queues=False):
+    """lnb_runtime_info as a dict: hardware queues the HIP runtime was told to use / really uses, clocks, device (VERDICT r5 #7)"""
+    ri = RuntimeInfo()
+    _chk(lib().lnb_runtime_info(device, 1 if probe_queues else 0, C.byref(ri)))
+    d = {k: getattr(ri, k) for k, _ in RuntimeInfo._fields_}
+    d["device_name"] = ri.device_name.decode("utf-8", "replace"); d["arch"] = ri.arch.decode("utf-8", "replace")
+    d["probe_ms"] = round(float(ri.probe_ms), 3)
+    return d
+
+
+def queue_warning(contexts_in_flight, info):
+    """the sentence a host prints when it keeps more contexts in flight than the runtime has hardware queues (streams on one queue serialise)"""
+    q = info.get("hw_queues_measured") or info.get("hw_queues_expected") or 4
+    if contexts_in_flight <= q:
+        return None
+    why = (" -- HIP had been initialised before liblnb_hip.so was loaded, so its GPU_MAX_HW_QUEUES=16 default came too late: export the variable "
+           "before the process starts" if info.get("hip_initialised_before_load") and info.get("hw_queues_set_by_library") else "")
+    return "%d contexts in flight on %d hardware queues: streams that share a queue run one after the other%s" % (contexts_in_flight, q, why)
 
 
 def can_access_peer(device, peer):
@@ -449,6 +487,12 @@ class InferenceContext:
     def profile_kernel(self, which, pos, iters):
         ms = C.c_float(0)
         _chk(self.L.lnb_profile_kernel(self.h, which, pos, iters, C.byref(ms)))
+        return ms.value
+
+    def profile_ffn_pair(self, pos, iters, w2_delay_us=0, w2_lds_pad=0):
+        """gate|up and down kernels of a block on two streams, w2 launched w2_delay_us behind w1|w3 (lnb_profile_ffn_pair): ms per pair"""
+        ms = C.c_float(0)
+        _chk(self.L.lnb_profile_ffn_pair(self.h, pos, iters, w2_delay_us, w2_lds_pad, C.byref(ms)))
         return ms.value
 
     def profile_kernel_stamps(self, which, pos):

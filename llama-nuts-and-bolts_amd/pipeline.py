@@ -1049,16 +1049,52 @@ def bench_main(args, cfg, name):
             2*world groups in flight, whole-block stages, a pipe without a transport (run_ticks_batched_torch)"""
             lb, le = stage_layers(rank, world, cfg["n_layers"], head_cost=(costs[3] / max(1e-9, sum(costs[:3])) if costs else 1.2))
             G = 2 * world
-            st2 = LnbStage(lnb, torch, cfg, rank, world, G * nb, seq_len, local, parts=(3 * lb, 3 * le), costs=costs)
+            # Every rank agrees that its set-up worked BEFORE any rank enters a collective (ADVICE r5: a rank whose LnbStage / Batch / Pipeline raised
+            # used to leave while the others blocked in prefill_torch's recv until the backend's timeout -- the hang the preflight exists to remove).
+            # The unbatched stage is closed first: its weights, contexts and graphs are not needed any more and the second stage wants the memory.
+            cpu_dev = device if backend == "nccl" else "cpu"
+
+            def all_ok(ok, what):
+                flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=cpu_dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                return None if int(flag.item()) == 1 else {"skipped": "%s failed on at least one rank (this rank: %s)" % (what, "ok" if ok else "failed")}
+            st2 = pp = None
+            bats = []
             copy = True
+            err = None
             try:
-                st2.model.enable_batch()
-            except lnb.LnbError:
-                copy = False                                 # (no room for the matrix-core copy on this rank: its batches run as rows on the resident layouts)
+                stage.close()
+                st2 = LnbStage(lnb, torch, cfg, rank, world, G * nb, seq_len, local, parts=(3 * lb, 3 * le), costs=costs)
+                try:
+                    st2.model.enable_batch()
+                except lnb.LnbError:
+                    copy = False                             # (no room for the matrix-core copy on this rank: its batches run as rows on the resident layouts)
+                pp = lnb.Pipeline(st2.model, rank, world, host_transport=True)
+            except Exception as e:                           # noqa: BLE001 -- whatever it is, the other ranks must hear about it
+                err = "%s: %s" % (type(e).__name__, e)
+            skipped = all_ok(err is None, "batched stage set-up")
+            if skipped:
+                if err:
+                    skipped["this_rank_error"] = err[:300]
+                if pp:
+                    pp.close()
+                if st2:
+                    st2.close()
+                return skipped
             prm = [lnb.synth_tokens(99 + q, P, cfg["vocab_size"]) for q in range(G * nb)]
             firsts = prefill_torch(rank, world, st2, dist, torch, prm, device)
-            pp = lnb.Pipeline(st2.model, rank, world, host_transport=True)
-            bats = [lnb.Batch(st2.ctx[g * nb:(g + 1) * nb]).set_state(firsts[g * nb:(g + 1) * nb] if rank == 0 else None, [P] * nb) for g in range(G)]
+            try:
+                bats = [lnb.Batch(st2.ctx[g * nb:(g + 1) * nb]).set_state(firsts[g * nb:(g + 1) * nb] if rank == 0 else None, [P] * nb) for g in range(G)]
+            except Exception as e:                           # noqa: BLE001
+                err = "%s: %s" % (type(e).__name__, e)
+            skipped = all_ok(err is None, "batch creation")
+            if skipped:
+                if err:
+                    skipped["this_rank_error"] = err[:300]
+                for b_ in bats:
+                    b_.close()
+                pp.close(); st2.close()
+                return skipped
             sb = run_ticks_batched_torch(rank, world, pp, bats, dist, torch, W + K, device, cfg["dim"], 0, G * W)
             torch.cuda.synchronize(); dist.barrier(); torch.cuda.synchronize()
             t0 = time.perf_counter()

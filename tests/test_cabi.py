@@ -70,3 +70,29 @@ def test_cpp_host_mirror_builds_and_fails_loudly_without_gpu(lnb):
         pytest.skip("GPU present: covered by tests/test_gpu_parity.py")
     r = subprocess.run([exe, "40", "1", "2", "3"], capture_output=True, text=True)
     assert r.returncode == 3 and "error:" in r.stdout
+
+
+def test_abi_version_is_one_number_everywhere(lnb):
+    """include/lnb.h, the library and the ctypes binding agree on LNB_ABI_VERSION (ADVICE r5: a changed signature must not reach a stale binding);
+    lnb.lib() itself refuses a library that reports another number"""
+    hdr = open(os.path.join(ROOT, "include", "lnb.h")).read()
+    v = int(re.search(r"#define\s+LNB_ABI_VERSION\s+(\d+)", hdr).group(1))
+    L = C.CDLL(os.path.join(ROOT, "llama-nuts-and-bolts_amd", "liblnb_hip.so"))
+    assert L.lnb_abi_version() == v == lnb.ABI_VERSION
+    go = open(os.path.join(ROOT, "llama-nuts-and-bolts_amd", "go", "llamatransformer_hip.go")).read()
+    assert "C.lnb_abi_version()" in go and "C.LNB_ABI_VERSION" in go
+
+
+def test_load_time_queue_default_is_opt_out_and_recorded():
+    """the library exports GPU_MAX_HW_QUEUES=16 while it is loaded unless the host set a value or LNB_KEEP_HW_QUEUES=1 (VERDICT r5 #7)"""
+    import subprocess
+    import sys
+    so = os.path.join(ROOT, "llama-nuts-and-bolts_amd", "liblnb_hip.so")
+    code = "import ctypes, os; ctypes.CDLL(%r); print(os.environ.get('GPU_MAX_HW_QUEUES', 'unset'))" % so
+    env = {k: v for k, v in os.environ.items() if k not in ("GPU_MAX_HW_QUEUES", "LNB_KEEP_HW_QUEUES")}
+    # (os.environ is a snapshot taken at interpreter start: ask libc)
+    code = ("import ctypes; ctypes.CDLL(%r); libc = ctypes.CDLL(None); libc.getenv.restype = ctypes.c_char_p; "
+            "v = libc.getenv(b'GPU_MAX_HW_QUEUES'); print(v.decode() if v else 'unset')" % so)
+    assert subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True).stdout.strip() == "16"
+    assert subprocess.run([sys.executable, "-c", code], env=dict(env, LNB_KEEP_HW_QUEUES="1"), capture_output=True, text=True).stdout.strip() == "unset"
+    assert subprocess.run([sys.executable, "-c", code], env=dict(env, GPU_MAX_HW_QUEUES="8"), capture_output=True, text=True).stdout.strip() == "8"

@@ -181,6 +181,7 @@ def test_cgo_calls_name_functions_that_the_header_declares():
     """every C.lnb_* the Go files call is declared in include/lnb.h"""
     hdr = open(os.path.join(ROOT, "include", "lnb.h")).read()
     declared = set(re.findall(r"\b(lnb_\w+)\s*\(", hdr)) | set(re.findall(r"typedef\s+struct\s+\w+\s+(\w+);", hdr)) | {"lnb_model_args", "lnb_layer_cb"}
+    declared |= set(re.findall(r"typedef\s+struct\s+\w+\s*\{[^}]*\}\s*(\w+);", hdr, flags=re.S))      # struct typedefs with a body (lnb_runtime_info_t)
     used = set()
     for f in sorted(os.listdir(HIP_DIR)):
         if f.endswith(".go"):

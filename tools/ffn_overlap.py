@@ -1,9 +1,15 @@
 #!/usr/bin/env python3
-"""What would a w1|w3 -> w2 row-band pipeline have to work with?  (NOTES.md 6.1; run on the GPU box.)
- 1. the gate|up kernel cut into half-height row blocks, two per workgroup (LNB_RW_W13=28: rows [0, F/2) complete after the first block of
-    every workgroup -- the band order a pipeline needs) against the production 56-row blocks;
- 2. the gate|up kernel and the down kernel of a block launched CONCURRENTLY, one workgroup of each on every CU (lnb_profile_kernel 7 / 8):
-    the pair against the two launches back to back."""
+"""Rung (a) of the w1|w3 -> w2 streaming-stage ladder (VERDICT r5 task 1; profiles/r06_ffn_stream.md).  Run on the GPU box.
+
+What would a row-band pipeline have to work with -- measured on today's kernels, before anything is built:
+ 1. both kernel forms (latency / throughput) of gate|up and down, alone;
+ 2. the PAIR launched on two streams (lnb_profile_ffn_pair), the down kernel `delay` microseconds behind the gate|up kernel:
+      delay 0      = plain co-residency (does the dispatcher co-schedule one workgroup of each per CU at all?  r3: no -- measured with the
+                     runtime's 4 hardware queues and the 91-124 KB latency forms);
+      delay 15..35 = the timeline of a band pipeline whose first row band completes that long after the launch, WITHOUT any dependency stall
+                     (w2 reads stale activations: only the time means anything) -- an optimistic bound on what the real thing could reach;
+ 3. the gate|up kernel in band order (LNB_RW_W13=28: two half-height blocks per workgroup on ONE chain wave).
+Every number: microseconds per pair, best of three runs of 48 pairs cycling through 6 layers (weights from HBM)."""
 import json
 import os
 import subprocess
@@ -19,17 +25,30 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     c = lnb.InferenceContext(m, 320)
     _, t = c.Forward(lnb.synth_tokens(99, 128, cfg["vocab_size"]), 0, want_logits=False)
     c.decode_greedy(t, 128, 8)
-    res = {}
-    for which, name in ((3, "w1|w3"), (4, "w2"), (7, "pair, w2 launched first"), (8, "pair, w1|w3 launched first"), (6, "whole block")):
-        c.profile_kernel(which, 200, 4)
-        res[name] = round(1e3 * min(c.profile_kernel(which, 200, 48) for _ in range(3)), 2)
+    sched = os.environ.get("FFN_SCHED", "latency")
+    c.set_schedule(sched)
+    res = {"schedule": sched, "hw_queues": lnb.runtime_info(0, probe_queues=True)["hw_queues_measured"]}
+
+    def best(f):
+        f()
+        return round(1e3 * min(f() for _ in range(3)), 2)
+    res["w1|w3 alone"] = best(lambda: c.profile_kernel(3, 200, 48))
+    res["w2 alone"] = best(lambda: c.profile_kernel(4, 200, 48))
+    res["whole block"] = best(lambda: c.profile_kernel(6, 200, 48))
+    pads = [int(x) for x in os.environ.get("FFN_PADS", "0").split(",")]
+    for pad in pads:
+        for delay in [int(x) for x in os.environ.get("FFN_DELAYS", "0,10,15,20,25,30,35").split(",")]:
+            res["pair, w2 %d us behind, pad %d" % (delay, pad)] = best(lambda: c.profile_ffn_pair(200, 48, delay, pad))
     print(json.dumps(res))
     sys.exit(0)
 
 out = {}
-for label, env in (("production (56-row blocks)", {}), ("half-height blocks, two per workgroup (LNB_RW_W13=28)", {"LNB_RW_W13": "28"}),
-                   ("56-row blocks, w2 LDS pad 0 (co-residency not forced)", {"LNB_W2_LDS_PAD": "0"})):
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=600)
+runs = [("latency forms (production, 75 + 104 KB of LDS: cannot co-reside)", {"FFN_SCHED": "latency", "FFN_DELAYS": "0,25"}),
+        ("throughput forms (75 + 57 KB: one workgroup of each fits a CU)", {"FFN_SCHED": "throughput", "FFN_PADS": "0,28672"}),
+        ("throughput forms, 4 hardware queues (the runtime's default)", {"FFN_SCHED": "throughput", "GPU_MAX_HW_QUEUES": "4", "FFN_DELAYS": "0,25"}),
+        ("band order on one chain wave (LNB_RW_W13=28), throughput forms", {"FFN_SCHED": "throughput", "LNB_RW_W13": "28", "FFN_DELAYS": "0,25"})]
+for label, env in runs:
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "child"], capture_output=True, text=True, env=dict(os.environ, **env), timeout=900)
     line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    out[label] = json.loads(line[-1]) if line else {"error": r.stderr[-400:]}
+    out[label] = json.loads(line[-1]) if line else {"error": r.stderr[-600:]}
 print(json.dumps(out, indent=1))
