@@ -53,7 +53,7 @@ int lnb_device_count(int* out_count);
  * src/inference/inference.go:163-174).  The HIP runtime spreads a process's streams over GPU_MAX_HW_QUEUES hardware queues (default 4) and
  * streams that share a queue serialise; while it is being loaded this library exports 16 unless the host set a value or LNB_KEEP_HW_QUEUES=1 --
  * but the runtime reads the variable at ITS initialisation, so a host that used HIP before loading the library keeps its 4 queues (two
- * contexts in flight then run slower than one).  hw_queues_measured (probe_queues != 0, ~2 ms): streams that really ran concurrently.
+ * contexts in flight then run slower than one).  hw_queues_measured (probe_queues != 0, 4-20 ms): streams that really ran concurrently.
  * A host warns when contexts in flight > min(hw_queues_expected, hw_queues_measured or expected) (bench.py, go/inferencecontext_hip.go do). */
 typedef struct lnb_runtime_info_t {
     int32_t abi_version;
@@ -142,8 +142,12 @@ int lnb_ctx_set_schedule(lnb_ctx* c, int sched);
 int lnb_ctx_get_schedule(const lnb_ctx* c);
 /* Decode attention form (both bit-identical to the reference arithmetic): one-token calls whose context exceeds long_threshold
  * positions use the long-context kernels (scores over all CUs, PV per (head, 16-dim slice), softmax denominator certified against
- * the reference's serial f64 sum instead of walked).  long_threshold < 0: keep (default 512, env LNB_ATTN_LONG_T); force_zseq = 1:
- * always walk the serial sum (test hook).  lnb_ctx_zseq_count: rows that could not be certified and walked it. */
+ * the reference's serial f64 sum instead of walked).  long_threshold < 0: keep (default 512, env LNB_ATTN_LONG_T).  force_zseq is a set of
+ * test / experiment switches: bit 0 (1) = always walk the serial sum; bit 3 (8) = run both phases in ONE launch (attn_one_kernel, round 6: the
+ * (head, slice) workgroups exchange the scores inside the launch behind a BOUNDED poll -- a workgroup whose peers are not resident computes their
+ * share itself, so two contexts can never wait for each other; same bits; measured slower than the two launches, hence opt-in, also by
+ * LNB_ATTN_ONE=1; latency schedule only); bit 2 (4) = one launch with every poll timing out; bit 1 (2) = two launches whatever the environment says.
+ * lnb_ctx_zseq_count: rows that could not be certified and walked the serial sum. */
 int lnb_ctx_set_attention(lnb_ctx* c, int long_threshold, int force_zseq);
 int lnb_ctx_zseq_count(lnb_ctx* c, int* out);
 /* Diagnostics of the fused RMSNorm (llamatransformer.go:222, :237, :166: RMSNorm in front of wq|wk|wv, w1|w3, output): rows of one-token calls
@@ -306,7 +310,7 @@ int lnb_pipeline_selftest(int device, int n_bytes);
 int lnb_profile_kernel(lnb_ctx* c, int which, int pos, int iters, float* avg_ms_out);
 /* ... and of the gate|up (w1|w3) and down (w2) kernels of a block launched on TWO streams, w2 `w2_delay_us` behind w1|w3: the time a
  * w1|w3 -> w2 streaming stage (llamatransformer.go:593-624) would have to beat, measured without building it (w2 reads stale activations:
- * only the time means anything).  w2_lds_pad: extra dynamic LDS for the w2 launch (forces one workgroup of each kernel per CU). */
+ * only the time means anything; w2_delay_us < 0: w2 first, w1|w3 that long behind it).  w2_lds_pad: extra dynamic LDS for the w2 launch (forces one workgroup of each kernel per CU). */
 int lnb_profile_ffn_pair(lnb_ctx* c, int pos, int iters, int w2_delay_us, int w2_lds_pad, float* avg_ms_out);
 /* ... and the in-kernel cycle stamps of ONE launch of a GEMV class (which 0, 2, 3, 4 or 5): out[8 waves][16] doubles, per wave = {workgroups
  * that reported, avg total shader cycles, max total, avg barrier wait, avg "x staged / prologue end", avg "norm fold or walk" (wo / w2 chain

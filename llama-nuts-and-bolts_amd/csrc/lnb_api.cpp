@@ -26,6 +26,7 @@ hipError_t lnbk_gemv(const GemvParams* p, int rw, int nch, int epi, int norm, hi
 hipError_t lnbk_attn(const AttnParams* p, hipStream_t st);
 int lnbk_attn_short_max_T(int hd);
 size_t lnbk_attn_long_lds(int seq_len);
+size_t lnbk_attn_one_lds(int seq_len, int hd);
 hipError_t lnbk_exp_table(double* tab, float divisor, hipStream_t st);
 hipError_t lnbk_gemm(const GemmParams* p, int epi, hipStream_t st);
 hipError_t lnbk_rmsnorm_rows(const uint16_t* x, const uint16_t* w, uint16_t* out, int S, int K, float eps, hipStream_t st);
@@ -161,7 +162,8 @@ struct lnb_ctx {
     int batch_users = 0;                   // live lnb_batch handles this context is a member of: their device tables and captured graphs hold its raw pointers
     // long-context decode attention (attn_long_*_kernel): used for one-token calls whose context exceeds attn_long_T
     double* e_buf = nullptr; double* z_part = nullptr; int* zseq_count = nullptr;
-    int attn_long_T = 0; int force_zseq = 0;
+    unsigned* attn_cnt = nullptr;          // attn_one_kernel: [n_heads] arrival counters of its in-launch exchange + [n_heads] = polls that ran out
+    int attn_long_T = 0; int force_zseq = 0;   // force_zseq: bit 0 = walk the serial softmax denominator, bit 1 = keep the two-launch long-context form, bit 2 = one launch with every poll timing out (tests), bit 3 = one launch
     int attn_short_cap = 0;                // longest context the one-workgroup-per-head kernel can stage in the LDS
     bool attn_long = false;                // selection for the launches being enqueued (set per call / per captured graph)
     hipGraphExec_t graph_long = nullptr;   // the decode step captured with the long-context attention
@@ -232,7 +234,7 @@ extern "C" int lnb_device_count(int* out) { int n = 0; HIPCHK(hipGetDeviceCount(
 extern "C" int lnb_abi_version(void) { return LNB_ABI_VERSION; }
 // What the host should know before it trusts a multi-context run: the hardware queues the HIP runtime was told to use, who told it,
 // whether that was in time, and -- probe_queues != 0 -- how many streams REALLY run concurrently: 32 one-wave kernels that each hold their stream for
-// 200 us of wall clock, one per stream; with Q queues they finish in ceil(32 / Q) rounds (about 1-3 ms including the stream set-up).
+// 2 ms of wall clock, one per stream; with Q queues they finish in ceil(32 / Q) rounds (4-20 ms including the stream set-up).
 extern "C" int lnb_runtime_info(int device, int probe_queues, lnb_runtime_info_t* out) {
     if (!out) return fail("null argument");
     memset(out, 0, sizeof *out);
@@ -257,7 +259,7 @@ extern "C" int lnb_runtime_info(int device, int probe_queues, lnb_runtime_info_t
     // unless the HOST had exported a value -- which it read at its own initialisation)
     out->hw_queues_expected = (g_hip_live_at_load && g_hwq_set_by_library) ? 4 : (out->hw_queues_env > 0 ? out->hw_queues_env : 4);
     if (probe_queues) {
-        constexpr int NSTREAM = 32, SPIN_US = 200;
+        constexpr int NSTREAM = 32, SPIN_US = 2000;      // (2 ms per spin: the ~0.3 ms it takes the host to launch on 32 streams must not count as a round)
         hipStream_t sts[NSTREAM] = {}; hipEvent_t e0 = nullptr, e1 = nullptr, ej[NSTREAM] = {};
         hipError_t e = hipSuccess;
         for (int i = 0; i < NSTREAM && e == hipSuccess; i++) { e = hipStreamCreateWithFlags(&sts[i], hipStreamNonBlocking); if (e == hipSuccess) e = hipEventCreateWithFlags(&ej[i], hipEventDisableTiming); }
@@ -620,8 +622,9 @@ static int ctx_alloc(lnb_ctx* c) {
     HIPCHK(hipMalloc((void**)&c->ffn, S * m->ffn_hidden * 2));
     if (m->last()) { HIPCHK(hipMalloc((void**)&c->logits, (size_t)m->a.vocab_size * 2)); c->logits_rows = 1; }
     HIPCHK(hipMalloc((void**)&c->e_buf, (size_t)m->a.n_heads * S * 8));
-    HIPCHK(hipMalloc((void**)&c->z_part, (size_t)m->a.n_heads * ((S + 255) / 256) * 8));
+    HIPCHK(hipMalloc((void**)&c->z_part, (size_t)m->a.n_heads * ((S + 63) / 64 + 8) * 8));     // (two-launch form: one partial per 256 positions; attn_one_kernel: one per 64)
     HIPCHK(hipMalloc((void**)&c->zseq_count, 16)); HIPCHK(hipMemsetAsync(c->zseq_count, 0, 16, c->stream));
+    HIPCHK(hipMalloc((void**)&c->attn_cnt, ((size_t)m->a.n_heads + 4) * 4)); HIPCHK(hipMemsetAsync(c->attn_cnt, 0, ((size_t)m->a.n_heads + 4) * 4, c->stream));
     HIPCHK(hipStreamSynchronize(c->stream));
     // crossover measured on MI355X (tools/att_timing.py): the one-workgroup-per-head kernel wins below a few hundred positions
     c->attn_long_T = env_int("LNB_ATTN_LONG_T", 512);
@@ -641,7 +644,7 @@ extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
     if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
-    hipFree(c->e_buf); hipFree(c->z_part); hipFree(c->zseq_count);
+    hipFree(c->e_buf); hipFree(c->z_part); hipFree(c->zseq_count); hipFree(c->attn_cnt);
     for (auto p : c->ck) if (p) hipFree(p);
     for (auto p : c->cv) if (p) hipFree(p);
     hipFree(c->st); hipFree(c->dtok); hipFree(c->dnext); hipFree(c->derr); hipFree(c->dout);
@@ -719,7 +722,7 @@ extern "C" int lnb_ctx_set_attention(lnb_ctx* c, int long_threshold, int force_z
     HIPCHK(hipStreamSynchronize(c->stream));
     drop_graphs(c);
     if (long_threshold >= 0) c->attn_long_T = long_threshold;
-    c->force_zseq = force_zseq ? 1 : 0;
+    c->force_zseq = force_zseq & 15;                         // bit 0: serial denominator; bit 1: two-launch long-context form; bit 2: one launch, every poll times out (tests); bit 3: one launch
     return 0;
 }
 // how many (head, token, layer) rows of the long-context attention had to walk the serial Z chain because the estimate could not be certified
@@ -810,7 +813,19 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
         ap.host_T = c->call_T;
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
         ap.mfma = use_mfma(S) ? 1 : 0; ap.exp_tab = m->exp_tab;
-        ap.longctx = (S == 1 && c->attn_long) ? 1 : 0; ap.force_zseq = c->force_zseq; ap.e_buf = c->e_buf; ap.z_part = c->z_part; ap.zseq_count = c->zseq_count;
+        ap.longctx = 0; ap.force_zseq = c->force_zseq & 1; ap.e_buf = c->e_buf; ap.z_part = c->z_part; ap.zseq_count = c->zseq_count; ap.cnt = c->attn_cnt;
+        if (S == 1 && c->attn_long) {
+            // ONE launch (attn_one_kernel, round 6): built, bit-exact in every form (tests/test_gpu_round6.py), and NOT the default -- measured on MI355X
+            // (profiles/r06_att_timing.log, 8B head geometry): T = 4101: 26.3 us against 23.2 for the two launches; 1024: 14.1 / 11.5; 272: 8.2 against 7.7
+            // for the one-workgroup-per-head kernel.  What the launch boundary costs (~1.2 us + the PV kernel's cold reads of e_buf) comes back as the
+            // in-launch exchange (write-through stores drained + arrive + poll: 6.6 k cycles) plus a second dependent round trip for e_j (6.3 k).
+            // Opt-in: LNB_ATTN_ONE=1, or bit 3 (8) of lnb_ctx_set_attention's flags; only for a context whose stream owns the chip (latency schedule)
+            // and whose (head, slice) grid fits the CUs.  Bit 1 (2) of the flags keeps the two launches whatever the environment says.
+            static const int one_env = env_int("LNB_ATTN_ONE", 0);
+            const bool one = (one_env || (c->force_zseq & 12)) && !(c->force_zseq & 2) && c->sched == LNB_SCHED_LATENCY && m->head_dim % 16 == 0 &&
+                             a.n_heads * (m->head_dim / 16) <= g_num_cus && lnbk_attn_one_lds(c->seq_len, m->head_dim) <= (size_t)160 * 1024;
+            ap.longctx = one ? ((c->force_zseq & 4) ? 3 : 2) : 1;
+        }
         if (c->mode == LNB_MODE_FAST && ap.mfma) {           // tolerance mode prefill: flash form on the bf16 matrix cores
             hipError_t e = lnbk_fast_attn(&ap, st);
             if (e != hipErrorNotSupported) { HIPCHK(e); return 0; }
@@ -824,7 +839,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
         f.out = c->ffn; f.silu = m->silu; f.sched = c->sched;
         set_grid(f, L.w13); HIPCHK(gemv_dispatch(c, &f, L.w13.rw, 2, EPI_SILU_MUL, 1, st)); return 0; }
     case K_W2: {    // w2 + residual  (:619, :248)
-        GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = hbuf; d.lds_pad = lds_pad; d.sched = c->sched;
+        GemvParams d{}; d.w = L.w2.w; d.x = c->ffn; d.K = m->ffn_hidden; d.n_rows = a.dim; d.S = S; d.st = c->st; d.out = c->x; d.res = hbuf; d.lds_pad = lds_pad; d.sched = c->sched; d.prio = env_int("LNB_W2_PRIO", 0);
         set_grid(d, L.w2); HIPCHK(gemv_dispatch(c, &d, L.w2.rw, 1, EPI_RESID, 0, st)); return 0; }
     }
     return fail("bad kernel id");
@@ -1130,7 +1145,7 @@ extern "C" int lnb_profile_ffn_pair(lnb_ctx* c, int pos, int iters, int w2_delay
     if (!c || !avg_ms_out) return fail("null argument");
     lnb_model* m = c->m;
     HIPCHK(hipSetDevice(m->device));
-    if (iters <= 0 || w2_delay_us < 0) return fail("bad arguments");
+    if (iters <= 0) return fail("bad arguments");
     if (check_call(c, 1, pos)) return -1;
     const int nl2 = m->layer_end - m->layer_begin;
     if (nl2 <= 0) return fail("this stage holds no transformer block");
@@ -1142,9 +1157,15 @@ extern "C" int lnb_profile_ffn_pair(lnb_ctx* c, int pos, int iters, int w2_delay
     auto pair = [&](int i) -> int {
         const int l = m->layer_begin + i % nl2;
         HIPCHK(hipEventRecord(ef, st)); HIPCHK(hipStreamWaitEvent(st2, ef, 0));
-        if (enqueue_layer_kernel(c, l, 1, K_W13)) return -1;
-        if (w2_delay_us > 0) HIPCHK(lnbk_spin(w2_delay_us, st2));
-        if (enqueue_layer_kernel(c, l, 1, K_W2, st2, w2_lds_pad)) return -1;
+        if (w2_delay_us >= 0) {
+            if (enqueue_layer_kernel(c, l, 1, K_W13)) return -1;
+            if (w2_delay_us > 0) HIPCHK(lnbk_spin(w2_delay_us, st2));
+            if (enqueue_layer_kernel(c, l, 1, K_W2, st2, w2_lds_pad)) return -1;
+        } else {                                             // w2 first (its waves are the older ones), gate|up -delay behind it
+            if (enqueue_layer_kernel(c, l, 1, K_W2, st2, w2_lds_pad)) return -1;
+            if (w2_delay_us < -1) HIPCHK(lnbk_spin(-w2_delay_us, st));
+            if (enqueue_layer_kernel(c, l, 1, K_W13)) return -1;
+        }
         HIPCHK(hipEventRecord(ej, st2)); HIPCHK(hipStreamWaitEvent(st, ej, 0));
         return 0;
     };

@@ -101,6 +101,7 @@ struct GemvParams {
                                 // LNB_GEMV_TIMING=1), 0 = only the phase stamps and the exit record (bench.py's measured model: the launch runs as in production)
     int* norm_fb;               // optional counter: rows whose norm sum left the branch-free item walk for the record walk (counted by workgroup 0)
     int lds_pad;                // host side only: extra dynamic LDS requested for the launch (co-residency experiments: forces one workgroup per CU)
+    int prio;                   // measurement aid (tools/ffn_overlap.py): != 0 raises the wave priority of rowcast_kernel's (self-feeding) chain waves
     int sched;                  // host side only: 0 = latency forms (one stream owns the chip: every CU, eight or nine waves, up to 124 KB of LDS per
                                 // workgroup), 1 = throughput forms of the same arithmetic (lnb_ctx_set_schedule: at most 57 KB of LDS per workgroup, so
                                 // that a chain-bound launch of one context shares a CU with the HBM-bound gate|up launch of another)
@@ -138,11 +139,13 @@ struct AttnParams {
     int mfma;                   // S >= 16: 16-row tiles on the f32 matrix cores (attn_mfma_kernel), same bits
     const double* exp_tab;      // f64[65536]: exp(trunc(s / divisor)) of every raw bf16 score s (attn_mfma_kernel)
     // long-context decode (S == 1, attn_long_scores_kernel + attn_long_pv_kernel): scores over all CUs, PV per (head, 16-dim slice)
-    int longctx;                // 1: use the two-kernel form
+    int longctx;                // 1: the two-kernel form; 2: ONE launch (attn_one_kernel: the slice workgroups score their share and exchange in the launch); 3: the same
+                                // with every workgroup taking the bounded poll's time-out path (it scores every block itself: tests)
     int force_zseq;             // 1: always take the sequential-Z path of attn_long_pv_kernel (tests)
     double* e_buf;              // [H][seq_len] f64: exp of every score of the current token
     double* z_part;             // [H][ceil(seq_len / 256)] f64: per-block tree sums of e (only an ESTIMATE of Z, see the kernel)
     int* zseq_count;            // counts workgroups that had to fall back to the sequential Z chain (diagnostics)
+    unsigned* cnt;              // attn_one_kernel (longctx >= 2): [H] arrival counters of the in-launch exchange (never reset: a launch's generation is old / slices) + [H] = polls that timed out
     // batched decode (attn_exact_kernel, S = 1 per sequence): query row i belongs to sequence i of the batch -- its own position, caches and
     // cache length come from the tables; the output goes to out_xt in the B-operand layout of the wo product (lnb_batch_kernels.h)
     const struct BatchTab* btab; const struct BatchKV* bkv; uint16_t* out_xt;

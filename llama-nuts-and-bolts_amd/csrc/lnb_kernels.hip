@@ -1237,6 +1237,7 @@ __global__ __launch_bounds__(256) void rowcast_kernel(GemvParams p) {
     __syncthreads();
     if (p.dbg) t_x = clock64() - t_begin;
     LNB_STAMP(6);
+    if (p.prio) __builtin_amdgcn_s_setprio(3);               // (rung (a) of the FFN ladder: what a prioritised w2 chain keeps beside a co-resident gate|up workgroup)
     const float* xl = xT + (size_t)(lane & 15) * 8;
     float acc = 0.0f;
     float pr[8];
@@ -2806,6 +2807,246 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_one_kernel (round 6): the long-context decode attention in ONE launch.
+//
+// The two-launch form above pays, per layer at T = 4100: the scores launch (6.3 us), a kernel boundary, and ~8 k cycles at the head of
+// the PV launch in which every workgroup waits for e_buf / z_part to come back through the fabric (stamps: profiles/r06_att_timing.log) --
+// 23.1 us against a PV chain of 10.4 us.  Here the (head, 16-dim slice) workgroups of attn_long_pv_kernel compute the scores themselves:
+//   T <= 512  every slice workgroup of a head scores all positions (one per thread; the K rows are L2 hits for seven of the eight) and keeps
+//             the exponentials in its LDS: no exchange at all;
+//   T >  512  position block b (512 positions) belongs to slice b % slices: the workgroup scores its blocks, publishes e_j (f64) and the block's
+//             tree sum with WRITE-THROUGH stores (global_store ... sc1), drains them (s_waitcnt vmcnt(0)), arrives on the head's counter
+//             (one device-scope atomic; the generation of the launch is old / slices, so the counter never has to be reset and a replayed
+//             graph needs no per-launch argument), polls it with sc1 loads, and then reads the head's row with sc1 loads (L2 / fabric, never a
+//             stale L1 line) -- the flag form MI355X_MICROARCH.md lists as valid for any placement of the workgroups (no agent fence:
+//             round 3's single-launch attempt paid an L2 write-back + invalidate per fence, 34.5 us against 26.8).
+// A workgroup NEVER depends on another one being resident: the poll is bounded (ATT1_TIMEOUT ticks of the 100 MHz wall clock); when it
+// runs out -- another context's launch holds the CUs its peers need -- the workgroup scores the missing blocks itself (the values it stores
+// are the ones the owner would store: same instructions, same bits) and goes on.  Two such launches of two contexts can therefore never
+// wait for each other; the price of contention is time, not a hang (longctx == 3 forces that path for the tests).
+// Everything after the scores is attn_long_pv_kernel: tree estimate of Z + certified p_j (or the serial walk), the row-broadcast PV chain.
+// grid (H, hd / 16) through xcd_head_block (a head's slices and its GQA group share an XCD), block 512, dynamic LDS att1_lds_bytes().
+// ------------------------------------------------------------------------------------------------
+constexpr long long ATT1_TIMEOUT = 4000;                     // 40 us of wall clock: ~2x the whole kernel at 4 K positions
+__host__ __device__ inline size_t att1_lds_bytes(int seq_len, int hd) { return alp_lds_bytes(seq_len) + 64 + (size_t)hd * 4 + 64 + (size_t)ALP_BATCH * 8; }
+DEVINL void st_sc1_f64(double* p, double v) { __hip_atomic_store((unsigned long long*)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+DEVINL double ld_sc1_f64(const double* p) { return __longlong_as_double((long long)__hip_atomic_load((const unsigned long long*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)); }
+template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_one_kernel(AttnParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NK = HD / 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int h, ds; xcd_head_block(h, ds);
+    const int NSL = (int)gridDim.y;
+    const int T = p.st->pos + 1, nbatch = (T + ALP_BATCH - 1) / ALP_BATCH;      // 512-position blocks: the unit of the scores AND of the PV batches
+    const int Tpad = (nbatch + 1) * ALP_BATCH;
+    float* pw = (float*)smem;
+    float* ring = (float*)(smem + (size_t)((p.seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4);
+    double* zsh = (double*)(ring + 2 * ALP_SLOT);            // [0] serial Z | [1] flags (two ints) | [2..3] -
+    int* const flag = (int*)(zsh + 1);
+    double* wsum = zsh + 8;                                  // [8] wave partials of a block's tree sum
+    float* qf = (float*)(wsum + 8);                          // [HD]
+    double* e_s = (double*)(qf + HD);                        // [512] (T <= 512: the row's exponentials never leave the workgroup)
+    double* E = p.e_buf + (size_t)h * p.seq_len;
+    double* zp = p.z_part + (size_t)h * (((size_t)p.seq_len + 63) / 64 + 8);      // one partial per 64 positions (a wave of a block)
+    const int kvh = h / (p.H / p.KVH);
+    const bool local = nbatch <= 1;                          // (uniform over the grid: T comes from the device-side position)
+#define AT1_STAMP(n) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0) p.dbg[(wave >> 2) * 16 + (n)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    AT1_STAMP(0);
+    // ---- q and this workgroup's first TWO blocks of K rows go in flight first (a block = 512 positions, one per thread; block b belongs to slice
+    // b % NSL; at T = 4101 slice 0 owns two: scored one after the other with the second one's rows fetched behind the first one's chain they cost
+    // 11.7 k cycles, prefetched 6 k), then the producers' first three batches of V rows
+    const uint4* kbase = (const uint4*)p.cache_k + (size_t)kvh * NK * p.seq_len;
+    const uint16_t q16 = p.q[(size_t)h * HD + (tid < HD ? tid : 0)];
+    const int b_first = local ? 0 : ds;
+    uint4 ka[NK], kb[NK];
+    auto load_k = [&](uint4 (&k)[NK], int b) { const int j = b * ALP_BATCH + tid; attn_load_k<NK>(k, kbase, p.seq_len, j < T ? j : T - 1); };
+    load_k(ka, b_first);
+    if (!local && b_first + NSL < nbatch) load_k(kb, b_first + NSL);
+    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD + (size_t)ds * ALP_DS;
+    const size_t vrow = (size_t)p.KVH * HD;
+    const int pl = tid & 255, half8 = pl & 1, prow = pl >> 1;
+    auto load = [&](uint4 (&v)[4], int b) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int j = b * ALP_BATCH + r * 128 + prow; j = j < T ? j : T - 1;
+            v[r] = *(const uint4*)(vbase + (size_t)j * vrow + half8 * 8);
+        }
+    };
+    uint4 v0[4], v1[4], v2[4], v3[4];
+    if (wave >= 4) { load(v0, 0); load(v1, 1); load(v2, 2); }
+    if (tid < HD) qf[tid] = bf_wide(q16);
+    if (tid == 0) { flag[0] = 0; flag[1] = 0; }
+    __syncthreads();
+    AT1_STAMP(1);
+    // ---- scores of one 512-position block (llamatransformer.go:456-473, Softmax impl:498) + every WAVE's tree sum of its 64 exponentials (only ever
+    // an ESTIMATE of Z): no workgroup barrier in here
+    auto score_block = [&](const uint4 (&k)[NK], int b) {
+        const int j = b * ALP_BATCH + tid;
+        double ev = 0.0;
+        if (j < T) ev = attn_score_value<NK>(k, qf, p.divisor);
+        if (local) e_s[tid] = ev; else if (j < T) st_sc1_f64(E + j, ev);
+        double sm = ev;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+        if (lane == 0) { if (local) wsum[wave] = sm; else st_sc1_f64(zp + b * 8 + wave, sm); }
+    };
+    auto score_mine = [&](int ofs) {                         // blocks ofs, ofs + NSL, ... of this workgroup, the next one's K rows always in flight
+        for (int b = ofs; b < nbatch; b += 2 * NSL) {
+            if (b != ofs) { if (b + NSL < nbatch) load_k(kb, b + NSL); }
+            score_block(ka, b);
+            if (b + NSL < nbatch) {
+                if (b + 2 * NSL < nbatch) load_k(ka, b + 2 * NSL);
+                score_block(kb, b + NSL);
+            }
+        }
+    };
+    if (b_first < nbatch) score_mine(b_first);
+    if (!local) {
+        AT1_STAMP(2);
+        // ---- publish: the write-through stores have left this CU (vmcnt counts stores on gfx9), one lane arrives and polls
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            unsigned* cnt = (unsigned*)p.cnt + h;
+            const unsigned old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const unsigned target = (old / (unsigned)NSL + 1u) * (unsigned)NSL;
+            int ok = 0;
+            if (p.longctx != 3) {
+                const long long t0 = (long long)wall_clock64();
+                for (;;) {
+                    if ((int)(__hip_atomic_load(cnt, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) >= 0) { ok = 1; break; }
+                    if ((long long)wall_clock64() - t0 > ATT1_TIMEOUT) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                if (!ok) atomicAdd((unsigned*)p.cnt + p.H, 1u);      // (diagnostics: polls that ran out)
+            }
+            flag[1] = ok;
+        }
+        __syncthreads();
+        if (!flag[1]) {                                      // peers not resident (or the forced test path): score their blocks here -- same bits
+            for (int o = 1; o < NSL; o++) {
+                const int ofs = (ds + o) % NSL;
+                if (ofs < nbatch) { load_k(ka, ofs); if (ofs + NSL < nbatch) load_k(kb, ofs + NSL); score_mine(ofs); }
+            }
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+    } else __syncthreads();                                  // (e_s and wsum are complete)
+    AT1_STAMP(3);
+    // ---- Z estimate: the waves' tree sums (64 positions each), 64 of them per round, reduced by a fixed-shape butterfly: every thread of every
+    // workgroup of the head gets the same value (any order of adding T non-negative doubles is inside the certified band)
+    double zt = 0.0;
+    if (local) zt = ((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + ((wsum[4] + wsum[5]) + (wsum[6] + wsum[7]));
+    else {
+        const int nw = (T + 63) >> 6;                        // waves that stored a partial
+        for (int w0 = 0; w0 < nw; w0 += 64) {
+            double z = w0 + lane < nw ? ld_sc1_f64(zp + w0 + lane) : 0.0;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) z += __shfl_xor(z, o);
+            zt += z;
+        }
+    }
+    // ---- p_j with the estimate, certified (attn_long_pv_kernel's header); e_j from the LDS (local) or with sc1 loads
+    const unsigned delta32 = 4u * (unsigned)T + 12u;
+    const double epsr = (double)(4 * T + 8) * 1.1102230246251565e-16;
+    const double zlo = zt * (1.0 - epsr), zhi = zt * (1.0 + epsr), rzt = 1.0 / zt;
+    int bad = p.force_zseq;
+    double ev[ALP_EU];
+    for (int j0 = 0; j0 < Tpad; j0 += ALP_EU * ALP_NT) {
+#pragma unroll
+        for (int u = 0; u < ALP_EU; u++) {
+            const int j = j0 + u * ALP_NT + tid;
+            ev[u] = local ? (j < ALP_BATCH ? e_s[j] : 0.0) : ld_sc1_f64(E + (j < T ? j : T - 1));
+        }
+#pragma unroll
+        for (int u = 0; u < ALP_EU; u++) {
+            const int j = j0 + u * ALP_NT + tid;
+            if (j >= Tpad) continue;
+            float pj = 0.0f;
+            if (j < T) {
+                const double e = ev[u];
+                const double q = e * rzt;
+                pj = bf_wide(bf_trunc((float)q));
+                const unsigned qh = (unsigned)__double2hiint(q), ql = (unsigned)__double2loint(q);
+                const unsigned eq = (qh >> 20) & 0x7FFu;
+                if (eq - 897u <= 126u) {
+                    if ((qh & 0x1FFFu) == 0x1FFFu && ql - (0xF0000000u - delta32) <= 2u * delta32) bad = 1;
+                } else if (q != 0.0 && (alp_p(e, zlo) != alp_p(e, zhi) || pj != alp_p(e, zlo))) bad = 1;
+            }
+            pw[j] = pj;
+        }
+        if (local) break;                                    // (Tpad = 1024: one round covers it)
+    }
+    AT1_STAMP(4);
+    if (bad) flag[0] = 1;
+    __syncthreads();
+    if (flag[0]) {
+        // the reference's serial sum, j ascending, f64 (operations_impl.go:492-499)
+        if (wave == 0) {
+            double z = 0.0;
+            for (int j0 = 0; j0 < T; j0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) { const int j = j0 + u < T ? j0 + u : T - 1; v[u] = local ? e_s[j] : ld_sc1_f64(E + j); }
+#pragma unroll
+                for (int u = 0; u < 16; u++) z += (j0 + u < T) ? v[u] : 0.0;
+            }
+            if (lane == 0) { zsh[0] = z; if (p.zseq_count && ds == 0) atomicAdd(p.zseq_count, 1); }
+        }
+        __syncthreads();
+        const double z = zsh[0];
+        for (int j = tid; j < T; j += ALP_NT) pw[j] = alp_p(local ? e_s[j] : ld_sc1_f64(E + j), z);
+        __syncthreads();
+    }
+    // ---- PV: attn_long_pv_kernel's row-broadcast chain (llamatransformer.go:504-514)
+    float acc = 0.0f;
+    if (wave < 4) {
+        const int d = 4 * wave + (lane >> 4), jj = lane & 15;
+        AT1_STAMP(5);
+        for (int it = 0; it <= nbatch; it++) {
+            if (it > 0) {
+                const float* src = ring + (size_t)((it - 1) & 1) * ALP_SLOT + (size_t)d * ALP_BATCH + jj * 4;
+                float4 a0 = *(const float4*)(src), a1 = *(const float4*)(src + 64);
+#pragma unroll
+                for (int c = 0; c < 4; c++) {
+                    float pr[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    if (c < 3) { a0 = *(const float4*)(src + (c + 1) * 128); a1 = *(const float4*)(src + (c + 1) * 128 + 64); }
+                    asm volatile("" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]), "+v"(pr[4]), "+v"(pr[5]), "+v"(pr[6]), "+v"(pr[7]));
+                    __builtin_amdgcn_sched_barrier(0);
+                    chain128(acc, pr);
+                }
+            }
+            __syncthreads();
+        }
+        AT1_STAMP(6);
+        if (jj == 0) p.out[(size_t)h * HD + ds * ALP_DS + d] = bf_trunc(acc);
+    } else {
+        auto produce = [&](const uint4 (&v)[4], int b) {
+            float* dst = ring + (size_t)(b & 1) * ALP_SLOT + (size_t)(half8 * 8) * ALP_BATCH + ((prow >> 6) & 1) * 64 + (prow & 15) * 4 + ((prow >> 4) & 3);
+#pragma unroll
+            for (int r = 0; r < 4; r++) {
+                const float pj = pw[b * ALP_BATCH + r * 128 + prow];
+                const uint4 w = v[r];
+                float* q = dst + r * 128;
+                q[0 * ALP_BATCH] = pj * bf_lo(w.x); q[1 * ALP_BATCH] = pj * bf_hi(w.x); q[2 * ALP_BATCH] = pj * bf_lo(w.y); q[3 * ALP_BATCH] = pj * bf_hi(w.y);
+                q[4 * ALP_BATCH] = pj * bf_lo(w.z); q[5 * ALP_BATCH] = pj * bf_hi(w.z); q[6 * ALP_BATCH] = pj * bf_lo(w.w); q[7 * ALP_BATCH] = pj * bf_hi(w.w);
+            }
+        };
+        auto step = [&](int it, const uint4 (&cur)[4], uint4 (&nxt)[4]) {
+            if (it <= nbatch) {
+                if (it < nbatch) { load(nxt, it + 3); produce(cur, it); }
+                __syncthreads();
+            }
+        };
+        AT1_STAMP(5);
+        for (int it = 0; it <= nbatch; it += 4) { step(it, v0, v3); step(it + 1, v1, v0); step(it + 2, v2, v1); step(it + 3, v3, v2); }
+        AT1_STAMP(6);
+    }
+#undef AT1_STAMP
+}
+
+// ------------------------------------------------------------------------------------------------
 // small kernels
 // ------------------------------------------------------------------------------------------------
 // Fwd_Get_Rows (operations_impl.go:142-173): byte copy of embedding rows
@@ -3164,6 +3405,9 @@ extern "C" hipError_t lnbk_init(void) {
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_one_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_one_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_one_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if (getenv("LNB_ATTN_GQA_DBG") && !g_gqa_dbg) { if (hipMalloc(&g_gqa_dbg, 8 * 16 * 8) != hipSuccess) return hipErrorOutOfMemory; (void)hipMemset(g_gqa_dbg, 0, 8 * 16 * 8); }
     done = true;
     return hipSuccess;
@@ -3181,6 +3425,20 @@ static hipError_t launch_attn_long(const AttnParams* p, hipStream_t st) {
     }
     return hipGetLastError();
 }
+// the one-launch form (attn_one_kernel): scores, softmax and PV per (head, 16-dim slice) workgroup with a bounded in-launch exchange
+static hipError_t launch_attn_one(const AttnParams* p, hipStream_t st) {
+    const size_t lds = att1_lds_bytes(p->seq_len, p->hd);
+    if (lds > 160 * 1024 || p->hd % ALP_DS || !p->e_buf || !p->z_part || !p->cnt) return hipErrorInvalidValue;
+    const dim3 g(p->H, p->hd / ALP_DS);
+    switch (p->hd) {
+    case 128: hipLaunchKernelGGL(attn_one_kernel<128>, g, dim3(ALP_NT), lds, st, *p); break;
+    case 64: hipLaunchKernelGGL(attn_one_kernel<64>, g, dim3(ALP_NT), lds, st, *p); break;
+    case 32: hipLaunchKernelGGL(attn_one_kernel<32>, g, dim3(ALP_NT), lds, st, *p); break;
+    default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+extern "C" size_t lnbk_attn_one_lds(int seq_len, int hd) { return att1_lds_bytes(seq_len, hd); }
 extern "C" size_t lnbk_attn_long_lds(int seq_len) { return alp_lds_bytes(seq_len); }
 extern "C" size_t lnbk_attn_short_lds(int seq_len, int hd);
 
@@ -3196,6 +3454,7 @@ extern "C" void lnbk_attn_gqa_dbg_dump(void) {
 }
 static bool attn_batch_dense() { const char* e = getenv("LNB_ATTN_BATCH_DENSE"); return !(e && *e && atoi(e) == 0); }   // (read per launch: a test switches it inside one process)
 extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
+    if (p->longctx >= 2 && p->S == 1) return launch_attn_one(p, st);
     if (p->longctx && p->S == 1) return launch_attn_long(p, st);
     if (p->mfma && p->S >= 16 && (p->hd == 128 || p->hd == 64)) {       // prefill: 16 query rows per wave on the matrix cores
         if (p->hd == 128) hipLaunchKernelGGL(attn_mfma_kernel<128>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);

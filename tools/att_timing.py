@@ -9,7 +9,9 @@ m = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize(rope_row
 c = lnb.InferenceContext(m, 4400)
 for pos in (63, 127, 271, 383, 511, 767, 1023, 2047, 4100):
     row = []
-    for thr, z in ((10 ** 9, 0), (0, 0), (0, 1)):
+    for thr, z in ((10 ** 9, 0), (0, 2), (0, 8), (0, 4), (0, 1)):
+        if thr > 0 and pos + 1 > 7000:
+            row.append(float("nan")); continue
         c.set_attention(thr, z)
         row.append(c.profile_kernel(1, pos, 32) * 1e3)
-    print("attention at T=%5d: one workgroup per head %7.2f us | long-context kernels %7.2f us | with the serial Z walk %7.2f us" % (pos + 1, *row), flush=True)
+    print("attention at T=%5d: one workgroup per head %7.2f us | two launches (scores, PV) %7.2f us | ONE launch %7.2f us | ... every poll timing out %7.2f us | ... serial Z walk %7.2f us" % (pos + 1, *row), flush=True)

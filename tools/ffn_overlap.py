@@ -43,7 +43,9 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 
 out = {}
-runs = [("latency forms (production, 75 + 104 KB of LDS: cannot co-reside)", {"FFN_SCHED": "latency", "FFN_DELAYS": "0,25"}),
+runs = [("throughput forms, w2's chain waves at s_setprio 3", {"FFN_SCHED": "throughput", "LNB_W2_PRIO": "1", "FFN_DELAYS": "-1,0,10,20,25,30"}),
+        ("throughput forms, no priority, w2 launched first", {"FFN_SCHED": "throughput", "FFN_DELAYS": "-1,-10"}),
+        ("latency forms (production, 75 + 104 KB of LDS: cannot co-reside)", {"FFN_SCHED": "latency", "FFN_DELAYS": "0,25"}),
         ("throughput forms (75 + 57 KB: one workgroup of each fits a CU)", {"FFN_SCHED": "throughput", "FFN_PADS": "0,28672"}),
         ("throughput forms, 4 hardware queues (the runtime's default)", {"FFN_SCHED": "throughput", "GPU_MAX_HW_QUEUES": "4", "FFN_DELAYS": "0,25"}),
         ("band order on one chain wave (LNB_RW_W13=28), throughput forms", {"FFN_SCHED": "throughput", "LNB_RW_W13": "28", "FFN_DELAYS": "0,25"})]

@@ -1,0 +1,30 @@
+#!/bin/bash
+# round 6 GPU runner (one parametrised script; every mode writes under gpurun_out/r06_*).
+#   tools/gpu_r06.sh <mode> [args]
+cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}" || exit 1
+export TMPDIR=/tmp PYTHONPATH=$PWD:$PWD/llama-nuts-and-bolts_amd
+mkdir -p gpurun_out
+mode=$1; shift
+ab() {   # per-kernel decode timings of the 8B block shape (tools/kernel_ab.py); env passes through; label = $1
+  local label=$1; shift
+  echo "== $label"; timeout 300 python tools/kernel_ab.py ${AB_ITERS:-200} 2>&1 | tail -1
+}
+case "$mode" in
+  first)    # first contact: the round's new tests, rung (a) of the FFN ladder, per-kernel baseline
+    ( timeout 1500 python -m pytest tests/test_gpu_round6.py -x -q ) 2>&1 | tail -15 | tee gpurun_out/r06_round6_tests.log
+    ( timeout 1500 python tools/ffn_overlap.py ) > gpurun_out/r06_ffn_overlap.json 2> gpurun_out/r06_ffn_overlap.err; echo "ffn_overlap rc=$?"; cat gpurun_out/r06_ffn_overlap.json; tail -3 gpurun_out/r06_ffn_overlap.err
+    { ab "4 layers"; AB_SCHED=throughput ab "4 layers, throughput forms"; } 2>&1 | tee gpurun_out/r06_ab.log
+    ;;
+  att)      # decode attention per layer at several contexts, both forms, with the phase stamps of one workgroup
+    LNB_GEMV_TIMING=1 timeout 600 python tools/att_timing.py 2>&1 | tee gpurun_out/r06_att_timing.log
+    ;;
+  suite)
+    ( timeout 2400 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r06_gpu_suite.log
+    ;;
+  bench)
+    ( time timeout 1200 python bench.py ) > gpurun_out/r06_bench_default.json 2> gpurun_out/r06_bench_default.err; echo "bench rc=$?"; tail -3 gpurun_out/r06_bench_default.err
+    timeout 900 python bench.py --steps 20 --warmup 5 > gpurun_out/r06_bench_driver_args.json 2> gpurun_out/r06_bench_driver_args.err; echo "bench(20) rc=$?"
+    head -c 600 gpurun_out/r06_bench_default.json; echo
+    ;;
+  *) echo "unknown mode $mode"; exit 2;;
+esac
