@@ -2645,7 +2645,7 @@ constexpr int ALP_SLOT = ALP_DS * ALP_BATCH;                 // floats per ring 
 constexpr int ALP_EU = 12;                                   // e_j per thread and round
 __host__ __device__ inline size_t alp_lds_bytes(int seq_len) { return (size_t)((seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4 + 2 * (size_t)ALP_SLOT * 4 + 64; }
 DEVINL float alp_p(double e, double z) { return bf_wide(bf_trunc((float)(e / z))); }     // impl:506 + ToBFloat16 :493
-template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(AttnParams p) {
+template <int HD> DEVINL void alp_eager_body(const AttnParams& p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -2804,6 +2804,147 @@ template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(
         for (int it = 0; it <= nbatch; it += 4) { step(it, v0, v3); if (it == 0) ALP_STAMP(4); step(it + 1, v1, v0); step(it + 2, v2, v1); step(it + 3, v3, v2); }
         ALP_STAMP(5); ALP_STAMP(6);
     }
+}
+
+template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv_kernel(AttnParams p) { alp_eager_body<HD>(p); }
+
+// ------------------------------------------------------------------------------------------------
+// attn_long_pv2_kernel (round 6): attn_long_pv_kernel with the p_j evaluated LAZILY, off the critical path.
+//
+// Stamps of attn_long_pv_kernel at T = 4101 (profiles/r06_att_timing.log): 10.1 k cycles pass before the first product is made -- every
+// thread fetches eight e_j, forms eight certified p_j -- then 25.8 k of PV.  Only the first batch's p_j are needed to start the chain: here a
+// PRODUCER thread evaluates the p_j of a position right where it multiplies that position's V row (its e_j travels with the V rows, three batches
+// ahead), so what stands in front of the chain is the Z estimate and one batch.  The certification is the same (cert_p); an element that
+// cannot be certified is found while the chain already runs, so the kernel finishes the optimistic pass, and if ANY element failed (about
+// once in 1e9) or force_zseq is set it walks the reference's serial sum and runs the whole PV again with the exact Z: a certified pass
+// equals the reference's bits whatever the serial sum is (monotone step function, attn_long_pv_kernel's header); an uncertified one is discarded.
+// Same grid, block and LDS as attn_long_pv_kernel (the p array is unused).  The kernel symbol attn_long_pv2_kernel picks between the two bodies (below).
+// ------------------------------------------------------------------------------------------------
+template <int HD> DEVINL void alp_lazy_body(const AttnParams& p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int h, ds; xcd_head_block(h, ds);
+    const int T = p.st->pos + 1, nblk = (T + ALS_NT - 1) / ALS_NT, nbatch = (T + ALP_BATCH - 1) / ALP_BATCH;
+    float* ring = (float*)(smem + (size_t)((p.seq_len + ALP_BATCH - 1) / ALP_BATCH + 1) * ALP_BATCH * 4);   // [2][ALP_SLOT] products
+    double* zsh = (double*)(ring + 2 * ALP_SLOT);
+    int* const flag = (int*)(zsh + 1);
+    const double* E = p.e_buf + (size_t)h * p.seq_len;
+    const int kvh = h / (p.H / p.KVH);
+#define ALQ_STAMP(n) do { if (p.dbg && blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && (wave & 3) == 0) p.dbg[(wave >> 2) * 16 + (n)] = (long long)__builtin_amdgcn_s_memtime(); } while (0)
+    ALQ_STAMP(0);
+    // address-only loads first, oldest-needed first: the per-block partial sums, then the producers' first three batches of e_j and V rows
+    const int nblk_max = (p.seq_len + ALS_NT - 1) / ALS_NT;
+    const double* zp = p.z_part + (size_t)h * nblk_max;
+    double zmine = zp[lane < nblk_max ? lane : nblk_max - 1];
+    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD + (size_t)ds * ALP_DS;
+    const size_t vrow = (size_t)p.KVH * HD;
+    const int pl = tid & 255, half8 = pl & 1, prow = pl >> 1;                // producers: 128 positions x two 8-dim halves per round, 4 rounds per batch
+    struct Rows { uint4 v[4]; double e[4]; };
+    auto load = [&](Rows& r_, int b) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            int j = b * ALP_BATCH + r * 128 + prow; j = j < p.seq_len ? j : p.seq_len - 1;       // (clamped to the ARRAY end: no wait for the position word)
+            r_.e[r] = E[j];
+            r_.v[r] = *(const uint4*)(vbase + (size_t)j * vrow + half8 * 8);
+        }
+    };
+    Rows v0, v1, v2, v3;
+    if (wave >= 4) { load(v0, 0); load(v1, 1); load(v2, 2); }
+    if (tid == 0) *flag = 0;
+    // ---- Z estimate: the per-block tree sums in block order (same value in every thread)
+    double zt = 0.0;
+    for (int b0 = 0; b0 < nblk; b0 += 64) {
+        if (b0) zmine = zp[b0 + lane < nblk ? b0 + lane : nblk - 1];
+        const int nb = nblk - b0 < 64 ? nblk - b0 : 64;
+        const long long zbits = __double_as_longlong(zmine);
+        for (int b = 0; b < nb; b++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)zbits, b), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(zbits >> 32), b);
+            zt += __longlong_as_double((long long)(((unsigned long long)hi << 32) | lo));
+        }
+    }
+    const CertZ cz = cert_z(zt, T);
+    __syncthreads();
+    ALQ_STAMP(1);
+    float acc = 0.0f;
+    int bad = 0;
+    // one pass of PV over all batches; exact_z == 0: p_j = cert_p(e_j) (sets bad), else p_j = trunc(f32(e_j / z)) with the walked serial sum z
+    auto run_pv = [&](bool exact, double z) {
+        acc = 0.0f;
+        if (wave < 4) {
+            const int d = 4 * wave + (lane >> 4), jj = lane & 15;
+            for (int it = 0; it <= nbatch; it++) {
+                if (it > 0) {
+                    const float* src = ring + (size_t)((it - 1) & 1) * ALP_SLOT + (size_t)d * ALP_BATCH + jj * 4;
+                    float4 a0 = *(const float4*)(src), a1 = *(const float4*)(src + 64);
+#pragma unroll
+                    for (int c = 0; c < 4; c++) {
+                        float pr[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                        if (c < 3) { a0 = *(const float4*)(src + (c + 1) * 128); a1 = *(const float4*)(src + (c + 1) * 128 + 64); }   // in flight behind the 128 adds
+                        asm volatile("" : "+v"(pr[0]), "+v"(pr[1]), "+v"(pr[2]), "+v"(pr[3]), "+v"(pr[4]), "+v"(pr[5]), "+v"(pr[6]), "+v"(pr[7]));
+                        __builtin_amdgcn_sched_barrier(0);
+                        chain128(acc, pr);
+                    }
+                }
+                __syncthreads();
+            }
+        } else {
+            auto produce = [&](const Rows& r_, int b) {
+                float* dst = ring + (size_t)(b & 1) * ALP_SLOT + (size_t)(half8 * 8) * ALP_BATCH + ((prow >> 6) & 1) * 64 + (prow & 15) * 4 + ((prow >> 4) & 3);
+#pragma unroll
+                for (int r = 0; r < 4; r++) {                    // round r = chunk r of the batch; position prow of it
+                    const int j = b * ALP_BATCH + r * 128 + prow;
+                    float pj = 0.0f;                             // +0 past the row: products +-0, acc is never -0
+                    if (j < T) pj = exact ? alp_p(r_.e[r], z) : cert_p(r_.e[r], cz, bad);       // impl:506 + ToBFloat16 :493
+                    const uint4 w = r_.v[r];                     // exact products: 8-bit x 8-bit significands
+                    float* q = dst + r * 128;
+                    q[0 * ALP_BATCH] = pj * bf_lo(w.x); q[1 * ALP_BATCH] = pj * bf_hi(w.x); q[2 * ALP_BATCH] = pj * bf_lo(w.y); q[3 * ALP_BATCH] = pj * bf_hi(w.y);
+                    q[4 * ALP_BATCH] = pj * bf_lo(w.z); q[5 * ALP_BATCH] = pj * bf_hi(w.z); q[6 * ALP_BATCH] = pj * bf_lo(w.w); q[7 * ALP_BATCH] = pj * bf_hi(w.w);
+                }
+            };
+            auto step = [&](int it, const Rows& cur, Rows& nxt) {
+                if (it <= nbatch) {                              // (uniform; one barrier per iteration, like the adders)
+                    if (it < nbatch) { load(nxt, it + 3); produce(cur, it); }
+                    __syncthreads();
+                }
+            };
+            for (int it = 0; it <= nbatch; it += 4) { step(it, v0, v3); step(it + 1, v1, v0); step(it + 2, v2, v1); step(it + 3, v3, v2); }
+        }
+    };
+    if (!p.force_zseq) {
+        run_pv(false, 0.0);
+        ALQ_STAMP(2);
+        if (bad) *flag = 1;
+        __syncthreads();
+    }
+    if (p.force_zseq || *flag) {
+        // the reference's serial sum, j ascending, f64 (operations_impl.go:492-499): one wave, 16 values in flight ahead of the adds
+        if (wave == 0) {
+            double z = 0.0;
+            for (int j0 = 0; j0 < T; j0 += 16) {
+                double v[16];
+#pragma unroll
+                for (int u = 0; u < 16; u++) v[u] = E[j0 + u < T ? j0 + u : T - 1];
+#pragma unroll
+                for (int u = 0; u < 16; u++) z += (j0 + u < T) ? v[u] : 0.0;
+            }
+            if (lane == 0) { zsh[0] = z; if (p.zseq_count && ds == 0) atomicAdd(p.zseq_count, 1); }
+        }
+        if (wave >= 4) { load(v0, 0); load(v1, 1); load(v2, 2); }       // the producers' pipeline starts over
+        __syncthreads();
+        run_pv(true, zsh[0]);
+    }
+    ALQ_STAMP(5);
+    if (wave < 4 && (lane & 15) == 0) p.out[(size_t)h * HD + ds * ALP_DS + 4 * wave + (lane >> 4)] = bf_trunc(acc);
+    ALQ_STAMP(6);
+#undef ALQ_STAMP
+}
+
+// up to two batches (T <= 1024) the eager form is the faster one (all 512 threads share the first batch's p_j: 11.2 against 11.5 us at T = 768,
+// 9.6 against 10.1 at 272); from three batches on the lazy one (T = 2048: 15.1 -> 14.5 us, 4101: 23.0 -> 21.8).  T lives on the device (one captured
+// graph serves every position), so the choice is made here, per launch, uniformly over the grid.
+template <int HD> __global__ __launch_bounds__(ALP_NT) void attn_long_pv2_kernel(AttnParams p) {
+    if (p.st->pos + 1 <= 2 * ALP_BATCH) alp_eager_body<HD>(p); else alp_lazy_body<HD>(p);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -3405,6 +3546,9 @@ extern "C" hipError_t lnbk_init(void) {
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_long_pv_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_long_pv2_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_long_pv2_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
+    if ((e = hipFuncSetAttribute((const void*)attn_long_pv2_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_one_kernel<128>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_one_kernel<64>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
     if ((e = hipFuncSetAttribute((const void*)attn_one_kernel<32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return e;
@@ -3417,10 +3561,14 @@ static hipError_t launch_attn_long(const AttnParams* p, hipStream_t st) {
     const size_t lds = alp_lds_bytes(p->seq_len);
     if (lds > 160 * 1024 || p->hd % ALP_DS || !p->e_buf || !p->z_part) return hipErrorInvalidValue;
     const dim3 gs(p->H, (p->seq_len + ALS_NT - 1) / ALS_NT), gp(p->H, p->hd / ALP_DS);
+    const bool lazy = [] { const char* e = getenv("LNB_ATTN_LAZY"); return !(e && *e && atoi(e) == 0); }();      // (read per launch: a test switches it inside one process)
     switch (p->hd) {
-    case 128: hipLaunchKernelGGL(attn_long_scores_kernel<128>, gs, dim3(ALS_NT), 0, st, *p); hipLaunchKernelGGL(attn_long_pv_kernel<128>, gp, dim3(ALP_NT), lds, st, *p); break;
-    case 64: hipLaunchKernelGGL(attn_long_scores_kernel<64>, gs, dim3(ALS_NT), 0, st, *p); hipLaunchKernelGGL(attn_long_pv_kernel<64>, gp, dim3(ALP_NT), lds, st, *p); break;
-    case 32: hipLaunchKernelGGL(attn_long_scores_kernel<32>, gs, dim3(ALS_NT), 0, st, *p); hipLaunchKernelGGL(attn_long_pv_kernel<32>, gp, dim3(ALP_NT), lds, st, *p); break;
+    // PV: the lazily certified form (attn_long_pv2_kernel, round 6) unless LNB_ATTN_LAZY=0
+#define LNB_PV(HD_) do { if (lazy) hipLaunchKernelGGL(attn_long_pv2_kernel<HD_>, gp, dim3(ALP_NT), lds, st, *p); else hipLaunchKernelGGL(attn_long_pv_kernel<HD_>, gp, dim3(ALP_NT), lds, st, *p); } while (0)
+    case 128: hipLaunchKernelGGL(attn_long_scores_kernel<128>, gs, dim3(ALS_NT), 0, st, *p); LNB_PV(128); break;
+    case 64: hipLaunchKernelGGL(attn_long_scores_kernel<64>, gs, dim3(ALS_NT), 0, st, *p); LNB_PV(64); break;
+    case 32: hipLaunchKernelGGL(attn_long_scores_kernel<32>, gs, dim3(ALS_NT), 0, st, *p); LNB_PV(32); break;
+#undef LNB_PV
     default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
