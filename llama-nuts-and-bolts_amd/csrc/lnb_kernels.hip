@@ -3405,6 +3405,12 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     // very long rows (70B-like w2: K = 28672): x needs more staging registers than three stager waves hold -> four helpers
     if (p && !NORM && NCH == 1 && (rw == 16 || rw == 32) && xs_bytes(p->K, 8192 / (rw * 2)) / 4 > (size_t)XCh<false>::value * 3 * 512)
         return rw == 16 ? launch_chain_t<16, 1, 8192, 4, 7, EPI, false>(p, st) : launch_chain_t<32, 1, 8192, 4, 7, EPI, false>(p, st);
+    // rung (a') of the FFN ladder (profiles/r06_ffn_stream.md; LNB_RW_W2=16 LNB_W2_QUAD=1, measurement only): the down projection's 16 rows per CU on ONE
+    // quad_perm chain wave + four helpers -- the only w2 form that would leave a co-resident gate|up producer three SIMDs
+    if constexpr (NCH == 1 && !NORM && (EPI == EPI_RESID || EPI == EPI_STORE)) {
+        static const int quad16 = [] { const char* e = getenv("LNB_W2_QUAD"); return e && *e ? atoi(e) : 0; }();
+        if (rw == 16 && quad16 && (!p || p->K % 128 == 0)) return quad16 == 2 ? launch_quad_t<16, 256, 4, 7, EPI, false>(p, st) : launch_quad_t<16, 128, 4, 14, EPI, false>(p, st);
+    }
     if (rw == 16) return launch_chain_t<16, NCH, 8192, 2, 7, EPI, NORM>(p, st);
     if (rw == 32) return (NORM && NCH == 1) ? launch_chain_t<32, 1, 12288, 6, 5, EPI, NORM>(p, st) : launch_chain_t<32, NCH, 8192, 2, 7, EPI, NORM>(p, st);
     if (rw == 64) return launch_chain_t<64, NCH, 12288, 6, 8, EPI, NORM>(p, st);

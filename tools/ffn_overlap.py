@@ -43,7 +43,10 @@ if len(sys.argv) > 1 and sys.argv[1] == "child":
     sys.exit(0)
 
 out = {}
-runs = [("throughput forms, w2's chain waves at s_setprio 3", {"FFN_SCHED": "throughput", "LNB_W2_PRIO": "1", "FFN_DELAYS": "-1,0,10,20,25,30"}),
+runs = [("w2 as ONE quad_perm chain wave + 4 helpers (LNB_RW_W2=16 LNB_W2_QUAD=1: 128-step stages, 83 KB), gate|up as in production", {"FFN_SCHED": "latency", "LNB_RW_W2": "16", "LNB_W2_QUAD": "1", "FFN_DELAYS": "-1,0,10,15,20,25,30"}),
+        ("... 256-step stages (107 KB: cannot share a CU with gate|up)", {"FFN_SCHED": "latency", "LNB_RW_W2": "16", "LNB_W2_QUAD": "2", "FFN_DELAYS": "0,25"}),
+        ("... 128-step stages, gate|up in band order on one chain wave (LNB_RW_W13=28)", {"FFN_SCHED": "latency", "LNB_RW_W2": "16", "LNB_W2_QUAD": "1", "LNB_RW_W13": "28", "FFN_DELAYS": "0,25,30,35"}),
+        ("throughput forms, w2's chain waves at s_setprio 3", {"FFN_SCHED": "throughput", "LNB_W2_PRIO": "1", "FFN_DELAYS": "-1,0,10,20,25,30"}),
         ("throughput forms, no priority, w2 launched first", {"FFN_SCHED": "throughput", "FFN_DELAYS": "-1,-10"}),
         ("latency forms (production, 75 + 104 KB of LDS: cannot co-reside)", {"FFN_SCHED": "latency", "FFN_DELAYS": "0,25"}),
         ("throughput forms (75 + 57 KB: one workgroup of each fits a CU)", {"FFN_SCHED": "throughput", "FFN_PADS": "0,28672"}),
