@@ -2012,6 +2012,193 @@ template <int HD> __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(Att
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_mfma2_kernel (round 6): attn_mfma_kernel with TWO query tiles (32 rows) per wave against each tile of cached positions.
+//
+// attn_mfma_kernel was 0.517 MFMA-busy for three rounds (profiles/r05_prefill_mfma_counters.md): per tile a wave runs 32 DEPENDENT matrix
+// instructions (40 cycles of latency at a 32-cycle issue rate), waits for four table look-ups, turns the LDS patch twice, walks sixteen f64 adds on
+// a quarter of its lanes -- and then does it all again in pass 2.  With two query tiles A and B per wave the SAME K operand (one v_perm per k-group instead
+// of one per matrix instruction) feeds two independent accumulator chains, S_A^T and S_B^T, alternately: no dependent-issue stall; the V rows of a tile
+// are loaded and unpacked once for both; the serial Z adds of the 32 rows run on lanes 0..31 in the same sixteen instructions; the LDS turns, the look-up
+// latency and the loop overhead are paid once per 2 x 96 matrix instructions.  Same arithmetic per element, same order (j ascending inside and across the
+// matrix instructions), same bits.  Tile A's rows see the diagonal one tile earlier than B's: its masked elements are e = 0, p = +0 (wasted work, not wrong).
+// grid (H, ceil(S / 128)), block 256 = 4 independent waves x 32 query rows.  NOT the default (ATM2_MIN_S below): measured slower than the 16-row form.
+// (Found on the way: widening an operand with an `asm volatile` VALU instruction right in front of the matrix instruction that reads it gave WRONG scores -- the
+// compiler's hazard recognizer does not cover an asm-defined register feeding v_mfma; the packed words are made opaque with an EMPTY asm instead.)
+// ------------------------------------------------------------------------------------------------
+constexpr int ATM2_WLDS = 32 * ATM_ET + 32 * ATM_PT + 256;   // per-wave LDS patch: e tiles A|B | p tiles A|B | Z rows
+constexpr int ATM2_MIN_S = 0;                                // 0: off.  Measured (profiles/r06_prefill_attn.log, 8B shape, whole Forward): 4096 rows 536.1 -> 537.8 ms, 2048: 249.9 -> 256.8, 512: 62.2 -> 64.8 -- SLOWER:
+                                                             // the dependent-issue stall it removes is not what bounds the kernel (table look-up latency, eight f64 divisions and the LDS turns per tile are), and 32-row
+                                                             // waves halve the number of jobs on a triangular workload.  Kept bit-exact and selectable (LNB_ATTN_MFMA2=<min rows>) for the next attempt.
+template <int HD> __global__ __launch_bounds__(256, 2) void attn_mfma2_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sm[4 * ATM2_WLDS];
+    constexpr int NK = HD / 8, DPL = HD / 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int h, by_; xcd_head_block_bmajor(h, by_);
+    by_ = (int)gridDim.y - 1 - by_;                          // the last query rows see the longest context: handed out first
+    const int i0 = (by_ * 4 + wave) * 32;
+    const int S = p.S, H = p.H, KVH = p.KVH;
+    if (i0 >= S) return;                                     // (waves are independent)
+    const int pos0 = p.st->pos, T = pos0 + S;
+    const int kvh = h / (H / KVH);
+    const int fi = lane & 15, fk = lane >> 4;
+    char* et = sm + wave * ATM2_WLDS;
+    char* pt = et + 32 * ATM_ET;
+    double* zrow = (double*)(pt + 32 * ATM_PT);
+    const uint4* kbase = (const uint4*)p.cache_k + (size_t)kvh * NK * p.seq_len;
+    const uint16_t* vbase = p.cache_v + (size_t)kvh * HD + fi * DPL;
+    const size_t vrow = (size_t)KVH * HD;
+    const uint32_t sel = 0x0c0cu | ((uint32_t)(2 * fk) << 16) | ((uint32_t)(2 * fk + 1) << 24);
+    const int Tmax = (S > 1 && pos0 == 0) ? (i0 + 32 < T ? i0 + 32 : T) : T;       // tile B's diagonal
+    const int NJ = (Tmax + 15) >> 4;
+    const int irow[2] = {i0 + fi, i0 + 16 + fi};
+
+    // Q[irow][4g + kk] of both query tiles, PACKED: the values are bf16, so the two k-groups of an 8-chunk share a register (low half: k-group 2c, high
+    // half: 2c + 1) and are widened by one shift / mask in front of their matrix instruction -- 32 instead of 64 registers, which is what lets the kernel
+    // keep two workgroups per CU without spilling
+    uint32_t qp[2][NK];
+    const uint32_t selp = ((uint32_t)(2 * (fk & 1)) | ((uint32_t)(2 * (fk & 1) + 1) << 8)) | (((uint32_t)(4 + 2 * (fk & 1)) | ((uint32_t)(5 + 2 * (fk & 1)) << 8)) << 16);
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+        const uint4* q = (const uint4*)(p.q + ((size_t)(irow[t] < S ? irow[t] : S - 1) * H + h) * HD);
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+            const uint4 u = q[c];
+            const uint32_t lo = fk < 2 ? u.x : u.y, hi = fk < 2 ? u.z : u.w;      // element kk of the first / second four of the chunk
+            qp[t][c] = __builtin_amdgcn_perm(hi, lo, selp);                       // bytes: [elem kk of (x|y)] | [elem kk of (z|w)] << 16
+        }
+    }
+    auto load_k = [&](uint4 (&k)[NK], int j0) {
+        int j = j0 + fi; j = j < T ? j : T - 1;
+#pragma unroll
+        for (int c = 0; c < NK; c++) k[c] = kbase[(size_t)c * p.seq_len + j];
+    };
+    // raw scores of the tile for both query tiles: two independent chains fed by ONE K operand per k-group, d ascending (operations_matmul.go:37-55)
+    auto qk2 = [&](const uint4 (&k)[NK], f32x4& sa, f32x4& sb) {
+        sa = f32x4{0.f, 0.f, 0.f, 0.f}; sb = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+            const float k0 = __uint_as_float(__builtin_amdgcn_perm(k[c].y, k[c].x, sel)), k1 = __uint_as_float(__builtin_amdgcn_perm(k[c].w, k[c].z, sel));
+            // (the empty volatile asm makes the packed word opaque in every iteration: left to itself hipcc hoists the loop-invariant widening out of the
+            // tile loop and is back at 64 registers + spills)
+            uint32_t qa = qp[0][c], qb = qp[1][c];
+            asm volatile("" : "+v"(qa), "+v"(qb));
+            const float a0 = bf_lo(qa), a1 = bf_hi(qa), b0 = bf_lo(qb), b1 = bf_hi(qb);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k0, a0, sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k0, b0, sb, 0, 0, 0);
+            sa = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, a1, sa, 0, 0, 0);
+            sb = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, b1, sb, 0, 0, 0);
+        }
+    };
+    auto expo = [&](const f32x4& acc, int j0, int ir, double (&e)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = j0 + 4 * fk + r;
+            const bool dead = j >= T || ((S > 1) && ((pos0 == 0 ? j : j % S) > ir));   // triu(-inf,1) broadcast by modulo (tensoriterators.go:47-55)
+            const double ev = p.exp_tab[bf_trunc(acc[r])];                       // / sqrt(hd) :464, (+ mask 0 :469-473), exp impl:498: tabulated
+            e[r] = dead ? 0.0 : ev;
+        }
+    };
+#define ATM_LDS_TURN() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+    typedef double d2 __attribute__((ext_vector_type(2)));
+
+    // ---- pass 1: Z_i = sum_j exp(s_ij), f64, j ascending (lane i < 32 carries row i of the 32)
+    double z = 0.0;
+    uint4 kt[NK];
+    load_k(kt, 0);
+    for (int jt = 0; jt < NJ; jt++) {                        // (wave-uniform trip count)
+        const int j0 = jt * 16;
+        f32x4 sa, sb;
+        qk2(kt, sa, sb);
+        if (jt + 1 < NJ) load_k(kt, j0 + 16);
+        double ea[4], eb[4];
+        expo(sa, j0, irow[0], ea); expo(sb, j0, irow[1], eb);
+        d2* wa = (d2*)(et + fi * ATM_ET + fk * 32);
+        d2* wb = (d2*)(et + (16 + fi) * ATM_ET + fk * 32);
+        wa[0] = d2{ea[0], ea[1]}; wa[1] = d2{ea[2], ea[3]};
+        wb[0] = d2{eb[0], eb[1]}; wb[1] = d2{eb[2], eb[3]};
+        ATM_LDS_TURN();
+        if (lane < 32) {
+            const d2* row = (const d2*)(et + lane * ATM_ET);
+            d2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = row[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { z += v[u].x; z += v[u].y; }
+        }
+        ATM_LDS_TURN();
+    }
+    if (lane < 32) zrow[lane] = z;
+    ATM_LDS_TURN();
+    const double zia = zrow[fi], zib = zrow[16 + fi];
+
+    // ---- pass 2: p = trunc(f32(e / Z_i)), out = sum_j p_j v_j (j ascending)
+    f32x4 oa[DPL], ob[DPL];
+#pragma unroll
+    for (int t = 0; t < DPL; t++) { oa[t] = f32x4{0.f, 0.f, 0.f, 0.f}; ob[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    load_k(kt, 0);
+    for (int jt = 0; jt < NJ; jt++) {
+        const int j0 = jt * 16;
+        f32x4 sa, sb;
+        qk2(kt, sa, sb);
+        if (jt + 1 < NJ) load_k(kt, j0 + 16);
+        uint4 vv[4];                                         // V[j0 + 4g + kk][dims fi*DPL ..]: once for both query tiles
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            int j = j0 + 4 * g + fk; j = j < T ? j : T - 1;
+            const uint16_t* a = vbase + (size_t)j * vrow;
+            if (DPL == 8) vv[g] = *(const uint4*)a;
+            else { const uint2 t2 = *(const uint2*)a; vv[g] = make_uint4(t2.x, t2.y, 0, 0); }
+        }
+        double ea[4], eb[4];
+        expo(sa, j0, irow[0], ea); expo(sb, j0, irow[1], eb);
+        float4 pfa, pfb;                                     // impl:506 + ToBFloat16 :493
+        pfa.x = bf_wide(bf_trunc((float)(ea[0] / zia))); pfa.y = bf_wide(bf_trunc((float)(ea[1] / zia)));
+        pfa.z = bf_wide(bf_trunc((float)(ea[2] / zia))); pfa.w = bf_wide(bf_trunc((float)(ea[3] / zia)));
+        pfb.x = bf_wide(bf_trunc((float)(eb[0] / zib))); pfb.y = bf_wide(bf_trunc((float)(eb[1] / zib)));
+        pfb.z = bf_wide(bf_trunc((float)(eb[2] / zib))); pfb.w = bf_wide(bf_trunc((float)(eb[3] / zib)));
+        *(float4*)(pt + fi * ATM_PT + fk * 16) = pfa;        // p[i = fi][j = 4kk .. 4kk+3] of tile A, B
+        *(float4*)(pt + (16 + fi) * ATM_PT + fk * 16) = pfb;
+        ATM_LDS_TURN();
+        float pa[4], pb[4];
+#pragma unroll
+        for (int g = 0; g < 4; g++) {                        // A operands: p[i = fi][j = 4g + kk]
+            pa[g] = *(const float*)(pt + fi * ATM_PT + (4 * g + fk) * 4);
+            pb[g] = *(const float*)(pt + (16 + fi) * ATM_PT + (4 * g + fk) * 4);
+        }
+        ATM_LDS_TURN();
+#pragma unroll
+        for (int g = 0; g < 4; g++) {                        // MatMul p.v, j ascending (llamatransformer.go:504-514)
+            const uint32_t wd[4] = {vv[g].x, vv[g].y, vv[g].z, vv[g].w};
+#pragma unroll
+            for (int t = 0; t < DPL; t++) {
+                const float vf = (t & 1) ? bf_hi(wd[t >> 1]) : bf_lo(wd[t >> 1]);
+                oa[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[g], vf, oa[t], 0, 0, 0);
+                ob[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(pb[g], vf, ob[t], 0, 0, 0);
+            }
+        }
+    }
+#undef ATM_LDS_TURN
+    // D layout: lane holds query rows 4*kk + r, output dims fi*DPL + t
+#pragma unroll
+    for (int tile = 0; tile < 2; tile++) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int row = i0 + 16 * tile + 4 * fk + r;
+            if (row >= S) continue;
+            uint32_t w[DPL / 2];
+#pragma unroll
+            for (int t = 0; t < DPL; t += 2) w[t / 2] = tile ? ((uint32_t)bf_trunc(ob[t][r]) | ((uint32_t)bf_trunc(ob[t + 1][r]) << 16))
+                                                             : ((uint32_t)bf_trunc(oa[t][r]) | ((uint32_t)bf_trunc(oa[t + 1][r]) << 16));
+            uint16_t* dst = p.out + ((size_t)row * H + h) * HD + fi * DPL;
+            if (DPL == 8) *(uint4*)dst = make_uint4(w[0], w[1], w[2 % (DPL / 2)], w[3 % (DPL / 2)]);
+            else *(uint2*)dst = make_uint2(w[0], w[1]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Exact attention for one (head, query row): scores -> /sqrt(hd) -> mask -> f64 softmax -> PV.
 // llamatransformer.go:409-514.  GQA head h reads KV head h/n_rep straight from the un-repeated cache
 // (attentionRepeatKV :529-559 and the four Transposes :435-449 become index arithmetic).
@@ -3610,7 +3797,14 @@ static bool attn_batch_dense() { const char* e = getenv("LNB_ATTN_BATCH_DENSE");
 extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
     if (p->longctx >= 2 && p->S == 1) return launch_attn_one(p, st);
     if (p->longctx && p->S == 1) return launch_attn_long(p, st);
-    if (p->mfma && p->S >= 16 && (p->hd == 128 || p->hd == 64)) {       // prefill: 16 query rows per wave on the matrix cores
+    if (p->mfma && p->S >= 16 && (p->hd == 128 || p->hd == 64)) {       // prefill: 16 (attn_mfma_kernel) or 32 (attn_mfma2_kernel, round 6) query rows per wave on the matrix cores
+        const char* e2 = getenv("LNB_ATTN_MFMA2");                        // 0: never the two-tile form; N > 0: from N rows on (default ATM2_MIN_S)
+        const int min2 = (e2 && *e2) ? atoi(e2) : ATM2_MIN_S;              // (default 0 = off: measured slower, see attn_mfma2_kernel)
+        if (min2 > 0 && p->S >= min2) {
+            if (p->hd == 128) hipLaunchKernelGGL(attn_mfma2_kernel<128>, dim3(p->H, (p->S + 127) / 128), dim3(256), 0, st, *p);
+            else hipLaunchKernelGGL(attn_mfma2_kernel<64>, dim3(p->H, (p->S + 127) / 128), dim3(256), 0, st, *p);
+            return hipGetLastError();
+        }
         if (p->hd == 128) hipLaunchKernelGGL(attn_mfma_kernel<128>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
         else hipLaunchKernelGGL(attn_mfma_kernel<64>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
         return hipGetLastError();

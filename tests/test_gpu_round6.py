@@ -191,3 +191,32 @@ def test_two_contexts_in_one_launch_attention_never_wait_for_each_other(lnb):
     for c in ctxs:
         c.close()
     gm.close()
+
+
+@pytest.mark.parametrize("heads,kv_heads,dim,rows", [(4, 2, 512, 37), (4, 4, 256, 83), (8, 2, 1024, 16), (4, 2, 512, 160), (8, 2, 512, 530)])
+def test_two_query_tiles_per_wave_prefill_attention_ragged_rows(lnb, monkeypatch, heads, kv_heads, dim, rows):
+    """attn_mfma2_kernel (round 6: 32 query rows per wave, two accumulator chains fed by one K operand; llamatransformer.go:409-514 for multi-row calls)
+    forced on at every row count (LNB_ATTN_MFMA2=16; its default is 512 rows and up): row counts that leave tile B empty (16), partial (37, 83) or
+    cross several workgroups (160, 530), head_dim 128 and 64, then a ragged chunk at start_pos > 0 (the reference's modulo-broadcast mask over
+    T > S) and decode steps that read the cache it wrote -- logits bits against the oracle, and against the 16-row kernel it replaces."""
+    cfg = dict(orc.TINY, n_heads=heads, n_kv_heads=kv_heads, dim=dim, n_layers=2, vocab_size=512, max_seq_len=1024)
+    om = orc.Model(**cfg).fill_synthetic(31).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(31).finalize()
+    toks = orc.synth_tokens(8, 2 * rows, cfg["vocab_size"])
+    oc = orc.Context(om, 2 * rows + 8)
+    ref = [oc.forward(toks[lo_:hi_], lo_) for lo_, hi_ in ((0, rows), (rows, 2 * rows))]
+    for form in ("16", "0"):
+        monkeypatch.setenv("LNB_ATTN_MFMA2", form)
+        gc = lnb.InferenceContext(gm, 2 * rows + 8)
+        for (lo_, hi_), (lo, ao) in zip(((0, rows), (rows, 2 * rows)), ref):
+            lg, ag = gc.Forward(toks[lo_:hi_], lo_)
+            assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag, (form, lo_)
+        if form == "16":
+            tok = ag
+            for i in range(3):
+                lo, to = oc.forward([tok], 2 * rows + i)
+                lg, tg = gc.Forward(np.array([tok], dtype=np.int32), 2 * rows + i)
+                assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and to == tg
+                tok = to
+        gc.close()
+    oc.close(); gm.close(); om.close()

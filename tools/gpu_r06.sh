@@ -18,6 +18,9 @@ case "$mode" in
   att)      # decode attention per layer at several contexts, both forms, with the phase stamps of one workgroup
     LNB_GEMV_TIMING=1 timeout 600 python tools/att_timing.py 2>&1 | tee gpurun_out/r06_att_timing.log
     ;;
+  prefill)  # exact prefill of the 8B shape at several row counts: the 16-row attention waves against the two-query-tile form
+    for v in 0 16 512; do echo "== LNB_ATTN_MFMA2=$v"; LNB_ATTN_MFMA2=$v timeout 900 python tools/prefill_bench.py --sizes 128,256,512,2048,4096 --modes exact 2>&1 | tail -5; done | tee gpurun_out/r06_prefill_attn.log
+    ;;
   suite)
     ( timeout 2400 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r06_gpu_suite.log
     ;;
