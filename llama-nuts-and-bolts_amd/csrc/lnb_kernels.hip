@@ -181,6 +181,17 @@ DEVINL float wave_inclusive_sum(float v) {
     return v;
 }
 
+// sum of a double over the wave, every lane gets it: six DPP steps on the two 32-bit halves (VALU data movement) + two v_readlane, instead of the twelve
+// ds_bpermute round trips a __shfl_xor butterfly of doubles costs (~1.2 k cycles in front of attn_exact_kernel's certified p_j).  Only ever used for
+// ESTIMATES with a rigorous error bound (the softmax denominator's tree sum): the order of the additions is free.
+DEVINL double wave_sum_f64(double v) {
+#define LNB_DSUM_STEP(MOV) { const int lo_ = MOV(__double2loint(v), 0), hi_ = MOV(__double2hiint(v), 0); v += __hiloint2double(hi_, lo_); }
+    LNB_DSUM_STEP(dpp_row_shr<1>) LNB_DSUM_STEP(dpp_row_shr<2>) LNB_DSUM_STEP(dpp_row_shr<4>) LNB_DSUM_STEP(dpp_row_shr<8>)
+    LNB_DSUM_STEP(dpp_bcast15) LNB_DSUM_STEP(dpp_bcast31)
+#undef LNB_DSUM_STEP
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
 DEVINL void rms_load16(float (&tv)[16], const float* q, int c, int LEAF) {
 #pragma unroll
     for (int i = 0; i < 4; i++) {
@@ -2415,7 +2426,7 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
     const uint16_t* q = p.q + ((size_t)i * p.H + h) * HD;
     const uint16_t q16 = q[tid < HD ? tid : 0];             // unconditional: a predicated load would be waited on at once
     uint4 ka[NK], kb[NK];
-    attn_load_k<NK>(ka, kbase, seq_len, tid < T ? tid : T - 1);
+    attn_load_k<NK>(ka, kbase, seq_len, tid < seq_len ? tid : seq_len - 1);      // (clamped to the ARRAY end: the first pass's K rows do not wait for the position word; a row past T is never scored)
     if (tid < HD) qf[tid] = bf_wide(q16);
     __syncthreads();
     ATT_STAMP(1);
@@ -2471,8 +2482,7 @@ template <int HD, bool DENSE = false> __global__ __launch_bounds__(ATT_NT, DENSE
     {
         double part = 0.0;
         for (int j = tid; j < T; j += ATT_NT) part += e[j];
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) part += __shfl_xor(part, o);
+        part = wave_sum_f64(part);
         if (lane == 0) zb[4 + wave] = part;
         if (tid == 0) *zflag = 0;
     }
@@ -2818,8 +2828,7 @@ template <int HD> __global__ __launch_bounds__(ALS_NT) void attn_long_scores_ker
     double ev = 0.0;
     if (j < T) { ev = attn_score_value<NK>(k, qf, p.divisor); p.e_buf[(size_t)h * p.seq_len + j] = ev; }
     // tree sum of the block (fixed shape: deterministic); only ever used as an estimate with a rigorous error bound
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ev += __shfl_xor(ev, o);
+    ev = wave_sum_f64(ev);
     if ((tid & 63) == 0) wsum[tid >> 6] = ev;
     __syncthreads();
     if (tid == 0) p.z_part[(size_t)h * ((p.seq_len + ALS_NT - 1) / ALS_NT) + blk] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
