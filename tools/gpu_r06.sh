@@ -21,6 +21,15 @@ case "$mode" in
   prefill)  # exact prefill of the 8B shape at several row counts: the 16-row attention waves against the two-query-tile form
     for v in 0 16 512; do echo "== LNB_ATTN_MFMA2=$v"; LNB_ATTN_MFMA2=$v timeout 900 python tools/prefill_bench.py --sizes 128,256,512,2048,4096 --modes exact 2>&1 | tail -5; done | tee gpurun_out/r06_prefill_attn.log
     ;;
+  profile)  # rocprofv3 of the bench command: kernel trace + stats, and the FETCH_SIZE counter pass on its own (tools/summarize_profile.py r06 condenses them)
+    O=$PWD/gpurun_out/prof_r06; rm -rf $O; mkdir -p $O
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o trace -- python $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 4 --repeats 1 --cpu-steps 0 --profile-iters 8 --concurrent 0 --batch-sizes= --no-traffic-probe > $O/trace_bench.json 2> $O/trace.err; echo "trace rc=$?" )
+    ( cd /tmp && timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $O/pmc_fetch -o pmc -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --repeats 1 --cpu-steps 0 --profile-iters 4 --concurrent 0 --batch-sizes= --no-traffic-probe > $O/pmc_fetch_bench.json 2> $O/pmc_fetch.err; echo "pmc rc=$?" )
+    LNB_GEMV_TIMING=1 timeout 300 python tools/kernel_ab.py 50 > gpurun_out/r06_stamps.log 2>&1
+    python tools/summarize_profile.py r06 2>&1 | tail -5
+    mkdir -p gpurun_out/r06_profiles && cp profiles/r06_rocprofv3_kernel_stats.csv profiles/r06_summary.md profiles/r06_traffic.json gpurun_out/r06_profiles/ 2>/dev/null
+    find $O -name "*.csv" | head; du -sh gpurun_out
+    ;;
   suite)
     ( timeout 2400 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r06_gpu_suite.log
     ;;
