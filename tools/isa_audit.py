@@ -178,7 +178,8 @@ def main(asm_path=None):
         total += len(v) + (0 if ("mfma_stream" in name or "mfma_pair" in name or "gemm_stream" in name) else accv)
     # scratch memory and VGPR spills: never.  SGPR spills into VGPR lanes (v_writelane, no memory): tolerated for the kernels listed here only --
     # attn_gqa_kernel inlines the f64 exp (two dozen SGPRs of polynomial constants) and saves 18 scalars in one VGPR around it
-    SGPR_SPILL_OK = ("attn_gqa_kernel",)
+    # (round 6: attn_one_kernel inlines the same exp beside its in-launch exchange: 30 scalars parked in VGPR lanes; it is the opt-in one-launch form)
+    SGPR_SPILL_OK = ("attn_gqa_kernel", "attn_one_kernel")
     spills, cur = [], ""
     for l in txt:
         mname = re.search(r"\.name:\s+(\S+)", l)
