@@ -100,6 +100,10 @@ struct Model {                           // model.Model: what LoadModel returns 
 struct InferenceArgs { int SequenceLength = 0; };   // src/common/inferenceargs.go:3-11
 
 inline void check(int rc) { if (rc != 0) throw std::runtime_error(lnb_last_error()); }
+// the library behind this header must be the one it was written against (LNB_ABI_VERSION), and a host that keeps several generations in flight wants to
+// know how many hardware queues its streams really get (inference.go:163-174: one goroutine + one InferenceContext per generation)
+inline void CheckABI() { if (lnb_abi_version() != LNB_ABI_VERSION) throw std::runtime_error("liblnb_hip.so reports another ABI version than include/lnb.h"); }
+inline lnb_runtime_info_t RuntimeInfo(int device = 0, bool probeQueues = false) { lnb_runtime_info_t ri; check(lnb_runtime_info(device, probeQueues ? 1 : 0, &ri)); return ri; }
 
 // model.LoadModel (src/model/loader.go:18-70): <dir>/consolidated.00.pth (mmap'ed, tensors are views into it for the lifetime
 // of the returned Model, like the reference's never-unmapped mmap, src/torch/types.go:51-55) + <dir>/params.json.

@@ -6,6 +6,7 @@
 #include <cstdlib>
 int main(int argc, char** argv) {
     // LNB_MODEL_DIR=<dir with consolidated.00.pth + params.json>: the reference's LoadModel path instead of synthetic weights
+    try { lnb::CheckABI(); } catch (const std::exception& e) { printf("error: %s\n", e.what()); return 4; }
     std::shared_ptr<lnb::Model> loaded;
     lnb::Model synthetic;
     if (const char* dir = getenv("LNB_MODEL_DIR")) {
