@@ -30,6 +30,20 @@ case "$mode" in
     mkdir -p gpurun_out/r06_profiles && cp profiles/r06_rocprofv3_kernel_stats.csv profiles/r06_summary.md profiles/r06_traffic.json gpurun_out/r06_profiles/ 2>/dev/null
     find $O -name "*.csv" | head; du -sh gpurun_out
     ;;
+  records)  # the round's other records: the N-GPU code path on one GPU, the matrix-core counters of the exact prefill, batches without the second copy
+    LNB_FORCE_PIPELINE=1 LNB_FORCE_PREFLIGHT=1 timeout 900 python bench.py --gpus 1 --steps 64 --warmup 8 --cpu-steps 0 > gpurun_out/r06_bench_pipeline_one_gpu.json 2> gpurun_out/r06_bench_pipeline_one_gpu.err; echo "pipe rc=$?"; tail -3 gpurun_out/r06_bench_pipeline_one_gpu.err
+    O=$PWD/gpurun_out/prof_r06_mfma; rm -rf $O; mkdir -p $O
+    MD=gpurun_out/r06_prefill_mfma_counters.md; : > $MD
+    for S in 128 4096; do
+      ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_$S -o t_$S -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py --modes exact --sizes $S --layers 8 --reps 3 > $O/trace_$S.out 2> $O/trace_$S.err; echo "trace $S rc=$?" )
+      ( cd /tmp && timeout 240 rocprofv3 --kernel-trace --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CU_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 GRBM_GUI_ACTIVE --output-format csv -d $O/pmc_$S -o p_$S -- python $GRAFT_REPO_ROOT/tools/prefill_bench.py --modes exact --sizes $S --layers 8 --reps 3 > $O/pmc_$S.out 2> $O/pmc_$S.err; echo "pmc $S rc=$?" )
+      python tools/mfma_counters.py $O/pmc_$S $O/trace_$S "exact prefill, $S rows, gemm_stream_kernel on the resident weight layouts (no second copy), 8-block cut of the 8B shape" >> $MD
+      tail -1 $O/trace_$S.out
+    done
+    cat $MD | head -40
+    timeout 600 python tools/batch_bench.py --n 128 --steps 32 --profile-iters 8 2>&1 | tail -3 | tee gpurun_out/r06_batch_bench.log
+    du -sh gpurun_out
+    ;;
   suite)
     ( timeout 2400 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r06_gpu_suite.log
     ;;
