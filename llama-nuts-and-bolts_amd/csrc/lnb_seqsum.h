@@ -152,22 +152,33 @@ SEQ_HD SeqItem seq_item_of_node(const SeqNode& n) {             // a node of the
     SeqItem it; it.x = 0u; it.c0 = n.a & 0xFFFFFFu; it.d = (int32_t)(n.b & 0xFFFFFFu) - (int32_t)it.c0; it.e = n.a >> 24;
     return it;
 }
+// Round 6: a SINGLE-TERM item (x = the term, c0 = d = 0, e = SEQ_ANY_BINADE) is one exact f32 add with no assumption about the binade at all -- what a leaf
+// that sits too close to a binade edge for any guess is replayed as, INSIDE the branch-free walk instead of condemning the row to the record walk.
+#define SEQ_ANY_BINADE 0u
 SEQ_HD uint32_t seq_item_apply(uint32_t s, const SeqItem& it, uint32_t& bad) {
     const uint32_t u = seq_f2u(seq_u2f(s) + seq_u2f(it.x));
     const uint32_t t = u + it.c0 + (uint32_t)((int32_t)(u & 1u) * it.d);
-    bad |= ((t ^ u) >> 23) | (it.e ^ (u >> 23));
+    bad |= ((t ^ u) >> 23) | (it.e != SEQ_ANY_BINADE ? (it.e ^ (u >> 23)) : 0u);
     return t;
 }
+SEQ_HD SeqItem seq_item_of_term(float x) { SeqItem it; it.x = seq_f2u(x); it.c0 = 0u; it.d = 0; it.e = SEQ_ANY_BINADE; return it; }
 // binade guess with a margin just above the error of the approximate prefix sums (f32 tree sums of a few thousand non-negative terms:
 // ~1e-6 relative): a wrong guess costs a fallback, never a wrong result
+// Round 6: the margin is a parameter.  2e-6 was both too wide (1-2 % of gaussian rows had a crossing "too close to call") and too narrow (1-3 % had a leaf whose
+// TRUE f32 running sum -- which wanders ~sqrt(n) 6e-8 from the exact prefix -- crossed on the other side of the guess and failed the walk's check); either way the
+// whole row fell back to the record walk: 2.7 % of rows at K = 4096, 6.8 % at 8192.  With single-term items a leaf near an edge costs LEAF items instead of the
+// row, so the margin can be generous: SEQ_MARGIN = 8e-6.
+#ifndef SEQ_MARGIN
+#define SEQ_MARGIN 8e-6f
+#endif
 SEQ_HD int32_t seq_guess_tight(float lo, float hi) {
-    const uint32_t ul = seq_f2u(lo * 0.999998f), uh = seq_f2u(hi * 1.000002f);
+    const uint32_t ul = seq_f2u(lo * (1.0f - SEQ_MARGIN)), uh = seq_f2u(hi * (1.0f + SEQ_MARGIN));
     const int32_t el = (int32_t)((ul >> 23) & 0xFF), eh = (int32_t)((uh >> 23) & 0xFF);
     if (el != eh || el == 0 || el == 0xFF) return 0;
     return el;
 }
 // a leaf whose approximate prefix sums say "enters the next binade here": split at the term that takes the approximate running sum across
-// the edge, if that is unambiguous (no approximate sum of the leaf -- the one in front of it included -- within 2e-6 (relative) of the edge:
+// the edge, if that is unambiguous (no approximate sum of the leaf -- the one in front of it included -- within SEQ_MARGIN (relative) of the edge:
 // several times the error of the approximate prefix).  One pass, no data-dependent branch: the device runs it for a whole wave at once (terms in
 // front of the crossing feed the sums of binade el, terms behind it those of el + 1; + 0 leaves a sum unchanged).  p: 16-byte aligned,
 // n a multiple of 4.  A wrong split costs a fallback, never a wrong result -- the walk verifies every item.
@@ -201,7 +212,7 @@ SEQ_HD SeqSplit seq_split_leaf(const float* p, int n, float lo, float hi) {
         }
     }
     const SeqNode na = seq_sim_node(el, a0, a1), nb = seq_sim_node(eh, b0, b1);
-    r.ok = (cand && was && clear > edge * 2e-6f && (na.a >> 24) != 0u && (nb.a >> 24) != 0u) ? 1 : 0;
+    r.ok = (cand && was && clear > edge * SEQ_MARGIN && (na.a >> 24) != 0u && (nb.a >> 24) != 0u) ? 1 : 0;
     r.a = seq_item_of_node(na); r.b = seq_item_of_node(nb); r.b.x = seq_f2u(xs);
     return r;
 }

@@ -183,7 +183,13 @@ extern "C" float seqsum_items(const float* pin, int K, int NH, int head_terms, i
             if (!((mask >> l) & 1) || b < headleaf || b >= nleaf || zero[l]) continue;
             if (n[l].a >> 24) list.push_back(seq_item_of_node(n[l]));            // the end of a run: its composed map
             else if (sp[l].ok) { list.push_back(sp[l].a); list.push_back(sp[l].b); }
-            else { row_bad = true; dbg_reason |= 2; }                             // a leaf nothing covers: old walk
+            else {                                                                // round 6: a leaf no guess covers (too close to an edge): its terms one by one, as single-term items
+                const float* q = p + (size_t)b * LEAF;
+                bool finite = true;
+                for (int i = 0; i < LEAF; i++) if (!(q[i] <= 3.4028234e38f)) finite = false;      // inf / NaN squares: the record walk's business
+                if (!finite) { row_bad = true; dbg_reason |= 2; }
+                else for (int i = 0; i < LEAF; i++) list.push_back(seq_item_of_term(q[i]));
+            }
         }
     }
     if (n_items) *n_items = (int)list.size();
