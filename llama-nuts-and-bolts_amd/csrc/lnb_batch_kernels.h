@@ -711,3 +711,116 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
     }
     asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
 }
+
+// ------------------------------------------------------------------------------------------------
+// gemm_blgp_kernel<EPI, NCH> (round 6): the prefill / batch product for FEW batch rows straight from the CHAIN layouts, no transpose and no second copy.
+//
+// At one or two batch tiles per wave gemm_stream_kernel's chain-layout source (SRC 2) turns every load of eight consecutive k into 16x16x4 A operands with
+// 12 row swaps + 8 half-selects per 8 matrix instructions (wq|wk|wv of a 128-token prompt: 91 us against 67 from the M16 copy; batches of up to 32 sequences want
+// the 15 GB copy for that reason).  v_mfma_f32_16x16x1_f32 computes FOUR 16x16 blocks with one k per instruction, and BLGP = 4 + r broadcasts the B operand of lane row r
+// to all four (tools/mfma_x1_probe.hip: bit-identical to the sequential chain, 32 cycles per instruction even as one dependent chain).  With the four blocks = four
+// (weight tile, chain) pairs -- lane (i, b) = row i of block b -- every lane consumes exactly what a chain-layout unit holds, eight consecutive k of ITS row, in order:
+// one shift / mask per element, nothing crosses lanes.  The B operand of steps k0 + 4m + r is lane (n, r)'s activation x[n][k0 + 4m + r]: one ds_read2_b32 per eight steps.
+//   NCH = 1: a wave owns 4 weight tiles x 16 batch rows;  NCH = 2 (gate|up): 2 tiles x (gate, up) -- block 2t = gate, 2t + 1 = up of tile t, so SiLU*up stays lane-local.
+// The four waves of a workgroup take four neighbouring tile groups and share the batch tile's activations (staged per 128-step chunk as f32 rows, pitch GS_PITCH:
+// gemm_stream_kernel's conflict-free map); weights through the hand-counted register ring (two chunks of 16 units in flight).  k ascends inside a unit, across the
+// units of a chunk and across chunks: the reference's chain (operations_lineartransform.go:46-65), the same bits as every other form (tests/test_gpu_round6.py).
+// NOT the default (launch_gemm_stream, lnb_kernels.hip: measured slower than the transpose -- one dependent chain per wave, a quarter as many waves); opt-in LNB_GEMM_BLGP=1|2.
+// grid (ceil(tile groups / 4), batch tiles), block 256, dynamic LDS 2 * 16 * GS_PITCH * 4.
+// ------------------------------------------------------------------------------------------------
+template <int EPI, int NCH>
+__global__ __launch_bounds__(256, 2) void gemm_blgp_kernel(GemmParams p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int L = 17, R = 2;                             // loads per chunk and lane: 16 weight units + 1 activation unit; chunks in flight
+    constexpr int TPG = 4 / NCH;                             // weight tiles per wave
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int i = lane & 15, q = lane >> 4;
+    const int n_tiles = (p.n_rows + 15) >> 4, n_tg = (n_tiles + TPG - 1) / TPG, nchunks = p.K >> 7;
+    const int tg_raw = (int)blockIdx.x * 4 + wave, tg = tg_raw < n_tg ? tg_raw : n_tg - 1;       // (a wave past the end re-walks the last group and stores nothing: it still stages and meets the barriers)
+    const int m0 = (int)blockIdx.y * 16;
+    // this lane's weight row: block q of the wave
+    const int my_tile = tg * TPG + (NCH == 1 ? q : (q >> 1)), chain = NCH == 1 ? 0 : (q & 1);
+    int n = my_tile * 16 + i; n = n < p.n_rows ? n : p.n_rows - 1;
+    const int rw = p.rw, b0 = (tg * TPG * 16) / rw, b = n / rw, r = n - b * rw;
+    const unsigned s8 = (unsigned)(NCH * rw * 16);           // bytes from one 8-wide k unit of a row block to the next
+    const unsigned voff = (unsigned)(b - b0) * (unsigned)(p.K >> 3) * s8 + (unsigned)chain * (unsigned)(rw * 16) + (unsigned)r * 16u;
+    const size_t wbase = (size_t)b0 * (size_t)(p.K >> 3) * s8;
+    float* Bs = (float*)smem;                                // [2][16][GS_PITCH]
+    constexpr size_t bs_stride = (size_t)16 * GS_PITCH;
+    const int srow = tid & 15, scol = tid >> 4;              // staging: row of the batch tile, 16-byte k-unit of the chunk
+    int xr = m0 + srow; xr = xr < p.S ? xr : p.S - 1;
+    const uint16_t* xrow = p.x + (size_t)xr * p.K + scol * 8;
+    u32x4 buf[R][L];
+    int ic = 0;
+    auto issue_next = [&](u32x4 (&dst)[L]) {
+        const char* cb = (const char*)p.w + uniform_off(wbase + (size_t)(16 * ic) * s8);
+        const size_t su = uniform_off((size_t)s8);
+#pragma unroll
+        for (int u = 0; u < 16; u++) ld_w_plain(dst[u], voff, cb + (size_t)u * su);
+        ld_plain(dst[16], xrow + (size_t)ic * 128);
+        if (ic + 1 < nchunks) ic++;                          // past the last chunk: stays put, re-reads
+    };
+#pragma unroll
+    for (int j = 0; j < R; j++) issue_next(buf[j]);
+    f32x16 acc;
+#pragma unroll
+    for (int z = 0; z < 16; z++) acc[z] = 0.f;
+    for (int t0 = 0; t0 < nchunks; t0 += R) {
+#pragma unroll
+        for (int j = 0; j < R; j++) {
+            if (t0 + j < nchunks) {
+                wait_slot<(R - 1) * L, L>(buf[j]);
+                float* bw = Bs + (size_t)((t0 + j) & 1) * bs_stride;
+                {   // widen the chunk's activations once per element
+                    const u32x4 v = buf[j][16];
+                    float* d = bw + (size_t)srow * GS_PITCH + scol * 8;
+                    *(float2*)(d) = make_float2(bf_lo(v[0]), bf_hi(v[0])); *(float2*)(d + 2) = make_float2(bf_lo(v[1]), bf_hi(v[1]));
+                    *(float2*)(d + 4) = make_float2(bf_lo(v[2]), bf_hi(v[2])); *(float2*)(d + 6) = make_float2(bf_lo(v[3]), bf_hi(v[3]));
+                }
+                __syncthreads();                             // the chunk's activations are in the LDS (the other buffer may still be read by slower waves)
+                const float* bl = bw + (size_t)i * GS_PITCH + q;     // this lane's B operands: x[row i][k0 + 4 m + q]
+#pragma unroll
+                for (int u = 0; u < 16; u++) {
+                    const float b0v = bl[u * 8], b1v = bl[u * 8 + 4];
+                    const u32x4 w = buf[j][u];
+                    float a[8];
+#pragma unroll
+                    for (int e = 0; e < 8; e++) a[e] = (e & 1) ? bf_hi(w[e >> 1]) : bf_lo(w[e >> 1]);
+                    // k ascending: e = 0..7 (operations_lineartransform.go:46-65); step e takes its B operand from lane row e & 3
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[0], b0v, acc, 0, 0, 4);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[1], b0v, acc, 0, 0, 5);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[2], b0v, acc, 0, 0, 6);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[3], b0v, acc, 0, 0, 7);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[4], b1v, acc, 0, 0, 4);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[5], b1v, acc, 0, 0, 5);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[6], b1v, acc, 0, 0, 6);
+                    acc = __builtin_amdgcn_mfma_f32_16x16x1f32(a[7], b1v, acc, 0, 0, 7);
+                }
+                asm volatile("" : "+v"(acc));                // every weight register of the slot has been read: refill
+                issue_next(buf[j]);
+            }
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
+    // D layout: register 4 * blk + rr of lane (n, q) = block blk, row 4 q + rr of its tile, batch column n
+    if (tg_raw < n_tg) {
+        const int m = m0 + i;
+        if constexpr (NCH == 1) {
+#pragma unroll
+            for (int blk = 0; blk < 4; blk++) {
+                const int tile = tg * 4 + blk;
+                const f32x4 a0 = {acc[4 * blk], acc[4 * blk + 1], acc[4 * blk + 2], acc[4 * blk + 3]};
+                if (tile < n_tiles) gemm_epilogue4<EPI>(p, a0, a0, m, tile * 16 + q * 4);
+            }
+        } else {
+#pragma unroll
+            for (int t = 0; t < 2; t++) {
+                const int tile = tg * 2 + t;
+                const f32x4 g = {acc[8 * t], acc[8 * t + 1], acc[8 * t + 2], acc[8 * t + 3]}, uu = {acc[8 * t + 4], acc[8 * t + 5], acc[8 * t + 6], acc[8 * t + 7]};
+                if (tile < n_tiles) gemm_epilogue4<EPI>(p, g, uu, m, tile * 16 + q * 4);
+            }
+        }
+    }
+}

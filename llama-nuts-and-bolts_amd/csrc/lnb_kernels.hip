@@ -4009,6 +4009,22 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
     static const int force_ct = getenv("LNB_GS_NTW_CHAIN") ? atoi(getenv("LNB_GS_NTW_CHAIN")) : 0;    // (experiments: the chain layouts only)
     if (src == 2 && (force_ct == 1 || force_ct == 2 || force_ct == 4)) ntw = force_ct;
     GemmParams q = *p;
+    // round 6: few batch rows on the chain layouts -- the one-k matrix instruction with FOUR WEIGHT blocks and the B operand broadcast by BLGP (gemm_blgp_kernel):
+    // no transpose, no second copy.  Bit-exact and NOT the default: measured slower than the row-swap transpose it was meant to replace (profiles/r06_blgp.log: wq|wk|wv
+    // of a 128-token prompt 125-130 us against 91, gate|up 346 against 301; whole Forward 16 / 128 rows 13.2 / 20.7 ms against 9.2 / 19.4) -- a wave carries FOUR weight
+    // tiles as ONE dependent chain of 4 K one-k instructions with an unpack op in front of each (67 cycles per instruction instead of 32), and a quarter as many waves
+    // to spread over the SIMDs (96 for wq|wk|wv at 16 rows).  LNB_GEMM_BLGP=1: where gemm_stream_kernel would run one or two batch tiles per wave; =2: every chain-layout product
+    {
+        const char* eb = getenv("LNB_GEMM_BLGP");            // (read per launch: a test switches it inside one process)
+        const int blgp = (eb && *eb) ? atoi(eb) : 0;
+        if (src == 2 && blgp && (ntw <= 2 || blgp == 2) && p->rw % 8 == 0) {
+            const int tpg = 4 / NCH, n_tg = (n_tiles + tpg - 1) / tpg;
+            const dim3 g((unsigned)((n_tg + 3) / 4), (unsigned)ct);
+            const size_t l = (size_t)2 * 16 * GS_PITCH * 4;
+            hipLaunchKernelGGL((gemm_blgp_kernel<EPI, NCH>), g, dim3(256), l, st, q);
+            return hipGetLastError();
+        }
+    }
     const int rows_wg = 16 * ntw;
     unsigned gx = (unsigned)((n_tiles + 3) / 4); if (gx > (unsigned)num_cus) gx = (unsigned)num_cus;
     const dim3 grid(gx, (unsigned)((p->S + rows_wg - 1) / rows_wg));

@@ -220,3 +220,27 @@ def test_two_query_tiles_per_wave_prefill_attention_ragged_rows(lnb, monkeypatch
                 tok = to
         gc.close()
     oc.close(); gm.close(); om.close()
+
+
+@pytest.mark.parametrize("rows", [16, 40, 130])
+def test_blgp_matrix_core_feed_from_the_chain_layouts_is_bit_exact(lnb, monkeypatch, rows):
+    """gemm_blgp_kernel (round 6, opt-in LNB_GEMM_BLGP=2): v_mfma_f32_16x16x1_f32 with four WEIGHT blocks per wave and the B operand broadcast by BLGP -- every
+    chain-layout product (wq|wk|wv + RoPE + KV append, gate|up + SiLU, output) of a multi-row Forward, ragged row and tile counts, against the oracle's logits bits
+    (operations_lineartransform.go:46-65: the k-ordered chain), then decode steps on the cache it wrote."""
+    cfg = dict(orc.TINY, n_layers=2, vocab_size=1000, max_seq_len=512)       # vocab 1000: a partial last tile group of the output product
+    om = orc.Model(**cfg).fill_synthetic(11).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(11).finalize()
+    toks = orc.synth_tokens(3, rows, cfg["vocab_size"])
+    oc = orc.Context(om, rows + 8)
+    lo, ao = oc.forward(toks, 0)
+    monkeypatch.setenv("LNB_GEMM_BLGP", "2")
+    gc = lnb.InferenceContext(gm, rows + 8)
+    lg, ag = gc.Forward(toks, 0)
+    assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag
+    tok = ag
+    for i in range(3):
+        lo1, to = oc.forward([tok], rows + i)
+        lg1, tg = gc.Forward(np.array([tok], dtype=np.int32), rows + i)
+        assert (lo1.view(np.uint32) == lg1.view(np.uint32)).all() and to == tg
+        tok = to
+    gc.close(); oc.close(); gm.close(); om.close()
