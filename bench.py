@@ -672,7 +672,7 @@ def main():
             sys.exit(3)
     # fused-RMSNorm rows of the decode steps so far (2 per block + 1 per token) whose sum left the branch-free item walk (same bits, slower walk)
     n_norm_rows = (W + K * len(reps)) * (2 * cfg["n_layers"] + 1)
-    norm_walk = {"rows": n_norm_rows, "fallback_rows": ctx.norm_fallbacks(), "note": "rows summed by the record walk instead of the item list (a binade crossing too close to call)"} if args.mode == "exact" else None
+    norm_walk = {"rows": n_norm_rows, "fallback_rows": ctx.norm_fallbacks(), "note": "rows summed by the record walk instead of the branch-free item list (more than 64 items or non-finite terms; round 6: a leaf too close to a binade edge is replayed as single-term items inside the list)"} if args.mode == "exact" else None
     order = sorted(range(len(reps)), key=lambda i: reps[i][0])
     med = order[len(order) // 2]
     t0, t1, ev_ms, out = 0.0, reps[med][0], reps[med][1], np.array(reps[med][2], dtype=np.int32)
