@@ -244,3 +244,32 @@ def test_blgp_matrix_core_feed_from_the_chain_layouts_is_bit_exact(lnb, monkeypa
         assert (lo1.view(np.uint32) == lg1.view(np.uint32)).all() and to == tg
         tok = to
     gc.close(); oc.close(); gm.close(); om.close()
+
+
+@pytest.mark.parametrize("quad", ["1", "2"])
+def test_down_projection_on_one_quad_chain_wave_is_bit_exact(lnb, monkeypatch, quad):
+    """rung (a') of the FFN ladder (profiles/r06_ffn_stream.md): w2 re-tiled [N/16][K/8][16][8] and run by gemv_quad_kernel<16, KS, 4, R> -- its 16 rows per
+    workgroup on ONE quad_perm chain wave (LNB_RW_W2=16 LNB_W2_QUAD=1|2: 128- / 256-step stages).  A measurement form, but a reachable one: logits bits, tokens
+    and the captured greedy loop against the oracle (operations_lineartransform.go:46-65 for llamatransformer.go:619)."""
+    cfg = dict(orc.TINY, dim=512, n_heads=4, n_kv_heads=2, n_layers=2)        # ffn_hidden 1536 = 12 x 128 = 6 x 256 steps
+    om = orc.Model(**cfg).fill_synthetic(5).finalize()
+    monkeypatch.setenv("LNB_RW_W2", "16"); monkeypatch.setenv("LNB_W2_QUAD", quad)
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(5).finalize()
+    assert gm.ffn_hidden % 256 == 0
+    toks = orc.synth_tokens(9, 9, cfg["vocab_size"])
+    oc, gc = orc.Context(om, 40), lnb.InferenceContext(gm, 40)
+    lo, ao = oc.forward(toks, 0)
+    lg, ag = gc.Forward(toks, 0)
+    assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag
+    tok = ag
+    for i in range(4):
+        lo1, to = oc.forward([tok], 9 + i)
+        lg1, tg = gc.Forward(np.array([tok], dtype=np.int32), 9 + i)
+        assert (lo1.view(np.uint32) == lg1.view(np.uint32)).all() and to == tg
+        tok = to
+    got, _ = gc.decode_greedy(tok, 13, 8)
+    ref, _ = orc.Context(om, 40).generate(toks, 13)
+    assert [int(t) for t in got] == [int(t) for t in ref[5:13]]
+    ms = gc.profile_ffn_pair(20, 4, 5, 0)                    # (the pair-timing entry point itself: both kernels on two streams, w2 5 us behind)
+    assert ms > 0
+    gc.close(); oc.close(); gm.close(); om.close()
