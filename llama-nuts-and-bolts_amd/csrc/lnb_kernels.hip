@@ -3614,7 +3614,8 @@ static hipError_t launch_gemv_rw(const GemvParams* p, int rw, hipStream_t st) {
     // rung (a') of the FFN ladder (profiles/r06_ffn_stream.md; LNB_RW_W2=16 LNB_W2_QUAD=1, measurement only): the down projection's 16 rows per CU on ONE
     // quad_perm chain wave + four helpers -- the only w2 form that would leave a co-resident gate|up producer three SIMDs
     if constexpr (NCH == 1 && !NORM && (EPI == EPI_RESID || EPI == EPI_STORE)) {
-        static const int quad16 = [] { const char* e = getenv("LNB_W2_QUAD"); return e && *e ? atoi(e) : 0; }();
+        const char* eq = getenv("LNB_W2_QUAD");              // (read per launch: a test switches it inside one process)
+        const int quad16 = (eq && *eq) ? atoi(eq) : 0;
         if (rw == 16 && quad16 && (!p || p->K % 128 == 0)) return quad16 == 2 ? launch_quad_t<16, 256, 4, 7, EPI, false>(p, st) : launch_quad_t<16, 128, 4, 14, EPI, false>(p, st);
     }
     if (rw == 16) return launch_chain_t<16, NCH, 8192, 2, 7, EPI, NORM>(p, st);
