@@ -2833,6 +2833,22 @@ template <int HD> __global__ __launch_bounds__(ALS_NT) void attn_long_scores_ker
     const int j = j0 + tid;
     uint4 k[NK];
     attn_load_k<NK>(k, kbase, p.seq_len, j < T ? j : T - 1);
+    // round 6 (AttnParams.touch): the query heads of a GQA group touch the V rows of their block for the PV launch that follows -- these workgroups sit on the
+    // XCD whose L2 the PV workgroups of the group will read (xcd_head_block), so the lines land where they are needed (a touch from another XCD lands in the wrong L2, and the
+    // memory-side cache is barely faster than HBM: profiles/r06_kv_touch_ab.log).  Issued BEHIND the K rows.
+    // configs[2] step: attention 25.5 -> 23.7 us per layer (profiles/r06_attn_touch_ab.log)
+    // One plain load per thread, straight-line (a `volatile` access compiles to a system-scope load with a full vmcnt(0) wait behind it, a conditional one makes the
+    // destination a phi the compiler may copy in flight): the G heads of the group share the block's 256 * HD / 64 lines, the surplus heads repeat the first ones' (L2 hits);
+    // the destination register is held until the end of the kernel by the empty asm below, the data is never looked at.
+    unsigned vt;
+    {
+        constexpr int LPR = HD / 64 > 0 ? HD / 64 : 1;       // 128-byte lines per (row, kv head)
+        const int l = ((h % (p.H / p.KVH)) % LPR) * ALS_NT + tid;
+        int jl = j0 + l / LPR; jl = jl < T ? jl : T - 1;
+        const char* va = (const char*)p.cache_v + ((size_t)jl * p.KVH + kvh) * HD * 2 + (l % LPR) * 128;
+        va = p.touch ? va : (const char*)kbase;              // (off: a line this workgroup reads anyway)
+        asm volatile("global_load_dword %0, %1, off ; RING_LOAD (never retired: tools/isa_audit.py flags any later use of the register)" : "=v"(vt) : "v"(va));
+    }
     if (tid < HD) qf[tid] = bf_wide(q16);
     __syncthreads();
     double ev = 0.0;
@@ -2842,6 +2858,7 @@ template <int HD> __global__ __launch_bounds__(ALS_NT) void attn_long_scores_ker
     if ((tid & 63) == 0) wsum[tid >> 6] = ev;
     __syncthreads();
     if (tid == 0) p.z_part[(size_t)h * ((p.seq_len + ALS_NT - 1) / ALS_NT) + blk] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    asm volatile("" :: "v"(vt));                              // the touch's destination stays allocated up to here
 }
 
 constexpr int ALP_DS = 16;                                   // output dims per workgroup
@@ -3775,12 +3792,14 @@ static hipError_t launch_attn_long(const AttnParams* p, hipStream_t st) {
     if (lds > 160 * 1024 || p->hd % ALP_DS || !p->e_buf || !p->z_part) return hipErrorInvalidValue;
     const dim3 gs(p->H, (p->seq_len + ALS_NT - 1) / ALS_NT), gp(p->H, p->hd / ALP_DS);
     const bool lazy = [] { const char* e = getenv("LNB_ATTN_LAZY"); return !(e && *e && atoi(e) == 0); }();      // (read per launch: a test switches it inside one process)
+    AttnParams ps = *p;
+    { const char* e = getenv("LNB_ATTN_TOUCH"); ps.touch = (e && *e) ? (atoi(e) != 0) : 1; }      // (A/B switch; default on)
     switch (p->hd) {
     // PV: the lazily certified form (attn_long_pv2_kernel, round 6) unless LNB_ATTN_LAZY=0
-#define LNB_PV(HD_) do { if (lazy) hipLaunchKernelGGL(attn_long_pv2_kernel<HD_>, gp, dim3(ALP_NT), lds, st, *p); else hipLaunchKernelGGL(attn_long_pv_kernel<HD_>, gp, dim3(ALP_NT), lds, st, *p); } while (0)
-    case 128: hipLaunchKernelGGL(attn_long_scores_kernel<128>, gs, dim3(ALS_NT), 0, st, *p); LNB_PV(128); break;
-    case 64: hipLaunchKernelGGL(attn_long_scores_kernel<64>, gs, dim3(ALS_NT), 0, st, *p); LNB_PV(64); break;
-    case 32: hipLaunchKernelGGL(attn_long_scores_kernel<32>, gs, dim3(ALS_NT), 0, st, *p); LNB_PV(32); break;
+#define LNB_PV(HD_) do { if (lazy) hipLaunchKernelGGL(attn_long_pv2_kernel<HD_>, gp, dim3(ALP_NT), lds, st, ps); else hipLaunchKernelGGL(attn_long_pv_kernel<HD_>, gp, dim3(ALP_NT), lds, st, ps); } while (0)
+    case 128: hipLaunchKernelGGL(attn_long_scores_kernel<128>, gs, dim3(ALS_NT), 0, st, ps); LNB_PV(128); break;
+    case 64: hipLaunchKernelGGL(attn_long_scores_kernel<64>, gs, dim3(ALS_NT), 0, st, ps); LNB_PV(64); break;
+    case 32: hipLaunchKernelGGL(attn_long_scores_kernel<32>, gs, dim3(ALS_NT), 0, st, ps); LNB_PV(32); break;
 #undef LNB_PV
     default: return hipErrorInvalidValue;
     }

@@ -133,8 +133,9 @@ def test_one_launch_long_context_attention_every_form_against_the_oracle(lnb, na
             lo, tok_n = oc.forward([tok], P + i)
             ref.append((lo, tok_n)); tok = tok_n
         # (threshold 0 = the long-context forms at every context; flags: 8 one launch, 9 + serial Z, 2 two launches, 4 time-out path, 5 both)
-        for flags in (8, 9, 2, 3, 4, 5, 102, 103):           # (1xx: the two launches with the round-2 PV kernel, LNB_ATTN_LAZY=0, instead of the lazily certified one)
-            os.environ["LNB_ATTN_LAZY"] = "0" if flags >= 100 else "1"
+        for flags in (8, 9, 2, 3, 4, 5, 102, 103, 202):      # (1xx: the two launches with the round-2 PV kernel, LNB_ATTN_LAZY=0, instead of the lazily certified one;
+            os.environ["LNB_ATTN_LAZY"] = "0" if flags // 100 == 1 else "1"      #  2xx: the scores launch NOT touching the V rows for the PV launch, LNB_ATTN_TOUCH=0 -- the default does)
+            os.environ["LNB_ATTN_TOUCH"] = "0" if flags // 100 == 2 else "1"
             flags %= 100
             gc = lnb.InferenceContext(gm, P + 8).set_attention(0, flags)
             _, t0 = gc.Forward(toks, 0, want_logits=False)
@@ -149,7 +150,7 @@ def test_one_launch_long_context_attention_every_form_against_the_oracle(lnb, na
             for layer in range(cfg["n_layers"]):
                 assert (oc.cache(layer, 0)[:P + 4] == gc.CacheK(layer)[:P + 4]).all() and (oc.cache(layer, 1)[:P + 4] == gc.CacheV(layer)[:P + 4]).all()
             gc.close()
-        os.environ.pop("LNB_ATTN_LAZY", None)
+        os.environ.pop("LNB_ATTN_LAZY", None); os.environ.pop("LNB_ATTN_TOUCH", None)
         for flags in (8, 4, 2):                              # graph replays: the arrival counters carry over from launch to launch without a reset
             gc = lnb.InferenceContext(gm, P + 8).set_attention(0, flags)
             _, t0 = gc.Forward(toks, 0, want_logits=False)
