@@ -162,6 +162,7 @@ struct lnb_ctx {
     int batch_users = 0;                   // live lnb_batch handles this context is a member of: their device tables and captured graphs hold its raw pointers
     // long-context decode attention (attn_long_*_kernel): used for one-token calls whose context exceeds attn_long_T
     double* e_buf = nullptr; double* z_part = nullptr; int* zseq_count = nullptr;
+    uint64_t* score_idx = nullptr; size_t score_idx_bytes = 0; int sidx_jt = 0;      // attn_mfma3_kernel's scratch (the exp-table indices of pass 1), grown on demand by check_call; sidx_jt = 0: this call runs attn_mfma_kernel
     unsigned* attn_cnt = nullptr;          // attn_one_kernel: [n_heads] arrival counters of its in-launch exchange + [n_heads] = polls that ran out
     int attn_long_T = 0; int force_zseq = 0;   // force_zseq: bit 0 = walk the serial softmax denominator, bit 1 = keep the two-launch long-context form, bit 2 = one launch with every poll timing out (tests), bit 3 = one launch
     int attn_short_cap = 0;                // longest context the one-workgroup-per-head kernel can stage in the LDS
@@ -644,7 +645,7 @@ extern "C" int lnb_ctx_destroy(lnb_ctx* c) {
     if (c->ev_in) hipEventDestroy(c->ev_in);
     if (c->ev_sent) hipEventDestroy(c->ev_sent);
     if (c->ev_h2d) hipEventDestroy(c->ev_h2d);
-    hipFree(c->e_buf); hipFree(c->z_part); hipFree(c->zseq_count); hipFree(c->attn_cnt);
+    hipFree(c->e_buf); hipFree(c->z_part); hipFree(c->zseq_count); hipFree(c->attn_cnt); if (c->score_idx) hipFree(c->score_idx);
     for (auto p : c->ck) if (p) hipFree(p);
     for (auto p : c->cv) if (p) hipFree(p);
     hipFree(c->st); hipFree(c->dtok); hipFree(c->dnext); hipFree(c->derr); hipFree(c->dout);
@@ -814,6 +815,7 @@ static int enqueue_layer_kernel(lnb_ctx* c, int l, int S, int which, hipStream_t
         ap.divisor = bf_wide_h(bf_trunc_h((float)std::sqrt((double)m->head_dim)));           // llamatransformer.go:464
         ap.mfma = use_mfma(S) ? 1 : 0; ap.exp_tab = m->exp_tab;
         ap.longctx = 0; ap.force_zseq = c->force_zseq & 1; ap.e_buf = c->e_buf; ap.z_part = c->z_part; ap.zseq_count = c->zseq_count; ap.cnt = c->attn_cnt;
+        if (ap.mfma && c->sidx_jt > 0 && c->call_T > 0 && c->sidx_jt * 16 >= c->call_T) { ap.score_idx = c->score_idx; ap.sidx_jt = c->sidx_jt; }     // (round 6: scores once, attn_mfma3_kernel)
         if (S == 1 && c->attn_long) {
             // ONE launch (attn_one_kernel, round 6): built, bit-exact in every form (tests/test_gpu_round6.py), and NOT the default -- measured on MI355X
             // (profiles/r06_att_timing.log, 8B head geometry): T = 4101: 26.3 us against 23.2 for the two launches; 1024: 14.1 / 11.5; 272: 8.2 against 7.7
@@ -891,6 +893,23 @@ static int check_call(lnb_ctx* c, int seq, int start_pos) {
     // take) go through the row-per-workgroup kernel, whose LDS arrays are sized for attn_short_cap positions
     const bool mfma_attn = use_mfma(seq) && (c->m->head_dim == 64 || c->m->head_dim == 128);
     c->call_T = T;
+    // round 6: the matrix-core attention of an exact prefill keeps the table indices of its first pass (attn_mfma3_kernel): 512 bytes per (head, 16 query rows, 16
+    // positions), one buffer per context, reused by every layer.  Grown here, on the host side of the call (never inside a capture); above LNB_ATTN_SIDX_MB
+    // (default 4096; 0 = never) the call runs attn_mfma_kernel, which computes the scores twice instead.
+    c->sidx_jt = 0;
+    if (mfma_attn && c->mode != LNB_MODE_FAST) {
+        const int cap_mb = env_int("LNB_ATTN_SIDX_MB", 4096);                 // (read per call: a test switches it inside one process)
+        const size_t jt = (size_t)(T + 15) / 16, need = (size_t)c->m->a.n_heads * (size_t)((seq + 15) / 16) * jt * 512;
+        if (cap_mb > 0 && need <= ((size_t)cap_mb << 20)) {
+            if (need > c->score_idx_bytes) {
+                HIPCHK(hipStreamSynchronize(c->stream));
+                if (c->score_idx) { hipFree(c->score_idx); c->score_idx = nullptr; c->score_idx_bytes = 0; }
+                if (hipMalloc((void**)&c->score_idx, need) == hipSuccess) c->score_idx_bytes = need;
+                else { (void)hipGetLastError(); c->score_idx = nullptr; }             // (no room: the two-pass kernel needs none)
+            }
+            if (c->score_idx) c->sidx_jt = (int)jt;
+        }
+    }
     if (seq > 1 && !mfma_attn && T > c->attn_short_cap)
         return fail("a call of %d rows (2..15, or any multi-row call at head_dim 32) at context %d: the row-per-workgroup attention kernel stages "
                     "at most %d positions in the LDS; use one-token calls or 16 or more rows there", seq, T, c->attn_short_cap);

@@ -149,6 +149,8 @@ struct AttnParams {
     // batched decode (attn_exact_kernel, S = 1 per sequence): query row i belongs to sequence i of the batch -- its own position, caches and
     // cache length come from the tables; the output goes to out_xt in the B-operand layout of the wo product (lnb_batch_kernels.h)
     const struct BatchTab* btab; const struct BatchKV* bkv; uint16_t* out_xt;
+    uint64_t* score_idx;         // round 6, prefill (attn_mfma3_kernel): [H][ceil(S/16)][sidx_jt][64 lanes] x 8 bytes -- the sixteen-bit exp-table indices of pass 1, read back by pass 2; nullptr: attn_mfma_kernel (scores twice)
+    int sidx_jt;                // position tiles per (head, query tile) strip of score_idx
     int touch;                  // round 6, long-context decode: 1 = the scores launch touches its layer's V rows for the PV launch that follows, from a workgroup on the XCD whose L2 the PV workgroups read
     int head_major;             // batched dense grid: 1 = head-major dispatch order inside an XCD (the round-3 order), 0 = sequence-major (the heads of a KV head back to back)
 };

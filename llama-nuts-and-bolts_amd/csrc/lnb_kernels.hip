@@ -2033,6 +2033,241 @@ template <int HD> __global__ __launch_bounds__(256, 2) void attn_mfma_kernel(Att
 }
 
 // ------------------------------------------------------------------------------------------------
+// attn_mfma3_kernel (round 6): attn_mfma_kernel with the scores computed ONCE and the exp-table look-ups issued a tile ahead.
+//
+// profiles/r06_prefill_stalls.md: of the 11.3 k cycles a wave of attn_mfma_kernel spends per (query tile, position tile) pair, 7.0 k are issue stalls on the matrix pipe
+// (a wave's program is chains of dependent matrix instructions, 32 for q.k -- and pass 2 runs that chain a second time only to get the same sixteen-bit values back) and
+// 2.0 k are spent parked on the four table look-ups of each pass.  Here
+//   pass 1  keeps what the table is indexed with: the truncated raw score (0xFF80 = -inf -> exp == 0 for masked / past-the-end elements), four 16-bit values per lane and
+//           tile = one 8-byte store into score_idx[head][query tile][position tile][lane] (512 B per tile, coalesced; written and read by the same lane);
+//   pass 2  reads them back: no K rows, no q.k chain -- a third of the matrix instructions gone;
+//   both    issue a tile's look-ups and let the NEXT tile's matrix work run before the values are used (pass 1: tile t's exponentials are added to Z after tile t + 1's
+//           chain; pass 2: tile t + 1's indices, look-ups and V rows go in flight before tile t's 4 x HD/16 matrix instructions).
+// Every vector-memory load of the loops is an asm load with a hand-counted wait (hipcc drains vmcnt(0) around loop-carried loads, NOTES 5.1); tools/isa_audit.py follows the
+// registers.  Counts assume what LLVM assumes for gfx9: loads and stores retire in issue order on the one counter.  Loads are unconditional (clamped tile / position), the
+// tile loops of pass 2 are unrolled by two for static buffer indices; a padded tile is loaded and not consumed.
+// Same arithmetic per element in the same order as attn_mfma_kernel: same bits (tests/test_gpu_round6.py runs both).
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+DEVINL void atm_ld16(u32x4& d, unsigned voff, const char* sb) { asm volatile("global_load_dwordx4 %0, %1, %2 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory"); }
+DEVINL void atm_ld8(u32x2& d, unsigned voff, const char* sb) { asm volatile("global_load_dwordx2 %0, %1, %2 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory"); }
+DEVINL const char* atm_uniform(const char* a) {             // a pointer that IS wave-uniform, told to the compiler (an "s" operand must not be handed a VGPR pair)
+    const size_t v = (size_t)a;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const char*)(((size_t)hi << 32) | lo);
+}
+template <int HD> __global__ __launch_bounds__(256, 2) void attn_mfma3_kernel(AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char sm[4 * ATM_WLDS];
+    constexpr int NK = HD / 8, DPL = HD / 16;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int h, by_; xcd_head_block_bmajor(h, by_);
+    by_ = (int)gridDim.y - 1 - by_;                          // the last query rows see the longest context: handed out first
+    const int itile = by_ * 4 + wave, i0 = itile * 16;
+    const int S = p.S, H = p.H, KVH = p.KVH;
+    if (i0 >= S) return;                                     // (waves are independent)
+    const int pos0 = p.st->pos, T = pos0 + S;
+    const int kvh = h / (H / KVH);
+    const int fi = lane & 15, fk = lane >> 4;
+    char* et = sm + wave * ATM_WLDS;
+    char* pt = et + 16 * ATM_ET;
+    double* zrow = (double*)(pt + 16 * ATM_PT);
+    const uint32_t sel = 0x0c0cu | ((uint32_t)(2 * fk) << 16) | ((uint32_t)(2 * fk + 1) << 24);   // element kk of a 4-element word pair
+    const int Tmax = (S > 1 && pos0 == 0) ? (i0 + 16 < T ? i0 + 16 : T) : T;
+    const int NJ = (Tmax + 15) >> 4;
+    const int irow = i0 + fi;                                // this lane's query row in the S^T tile (column i)
+    const char* const kb = atm_uniform((const char*)p.cache_k + (size_t)kvh * NK * p.seq_len * 16);            // K runs of the KV head: [d / 8][position][8]
+    const size_t krun = (size_t)p.seq_len * 16;
+    const char* const vb = atm_uniform((const char*)p.cache_v + (size_t)kvh * HD * 2);
+    const unsigned vrow2 = (unsigned)(KVH * HD * 2), vlane = (unsigned)(fi * DPL * 2);
+    const char* const xb = atm_uniform((const char*)(p.score_idx + ((size_t)(h * ((S + 15) >> 4) + itile) * p.sidx_jt) * 64));
+    const char* const tab = atm_uniform((const char*)p.exp_tab);
+
+    float qf[2 * NK];                                        // Q[irow][4g + kk], g = 0 .. HD/4-1
+    {
+        const uint4* q = (const uint4*)(p.q + ((size_t)(irow < S ? irow : S - 1) * H + h) * HD);
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+            const uint4 u = q[c];
+            qf[2 * c] = __uint_as_float(__builtin_amdgcn_perm(u.y, u.x, sel));
+            qf[2 * c + 1] = __uint_as_float(__builtin_amdgcn_perm(u.w, u.z, sel));
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);                       // (the compiler's own loads are consumed in front of the first asm load)
+#define ATM_LDS_TURN() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); \
+                            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); } while (0)
+#define ATM_RETIRE(r) asm volatile("; RING_RETIRE %0" : "+v"(r))
+    typedef double d2 __attribute__((ext_vector_type(2)));
+    auto as_double = [](const u32x2& v) { return __hiloint2double((int)v.y, (int)v.x); };
+
+    // ---- pass 1: raw scores -> table indices (kept) -> Z_i = sum_j exp(s_ij), f64, j ascending (lane i < 16 carries row i)
+    u32x4 kr[NK];
+    u32x2 er[4];
+    auto k_issue = [&](int jt) {
+        int j = jt * 16 + fi; j = j < T ? j : T - 1;
+        const unsigned voff = (unsigned)j * 16u;
+#pragma unroll
+        for (int c = 0; c < NK; c++) atm_ld16(kr[c], voff, kb + (size_t)c * krun);
+    };
+    double z = 0.0;
+    auto zadd = [&]() {                                      // the look-ups in er have landed: the tile goes through the LDS patch, lane i walks row i's sixteen values
+        d2* w = (d2*)(et + fi * ATM_ET + fk * 32);
+        w[0] = d2{as_double(er[0]), as_double(er[1])}; w[1] = d2{as_double(er[2]), as_double(er[3])};
+        ATM_LDS_TURN();
+        if (lane < 16) {
+            const d2* row = (const d2*)(et + lane * ATM_ET);
+            d2 v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) v[u] = row[u];
+#pragma unroll
+            for (int u = 0; u < 8; u++) { z += v[u].x; z += v[u].y; }
+        }
+        ATM_LDS_TURN();
+    };
+    k_issue(0);
+#pragma unroll
+    for (int r = 0; r < 4; r++) atm_ld8(er[r], 0xFF80u * 8u, tab);     // "tile -1": four zeros (exp(-inf)), so that the loop has one shape; z + 0.0 == z
+    u32x2 pk = {0u, 0u};                                     // the previous tile's packed indices: stored one tile late, right behind the next K rows -- by the time a
+                                                             // counted wait has the store in front of it, the store is a whole chain old (the counts below count LOADS only)
+    for (int jt = 0; jt < NJ; jt++) {                        // (wave-uniform trip count)   in flight here: K(jt) [NK], (store), look-ups(jt - 1) [4]
+        const int j0 = jt * 16;
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");     // K(jt) has landed; the four look-ups behind it may not have
+#pragma unroll
+        for (int c = 0; c < NK; c++) ATM_RETIRE(kr[c]);
+        float ko[2 * NK];
+#pragma unroll
+        for (int c = 0; c < NK; c++) {
+            ko[2 * c] = __uint_as_float(__builtin_amdgcn_perm(kr[c].y, kr[c].x, sel));
+            ko[2 * c + 1] = __uint_as_float(__builtin_amdgcn_perm(kr[c].w, kr[c].z, sel));
+        }
+#pragma unroll
+        for (int g = 0; g < 2 * NK; g++) asm volatile("" : "+v"(ko[g]));      // widened in front of the refill
+        __builtin_amdgcn_sched_barrier(0);
+        k_issue(jt + 1 < NJ ? jt + 1 : jt);                  // in flight: look-ups(jt - 1) [4], K(jt + 1) [NK], store
+        if (jt > 0) asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"((unsigned)(lane * 8 + (jt - 1) * 512)), "v"(pk), "s"(xb) : "memory");
+        __builtin_amdgcn_sched_barrier(0);
+        f32x4 sc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int g = 0; g < 2 * NK; g++) sc = __builtin_amdgcn_mfma_f32_16x16x4f32(ko[g], qf[g], sc, 0, 0, 0);      // MatMul q.k, d ascending (operations_matmul.go:37-55)
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt vmcnt(%0)" :: "n"(NK) : "memory");             // the PREVIOUS tile's exponentials: their latency ran under this tile's chain
+#pragma unroll
+        for (int r = 0; r < 4; r++) ATM_RETIRE(er[r]);
+        zadd();
+        unsigned ix[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const int j = j0 + 4 * fk + r;
+            const bool dead = j >= T || ((S > 1) && ((pos0 == 0 ? j : j % S) > irow));   // triu(-inf,1) broadcast by modulo (tensoriterators.go:47-55)
+            ix[r] = dead ? 0xFF80u : (unsigned)bf_trunc(sc[r]);                          // -inf: exp == 0 (the mask's -inf added to the score, :469-473)
+        }
+        asm volatile("" : "+v"(ix[0]), "+v"(ix[1]), "+v"(ix[2]), "+v"(ix[3]));
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 4; r++) atm_ld8(er[r], ix[r] * 8u, tab);           // / sqrt(hd) :464, exp impl:498: tabulated over the raw score (exp_table_kernel)
+        pk = u32x2{ix[0] | (ix[1] << 16), ix[2] | (ix[3] << 16)};
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    asm volatile("global_store_dwordx2 %0, %1, %2" :: "v"((unsigned)(lane * 8 + (NJ - 1) * 512)), "v"(pk), "s"(xb) : "memory");
+    asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
+#pragma unroll
+    for (int c = 0; c < NK; c++) ATM_RETIRE(kr[c]);
+#pragma unroll
+    for (int r = 0; r < 4; r++) ATM_RETIRE(er[r]);
+    zadd();                                                  // the last tile's
+    if (lane < 16) zrow[lane] = z;
+    ATM_LDS_TURN();
+    const double zi = zrow[fi];
+    __builtin_amdgcn_sched_barrier(0);
+
+    // ---- pass 2: p = trunc(f32(e / Z_i)), out = sum_j p_j v_j (j ascending); e from the kept indices
+    f32x4 o[DPL];
+#pragma unroll
+    for (int t = 0; t < DPL; t++) o[t] = f32x4{0.f, 0.f, 0.f, 0.f};
+    u32x2 ixn;                                               // the NEXT tile's packed indices
+    u32x2 e2[2][4];
+    using VT = std::conditional_t<DPL == 8, u32x4, u32x2>;   // HD / 16 dims of a V row per lane: 16 or 8 bytes
+    VT vv[2][4];
+    auto idx_issue = [&](int t) { t = t < NJ ? t : NJ - 1; atm_ld8(ixn, (unsigned)(lane * 8 + t * 512), xb); };
+    auto look_issue = [&](u32x2 (&e)[4], const unsigned (&o8)[4]) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) atm_ld8(e[r], o8[r], tab);
+    };
+    auto v_issue = [&](VT (&v)[4], int t) {                  // V[16 t + 4g + kk][dims fi*DPL ..]
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            int j = t * 16 + 4 * g + fk; j = j < T ? j : T - 1;
+            const unsigned voff = (unsigned)j * vrow2 + vlane;
+            if constexpr (DPL == 8) atm_ld16(v[g], voff, vb); else atm_ld8(v[g], voff, vb);
+        }
+    };
+    auto offs_of = [&](unsigned (&o8)[4]) {                  // byte offsets into the table from the packed indices in ixn
+        o8[0] = (ixn.x & 0xFFFFu) * 8u; o8[1] = (ixn.x >> 16) * 8u; o8[2] = (ixn.y & 0xFFFFu) * 8u; o8[3] = (ixn.y >> 16) * 8u;
+        asm volatile("" : "+v"(o8[0]), "+v"(o8[1]), "+v"(o8[2]), "+v"(o8[3]));
+    };
+    {
+        idx_issue(0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); ATM_RETIRE(ixn);
+        unsigned o8[4]; offs_of(o8);
+        __builtin_amdgcn_sched_barrier(0);
+        idx_issue(1); look_issue(e2[0], o8); v_issue(vv[0], 0);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    auto tile = [&](auto curc, int t) __attribute__((always_inline)) {
+        constexpr int cur = decltype(curc)::value, nxt = cur ^ 1;
+        // in flight: look-ups(t) [4], V(t) [4], indices(t + 1) [1] -- all issued a whole tile ago
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int r = 0; r < 4; r++) { ATM_RETIRE(e2[cur][r]); ATM_RETIRE(vv[cur][r]); }
+        ATM_RETIRE(ixn);
+        unsigned o8[4]; offs_of(o8);
+        __builtin_amdgcn_sched_barrier(0);
+        idx_issue(t + 2); look_issue(e2[nxt], o8); v_issue(vv[nxt], t + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        if (t < NJ) {                                        // (wave-uniform; a padded tile is loaded and not consumed)
+            float4 pf;                                       // impl:506 + ToBFloat16 :493
+            pf.x = bf_wide(bf_trunc((float)(as_double(e2[cur][0]) / zi))); pf.y = bf_wide(bf_trunc((float)(as_double(e2[cur][1]) / zi)));
+            pf.z = bf_wide(bf_trunc((float)(as_double(e2[cur][2]) / zi))); pf.w = bf_wide(bf_trunc((float)(as_double(e2[cur][3]) / zi)));
+            *(float4*)(pt + fi * ATM_PT + fk * 16) = pf;     // p[i = fi][j = 4kk .. 4kk+3]
+            ATM_LDS_TURN();
+            float pa[4];
+#pragma unroll
+            for (int g = 0; g < 4; g++) pa[g] = *(const float*)(pt + fi * ATM_PT + (4 * g + fk) * 4);     // A operand: p[i = fi][j = 4g + kk]
+            ATM_LDS_TURN();
+#pragma unroll
+            for (int g = 0; g < 4; g++) {                    // MatMul p.v, j ascending (llamatransformer.go:504-514)
+                uint32_t wd[DPL / 2];
+#pragma unroll
+                for (int q = 0; q < DPL / 2; q++) wd[q] = vv[cur][g][q];
+#pragma unroll
+                for (int t2 = 0; t2 < DPL; t2++)
+                    o[t2] = __builtin_amdgcn_mfma_f32_16x16x4f32(pa[g], (t2 & 1) ? bf_hi(wd[t2 >> 1]) : bf_lo(wd[t2 >> 1]), o[t2], 0, 0, 0);
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    for (int t = 0; t < NJ; t += 2) {
+        tile(std::integral_constant<int, 0>{}, t);
+        tile(std::integral_constant<int, 1>{}, t + 1);
+    }
+    asm volatile("s_waitcnt vmcnt(0) ; RING_RETIRE_ALL" ::: "memory");
+#undef ATM_RETIRE
+#undef ATM_LDS_TURN
+    // D layout: lane holds query rows 4*kk + r, output dims fi*DPL + t
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int row = i0 + 4 * fk + r;
+        if (row >= S) continue;
+        uint32_t w[DPL / 2];
+#pragma unroll
+        for (int t = 0; t < DPL; t += 2) w[t / 2] = (uint32_t)bf_trunc(o[t][r]) | ((uint32_t)bf_trunc(o[t + 1][r]) << 16);
+        uint16_t* dst = p.out + ((size_t)row * H + h) * HD + fi * DPL;
+        if (DPL == 8) *(uint4*)dst = make_uint4(w[0], w[1], w[2 % (DPL / 2)], w[3 % (DPL / 2)]);
+        else *(uint2*)dst = make_uint2(w[0], w[1]);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // attn_mfma2_kernel (round 6): attn_mfma_kernel with TWO query tiles (32 rows) per wave against each tile of cached positions.
 //
 // attn_mfma_kernel was 0.517 MFMA-busy for three rounds (profiles/r05_prefill_mfma_counters.md): per tile a wave runs 32 DEPENDENT matrix
@@ -3842,6 +4077,11 @@ extern "C" hipError_t lnbk_attn(const AttnParams* p, hipStream_t st) {
         if (min2 > 0 && p->S >= min2) {
             if (p->hd == 128) hipLaunchKernelGGL(attn_mfma2_kernel<128>, dim3(p->H, (p->S + 127) / 128), dim3(256), 0, st, *p);
             else hipLaunchKernelGGL(attn_mfma2_kernel<64>, dim3(p->H, (p->S + 127) / 128), dim3(256), 0, st, *p);
+            return hipGetLastError();
+        }
+        if (p->score_idx && p->host_T > 0 && p->sidx_jt * 16 >= p->host_T) {              // round 6: scores once, indices kept (the caller sized the scratch for this call's context)
+            if (p->hd == 128) hipLaunchKernelGGL(attn_mfma3_kernel<128>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
+            else hipLaunchKernelGGL(attn_mfma3_kernel<64>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);
             return hipGetLastError();
         }
         if (p->hd == 128) hipLaunchKernelGGL(attn_mfma_kernel<128>, dim3(p->H, (p->S + 63) / 64), dim3(256), 0, st, *p);

@@ -223,6 +223,38 @@ def test_two_query_tiles_per_wave_prefill_attention_ragged_rows(lnb, monkeypatch
     oc.close(); gm.close(); om.close()
 
 
+@pytest.mark.parametrize("heads,kv_heads,dim,rows", [(4, 2, 512, 37), (4, 4, 256, 83), (8, 2, 1024, 16), (4, 2, 512, 160), (8, 2, 512, 530)])
+def test_prefill_attention_with_the_scores_kept_between_its_passes(lnb, monkeypatch, heads, kv_heads, dim, rows):
+    """attn_mfma3_kernel (round 6, the default of an exact prefill: pass 1 keeps the sixteen-bit exp-table indices of its scores in the context's score_idx
+    scratch, pass 2 reads them back instead of running the q.k chain again, look-ups issued a tile ahead; llamatransformer.go:409-514 for multi-row calls,
+    operations_impl.go:478-511) against the oracle and against attn_mfma_kernel (LNB_ATTN_SIDX_MB=0), which computes the scores twice: odd and even tile
+    counts, partial last tiles, head_dim 128 and 64, a ragged chunk at start_pos > 0 (the modulo-broadcast mask over T > S; the scratch grows between the two
+    calls), a scratch too small for the call (1 MB cap: the old kernel runs, same bits), then decode steps that read the cache the prefill wrote."""
+    cfg = dict(orc.TINY, n_heads=heads, n_kv_heads=kv_heads, dim=dim, n_layers=2, vocab_size=512, max_seq_len=1100)
+    om = orc.Model(**cfg).fill_synthetic(33).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(33).finalize()
+    toks = orc.synth_tokens(9, 2 * rows, cfg["vocab_size"])
+    oc = orc.Context(om, 2 * rows + 8)
+    ref = [oc.forward(toks[lo_:hi_], lo_) for lo_, hi_ in ((0, rows), (rows, 2 * rows))]
+    for cap in ("4096", "0", "1"):
+        monkeypatch.setenv("LNB_ATTN_SIDX_MB", cap)
+        gc = lnb.InferenceContext(gm, 2 * rows + 8)
+        for (lo_, hi_), (lo, ao) in zip(((0, rows), (rows, 2 * rows)), ref):
+            lg, ag = gc.Forward(toks[lo_:hi_], lo_)
+            assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag, (cap, lo_)
+        for layer in range(cfg["n_layers"]):
+            assert (oc.cache(layer, 0)[:2 * rows] == gc.CacheK(layer)[:2 * rows]).all() and (oc.cache(layer, 1)[:2 * rows] == gc.CacheV(layer)[:2 * rows]).all()
+        if cap == "4096":
+            tok = ag
+            for i in range(3):
+                lo, to = oc.forward([tok], 2 * rows + i)
+                lg, tg = gc.Forward(np.array([tok], dtype=np.int32), 2 * rows + i)
+                assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and to == tg
+                tok = to
+        gc.close()
+    oc.close(); gm.close(); om.close()
+
+
 @pytest.mark.parametrize("rows", [16, 40, 130])
 def test_blgp_matrix_core_feed_from_the_chain_layouts_is_bit_exact(lnb, monkeypatch, rows):
     """gemm_blgp_kernel (round 6, opt-in LNB_GEMM_BLGP=2): v_mfma_f32_16x16x1_f32 with four WEIGHT blocks per wave and the B operand broadcast by BLGP -- every

@@ -152,7 +152,7 @@ def main(asm_path=None):
         txt = open(asm).read().split("\n")
     funcs, cur = {}, None
     for i, ln in enumerate(txt):
-        m = re.match(r"^(_Z\d\d(?:gemv_chain|gemv_quad|attn_exact|attn_gqa|attn_long_scores|rowcast|rowcast_lds|mfma_stream|mfma_pair|gemm_stream)_kernel\S*):", ln)
+        m = re.match(r"^(_Z\d\d(?:gemv_chain|gemv_quad|attn_exact|attn_gqa|attn_long_scores|attn_mfma3|rowcast|rowcast_lds|mfma_stream|mfma_pair|gemm_stream)_kernel\S*):", ln)
         if m:
             cur = []; funcs[m.group(1)] = cur
             continue
