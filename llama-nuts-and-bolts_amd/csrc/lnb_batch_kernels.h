@@ -427,6 +427,9 @@ DEVINL void ld_plain(u32x4& d, const void* a) { asm volatile("global_load_dwordx
 #define GS_R1 3                                              // ring depth at NTW = 1 / NTW = 2 (one chain)
 #define GS_R2 3
 #endif
+#ifndef GS_RT
+#define GS_RT 2                                              // ring depth with two weight tiles per wave (TT): a chunk is 256 matrix instructions of lookahead
+#endif
 #ifndef GS_OCC1
 #define GS_OCC1 2                                            // waves per SIMD the register budget is set for at NTW = 1 / NTW = 2 (tools/gemmstream_bench.hip sweeps them)
 #define GS_OCC2 2
@@ -470,11 +473,16 @@ template <int M> DEVINL void ld_rc_unit(u32x4& d, unsigned voff, const char* sb)
     if constexpr (M == 2) asm volatile("global_load_dwordx4 %0, %1, %2 offset:128 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
     if constexpr (M == 3) asm volatile("global_load_dwordx4 %0, %1, %2 offset:192 ; RING_LOAD" : "=&v"(d) : "v"(voff), "s"(sb) : "memory");
 }
-template <int EPI, int NCH, int NTW, int SRC = 0>
+template <int EPI, int NCH, int NTW, int SRC = 0, int TT = 0>
 __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW == 4 ? 2 : 1) void gemm_stream_kernel(GemmParams p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int L = NCH * 4 + NTW;                         // loads per chunk and lane: NCH * 4 weight units + NTW activation units
-    constexpr int R = NCH == 1 ? (NTW == 1 ? GS_R1 : NTW == 2 ? GS_R2 : 3) : (SRC == 2 && NTW == 4) ? GS_RX : 3;   // chunks in flight (two chains x four batch tiles from a chain
+    // TT (round 6): a wave of a ONE-chain product (wo, w2: M16 copy or row-broadcast layout) carries TWO neighbouring weight tiles x NTW batch tiles, the shape the gate|up
+    // product has by construction: every B operand read from the LDS feeds two matrix instructions instead of one, staging and the chunk barrier are paid once per 256 instead of
+    // 128 of them.  The unit a wave owns is then a tile PAIR (2 u, 2 u + 1); an odd last tile is computed twice and stored once.
+    static_assert(!TT || (NCH == 1 && SRC != 2 && NTW == 4), "two tiles per wave: one-chain products from the M16 copy or the row-broadcast layout, four batch tiles");
+    constexpr int NC = TT ? 2 : NCH;                         // chains (accumulator sets) per wave
+    constexpr int L = NC * 4 + NTW;                          // loads per chunk and lane: NC * 4 weight units + NTW activation units
+    constexpr int R = TT ? GS_RT : NCH == 1 ? (NTW == 1 ? GS_R1 : NTW == 2 ? GS_R2 : 3) : (SRC == 2 && NTW == 4) ? GS_RX : 3;   // chunks in flight (two chains x four batch tiles from a chain
                                                              // layout: 2 -- a chunk is then 256 matrix instructions = 3.6 us of lookahead each, and the third slot's 48
                                                              // registers spilled).  A chunk of one batch tile is 32 matrix instructions = ~1.5k
                                                              // cycles of a wave: three of them in flight are less than HBM's latency under load
@@ -488,8 +496,8 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
     const int lin_wg = (int)(blockIdx.y * gridDim.x + blockIdx.x);
     const int by = p.rows_fastest ? lin_wg % (int)gridDim.y : (int)blockIdx.y, bx = p.rows_fastest ? lin_wg / (int)gridDim.y : (int)blockIdx.x;
     const int m0 = by * rows_wg;
-    const int nchunks = p.K >> 7, n_tiles = (p.n_rows + 15) >> 4;
-    const int rounds = (n_tiles + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
+    const int nchunks = p.K >> 7, n_tiles = (p.n_rows + 15) >> 4, n_units = TT ? (n_tiles + 1) >> 1 : n_tiles;       // units: what a wave owns -- a tile, or a tile pair
+    const int rounds = (n_units + (int)gridDim.x * 4 - 1) / ((int)gridDim.x * 4);
     const int T = rounds * nchunks;
     const size_t chain_bytes = (size_t)nchunks * 4096;
     const unsigned aoff = (unsigned)(((lane & 15) * 4 + (lane >> 4)) * 16);
@@ -507,7 +515,8 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
     for (int u = 0; u < NTW; u++) { int row = m0 + u * 16 + srow; row = row < p.S ? row : p.S - 1; xrow[u] = p.x + (size_t)row * p.K + scol * 8; }
     u32x4 buf[R][L];
     int ir = 0, ic = 0, issued = 0;                          // issue cursor: (round, chunk)
-    auto tile_of = [&](int round) { int t = (round * (int)gridDim.x + bx) * 4 + wave; return t < n_tiles ? t : n_tiles - 1; };
+    auto tile_of = [&](int round) { int t = (round * (int)gridDim.x + bx) * 4 + wave; return t < n_units ? t : n_units - 1; };
+    auto tile_c = [&](int unit, int c) { int t = TT ? unit * 2 + c : unit; return t < n_tiles ? t : n_tiles - 1; };        // chain c's weight tile
     auto issue_next = [&](u32x4 (&dst)[L]) {
         const int tile = tile_of(ir);
         if constexpr (SRC == 2) {
@@ -520,9 +529,9 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
             }
         }
 #pragma unroll
-        for (int c = 0; c < NCH; c++) {
+        for (int c = 0; c < NC; c++) {
             if constexpr (SRC == 1) {
-                const char* wb = (const char*)p.w + uniform_off(((size_t)tile * 4 * nchunks + (size_t)ic) * 1024);
+                const char* wb = (const char*)p.w + uniform_off(((size_t)tile_c(tile, c) * 4 * nchunks + (size_t)ic) * 1024);
                 ld_rc_unit<0>(dst[c * 4 + 0], rc_voff, wb); ld_rc_unit<1>(dst[c * 4 + 1], rc_voff, wb);
                 ld_rc_unit<2>(dst[c * 4 + 2], rc_voff, wb); ld_rc_unit<3>(dst[c * 4 + 3], rc_voff, wb);
                 continue;
@@ -533,7 +542,7 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                 for (int jj = 0; jj < 4; jj++) ld_w_plain(dst[c * 4 + jj], ct_voff, (const char*)p.w + o0 + (size_t)jj * oj);
                 continue;
             }
-            const char* wb = (const char*)p.w16 + (size_t)(tile * NCH + c) * chain_bytes + ((GS_DBG & 16) ? 0 : (size_t)ic * 4096);
+            const char* wb = (const char*)p.w16 + (size_t)(TT ? tile_c(tile, c) : tile * NCH + c) * chain_bytes + ((GS_DBG & 16) ? 0 : (size_t)ic * 4096);
             if constexpr (GS_W_NT) {
                 ld_unit_nt<0>(dst[c * 4 + 0], aoff, wb); ld_unit_nt<1>(dst[c * 4 + 1], aoff, wb);
                 ld_unit_nt<2>(dst[c * 4 + 2], aoff, wb); ld_unit_nt<3>(dst[c * 4 + 3], aoff, wb);
@@ -543,14 +552,14 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
             }
         }
 #pragma unroll
-        for (int u = 0; u < NTW; u++) ld_plain(dst[NCH * 4 + u], (GS_DBG & 8) ? p.x : xrow[u] + (size_t)ic * 128);
+        for (int u = 0; u < NTW; u++) ld_plain(dst[NC * 4 + u], (GS_DBG & 8) ? p.x : xrow[u] + (size_t)ic * 128);
         if (issued + 1 < T) { issued++; if (++ic == nchunks) { ic = 0; ir++; } }
     };
 #pragma unroll
     for (int j = 0; j < R; j++) issue_next(buf[j]);
-    f32x4 acc[NCH][NTW];
+    f32x4 acc[NC][NTW];
 #pragma unroll
-    for (int cc = 0; cc < NCH; cc++)
+    for (int cc = 0; cc < NC; cc++)
 #pragma unroll
         for (int t = 0; t < NTW; t++) acc[cc][t] = f32x4{0.f, 0.f, 0.f, 0.f};
     // X1 (chain layouts, four batch tiles per wave): the four BLOCKS of v_mfma_f32_16x16x1_f32 are the four batch tiles, one k per instruction, and CBSZ = 2
@@ -575,7 +584,7 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                 if (!(GS_DBG & 1) || t0 + j < 2) {
 #pragma unroll
                     for (int u = 0; u < NTW; u++) {          // widen once per element: bf16 -> f32 is a shift / a mask
-                        const u32x4 v = buf[j][NCH * 4 + u];
+                        const u32x4 v = buf[j][NC * 4 + u];
                         float* d = bw + (size_t)(u * 16 + srow) * GS_PITCH + scol * 8;
                         *(float2*)(d) = make_float2(bf_lo(v[0]), bf_hi(v[0])); *(float2*)(d + 2) = make_float2(bf_lo(v[1]), bf_hi(v[1]));
                         *(float2*)(d + 4) = make_float2(bf_lo(v[2]), bf_hi(v[2])); *(float2*)(d + 6) = make_float2(bf_lo(v[3]), bf_hi(v[3]));
@@ -657,19 +666,19 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                         }
                 };
                 if constexpr (!(GS_DBG & 64)) static_for<0, D>(lds_issue);
-                float opq[NCH][8];                           // (chain layouts) the operands of the current load's eight k-groups
+                float opq[NC][8];                           // (chain layouts) the operands of the current load's eight k-groups
                 static_for<0, 8>([&](auto ec) __attribute__((always_inline)) {
                     constexpr int e = decltype(ec)::value;
                     if constexpr (e + D < 8 && !(GS_DBG & 64)) lds_issue(std::integral_constant<int, e + D>{});
-                    float av[NCH][4];
+                    float av[NC][4];
                     if constexpr (SRC == 2 && (e & 1) == 0) {      // chain layouts: load e / 2 of the chunk carries the k-groups 4 e .. 4 e + 7; all eight operands at once
 #pragma unroll
-                        for (int cc = 0; cc < NCH; cc++) ct_ops(opq[cc], buf[j][cc * 4 + (e >> 1)], ct_sel);
+                        for (int cc = 0; cc < NC; cc++) ct_ops(opq[cc], buf[j][cc * 4 + (e >> 1)], ct_sel);
                     }
 #pragma unroll
                     for (int m = 0; m < 4; m++)
 #pragma unroll
-                        for (int cc = 0; cc < NCH; cc++) {
+                        for (int cc = 0; cc < NC; cc++) {
                             if constexpr (SRC == 2) av[cc][m] = opq[cc][4 * (e & 1) + m];
                             else av[cc][m] = (GS_DBG & 32) ? __uint_as_float(buf[j][cc * 4 + m][e >> 1]) : unit_elem(buf[j][cc * 4 + m], e);
                         }
@@ -677,7 +686,7 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
 #pragma unroll
                         for (int m = 0; m < 4; m++)
 #pragma unroll
-                            for (int cc = 0; cc < NCH; cc++) asm volatile("" : "+v"(av[cc][m]));
+                            for (int cc = 0; cc < NC; cc++) asm volatile("" : "+v"(av[cc][m]));
                         issue_next(buf[j]);
                     }
                     constexpr int ahead = (e + D < 8 ? D : 7 - e) * 2 * NTW;             // ds_read2 instructions issued after the ones of step e
@@ -690,7 +699,7 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                         for (int t = 0; t < NTW; t++) {
                             const float b = (GS_DBG & 4) ? __int_as_float(0x3f800000 + lane + m + t) : bq[e % (D + 1)][(m >> 1) * NTW + t][m & 1];
 #pragma unroll
-                            for (int cc = 0; cc < NCH; cc++) {
+                            for (int cc = 0; cc < NC; cc++) {
                                 if (e == 0 && m == 0 && c == 0) acc[cc][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][m], b, f32x4{0.f, 0.f, 0.f, 0.f}, 0, 0, 0);
                                 else acc[cc][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cc][m], b, acc[cc][t], 0, 0, 0);
                             }
@@ -699,7 +708,16 @@ __global__ __launch_bounds__(256, NTW == 1 ? GS_OCC1 : NTW == 2 ? GS_OCC2 : NTW 
                 });
                 if (++c == nchunks) {                        // D layout: column lane & 15 of the batch tile, rows (lane >> 4) * 4 + r of the weight tile
                     const int tile = (round * (int)gridDim.x + bx) * 4 + wave;
-                    if (tile < n_tiles) {
+                    if constexpr (TT) {                      // two tiles, each with the one-chain epilogue
+#pragma unroll
+                        for (int cc = 0; cc < 2; cc++) {
+                            const int tt = tile * 2 + cc;
+                            if (tile < n_units && tt < n_tiles) {
+#pragma unroll
+                                for (int t = 0; t < NTW; t++) gemm_epilogue4<EPI>(p, acc[cc][t], acc[cc][t], m0 + t * 16 + (lane & 15), tt * 16 + (lane >> 4) * 4);
+                            }
+                        }
+                    } else if (tile < n_tiles) {
 #pragma unroll
                         for (int t = 0; t < NTW; t++)
                             gemm_epilogue4<EPI>(p, acc[0][t], acc[NCH - 1][t], m0 + t * 16 + (lane & 15), tile * 16 + (lane >> 4) * 4);

@@ -4254,6 +4254,10 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
         LNB_GS_PREP(1, 0); LNB_GS_PREP(2, 0); LNB_GS_PREP(4, 0);
         LNB_GS_PREP(1, 2); LNB_GS_PREP(2, 2); LNB_GS_PREP(4, 2);
         if constexpr (NCH == 1 && (EPI == EPI_STORE || EPI == EPI_RESID)) { LNB_GS_PREP(1, 1); LNB_GS_PREP(2, 1); LNB_GS_PREP(4, 1); }
+        if constexpr (NCH == 1 && (EPI == EPI_STORE || EPI == EPI_RESID)) {        // two weight tiles per wave (TT)
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, NCH, 4, 0, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void*)gemm_stream_kernel<EPI, NCH, 4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
 #undef LNB_GS_PREP
         return e;
     }
@@ -4264,7 +4268,7 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
     const int n_tiles = (p->n_rows + 15) / 16;
     const int ct = (p->S + 15) / 16;                         // batch tiles of 16 rows
     int ntw = lnb_gemm_stream_ntw(n_tiles, ct, NCH, num_cus);
-    static const int force = getenv("LNB_GS_NTW") ? atoi(getenv("LNB_GS_NTW")) : 0;    // (tools / experiments)
+    const int force = getenv("LNB_GS_NTW") ? atoi(getenv("LNB_GS_NTW")) : 0;    // (tools / experiments / tests; read per launch)
     if (force == 1 || force == 2 || force == 4) ntw = force;
     static const int force_ct = getenv("LNB_GS_NTW_CHAIN") ? atoi(getenv("LNB_GS_NTW_CHAIN")) : 0;    // (experiments: the chain layouts only)
     if (src == 2 && (force_ct == 1 || force_ct == 2 || force_ct == 4)) ntw = force_ct;
@@ -4286,7 +4290,16 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
         }
     }
     const int rows_wg = 16 * ntw;
-    unsigned gx = (unsigned)((n_tiles + 3) / 4); if (gx > (unsigned)num_cus) gx = (unsigned)num_cus;
+    // round 6: wo / w2 with many rows -- two neighbouring weight tiles per wave (gemm_stream_kernel's TT form: the gate|up product's shape), as long as the tile PAIRS still
+    // give every CU its two workgroups.  LNB_GS_TT=0: never, 1: whenever the form exists
+    bool tt = false;
+    if constexpr (NCH == 1 && (EPI == EPI_STORE || EPI == EPI_RESID)) {
+        const char* et = getenv("LNB_GS_TT");                // (read per launch: a test switches it inside one process)
+        const int ttm = (et && *et) ? atoi(et) : -1;
+        const long wgs = (long)(((n_tiles + 1) / 2 + 3) / 4) * ((p->S + rows_wg - 1) / rows_wg);
+        tt = ntw == 4 && (src == 0 || src == 1) && ttm != 0 && (ttm == 1 || wgs >= 2L * num_cus);
+    }
+    unsigned gx = (unsigned)(((tt ? (n_tiles + 1) / 2 : n_tiles) + 3) / 4); if (gx > (unsigned)num_cus) gx = (unsigned)num_cus;
     const dim3 grid(gx, (unsigned)((p->S + rows_wg - 1) / rows_wg));
     // Dispatch order (workgroup id % 8 = XCD, each with its own L2).  Weight-tile groups fastest: an XCD owns 1/8 of the tile groups for every
     // row group -- right while all row groups are in flight together (<= 8 of them: short prompts, batches), each weight byte is then fetched
@@ -4300,6 +4313,13 @@ template <int EPI, int NCH> static hipError_t launch_gemm_stream(const GemmParam
     case 1: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 1, SRC_>), grid, dim3(256), lds, st, q); break; \
     case 2: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 2, SRC_>), grid, dim3(256), lds, st, q); break; \
     default: hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 4, SRC_>), grid, dim3(256), lds, st, q); break; }
+    if constexpr (NCH == 1 && (EPI == EPI_STORE || EPI == EPI_RESID)) {
+        if (tt) {
+            if (src == 0) hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 4, 0, 1>), grid, dim3(256), lds, st, q);
+            else hipLaunchKernelGGL((gemm_stream_kernel<EPI, NCH, 4, 1, 1>), grid, dim3(256), lds, st, q);
+            return hipGetLastError();
+        }
+    }
     if (src == 0) { LNB_GS_LAUNCH(0) }
     else if (src == 2) { LNB_GS_LAUNCH(2) }
     else if constexpr (NCH == 1 && (EPI == EPI_STORE || EPI == EPI_RESID)) { LNB_GS_LAUNCH(1) }

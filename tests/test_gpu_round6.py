@@ -279,6 +279,29 @@ def test_blgp_matrix_core_feed_from_the_chain_layouts_is_bit_exact(lnb, monkeypa
     gc.close(); oc.close(); gm.close(); om.close()
 
 
+@pytest.mark.parametrize("rows,copy", [(64, False), (100, False), (200, True), (130, True)])
+def test_two_weight_tiles_per_wave_in_the_prefill_products_is_bit_exact(lnb, monkeypatch, rows, copy):
+    """gemm_stream_kernel's TT form (round 6: a wave of wo / w2 carries two neighbouring weight tiles x four batch tiles, the gate|up product's shape; on by itself
+    for long prompts, forced here with LNB_GS_TT=1 + LNB_GS_NTW=4) from the row-broadcast layout and from the M16 copy, ragged row counts, against the oracle's logits
+    bits (operations_lineartransform.go:46-65) and against the one-tile form (LNB_GS_TT=0)."""
+    cfg = dict(orc.TINY, dim=384, n_heads=6, n_kv_heads=2, n_layers=2, vocab_size=1000, max_seq_len=512, multiple_of=128)       # (ffn hidden 1408 = 11 chunks of 128)
+    om = orc.Model(**cfg).fill_synthetic(12).finalize()
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(12).finalize()
+    if copy:
+        gm.enable_batch()
+    toks = orc.synth_tokens(4, rows, cfg["vocab_size"])
+    oc = orc.Context(om, rows + 8)
+    lo, ao = oc.forward(toks, 0)
+    monkeypatch.setenv("LNB_GS_NTW", "4")
+    for tt in ("1", "0"):
+        monkeypatch.setenv("LNB_GS_TT", tt)
+        gc = lnb.InferenceContext(gm, rows + 8)
+        lg, ag = gc.Forward(toks, 0)
+        assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag, tt
+        gc.close()
+    oc.close(); gm.close(); om.close()
+
+
 @pytest.mark.parametrize("quad", ["1", "2"])
 def test_down_projection_on_one_quad_chain_wave_is_bit_exact(lnb, monkeypatch, quad):
     """rung (a') of the FFN ladder (profiles/r06_ffn_stream.md): w2 re-tiled [N/16][K/8][16][8] and run by gemv_quad_kernel<16, KS, 4, R> -- its 16 rows per
