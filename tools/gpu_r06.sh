@@ -44,6 +44,10 @@ case "$mode" in
     timeout 600 python tools/batch_bench.py --n 128 --steps 32 --profile-iters 8 2>&1 | tail -3 | tee gpurun_out/r06_batch_bench.log
     du -sh gpurun_out
     ;;
+  tt)       # gemm_stream_kernel's two-weight-tiles-per-wave form (wo / w2 of long prompts): parity test, then the exact prefill with the form off / on (default) / forced
+    ( timeout 900 python -m pytest tests/test_gpu_round6.py -x -q -k two_weight_tiles ) 2>&1 | tail -5 | tee gpurun_out/r06_tt.log
+    for v in 0 "" 1; do echo "== LNB_GS_TT='$v'"; LNB_GS_TT=$v timeout 900 python tools/prefill_bench.py --sizes 128,512,2048,4096 --modes exact 2>&1 | tail -5; done | tee -a gpurun_out/r06_tt.log
+    ;;
   suite)
     ( timeout 2400 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r06_gpu_suite.log
     ;;
