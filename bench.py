@@ -167,6 +167,7 @@ def configs2_record(lnb, model, cfg, args, a):
     t0 = time.perf_counter()
     _, first = ctx.Forward(prompt, 0, want_logits=False)
     t_pf = time.perf_counter() - t0
+    att_form = ctx.prefill_attention_form()
     # ... and once more on a second context: the WARM time (kernels loaded, clocks up, allocator settled) next to the cold first call
     ctx_w = lnb.InferenceContext(model, P + 8).set_mode(args.mode)
     lnb._chk(lnb.lib().lnb_ctx_synchronize(ctx_w.h))
@@ -205,7 +206,9 @@ def configs2_record(lnb, model, cfg, args, a):
                         "frac_of_bf16_mfma_peak_2500": round(2.0 * P * mm / t_pf_warm / 1e12 / 2500.0, 4),
                         "note": "ms = the first call of the process at this row count (cold: what a driver sees), warm_ms = the same prompt again on a second context; the exact "
                                 "order forces the f32 matrix instruction (1/16 of the bf16 rate): both peaks are quoted",
-                        "kernel": "gemm_stream_kernel fed from the RESIDENT weight layouts (no second copy) + attn_mfma_kernel; v_mfma_f32_16x16x4_f32 = the k-ordered chain; matmul FLOPs only"},
+                        "attention_kernel": {3: "attn_mfma3_kernel (scores computed once, exp-table indices kept in the context's scratch)",
+                                             1: "attn_mfma_kernel (scores computed twice: the score-index scratch was REFUSED -- LNB_ATTN_SIDX_MB or no device memory; ~35 ms slower, same bits)"}.get(att_form, "form %d" % att_form),
+                        "kernel": "gemm_stream_kernel fed from the RESIDENT weight layouts (no second copy; wo / w2 two weight tiles per wave) + the matrix-core attention above; v_mfma_f32_16x16x4_f32 = the k-ordered chain; matmul FLOPs only"},
             "decode": {"steps": K, "tokens_per_s": round(tps, 2), "ms_per_step": round(1e3 * wall / K, 4), "hip_event_ms_per_step": round(ev_ms / K, 4),
                        "repeats_ms_per_step": [round(1e3 * r[0] / K, 4) for r in reps], "mean_context": Tbar,
                        "frac_of_hbm_roofline": round(tps * B / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_token": int(B),

@@ -153,6 +153,11 @@ int lnb_ctx_zseq_count(lnb_ctx* c, int* out);
 /* Diagnostics of the fused RMSNorm (llamatransformer.go:222, :237, :166: RMSNorm in front of wq|wk|wv, w1|w3, output): rows of one-token calls
  * whose sum of squares left the branch-free item walk for the slower record walk (same bits either way; ~2.5 % of gaussian rows). */
 int lnb_ctx_norm_fallbacks(lnb_ctx* c, int* out);
+/* Which matrix-core attention the context's LAST multi-row call (llamatransformer.go:409-514 with S >= 16, exact mode) ran: 3 = attn_mfma3_kernel (the scores
+ * computed once, their 16-bit exp-table indices kept in the context's scratch), 1 = attn_mfma_kernel (the scores computed twice: the scratch was refused --
+ * above LNB_ATTN_SIDX_MB, or no device memory for it), 0 = none (no such call yet, fewer than 16 rows, head_dim 32, tolerance mode).  Same bits either way;
+ * a bench prints it so that a silently refused scratch shows. */
+int lnb_ctx_prefill_attention_form(const lnb_ctx* c, int* out);
 /* optional per-layer progress hook = infContext.Logf("Transformer block layer %d / %d was run, took %.4f sec(s)")
  * (llamatransformer.go:157-163); forces a per-layer stream sync, so it is off by default */
 typedef void (*lnb_layer_cb)(int layer_1based, int n_layers, double secs, void* user);

@@ -162,6 +162,7 @@ struct lnb_ctx {
     int batch_users = 0;                   // live lnb_batch handles this context is a member of: their device tables and captured graphs hold its raw pointers
     // long-context decode attention (attn_long_*_kernel): used for one-token calls whose context exceeds attn_long_T
     double* e_buf = nullptr; double* z_part = nullptr; int* zseq_count = nullptr;
+    int last_prefill_form = 0;         // lnb_ctx_prefill_attention_form
     uint64_t* score_idx = nullptr; size_t score_idx_bytes = 0; int sidx_jt = 0;      // attn_mfma3_kernel's scratch (the exp-table indices of pass 1), grown on demand by check_call; sidx_jt = 0: this call runs attn_mfma_kernel
     unsigned* attn_cnt = nullptr;          // attn_one_kernel: [n_heads] arrival counters of its in-launch exchange + [n_heads] = polls that ran out
     int attn_long_T = 0; int force_zseq = 0;   // force_zseq: bit 0 = walk the serial softmax denominator, bit 1 = keep the two-launch long-context form, bit 2 = one launch with every poll timing out (tests), bit 3 = one launch
@@ -744,6 +745,12 @@ extern "C" int lnb_ctx_norm_fallbacks(lnb_ctx* c, int* out) {
     *out = c->h_io[0];
     return 0;
 }
+// which matrix-core attention the last multi-row call of the context ran (check_call decides, per call): 3 scores once / 1 scores twice / 0 none
+extern "C" int lnb_ctx_prefill_attention_form(const lnb_ctx* c, int* out) {
+    if (!c || !out) return fail("null argument");
+    *out = c->last_prefill_form;
+    return 0;
+}
 extern "C" int lnb_ctx_set_layer_callback(lnb_ctx* c, lnb_layer_cb cb, void* user) { if (!c) return fail("null argument"); c->cb = cb; c->cb_user = user; return 0; }
 extern "C" void* lnb_ctx_hidden_ptr(lnb_ctx* c, int which) { return !c ? nullptr : which == 2 ? (void*)c->ffn : (void*)c->x; }
 extern "C" void* lnb_ctx_stream(lnb_ctx* c) { return c ? (void*)c->stream : nullptr; }
@@ -910,6 +917,7 @@ static int check_call(lnb_ctx* c, int seq, int start_pos) {
             if (c->score_idx) c->sidx_jt = (int)jt;
         }
     }
+    if (seq > 1) c->last_prefill_form = !mfma_attn || c->mode == LNB_MODE_FAST ? 0 : c->sidx_jt > 0 ? 3 : 1;
     if (seq > 1 && !mfma_attn && T > c->attn_short_cap)
         return fail("a call of %d rows (2..15, or any multi-row call at head_dim 32) at context %d: the row-per-workgroup attention kernel stages "
                     "at most %d positions in the LDS; use one-token calls or 16 or more rows there", seq, T, c->attn_short_cap);

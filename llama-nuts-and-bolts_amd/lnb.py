@@ -52,7 +52,7 @@ EXPORTS = [
     "lnb_model_set_tensor", "lnb_model_get_tensor", "lnb_model_fill_synthetic", "lnb_model_finalize",
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
-    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear", "lnb_op_argmax", "lnb_op_linear_mode", "lnb_ctx_set_mode", "lnb_ctx_get_mode", "lnb_ctx_set_schedule", "lnb_ctx_get_schedule", "lnb_ctx_set_attention", "lnb_ctx_zseq_count", "lnb_ctx_norm_fallbacks",
+    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear", "lnb_op_argmax", "lnb_op_linear_mode", "lnb_ctx_set_mode", "lnb_ctx_get_mode", "lnb_ctx_set_schedule", "lnb_ctx_get_schedule", "lnb_ctx_set_attention", "lnb_ctx_zseq_count", "lnb_ctx_norm_fallbacks", "lnb_ctx_prefill_attention_form",
     "lnb_profile_kernel", "lnb_profile_kernel_stamps", "lnb_model_num_tensors", "lnb_model_tensor_info",
     "lnb_checkpoint_open", "lnb_checkpoint_close", "lnb_checkpoint_num_tensors", "lnb_checkpoint_find", "lnb_checkpoint_tensor",
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
@@ -132,6 +132,7 @@ def lib():
     L.lnb_ctx_set_attention.argtypes = [vp, C.c_int, C.c_int]
     L.lnb_ctx_zseq_count.argtypes = [vp, C.POINTER(C.c_int)]
     L.lnb_ctx_norm_fallbacks.argtypes = [vp, C.POINTER(C.c_int)]
+    L.lnb_ctx_prefill_attention_form.argtypes = [vp, C.POINTER(C.c_int)]
     L.lnb_pipeline_unique_id.argtypes = [vp]
     L.lnb_pipeline_init.argtypes = [vp, C.c_int, C.c_int, vp, C.POINTER(vp)]
     L.lnb_pipeline_init_loopback.argtypes = [vp, C.c_int, C.c_int, C.c_char_p, C.POINTER(vp)]
@@ -467,6 +468,12 @@ class InferenceContext:
         """fused-RMSNorm rows (decode) that left the branch-free item walk for the record walk since the context was created"""
         n = C.c_int(0)
         _chk(self.L.lnb_ctx_norm_fallbacks(self.h, C.byref(n)))
+        return n.value
+
+    def prefill_attention_form(self):
+        """3: the last multi-row call ran attn_mfma3_kernel (scores once), 1: attn_mfma_kernel (scores twice: scratch refused), 0: neither"""
+        n = C.c_int(0)
+        _chk(self.L.lnb_ctx_prefill_attention_form(self.h, C.byref(n)))
         return n.value
 
     def Forward(self, tokens, start_pos, want_logits=True):

@@ -242,6 +242,8 @@ def test_prefill_attention_with_the_scores_kept_between_its_passes(lnb, monkeypa
         for (lo_, hi_), (lo, ao) in zip(((0, rows), (rows, 2 * rows)), ref):
             lg, ag = gc.Forward(toks[lo_:hi_], lo_)
             assert (lo.view(np.uint32) == lg.view(np.uint32)).all() and ao == ag, (cap, lo_)
+            need = heads * ((rows + 15) // 16) * ((hi_ + 15) // 16) * 512                     # bytes of score indices this call keeps (lnb_api.cpp: check_call)
+            assert gc.prefill_attention_form() == (3 if need <= (int(cap) << 20) else 1), (cap, lo_, need)      # lnb_ctx_prefill_attention_form: which kernel really ran
         for layer in range(cfg["n_layers"]):
             assert (oc.cache(layer, 0)[:2 * rows] == gc.CacheK(layer)[:2 * rows]).all() and (oc.cache(layer, 1)[:2 * rows] == gc.CacheV(layer)[:2 * rows]).all()
         if cap == "4096":

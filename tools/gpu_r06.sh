@@ -48,6 +48,11 @@ case "$mode" in
     ( timeout 900 python -m pytest tests/test_gpu_round6.py -x -q -k two_weight_tiles ) 2>&1 | tail -5 | tee gpurun_out/r06_tt.log
     for v in 0 "" 1; do echo "== LNB_GS_TT='$v'"; LNB_GS_TT=$v timeout 900 python tools/prefill_bench.py --sizes 128,512,2048,4096 --modes exact 2>&1 | tail -5; done | tee -a gpurun_out/r06_tt.log
     ;;
+  batchsweep)   # batched exact decode: batch tiles per wave forced (LNB_GS_NTW) against the launch rule, with and without the second weight copy
+    for n in ${BS_N:-32 64 128}; do for nc in "" "--no-copy"; do for v in "" 1 2 4; do
+      LNB_GS_NTW=$v timeout 300 python tools/batch_bench.py --n $n --steps 16 --profile-iters 6 $nc 2>&1 | tail -1
+    done; done; done | tee gpurun_out/r06_batch_sweep.log
+    ;;
   suite)
     ( timeout 2400 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r06_gpu_suite.log
     ;;
