@@ -53,6 +53,9 @@ case "$mode" in
       LNB_GS_NTW=$v timeout 300 python tools/batch_bench.py --n $n --steps 16 --profile-iters 6 $nc 2>&1 | tail -1
     done; done; done | tee gpurun_out/r06_batch_sweep.log
     ;;
+  dvfs)     # are the chain-bound launches clocked by the power budget?  the same kernels on zeroed block matrices (tools/kernel_ab.py AB_ZERO), with the stamps' shader clock
+    for z in "" 1; do echo "== AB_ZERO='$z'"; AB_ZERO=$z timeout 600 python tools/kernel_ab.py 200 2>&1 | tail -1; AB_ZERO=$z LNB_GEMV_TIMING=1 timeout 300 python tools/kernel_ab.py 30 2>&1 | grep -E "kernel class|wave 0: n" | head -12; done | tee gpurun_out/r06_dvfs.log
+    ;;
   suite)
     ( timeout 2400 python -m pytest tests -m gpu -x -q ) 2>&1 | tail -8 | tee gpurun_out/r06_gpu_suite.log
     ;;

@@ -8,7 +8,13 @@ import lnb
 
 cfg = dict(lnb.LLAMA_8B); cfg["n_layers"] = int(os.environ.get("AB_LAYERS", "4"))     # (AB_LAYERS=32: the launches cycle through the full model's weights, as a decode step does)
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 200
-m = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234).finalize()
+m = lnb.LlamaTransformer(device=0, **cfg).fill_synthetic(1234)
+if os.environ.get("AB_ZERO"):     # DVFS experiment: the blocks' matrices zeroed (AB_ZERO=1) -- same instruction stream, less switching; do the chain-bound launches clock higher?
+    import numpy as np
+    for name, shape in m.tensor_infos():
+        if name.startswith("layers.") and ("attention.w" in name or "feed_forward.w" in name):
+            m.set_tensor(name, np.zeros(shape, dtype=np.uint16))
+m.finalize()
 c = lnb.InferenceContext(m, 512)
 prompt = lnb.synth_tokens(99, 128, cfg["vocab_size"])
 _, first = c.Forward(prompt, 0, want_logits=False)
