@@ -156,7 +156,8 @@ int lnb_ctx_norm_fallbacks(lnb_ctx* c, int* out);
 /* Which matrix-core attention the context's LAST multi-row call (llamatransformer.go:409-514 with S >= 16, exact mode) ran: 3 = attn_mfma3_kernel (the scores
  * computed once, their 16-bit exp-table indices kept in the context's scratch), 1 = attn_mfma_kernel (the scores computed twice: the scratch was refused --
  * above LNB_ATTN_SIDX_MB, or no device memory for it), 0 = none (no such call yet, fewer than 16 rows, head_dim 32, tolerance mode).  Same bits either way;
- * a bench prints it so that a silently refused scratch shows. */
+ * a bench prints it so that a silently refused scratch shows.  The scratch is 512 bytes per (head, 16 query rows, 16 positions) -- 1.07 GB for a 4096-row prompt of the
+ * 8B shape --, one per context, grown on demand; a context's first one-token call after the prompt frees it when it is larger than LNB_ATTN_SIDX_KEEP_MB (default 256). */
 int lnb_ctx_prefill_attention_form(const lnb_ctx* c, int* out);
 /* optional per-layer progress hook = infContext.Logf("Transformer block layer %d / %d was run, took %.4f sec(s)")
  * (llamatransformer.go:157-163); forces a per-layer stream sync, so it is off by default */

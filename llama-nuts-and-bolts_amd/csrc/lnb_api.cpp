@@ -904,7 +904,15 @@ static int check_call(lnb_ctx* c, int seq, int start_pos) {
     // positions), one buffer per context, reused by every layer.  Grown here, on the host side of the call (never inside a capture); above LNB_ATTN_SIDX_MB
     // (default 4096; 0 = never) the call runs attn_mfma_kernel, which computes the scores twice instead.
     c->sidx_jt = 0;
-    if (mfma_attn && c->mode != LNB_MODE_FAST) {
+    bool stage_has_attn = false;                             // (a pipeline stage cut inside a block may hold FFN parts only: no attention, no scratch)
+    for (int l = c->m->layer_begin; l < c->m->layer_end && !stage_has_attn; l++) stage_has_attn = c->m->has_attn(l);
+    // a one-token call on a context that still holds a LARGE scratch from its prompt (1.07 GB for 4096 rows of the 8B shape) gives it back: the decode steps never read it,
+    // and a host that prefills many contexts would otherwise keep a gigabyte per context for their whole life.  Up to LNB_ATTN_SIDX_KEEP_MB (default 256) it stays for the next prompt.
+    if (seq == 1 && c->score_idx && c->score_idx_bytes > ((size_t)env_int("LNB_ATTN_SIDX_KEEP_MB", 256) << 20)) {
+        HIPCHK(hipStreamSynchronize(c->stream));
+        hipFree(c->score_idx); c->score_idx = nullptr; c->score_idx_bytes = 0;
+    }
+    if (mfma_attn && stage_has_attn && c->mode != LNB_MODE_FAST) {
         const int cap_mb = env_int("LNB_ATTN_SIDX_MB", 4096);                 // (read per call: a test switches it inside one process)
         const size_t jt = (size_t)(T + 15) / 16, need = (size_t)c->m->a.n_heads * (size_t)((seq + 15) / 16) * jt * 512;
         if (cap_mb > 0 && need <= ((size_t)cap_mb << 20)) {
