@@ -796,8 +796,8 @@ def bench_main(args, cfg, name):
         local %= max(1, n_dev)
         # the torchrun agent's own store listens on MASTER_PORT: the control star takes a port next to it
         # first contact is bounded: a rank that never shows up, a device without peer access or an RCCL that cannot start ends ALL ranks with one
-        # message inside LNB_PREFLIGHT_TIMEOUT seconds (default 60) instead of a hang somewhere inside the first exchange
-        t_first = float(os.environ.get("LNB_PREFLIGHT_TIMEOUT", "60"))
+        # message inside LNB_PREFLIGHT_TIMEOUT seconds (default 120: eight ranks initialising HIP on a cold node at once have never been timed here) instead of a hang somewhere inside the first exchange
+        t_first = float(os.environ.get("LNB_PREFLIGHT_TIMEOUT", "120"))
         try:
             grp = TcpGroup(rank, world, os.environ["MASTER_ADDR"], int(os.environ["MASTER_PORT"]) + int(os.environ.get("LNB_CONTROL_PORT_OFFSET", "23")), timeout=t_first)
         except Exception as e:
@@ -810,7 +810,7 @@ def bench_main(args, cfg, name):
             abort_all(rank, "in the preflight (before anything was built or timed)", bad)
         # every rank is there and healthy: from here the control star only has to notice a rank that DIES (its socket closes at once); the
         # patience covers rank 0's probe and the slowest rank's stage build on a cold box.  Forming the communicator stays bounded by the watchdog below.
-        grp.set_timeout(max(t_first, 180.0))
+        grp.set_timeout(max(t_first, 180.0, float(os.environ.get("LNB_COMM_INIT_TIMEOUT", "180")) + 60.0))
         n_seq = 2 * world if world > 1 else int(os.environ.get("LNB_PIPELINE_SEQS", "2"))
         costs = None
         if world > 1 and os.environ.get("LNB_PIPELINE_PROBE", "1") != "0":
@@ -822,8 +822,11 @@ def bench_main(args, cfg, name):
         ok, pipe, why = 1, None, None
         import threading
         # ncclCommInitRank blocks until all N ranks have joined: a watchdog ends this rank (and, through the launcher, the others) if it does not return
-        dog = threading.Timer(t_first, lambda: (sys.stderr.write("bench.py --gpus %d ABORTED: rank %d's ncclCommInitRank did not return within %.0f s "
-                                                                  "(a peer missing, or no peer-to-peer path between the GPUs)\n" % (world, rank, t_first)), os._exit(4)))
+        # (its own, longer patience -- LNB_COMM_INIT_TIMEOUT, default 180 s: the first communicator of a cold 8-GPU node detects the topology and opens its xGMI
+        # rings, which has never been timed here; a false abort would cost the run, a true hang still ends)
+        t_comm = max(t_first, float(os.environ.get("LNB_COMM_INIT_TIMEOUT", "180")))
+        dog = threading.Timer(t_comm, lambda: (sys.stderr.write("bench.py --gpus %d ABORTED: rank %d's ncclCommInitRank did not return within %.0f s "
+                                                                "(a peer missing, or no peer-to-peer path between the GPUs)\n" % (world, rank, t_comm)), os._exit(4)))
         dog.daemon = True
         try:
             uid = grp.broadcast(lnb.Pipeline.unique_id() if (rank == 0 and world > 1) else None)
