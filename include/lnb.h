@@ -73,6 +73,9 @@ int lnb_runtime_info(int device, int probe_queues, lnb_runtime_info_t* out);
  * NULL) and whether `device` can map `peer`'s memory -- the peer-to-peer path RCCL's ncclSend / ncclRecv ride on (xGMI inside a node) */
 int lnb_device_info(int device, char* name, int name_cap, int64_t* hbm_bytes, int* n_cus, char* arch, int arch_cap);
 int lnb_device_can_access_peer(int device, int peer, int* out);
+/* The PCI bus id of a device index ("0000:c1:00.0"): what tells two ranks apart that both say "device 0" because their launcher gave each of them
+ * one visible GPU (a multi-GPU preflight compares these, not the indices). */
+int lnb_device_pci_bus_id(int device, char* out, int cap);
 
 /* ---- model: replaces model.NewLlamaTransformer (src/model/llamatransformer.go:64-113) --------------
  * A model handle owns the device copy of one pipeline STAGE: transformer blocks [layer_begin,layer_end),

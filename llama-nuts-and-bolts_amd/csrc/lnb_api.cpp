@@ -300,6 +300,13 @@ extern "C" int lnb_device_info(int device, char* name, int name_cap, int64_t* hb
     if (n_cus) *n_cus = prop.multiProcessorCount;
     return 0;
 }
+extern "C" int lnb_device_pci_bus_id(int device, char* out, int cap) {
+    if (!out || cap < 16) return fail("null argument or a buffer under 16 bytes");
+    int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
+    if (device < 0 || device >= ndev) return fail("device %d out of range (%d devices)", device, ndev);
+    HIPCHK(hipDeviceGetPCIBusId(out, cap, device));
+    return 0;
+}
 extern "C" int lnb_device_can_access_peer(int device, int peer, int* out) {
     if (!out) return fail("null argument");
     int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));

@@ -48,7 +48,7 @@ LLAMA_8B = dict(dim=4096, n_layers=32, n_heads=32, n_kv_heads=8, vocab_size=1282
 
 _lib = None
 EXPORTS = [
-    "lnb_last_error", "lnb_device_count", "lnb_device_info", "lnb_device_can_access_peer", "lnb_model_create", "lnb_model_create_parts", "lnb_model_destroy", "lnb_model_ffn_hidden_dim",
+    "lnb_last_error", "lnb_device_count", "lnb_device_info", "lnb_device_can_access_peer", "lnb_device_pci_bus_id", "lnb_model_create", "lnb_model_create_parts", "lnb_model_destroy", "lnb_model_ffn_hidden_dim",
     "lnb_model_set_tensor", "lnb_model_get_tensor", "lnb_model_fill_synthetic", "lnb_model_finalize",
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
@@ -95,6 +95,7 @@ def lib():
     L.lnb_device_count.argtypes = [C.POINTER(C.c_int)]
     L.lnb_device_info.argtypes = [C.c_int, C.c_char_p, C.c_int, C.POINTER(C.c_int64), C.POINTER(C.c_int), C.c_char_p, C.c_int]
     L.lnb_device_can_access_peer.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_int)]
+    L.lnb_device_pci_bus_id.argtypes = [C.c_int, C.c_char_p, C.c_int]
     L.lnb_model_create.argtypes = [C.POINTER(ModelArgs), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.lnb_model_create_parts.argtypes = [C.POINTER(ModelArgs), C.c_int, C.c_int, C.c_int, C.POINTER(vp)]
     L.lnb_model_destroy.argtypes = [vp]
@@ -236,6 +237,12 @@ def can_access_peer(device, peer):
     out = C.c_int(0)
     _chk(lib().lnb_device_can_access_peer(device, peer, C.byref(out)))
     return bool(out.value)
+
+
+def pci_bus_id(device):
+    buf = C.create_string_buffer(32)
+    _chk(lib().lnb_device_pci_bus_id(device, buf, 32))
+    return buf.value.decode()
 
 
 def rccl_selftest(device=0, n_bytes=1 << 20):

@@ -738,13 +738,15 @@ def preflight(lnb, grp, rank, world, local):
         rec["visible_devices"] = n_dev
         rec.update(lnb.device_info(local))
         rec["peer_access"] = [lnb.can_access_peer(local, j) for j in range(n_dev)]
+        rec["pci"] = lnb.pci_bus_id(local)
         t0 = time.perf_counter()
         lnb.rccl_selftest(local, 1 << 16)
         rec["rccl_selftest"] = "ok (%.1f s incl. loading librccl)" % (time.perf_counter() - t0)
     except Exception as e:
         rec["error"] = "%s: %s" % (type(e).__name__, e)
     recs = grp.all_reduce([rec], lambda vs: sorted(sum(vs, []), key=lambda r: r["rank"]))
-    devs = [r["device"] for r in recs]
+    # the GPU a rank sits on is its PCI bus id, not its index: a launcher that hands every rank ONE visible device makes them all "device 0"
+    devs = [r.get("pci") or r["device"] for r in recs]
     bad = ["rank %d: %s" % (r["rank"], r["error"]) for r in recs if "error" in r]
     if world > 1 and len(set(devs)) != len(devs) and os.environ.get("LNB_PIPELINE_BACKEND", "nccl") == "nccl":
         bad.append("ranks share a GPU (devices %s): RCCL wants one GPU per rank" % devs)

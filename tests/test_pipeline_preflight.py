@@ -26,6 +26,8 @@ WORKER = textwrap.dedent("""
         @staticmethod
         def can_access_peer(a, b): return True
         @staticmethod
+        def pci_bus_id(d): return "0000:{:02x}:00.0".format(0xc1 + (rank if scenario == "one_visible_gpu_per_rank" else d))
+        @staticmethod
         def rccl_selftest(d, n):
             if scenario == "selftest_fails_on_rank_1" and rank == 1:
                 raise RuntimeError("ncclCommInitRank failed: unhandled system error")
@@ -37,7 +39,7 @@ WORKER = textwrap.dedent("""
         grp = pipeline.TcpGroup(rank, world, "127.0.0.1", port, timeout=float(os.environ["LNB_PREFLIGHT_TIMEOUT"]))
     except Exception as e:
         print(json.dumps({"rank": rank, "rendezvous_failed": type(e).__name__, "after_s": round(time.time() - t0, 1)})); sys.exit(4)
-    local = 0 if scenario == "two_ranks_on_one_gpu" else rank
+    local = 0 if scenario in ("two_ranks_on_one_gpu", "one_visible_gpu_per_rank") else rank
     recs, bad = pipeline.preflight(FakeLnb, grp, rank, world, local)
     print(json.dumps({"rank": rank, "records": recs, "bad": bad}))
     sys.stdout.flush()
@@ -93,3 +95,13 @@ def test_a_rank_that_never_shows_up_ends_the_rendezvous_within_the_timeout():
     assert rcs[0] == 4 and secs < 15, (rcs, outs, secs)
     d = json.loads(outs[0][0].strip().splitlines()[-1])
     assert d["rendezvous_failed"] and d["after_s"] <= 5
+
+
+def test_ranks_that_all_say_device_0_are_told_apart_by_their_pci_bus_id():
+    """a launcher that gives every rank ONE visible GPU makes each of them "device 0": the preflight compares PCI bus ids (lnb_device_pci_bus_id), so that
+    is not taken for two ranks sharing a GPU -- which still is (test above: same index AND same bus id)"""
+    rcs, outs, _ = _run("one_visible_gpu_per_rank", world=2)
+    assert rcs == [0, 0], outs
+    d = json.loads(outs[0][0].strip().splitlines()[-1])
+    assert d["bad"] == [] and [x["device"] for x in d["records"]] == [0, 0] and len({x["pci"] for x in d["records"]}) == 2
+
