@@ -102,7 +102,8 @@ def pmc_traffic(kernel_name, model_name, mode):
 
 
 GOLDENS = {("llama8b", 128): "configs1_tokens.json", ("llama8b-2l", 4096): "configs2_2layer_tokens.json", ("llama8b-8l", 4096): "configs2_8layer_tokens.json",
-           ("llama8b", 4096): "configs2_32layer_tokens.json"}      # configs[2] at FULL depth: made once by tests/golden/make_configs2_cut_tokens.py 32 (hours of host cores)
+           ("llama8b", 4096): "configs2_32layer_tokens.json",
+           ("llama70b-like", 16): "configs4_80layer_tokens.json"}     # configs[4] at FULL depth (80 layers, 141 GB in the oracle's memory: made on the GPU box's host, make_configs4_cut_tokens.py 80)      # configs[2] at FULL depth: made once by tests/golden/make_configs2_cut_tokens.py 32 (hours of host cores)
 
 
 def check_golden(args, first_tok, warm_toks, timed_toks, key=None):
@@ -224,9 +225,9 @@ CFG4_P, CFG4_W, CFG4_K = 16, 2, 16
 def configs4_record(lnb, args):
     """BASELINE configs[4]'s shape (random-init Llama shape dim 8192 x 80 layers, "70B-like") on ONE GPU, inside the default line: 141 GB of synthetic
     weights resident, a 16-token prompt (one Forward on the f32 matrix cores), 2 warm-up + 16 timed greedy steps (two repeats, the faster one).  The
-    first 17 tokens of the 10-LAYER cut of this shape are pinned to the CPU oracle (tests/golden/configs4_10layer_tokens.json, replayed by
-    tests/test_gpu_round6.py); at 80 layers no oracle run exists, so the line carries a device self-check instead and says so: the same continuation
-    through the throughput kernel forms and through the forced serial softmax denominator, token for token."""
+    run's 19 tokens are compared with the CPU oracle's continuation of the FULL 80-layer model (tests/golden/configs4_80layer_tokens.json, made once on the
+    GPU box's host: the oracle holds the 141 GB in memory); the 10-layer cut (one pipeline stage) is pinned too.  Next to it the device self-check: the same
+    continuation through the throughput kernel forms and through the forced serial softmax denominator, token for token."""
     cfg = dict(lnb.LLAMA_8B, **CFG4)
     P, W, K = CFG4_P, CFG4_W, CFG4_K
     t0 = time.time()
@@ -252,6 +253,7 @@ def configs4_record(lnb, args):
         sys.exit(3)
     wall, ev_ms, out = min(reps, key=lambda r: r[0])
     run = [int(first)] + [int(t) for t in warm] + out
+    golden = check_golden(args, first, [int(t) for t in warm], out, key=("llama70b-like", CFG4_P))      # exact mode: a mismatch ends the bench (PARITY FAILURE)
     n_rows = (W + 2 * K) * (2 * cfg["n_layers"] + 1)
     fb = ctx.norm_fallbacks() if args.mode == "exact" else None
     forms = {}
@@ -268,8 +270,6 @@ def configs4_record(lnb, args):
         if args.mode == "exact" and same != len(run):
             sys.stderr.write("PARITY FAILURE (configs[4] shape): the %s disagree with the latency forms at token %d\n" % (label, same))
             sys.exit(3)
-    # the 10-layer golden's prompt and seeds are the ones used here: the FIRST token of the 80-layer model is not comparable, but the cut is what
-    # tests/test_gpu_round6.py replays -- say where the oracle evidence lives
     Tbar = pos + (K - 1) / 2.0 + 1.0
     B = algorithmic_bytes_per_token(a, model.ffn_hidden, Tbar)
     tps = K / wall
@@ -279,8 +279,9 @@ def configs4_record(lnb, args):
             "tokens_per_s": round(tps, 2), "ms_per_step": round(1e3 * wall / K, 3), "hip_event_ms_per_step": round(ev_ms / K, 3),
             "frac_of_hbm_roofline": round(tps * B / 1e9 / PEAK_HBM_GBS, 4), "algorithmic_bytes_per_token": int(B), "weight_bytes_resident": wb, "model_build_s": round(t_build, 1),
             "norm_item_walk": {"rows": n_rows, "fallback_rows": fb}, "device_self_check": forms,
-            "oracle_evidence": "the 10-layer cut of this shape (one stage of the 8-GPU pipeline) is pinned to the CPU oracle: tests/golden/configs4_10layer_tokens.json, "
-                               "replayed by tests/test_gpu_round6.py; no oracle run exists at 80 layers",
+            "tokens_vs_oracle_golden": golden if golden else {"compared": 0, "note": "tests/golden/configs4_80layer_tokens.json is missing"},
+            "oracle_evidence": "this run's tokens against the CPU oracle's continuation of the FULL 80-layer model (tests/golden/configs4_80layer_tokens.json, made on the GPU box's "
+                               "host cores); the 10-layer cut (one stage of the 8-GPU pipeline) is pinned as well (configs4_10layer_tokens.json); both replayed by tests/test_gpu_round6.py",
             "last_tokens": out[-4:]}
 
 

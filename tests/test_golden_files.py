@@ -32,17 +32,20 @@ def test_bench_knows_the_full_depth_golden():
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     assert b.GOLDENS[("llama8b", 4096)] == "configs2_32layer_tokens.json" and b.CFG2_P == 4096 and b.CFG2_W + b.CFG2_K + 1 <= 65 + 4
+    assert b.GOLDENS[("llama70b-like", 16)] == "configs4_80layer_tokens.json" and b.CFG4_P == 16 and b.CFG4["n_layers"] == 80
 
 
-def test_configs4_ten_layer_golden_is_committed():
-    """one stage of the 8-GPU pipeline of configs[4] (10 of the 80 layers of the 70B-like shape): tests/test_gpu_round6.py replays it on the device"""
-    path = os.path.join(GOLD, "configs4_10layer_tokens.json")
-    assert os.path.exists(path), "run tests/golden/make_configs4_cut_tokens.py 10"
+@pytest.mark.parametrize("n_layers,n_min", [(10, 17), (80, 19)])
+def test_configs4_goldens_are_committed(n_layers, n_min):
+    """configs[4] (the 70B-like shape): one stage of its 8-GPU pipeline (10 of the 80 layers) and the FULL 80-layer model (made on the GPU box's host: 141 GB of
+    synthetic weights in the oracle's memory, 64 threads); tests/test_gpu_round6.py replays both on the device, bench.py checks its configs4_one_gpu run against the second"""
+    path = os.path.join(GOLD, "configs4_%dlayer_tokens.json" % n_layers)
+    assert os.path.exists(path), "run tests/golden/make_configs4_cut_tokens.py %d" % n_layers
     g = json.load(open(path))
-    assert g["n_layers"] == 10 and g["model"]["dim"] == 8192 and g["model"]["n_heads"] == 64 and g["model"]["n_kv_heads"] == 8 and g["model"]["multiple_of"] == 4096
+    assert g["n_layers"] == n_layers and g["model"]["dim"] == 8192 and g["model"]["n_heads"] == 64 and g["model"]["n_kv_heads"] == 8 and g["model"]["multiple_of"] == 4096
     assert g["prompt_len"] == 16 and g["weights_seed"] == 1234 and g["prompt_seed"] == 99
     toks = np.array(g["tokens"], dtype="<i4")
-    assert len(toks) >= 17 and ((0 <= toks) & (toks < g["model"]["vocab_size"])).all()
+    assert len(toks) >= n_min and ((0 <= toks) & (toks < g["model"]["vocab_size"])).all()        # (80 layers: bench.py's configs4_one_gpu run is 1 + 2 + 16 tokens)
     assert hashlib.sha256(toks.tobytes()).hexdigest() == g["tokens_sha256"]
     prompt = orc.synth_tokens(g["prompt_seed"], g["prompt_len"], g["model"]["vocab_size"])
     assert hashlib.sha256(prompt.astype("<i4").tobytes()).hexdigest() == g["prompt_sha256"]

@@ -48,6 +48,32 @@ def test_committed_configs4_ten_layer_golden_is_reproduced_by_the_device(lnb):
     gm.close()
 
 
+def test_committed_configs4_eighty_layer_golden_is_reproduced_by_the_device(lnb):
+    """BASELINE.json configs[4] at FULL depth: dim 8192 x 80 layers, 141 GB of synthetic weights on the one GPU, 16-token prompt + the CPU oracle's greedy continuation
+    (tests/golden/configs4_80layer_tokens.json: made by make_configs4_cut_tokens.py 80 on the GPU box's host cores -- the oracle holds the whole model in memory).  Latency
+    and throughput kernel forms, and the forced serial softmax denominator (llamatransformer.go:145-180 at the shape the 8-GPU pipeline shards)."""
+    path = os.path.join(ROOT, "tests", "golden", "configs4_80layer_tokens.json")
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/configs4_80layer_tokens.json not generated yet")
+    gold = json.load(open(path))
+    cfg = dict(orc.LLAMA_8B, **{k: gold["model"][k] for k in ("dim", "n_layers", "n_heads", "n_kv_heads", "multiple_of")})
+    assert cfg["dim"] == 8192 and cfg["n_layers"] == 80
+    P, n = gold["prompt_len"], len(gold["tokens"])
+    try:
+        gm = lnb.LlamaTransformer(**cfg).fill_synthetic(gold["weights_seed"]).finalize()
+    except lnb.LnbError as e:                                # (a GPU with less than 141 GB free)
+        pytest.skip("the 80-layer model does not fit: %s" % str(e)[:120])
+    assert gm.weight_bytes() > 140e9
+    prompt = lnb.synth_tokens(gold["prompt_seed"], P, cfg["vocab_size"])
+    for label, setup in (("latency", lambda c: c), ("throughput", lambda c: c.set_schedule("throughput")), ("serial Z", lambda c: c.set_attention(-1, 1))):
+        gc = setup(lnb.InferenceContext(gm, P + n + 1))
+        _, first = gc.Forward(prompt, 0, want_logits=False)
+        got, _ = gc.decode_greedy(first, P, n - 1)
+        assert [first] + [int(t) for t in got] == gold["tokens"], label
+        gc.close()
+    gm.close()
+
+
 def test_configs3_literal_eight_stages_of_four_blocks_on_one_gpu(lnb):
     """llamatransformer.go:156-164 cut as BASELINE.json configs[3] says: 8 stages x 4 whole blocks of the Llama-3.1-8B shape, 512-token prompts
     ([512, 4096] bf16 = 4 MiB per hop), 2N = 16 sequences in flight on the N = 8 schedule (pipeline.run_ticks_native: rank r runs item t - 2r at

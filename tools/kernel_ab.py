@@ -14,8 +14,9 @@ if os.environ.get("AB_ZERO"):     # DVFS experiment: the blocks' matrices zeroed
     for name, shape in m.tensor_infos():
         if name.startswith("layers.") and ("attention.w" in name or "feed_forward.w" in name):
             m.set_tensor(name, np.zeros(shape, dtype=np.uint16))
-m.finalize()
-c = lnb.InferenceContext(m, 512)
+m.finalize(rope_rows=max(0, int(os.environ.get("AB_POS", "272")) + 64))
+POS = int(os.environ.get("AB_POS", "272"))          # context length the attention is timed at (AB_POS=4100: configs[2]'s decode)
+c = lnb.InferenceContext(m, max(512, POS + 64))
 prompt = lnb.synth_tokens(99, 128, cfg["vocab_size"])
 _, first = c.Forward(prompt, 0, want_logits=False)
 toks, _ = c.decode_greedy(first, 128, 16)
@@ -25,7 +26,7 @@ if os.environ.get("AB_SCHED"):
 out, reps = {}, {}
 for rep in range(3):
     for w, n in enumerate(names):
-        ms = c.profile_kernel(w, 272, iters)
+        ms = c.profile_kernel(w, POS, iters)
         out[n] = min(out.get(n, 1e9), round(ms * 1e3, 2))
         reps.setdefault(n, []).append(round(ms * 1e3, 2))
-print(json.dumps({"so": os.path.basename(os.environ.get("LNB_SO", "default")), "layers": cfg["n_layers"], "us": out, "reps": reps, "tok": [int(t) for t in toks[-3:]]}))
+print(json.dumps({"so": os.path.basename(os.environ.get("LNB_SO", "default")), "layers": cfg["n_layers"], "pos": POS, "us": out, "reps": reps, "tok": [int(t) for t in toks[-3:]]}))
