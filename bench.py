@@ -126,6 +126,34 @@ def check_golden(args, first_tok, warm_toks, timed_toks, key=None):
     return {"compared": n, "identical_prefix": agree, "golden": "tests/golden/%s (CPU oracle)" % fn}
 
 
+_MULTI = {}
+
+
+def check_multi_golden(args, P, seqs, what):
+    """Every sequence of a multi-prompt section (sequence s has the prompt synth_tokens(99 + s, P)) against the CPU ORACLE's continuation of ITS prompt on the full
+    32-layer model: tests/golden/configs1_multi_P<P>_tokens.json (made on the GPU box's host cores by tests/golden/make_multi_prompt_tokens.py).  `seqs` = one token list
+    per sequence, first token first.  exact mode: a mismatch is a parity failure and the bench refuses to print; None when no file covers the section."""
+    if args.model != "llama8b":
+        return None
+    path = os.path.join(ROOT, "tests", "golden", "configs1_multi_P%d_tokens.json" % P)
+    if path not in _MULTI:
+        _MULTI[path] = json.load(open(path)) if os.path.exists(path) else None
+    g = _MULTI[path]
+    if not g:
+        return None
+    n, agree_all, per = min(len(seqs), g["n_seq"]), 0, 0
+    for s_ in range(n):
+        got, gold = [int(t) for t in seqs[s_]], g["tokens"][s_]
+        m_ = min(len(got), len(gold))
+        per = m_
+        agree = next((i for i in range(m_) if got[i] != gold[i]), m_)
+        if agree < m_ and args.mode == "exact":
+            sys.stderr.write("PARITY FAILURE (%s): token %d of sequence %d is %d, the CPU oracle's is %d (tests/golden/configs1_multi_P%d_tokens.json)\n" % (what, agree, s_, got[agree], gold[agree], P))
+            sys.exit(3)
+        agree_all += int(agree == m_)
+    return {"sequences_compared": n, "sequences_identical": agree_all, "tokens_each": per, "golden": "tests/golden/configs1_multi_P%d_tokens.json (CPU oracle, every sequence its own prompt)" % P}
+
+
 def device_self_check(lnb, model, args, prompt, seq_len, run_tokens):
     """No oracle golden exists for this workload (the CPU oracle cannot walk a 32-layer model over thousands of positions in a test's
     time): the number is backed by a DEVICE-side consistency check instead, and says so.  The same continuation is replayed on fresh
@@ -317,6 +345,7 @@ def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens, n_seq=None
     pipe.sync()
     wall = time.perf_counter() - t0
     toks0 = [int(pipe.read_tokens(q, 1)[0]) for q in st["slots"][0]]
+    multi = check_multi_golden(args, P, [[int(pipe.read_tokens(q, 1)[0]) for q in st["slots"][s_]] for s_ in range(n_seq)], "%d sequences in flight (%s forms)" % (n_seq, sched))
     n_cmp = min(len(toks0), len(single_run_tokens))
     same = 0
     while same < n_cmp and toks0[same] == single_run_tokens[same]:
@@ -329,7 +358,7 @@ def concurrent_sequences(lnb, model, cfg, args, a, single_run_tokens, n_seq=None
     B = algorithmic_bytes_per_token(a, model.ffn_hidden, Tbar)
     return {"n": n_seq, "schedule": sched, "GPU_MAX_HW_QUEUES": _c_getenv("GPU_MAX_HW_QUEUES"), "tokens_per_s": round(tps, 2), "steps_each": K, "ms_per_token": round(1e3 * wall / (n_seq * K), 4),
             "frac_of_hbm_roofline": round(tps * B / 1e9 / PEAK_HBM_GBS, 4),
-            "sequence0_tokens_vs_single_run": {"compared": n_cmp, "identical_prefix": same},
+            "sequence0_tokens_vs_single_run": {"compared": n_cmp, "identical_prefix": same}, "every_sequence_vs_oracle_golden": multi,
             "note": "aggregate of independent prompts on ONE GPU; weights are re-read per sequence (no batching: every token keeps its own exact chains)"}
 
 
@@ -357,6 +386,7 @@ def batched_sequences(lnb, model, cfg, args, a, single_run_tokens):
         got, ev_ms = b.decode(toks, [P + W] * n, K)
         wall = time.perf_counter() - t1
         seq0 = [firsts[0]] + [int(t) for t in warm[0]] + [int(t) for t in got[0]]
+        multi = check_multi_golden(args, P, [[firsts[s]] + [int(t) for t in warm[s]] + [int(t) for t in got[s]] for s in range(n)], "batch of %d" % n)
         n_cmp = min(len(seq0), len(single_run_tokens))
         same = next((i for i in range(n_cmp) if seq0[i] != single_run_tokens[i]), n_cmp)
         Tbar = P + W + (K - 1) / 2.0 + 1.0
@@ -369,6 +399,8 @@ def batched_sequences(lnb, model, cfg, args, a, single_run_tokens):
                "hbm_frac_of_bytes_actually_needed": round(step_bytes * (K / wall) / 1e9 / PEAK_HBM_GBS, 4),
                "equivalent_frac_if_each_sequence_read_the_weights": round(tps * per_seq / 1e9 / PEAK_HBM_GBS, 4),
                "sequence0_tokens_vs_single_run": {"compared": n_cmp, "identical_prefix": same}}
+        if multi:
+            run["every_sequence_vs_oracle_golden"] = multi
         if with_kernels:
             names = ["norm+wqkv+rope", "attention", "wo+residual", "norm+w1|w3+silu", "w2+residual", "norm+output", "whole block"]
             run["kernels_us"] = {names[w]: round(1e3 * b.profile_kernel(w, int(Tbar) - 1, 16), 2) for w in range(7)}

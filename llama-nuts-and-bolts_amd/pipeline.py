@@ -674,6 +674,26 @@ def _golden_check(tokens, prompt_len, model_name):
     return {"compared": n, "identical_prefix": agree, "golden": "tests/golden/configs1_tokens.json (CPU oracle)"}
 
 
+def _multi_golden_check(seqs, prompt_len, model_name):
+    """EVERY sequence in flight (sequence s has the prompt synth_tokens(99 + s, P)) against the CPU oracle's continuation of its own prompt on the full model:
+    tests/golden/configs1_multi_P<P>_tokens.json (tests/golden/make_multi_prompt_tokens.py), as bench.py's one-GPU sections do"""
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "configs1_multi_P%d_tokens.json" % prompt_len)
+    if model_name != "Llama-3.1-8B" or not seqs or not os.path.exists(path):
+        return None
+    g = json.load(open(path))
+    n = min(len(seqs), g["n_seq"])
+    same, per, first_bad = 0, 0, None
+    for q in range(n):
+        got, gold = [int(t) for t in seqs[q]], g["tokens"][q]
+        per = min(len(got), len(gold))
+        agree = next((i for i in range(per) if got[i] != gold[i]), per)
+        same += int(agree == per)
+        if agree < per and first_bad is None:
+            first_bad = {"sequence": q, "token": agree, "got": got[agree], "oracle": gold[agree]}
+    return {"sequences_compared": n, "sequences_identical": same, "tokens_each": per, "first_mismatch": first_bad,
+            "golden": "tests/golden/configs1_multi_P%d_tokens.json (CPU oracle, every sequence its own prompt)" % prompt_len}
+
+
 def one_gpu_anchor(lnb, grp, rank, world, cfg, local, mode, P, W, K, n_seq, seq_len, batched, sched="throughput"):
     """The same workloads on ONE GPU holding the whole model, measured in this run on rank 0's GPU while the other ranks wait: the anchor
     of the line's efficiency figures (value_N / (N x anchor)).  Unbatched: n_seq sequences in flight through the one-GPU form of the tick
@@ -874,6 +894,12 @@ def bench_main(args, cfg, name):
             pipe.sync(); grp.barrier()
             wall = grp.all_reduce(time.perf_counter() - t0, max)
             toks0 = slots_tokens(st["slots"][0]) if rank == world - 1 else None
+            toks_all = None
+            if rank == world - 1:
+                try:
+                    toks_all = [slots_tokens(st["slots"][q]) for q in range(n_seq)]
+                except lnb.LnbError:                          # (log wrapped on a very long run: sequence 0 above was read first and still stands)
+                    toks_all = None
             # single stream: sequence 0 again on its (reset) context, W_s warm-up + K_s timed steps
             Ks, Ws = min(K, int(os.environ.get("LNB_SINGLE_STREAM_STEPS", "32"))), min(W, 4)
             c0 = stage.ctx[0]; c0.reset()
@@ -886,10 +912,10 @@ def bench_main(args, cfg, name):
             wall_s = grp.all_reduce(time.perf_counter() - t1, max)
             toks_s = slots_tokens(ss["slots"]) if rank == world - 1 else None
             c0.set_schedule(sched)
-            info = grp.all_reduce([(rank, pipe.comm_count(), toks0, toks_s)], lambda vs: sorted(sum(vs, [])))
-            toks0 = info[-1][2]; toks_s = info[-1][3]
+            info = grp.all_reduce([(rank, pipe.comm_count(), toks0, toks_s, toks_all)], lambda vs: sorted(sum(vs, [])))
+            toks0 = info[-1][2]; toks_s = info[-1][3]; toks_all = info[-1][4]
             return {"wall": wall, "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * n_seq), 1),
-                    "rccl_comm_count_per_rank": [c for _, c, _, _ in info], "tokens_seq0": toks0,
+                    "rccl_comm_count_per_rank": [c for _, c, _, _, _ in info], "tokens_seq0": toks0, "tokens_all": toks_all,
                     "single_stream": {"tokens_per_s": round(Ks / wall_s, 2), "steps": Ks, "ms_per_token": round(1e3 * wall_s / Ks, 4),
                                       "tokens_equal_sequence0_of_the_batch": bool(toks_s is not None and toks0 is not None and toks_s[:len(toks0)] == toks0[:len(toks_s)])}}
 
@@ -917,9 +943,10 @@ def bench_main(args, cfg, name):
             uid2 = grp.broadcast(lnb.Pipeline.unique_id() if (rank == 0 and world > 1) else None)
             pp = lnb.Pipeline(st.model, rank, world, uid2)
             prm = [lnb.synth_tokens(99 + q, P, cfg["vocab_size"]) for q in range(G * nb)]          # sequence 0 = the headline's prompt
-            first_slot0 = None
+            first_slot0, first_slots = None, []
             for q in range(G * nb):
                 sl = prefill_through_pipeline(rank, world, pp, st.ctx[q], prm[q])
+                first_slots.append(sl)
                 if q == 0:
                     first_slot0 = sl
             pp.sync(); grp.barrier()
@@ -937,13 +964,22 @@ def bench_main(args, cfg, name):
             toks0 = None
             if rank == world - 1:
                 toks0 = [int(pp.read_tokens(first_slot0, 1)[0])] + [int(pp.read_tokens(q, 1)[0]) for q in sb["slots"][0]]
+            multi = None
+            if rank == world - 1:                            # every sequence of every group: its prefill token + the group's steps (a step's nb tokens are one contiguous run of the log)
+                try:
+                    steps = [[pp.read_tokens(q, nb) for q in sb["slots"][g_]] for g_ in range(G)]
+                    multi = _multi_golden_check([[int(pp.read_tokens(first_slots[g_ * nb + j_], 1)[0])] + [int(stp[j_]) for stp in steps[g_]] for g_ in range(G) for j_ in range(nb)], P, name)
+                except lnb.LnbError as e:                    # (a long run: the log keeps the newest 65536 tokens, the early slots are gone -- no rank may leave the collectives for that)
+                    multi = {"skipped": str(e)[:200]}
             info = grp.all_reduce([(rank, pp.comm_count(), toks0)], lambda vs: sorted(sum(vs, [])))
+            multi = grp.all_reduce([(rank, multi)], lambda vs: sorted(sum(vs, [])))[-1][1]
             cuts = grp.all_reduce([(rank, lb, le, copy)], lambda vs: sorted(sum(vs, [])))
             res_b = {"wall": wall_b, "sequences_in_flight": G * nb, "groups": G, "batch": nb, "blocks_per_gpu": [e_ - b_ for _, b_, e_, _ in cuts],
                      "second_weight_copy_per_rank": [bool(c_) for _, _, _, c_ in cuts],
                      "cut": "whole blocks (lnb_model_enable_batch refuses a stage cut inside a block: the batched hand-off is [n, dim] only)",
                      "tokens_per_s": round(K * G * nb / wall_b, 2), "host_enqueue_us_per_tick": round(1e6 * t_host / max(1, K * G), 1),
-                     "rccl_comm_count_per_rank": [c for _, c, _ in info], "tokens_vs_oracle_golden": _golden_check(info[-1][2], P, name) if info[-1][2] else None}
+                     "rccl_comm_count_per_rank": [c for _, c, _ in info], "tokens_vs_oracle_golden": _golden_check(info[-1][2], P, name) if info[-1][2] else None,
+                     "every_sequence_vs_oracle_golden": multi}
             for b_ in bats:
                 b_.close()
             pp.close(); st.close()
@@ -952,7 +988,9 @@ def bench_main(args, cfg, name):
         m_bal = measure()
         wall = m_bal["wall"]
         toks0 = m_bal.pop("tokens_seq0")
+        toks_all = m_bal.pop("tokens_all")
         extra = {"exchange": "RCCL point-to-point inside the library (lnb_pipeline_tick), stage steps as captured graphs",
+                 "every_sequence_vs_oracle_golden": _multi_golden_check(toks_all, P, name),
                  "host_enqueue_us_per_tick": m_bal["host_enqueue_us_per_tick"], "rccl_comm_count_per_rank": m_bal["rccl_comm_count_per_rank"],
                  "single_stream": m_bal["single_stream"], "tokens_vs_oracle_golden": _golden_check(toks0, P, name) if toks0 else None}
         if rank == world - 1 and os.environ.get("LNB_PIPELINE_DUMP_TOKENS"):

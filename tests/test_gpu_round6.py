@@ -111,8 +111,41 @@ def test_configs3_literal_eight_stages_of_four_blocks_on_one_gpu(lnb):
         more, _ = wc.decode_greedy(first, P, n_decode)
         assert got[s] == [first] + [int(t) for t in more], s
         wc.close()
-    # sequence 0 has the headline's seed: its first 128 prompt tokens are configs[1]'s prompt, but a 512-token prompt is another computation -- no golden here
     whole.close()
+    # ... and every sequence against the CPU ORACLE's continuation of its 512-token prompt on the full 32-layer model (tests/golden/configs1_multi_P512_tokens.json:
+    # made on the GPU box's host cores by tests/golden/make_multi_prompt_tokens.py 512 16 10; tests/test_golden_files.py checks that the file is there)
+    gpath = os.path.join(ROOT, "tests", "golden", "configs1_multi_P512_tokens.json")
+    if os.path.exists(gpath):
+        g = json.load(open(gpath))
+        assert g["prompt_len"] == P and g["n_seq"] >= n_seq
+        for s in range(n_seq):
+            m_ = min(len(got[s]), len(g["tokens"][s]))
+            assert m_ >= 1 + n_decode and got[s][:m_] == g["tokens"][s][:m_], s
+
+
+@pytest.mark.parametrize("copy", [False, True])
+def test_every_sequence_of_a_128_batch_on_the_full_model_is_its_oracle_continuation(lnb, copy):
+    """Batched exact decode at FULL depth (llamatransformer.go:215-254 for 128 generations at once): 128 prompts of 128 tokens on the 32-layer 8B shape, one pass over the
+    weights per step for all of them (rows of gemm_stream_kernel; without and with the matrix-core copy), 1 + 11 tokens each -- every sequence against the CPU ORACLE's
+    continuation of ITS OWN prompt (tests/golden/configs1_multi_P128_tokens.json, tests/golden/make_multi_prompt_tokens.py 128 128 56 on the GPU box's host cores)."""
+    gpath = os.path.join(ROOT, "tests", "golden", "configs1_multi_P128_tokens.json")
+    if not os.path.exists(gpath):
+        pytest.skip("tests/golden/configs1_multi_P128_tokens.json not generated yet")
+    g = json.load(open(gpath))
+    cfg, P, n, K = dict(lnb.LLAMA_8B), g["prompt_len"], min(128, g["n_seq"]), 11
+    gm = lnb.LlamaTransformer(**cfg).fill_synthetic(g["weights_seed"]).finalize()
+    if copy:
+        gm.enable_batch()
+    ctxs = [lnb.InferenceContext(gm, P + K + 8) for _ in range(n)]
+    firsts = [c.Forward(lnb.synth_tokens(g["prompt_seed_base"] + s, P, cfg["vocab_size"]), 0, want_logits=False)[1] for s, c in enumerate(ctxs)]
+    b = lnb.Batch(ctxs)
+    got, _ = b.decode(firsts, [P] * n, K)
+    for s in range(n):
+        assert [firsts[s]] + [int(t) for t in got[s]] == g["tokens"][s][:1 + K], s
+    b.close()
+    for c in ctxs:
+        c.close()
+    gm.close()
 
 
 def test_runtime_info_reports_the_queues_the_streams_really_get(lnb):
