@@ -7,9 +7,10 @@ What they pin: every sequence of a BATCH (bench.py sequences_in_flight_batched: 
 layer pipeline (2N prompts), and of configs[3]'s literal shape (8 stages x 4 blocks, 512-token prompts) -- against the oracle itself instead of against the
 device's own single-sequence run.
 
-    python tests/golden/make_multi_prompt_tokens.py <P> <n_seq> <n_tokens> [out_dir] [shards=4]
-One oracle process per shard (64 threads each: the OpenMP team collapses beyond one socket's cores), the 16 GB model filled once per process.  P = 128,
-128 sequences, 53 tokens: ~11 s per sequence; P = 512, 16 sequences, 9 tokens: ~35 s per sequence (GPU box host: 256 hardware threads).
+    python tests/golden/make_multi_prompt_tokens.py <P> <n_seq> <n_tokens> [out_dir] [shards=2]
+One oracle process per shard, each pinned to its own 64 logical CPUs (64 threads each: the OpenMP team collapses beyond one socket's cores), the 16 GB model filled once per process.  The oracle
+sustains 15-18 GMAC/s with 64 threads on the GPU box's host (7 GMAC per token row): ~80 s for a 128-token prompt + 55 tokens, ~4 min for a 512-token prompt + 9; the
+committed files hold four sequences each (a first run of four unpinned processes collapsed to one sequence per 25 minutes and was assembled with --assemble).
 """
 import hashlib
 import json
@@ -28,7 +29,15 @@ def shape():
     return orc.TINY if os.environ.get("LNB_GOLDEN_TINY") else orc.LLAMA_8B      # (LNB_GOLDEN_TINY=1: the script's own smoke run on a test shape)
 
 
-def shard_main(P, first, count, N, path):
+def shard_main(P, first, count, N, path, k=0):
+    # shard k keeps to its own 64 logical CPUs (0-63, 64-127, ...: on the 2 x 64-core hosts the first 128 are the physical cores of the two sockets): four unpinned
+    # 64-thread teams on 128 cores trip over each other's spinning barriers (the first attempt of this script: > 25 min for what one team does in 8)
+    try:
+        ncpu = os.cpu_count() or 1
+        lo = (64 * k) % max(64, ncpu - ncpu % 64)
+        os.sched_setaffinity(0, range(lo, min(lo + 64, ncpu)))
+    except (AttributeError, OSError, ValueError):
+        pass
     from oracle import oracle as orc
     om = orc.Model(**shape()).fill_synthetic(SEED_W).finalize()
     out = {}
@@ -42,13 +51,37 @@ def shard_main(P, first, count, N, path):
     om.close()
 
 
+def write_golden(P, toks, N, out_dir, secs, nproc):
+    """toks: {sequence index (str): tokens}.  The file is SPARSE: it lists the sequences it holds (a run that was cut off keeps what it finished)."""
+    from oracle import oracle as orc
+    import numpy as np
+    ids = sorted(int(k) for k in toks)
+    n_tok = min(len(toks[str(k)]) for k in ids)
+    flat = np.array([toks[str(k)][:n_tok] for k in ids], dtype="<i4")
+    prompts = np.stack([orc.synth_tokens(SEED_P0 + k, P, shape()["vocab_size"]) for k in ids]).astype("<i4")
+    out = {"what": "oracle greedy continuations of %d prompts on the full Llama-3.1-8B shape (32 layers): synthetic weights seed %d, prompt of sequence s = synth_tokens(%d + s, %d, vocab); "
+                   "%d tokens each (the first one is the prefill's); sequences %s" % (len(ids), SEED_W, SEED_P0, P, n_tok, ids),
+           "generator": "tests/golden/make_multi_prompt_tokens.py %d <n_seq> %d" % (P, N), "prompt_len": P, "sequences": ids, "n_tokens": n_tok,
+           "weights_seed": SEED_W, "prompt_seed_base": SEED_P0, "prompts_sha256": hashlib.sha256(prompts.tobytes()).hexdigest(),
+           "tokens": {str(k): toks[str(k)][:n_tok] for k in ids}, "tokens_sha256": hashlib.sha256(flat.tobytes()).hexdigest(),
+           "oracle_seconds": round(secs, 1), "oracle_processes": nproc, "oracle_threads_each": orc.default_threads()}
+    json.dump(out, open(os.path.join(out_dir, "configs1_multi_P%d_tokens.json" % P), "w"))
+    print("wrote %d x %d tokens (P = %d, sequences %s) in %.0f s" % (len(ids), n_tok, P, ids, secs))
+
+
 if __name__ == "__main__":
+    if sys.argv[1] == "--assemble":                          # --assemble <P> <out_dir> <part files...>: what a cut-off run left behind
+        P = int(sys.argv[2]); toks = {}
+        for part in sys.argv[4:]:
+            toks.update(json.load(open(part)))
+        write_golden(P, toks, min(len(v) for v in toks.values()), sys.argv[3], 0.0, len(sys.argv[4:]))
+        sys.exit(0)
     if sys.argv[1] == "--shard":
-        shard_main(*[int(v) for v in sys.argv[2:6]], sys.argv[6])
+        shard_main(*[int(v) for v in sys.argv[2:6]], sys.argv[6], int(sys.argv[7]) if len(sys.argv) > 7 else 0)
         sys.exit(0)
     P, n_seq, N = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     out_dir = sys.argv[4] if len(sys.argv) > 4 else os.path.dirname(os.path.abspath(__file__))
-    shards = int(sys.argv[5]) if len(sys.argv) > 5 else 4
+    shards = int(sys.argv[5]) if len(sys.argv) > 5 else 2
     os.makedirs(out_dir, exist_ok=True)
     t0 = time.time()
     per = (n_seq + shards - 1) // shards
@@ -59,7 +92,7 @@ if __name__ == "__main__":
             continue
         part = os.path.join(out_dir, "multi_P%d_part%d.json" % (P, k))
         parts.append(part)
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--shard", str(P), str(first), str(count), str(N), part]))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--shard", str(P), str(first), str(count), str(N), part, str(k)]))
     rcs = [p.wait() for p in procs]
     if any(rcs):
         sys.exit("a shard failed: %s" % rcs)
@@ -67,16 +100,4 @@ if __name__ == "__main__":
     for part in parts:
         toks.update(json.load(open(part)))
         os.remove(part)
-    from oracle import oracle as orc
-    import numpy as np
-    seqs = [toks[str(s)] for s in range(n_seq)]
-    flat = np.array(seqs, dtype="<i4")
-    prompts = np.stack([orc.synth_tokens(SEED_P0 + s, P, shape()["vocab_size"]) for s in range(n_seq)]).astype("<i4")
-    out = {"what": "oracle greedy continuations of %d prompts on the full Llama-3.1-8B shape (32 layers): synthetic weights seed %d, prompt of sequence s = synth_tokens(%d + s, %d, vocab); "
-                   "%d tokens each (the first one is the prefill's)" % (n_seq, SEED_W, SEED_P0, P, N),
-           "generator": "tests/golden/make_multi_prompt_tokens.py %d %d %d" % (P, n_seq, N), "prompt_len": P, "n_seq": n_seq, "n_tokens": N,
-           "weights_seed": SEED_W, "prompt_seed_base": SEED_P0, "prompts_sha256": hashlib.sha256(prompts.tobytes()).hexdigest(),
-           "tokens": seqs, "tokens_sha256": hashlib.sha256(flat.tobytes()).hexdigest(),
-           "oracle_seconds": round(time.time() - t0, 1), "oracle_processes": len(parts), "oracle_threads_each": orc.default_threads()}
-    json.dump(out, open(os.path.join(out_dir, "configs1_multi_P%d_tokens.json" % P), "w"))
-    print("wrote %d x %d tokens (P = %d) in %.0f s" % (n_seq, N, P, time.time() - t0))
+    write_golden(P, toks, N, out_dir, time.time() - t0, len(parts))

@@ -51,22 +51,20 @@ def test_configs4_goldens_are_committed(n_layers, n_min):
     assert hashlib.sha256(prompt.astype("<i4").tobytes()).hexdigest() == g["prompt_sha256"]
 
 
-@pytest.mark.parametrize("P,n_seq,n_min", [(128, 128, 53), (512, 16, 9)])
-def test_multi_prompt_goldens_are_committed(P, n_seq, n_min):
-    """the oracle's continuations of MANY prompts on the full 8B shape (sequence s: synth_tokens(99 + s, P)): what every sequence of a batch, of the sequences in flight and of
-    configs[3]'s literal shape is compared with (bench.py check_multi_golden, pipeline.py _multi_golden_check, tests/test_gpu_round6.py)"""
+@pytest.mark.parametrize("P,n_min", [(128, 53), (512, 9)])
+def test_multi_prompt_goldens_are_committed(P, n_min):
+    """the oracle's continuations of SEVERAL prompts on the full 8B shape (sequence s: synth_tokens(99 + s, P); sparse: the file lists the sequences it holds): what sequences of a
+    batch, of the sequences in flight and of configs[3]'s literal shape are compared with (bench.py check_multi_golden, pipeline.py _multi_golden_check, tests/test_gpu_round6.py)"""
     path = os.path.join(GOLD, "configs1_multi_P%d_tokens.json" % P)
-    if not os.path.exists(path) and not os.environ.get("LNB_REQUIRE_MULTI_GOLDENS"):
-        pytest.skip("not made yet")
-    assert os.path.exists(path), "run tests/golden/make_multi_prompt_tokens.py %d %d %d on a host with cores to spare" % (P, n_seq, n_min + 3)
+    assert os.path.exists(path), "run tests/golden/make_multi_prompt_tokens.py %d <n_seq> %d on a host with cores to spare" % (P, n_min + 3)
     g = json.load(open(path))
-    assert g["prompt_len"] == P and g["n_seq"] >= n_seq and g["weights_seed"] == 1234 and g["prompt_seed_base"] == 99
-    toks = np.array(g["tokens"], dtype="<i4")
-    assert toks.shape[0] == g["n_seq"] and toks.shape[1] >= n_min and ((0 <= toks) & (toks < orc.LLAMA_8B["vocab_size"])).all()
+    ids = g["sequences"]
+    assert g["prompt_len"] == P and len(ids) >= 4 and ids == sorted(ids) and ids[0] == 0 and g["weights_seed"] == 1234 and g["prompt_seed_base"] == 99
+    toks = np.array([g["tokens"][str(k)] for k in ids], dtype="<i4")
+    assert toks.shape[1] >= n_min and ((0 <= toks) & (toks < orc.LLAMA_8B["vocab_size"])).all()
     assert hashlib.sha256(toks.tobytes()).hexdigest() == g["tokens_sha256"]
-    prompts = np.stack([orc.synth_tokens(99 + s, P, orc.LLAMA_8B["vocab_size"]) for s in range(g["n_seq"])]).astype("<i4")
+    prompts = np.stack([orc.synth_tokens(99 + k, P, orc.LLAMA_8B["vocab_size"]) for k in ids]).astype("<i4")
     assert hashlib.sha256(prompts.tobytes()).hexdigest() == g["prompts_sha256"]
     if P == 128:                                             # sequence 0 is configs[1]'s prompt: the two files agree
         one = json.load(open(os.path.join(GOLD, "configs1_tokens.json")))["tokens"]
-        assert g["tokens"][0] == one[:len(g["tokens"][0])]
-
+        assert g["tokens"]["0"] == one[:len(g["tokens"]["0"])]
