@@ -68,3 +68,19 @@ def test_multi_prompt_goldens_are_committed(P, n_min):
     if P == 128:                                             # sequence 0 is configs[1]'s prompt: the two files agree
         one = json.load(open(os.path.join(GOLD, "configs1_tokens.json")))["tokens"]
         assert g["tokens"]["0"] == one[:len(g["tokens"]["0"])]
+
+
+@pytest.mark.parametrize("which,P,layers", [("configs4", 16, 80), ("configs1", 128, 32)])
+def test_logits_hash_goldens_are_committed(which, P, layers):
+    """every logit of every row at full depth (tests/golden/make_logits_hashes.py; replayed by tests/test_gpu_round6.py)"""
+    path = os.path.join(GOLD, "%s_logits.json" % which)
+    if not os.path.exists(path) and not os.environ.get("LNB_REQUIRE_LOGITS_GOLDENS"):
+        pytest.skip("not made yet")
+    g = json.load(open(path))
+    assert g["prompt_len"] == P and g["model"]["n_layers"] == layers and g["weights_seed"] == 1234 and g["prompt_seed"] == 99
+    assert len(g["prompt_rows_logits_sha256"]) == P and len(g["steps"]) >= 4 and all(len(h) == 64 for h in g["prompt_rows_logits_sha256"])
+    assert g["steps"][0]["input_token"] == g["first_token"] and all(a["argmax"] == b["input_token"] for a, b in zip(g["steps"], g["steps"][1:]))
+    tok_file = "configs4_80layer_tokens.json" if which == "configs4" else "configs1_tokens.json"
+    toks = json.load(open(os.path.join(GOLD, tok_file)))["tokens"]                       # the token goldens tell the same story
+    assert [g["first_token"]] + [st["argmax"] for st in g["steps"]] == toks[:1 + len(g["steps"])]
+

@@ -74,6 +74,37 @@ def test_committed_configs4_eighty_layer_golden_is_reproduced_by_the_device(lnb)
     gm.close()
 
 
+@pytest.mark.parametrize("which", ["configs4", "configs1"])
+def test_every_logit_of_every_row_at_full_depth_is_the_oracles(lnb, which):
+    """Not only the argmax: SHA-256 of the raw f32 bits of EVERY logits row -- all rows of the prompt's Forward (f32 matrix cores) and the row of each of the next greedy
+    one-token steps (the chain kernels) -- against the CPU oracle's (tests/golden/<which>_logits.json, made by tests/golden/make_logits_hashes.py on the GPU box's host:
+    configs4 = dim 8192 x 80 layers, 141 GB; configs1 = the 8B shape, 128-token prompt).  llamatransformer.go:145-180 returns these rows; any rounding anywhere in the 80 / 32
+    blocks that differed from the reference's would change a hash."""
+    import hashlib
+    path = os.path.join(ROOT, "tests", "golden", "%s_logits.json" % which)
+    if not os.path.exists(path):
+        pytest.skip("tests/golden/%s_logits.json not generated yet" % which)
+    g = json.load(open(path))
+    cfg = dict(orc.LLAMA_8B, **{k: g["model"][k] for k in ("dim", "n_layers", "n_heads", "n_kv_heads", "multiple_of")})
+    P, K = g["prompt_len"], len(g["steps"])
+    try:
+        gm = lnb.LlamaTransformer(**cfg).fill_synthetic(g["weights_seed"]).finalize()
+    except lnb.LnbError as e:
+        pytest.skip("the model does not fit: %s" % str(e)[:120])
+
+    def row_hash(row):
+        return hashlib.sha256(np.ascontiguousarray(row, dtype=np.float32).view(np.uint32).astype("<u4").tobytes()).hexdigest()
+
+    gc = lnb.InferenceContext(gm, P + K + 2)
+    lg, tok = gc.Forward(lnb.synth_tokens(g["prompt_seed"], P, cfg["vocab_size"]), 0)
+    assert [row_hash(lg[i]) for i in range(P)] == g["prompt_rows_logits_sha256"] and int(tok) == g["first_token"]
+    for k, st in enumerate(g["steps"]):
+        assert int(tok) == st["input_token"]
+        lg, tok = gc.Forward(np.array([tok], dtype=np.int32), P + k)
+        assert row_hash(lg[0]) == st["logits_sha256"] and int(tok) == st["argmax"], k
+    gc.close(); gm.close()
+
+
 def test_configs3_literal_eight_stages_of_four_blocks_on_one_gpu(lnb):
     """llamatransformer.go:156-164 cut as BASELINE.json configs[3] says: 8 stages x 4 whole blocks of the Llama-3.1-8B shape, 512-token prompts
     ([512, 4096] bf16 = 4 MiB per hop), 2N = 16 sequences in flight on the N = 8 schedule (pipeline.run_ticks_native: rank r runs item t - 2r at
