@@ -932,7 +932,7 @@ static int check_call(lnb_ctx* c, int seq, int start_pos) {
             if (c->score_idx) c->sidx_jt = (int)jt;
         }
     }
-    if (seq > 1) c->last_prefill_form = !mfma_attn || c->mode == LNB_MODE_FAST ? 0 : c->sidx_jt > 0 ? 3 : 1;
+    if (seq > 1) c->last_prefill_form = (!mfma_attn || !stage_has_attn || c->mode == LNB_MODE_FAST) ? 0 : c->sidx_jt > 0 ? 3 : 1;
     if (seq > 1 && !mfma_attn && T > c->attn_short_cap)
         return fail("a call of %d rows (2..15, or any multi-row call at head_dim 32) at context %d: the row-per-workgroup attention kernel stages "
                     "at most %d positions in the LDS; use one-token calls or 16 or more rows there", seq, T, c->attn_short_cap);
