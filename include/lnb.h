@@ -341,6 +341,10 @@ int lnb_op_linear_mode(int device, const uint16_t* x, const uint16_t* norm_w, fl
 /* ml.Argmax (operations_impl.go:513-548) of n bf16 values: strict '<' scan from -MaxFloat32, so the FIRST maximum wins and
  * NaN / -inf are never selected (-1 when nothing qualifies); the kernel the device greedy loop uses (inference.go:207-211) */
 int lnb_op_argmax(int device, const uint16_t* logits_bf16, int n, int32_t* out);
+/* The softmax numerator as the device evaluates it, over ALL 65536 possible bf16 raw scores s: out[s] = exp(float64(trunc_bf16(float32(s) / divisor)))
+ * (llamatransformer.go:464 DivToScalar, operations_impl.go:498 math.Exp) -- the table every attention kernel either looks up or computes inline with the same
+ * instructions.  divisor = 1: the device's f64 exp on every bf16 value, which a test compares bit for bit with the host libm the oracle uses. */
+int lnb_op_exp_table(int device, float divisor, double* out65536);
 
 /* ---- weight ingestion: replaces torch.TorchModelReader + model.loadModelArgsFromFile (SURVEY.md 8f "next" #2) -------
  * src/torch/torchmodelreader.go:39-145, src/torch/types.go:9-56, src/pickle/pickledispatch.go:13-78,

@@ -2235,6 +2235,21 @@ extern "C" int lnb_op_argmax(int device, const uint16_t* logits_bf16, int n, int
     HIPCHK(e);
     return 0;
 }
+extern "C" int lnb_op_exp_table(int device, float divisor, double* out65536) {
+    if (!out65536) return fail("null argument");
+    if (!(divisor > 0.0f)) return fail("divisor must be positive");
+    int ndev = 0; HIPCHK(hipGetDeviceCount(&ndev));
+    if (ndev == 0) return fail("no HIP device: liblnb_hip.so has no CPU fallback");
+    HIPCHK(hipSetDevice(device));
+    double* d = nullptr;
+    HIPCHK(hipMalloc((void**)&d, (size_t)65536 * 8));
+    hipError_t e = lnbk_exp_table(d, divisor, nullptr);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e == hipSuccess) e = hipMemcpy(out65536, d, (size_t)65536 * 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    HIPCHK(e);
+    return 0;
+}
 extern "C" int lnb_op_linear(int device, const uint16_t* x, const uint16_t* w, uint16_t* y, int rows, int n_out, int k_in, int rw) {
     return op_linear_impl(device, x, nullptr, 0.0f, w, y, rows, n_out, k_in, rw);
 }

@@ -52,7 +52,7 @@ EXPORTS = [
     "lnb_model_set_tensor", "lnb_model_get_tensor", "lnb_model_fill_synthetic", "lnb_model_finalize",
     "lnb_model_rope_table", "lnb_model_weight_bytes", "lnb_ctx_create", "lnb_ctx_destroy", "lnb_ctx_reset",
     "lnb_ctx_read_kv", "lnb_ctx_set_layer_callback", "lnb_forward", "lnb_decode_greedy", "lnb_ctx_hidden_ptr",
-    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear", "lnb_op_argmax", "lnb_op_linear_mode", "lnb_ctx_set_mode", "lnb_ctx_get_mode", "lnb_ctx_set_schedule", "lnb_ctx_get_schedule", "lnb_ctx_set_attention", "lnb_ctx_zseq_count", "lnb_ctx_norm_fallbacks", "lnb_ctx_prefill_attention_form",
+    "lnb_forward_stage", "lnb_forward_stage_begin", "lnb_forward_stage_end", "lnb_ctx_synchronize", "lnb_ctx_stream", "lnb_op_linear", "lnb_op_rmsnorm_linear", "lnb_op_argmax", "lnb_op_exp_table", "lnb_op_linear_mode", "lnb_ctx_set_mode", "lnb_ctx_get_mode", "lnb_ctx_set_schedule", "lnb_ctx_get_schedule", "lnb_ctx_set_attention", "lnb_ctx_zseq_count", "lnb_ctx_norm_fallbacks", "lnb_ctx_prefill_attention_form",
     "lnb_profile_kernel", "lnb_profile_kernel_stamps", "lnb_model_num_tensors", "lnb_model_tensor_info",
     "lnb_checkpoint_open", "lnb_checkpoint_close", "lnb_checkpoint_num_tensors", "lnb_checkpoint_find", "lnb_checkpoint_tensor",
     "lnb_model_load_checkpoint", "lnb_model_args_from_json",
@@ -161,6 +161,7 @@ def lib():
     L.lnb_pipeline_read_tokens.argtypes = [vp, C.c_int, C.c_int, vp]
     L.lnb_op_linear_mode.argtypes = [C.c_int, vp, vp, C.c_float, vp, vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int]
     L.lnb_op_argmax.argtypes = [C.c_int, vp, C.c_int, i32p]
+    L.lnb_op_exp_table.argtypes = [C.c_int, C.c_float, vp]
     L.lnb_model_num_tensors.argtypes = [vp]
     L.lnb_model_tensor_info.argtypes = [vp, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int)]
     L.lnb_checkpoint_open.argtypes = [C.c_char_p, C.POINTER(vp)]
@@ -734,6 +735,13 @@ def op_argmax(logits_u16, device=0):
     out = C.c_int32(-2)
     _chk(lib().lnb_op_argmax(device, _p(a), a.size, C.byref(out)))
     return out.value
+
+
+def op_exp_table(divisor=1.0, device=0):
+    """out[s] = exp(float64(trunc_bf16(float32(bf16 s) / divisor))) for all 65536 raw scores, as the attention kernels evaluate it (lnb_op_exp_table)"""
+    out = np.empty(65536, dtype=np.float64)
+    _chk(lib().lnb_op_exp_table(device, C.c_float(divisor), _p(out)))
+    return out
 
 
 _M64 = (1 << 64) - 1
