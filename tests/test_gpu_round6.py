@@ -154,6 +154,54 @@ def test_configs3_literal_eight_stages_of_four_blocks_on_one_gpu(lnb):
             assert m_ >= 1 + n_decode and got[s][:m_] == g["tokens"][str(s)][:m_], s
 
 
+def test_configs4_literal_eight_stages_of_ten_blocks_on_one_gpu(lnb):
+    """BASELINE.json configs[4] cut as it says -- the 70B-like shape (dim 8192 x 80 layers) as an 8-stage layer pipeline, 10 whole blocks per stage (17.1 GB each, + the
+    2.1 GB head on the last), llamatransformer.go:156-164 sharded -- with all eight stages resident on ONE GPU (the same 141 GB), 2N = 16 sequences in flight on the N = 8
+    schedule (pipeline.run_ticks_native), hand-offs of [rows, 8192] bf16 through the in-process transport, every rank stepped tick by tick as 8 processes would.  Sequence 0
+    has the prompt of tests/golden/configs4_80layer_tokens.json: its tokens must be the CPU ORACLE's; every sequence must equal the single-process whole-model run."""
+    import pipeline
+    gpath = os.path.join(ROOT, "tests", "golden", "configs4_80layer_tokens.json")
+    if not os.path.exists(gpath):
+        pytest.skip("tests/golden/configs4_80layer_tokens.json not generated yet")
+    gold = json.load(open(gpath))
+    cfg = dict(orc.LLAMA_8B, **{k: gold["model"][k] for k in ("dim", "n_layers", "n_heads", "n_kv_heads", "multiple_of")})
+    world, P, n_decode = 8, gold["prompt_len"], 8
+    n_seq = 2 * world
+    cuts = [3 * 10 * r for r in range(world + 1)]             # thirds of a block: 10 whole blocks per stage
+    try:
+        stages = [lnb.LlamaTransformer(part_begin=a, part_end=b, **cfg).fill_synthetic(gold["weights_seed"]).finalize() for a, b in zip(cuts[:-1], cuts[1:])]
+    except lnb.LnbError as e:
+        pytest.skip("the eight stages do not fit: %s" % str(e)[:120])
+    assert sum(st.weight_bytes() for st in stages) > 140e9
+    ctxs = [[lnb.InferenceContext(st, P + n_decode + 2).set_schedule("throughput") for _ in range(n_seq)] for st in stages]
+    pipes = [lnb.Pipeline(stages[r], r, world, loopback_group="cfg4") for r in range(world)]
+    prompts = [lnb.synth_tokens(gold["prompt_seed"] + s, P, cfg["vocab_size"]) for s in range(n_seq)]
+    n_ticks = (1 + n_decode) * n_seq + 2 * (world - 1)
+    state = [None] * world
+    for t in range(n_ticks):
+        for r in range(world):
+            state[r] = pipeline.run_ticks_native(r, world, pipes[r], ctxs[r], prompts, n_decode, t, t + 1, state[r])
+    for p_ in pipes:
+        p_.sync()
+    got = [[int(pipes[-1].read_tokens(q, 1)[0]) for q in state[-1]["slots"][s]] for s in range(n_seq)]
+    for p_ in pipes:
+        p_.close()
+    for cs in ctxs:
+        for c in cs:
+            c.close()
+    for st in stages:
+        st.close()
+    assert got[0] == gold["tokens"][:1 + n_decode]           # sequence 0 = the oracle's continuation of the full 80-layer model
+    whole = lnb.LlamaTransformer(**cfg).fill_synthetic(gold["weights_seed"]).finalize()
+    for s in range(n_seq):
+        wc = lnb.InferenceContext(whole, P + n_decode + 2)
+        _, first = wc.Forward(prompts[s], 0, want_logits=False)
+        more, _ = wc.decode_greedy(first, P, n_decode)
+        assert got[s] == [first] + [int(t) for t in more], s
+        wc.close()
+    whole.close()
+
+
 @pytest.mark.parametrize("copy", [False, True])
 def test_sequences_of_a_128_batch_on_the_full_model_are_their_oracle_continuations(lnb, copy):
     """Batched exact decode at FULL depth (llamatransformer.go:215-254 for 128 generations at once): 128 prompts of 128 tokens on the 32-layer 8B shape, one pass over the
