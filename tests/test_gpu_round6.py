@@ -202,6 +202,66 @@ def test_configs4_literal_eight_stages_of_ten_blocks_on_one_gpu(lnb):
     whole.close()
 
 
+def test_configs4_literal_batched_ticks_eight_stages_without_the_second_copy(lnb):
+    """The same literal cut of configs[4] (8 stages x 10 blocks of the dim-8192 shape on one GPU) with BATCHES as the unit that moves through the stages
+    (lnb_pipeline_tick_batch; 2N = 16 groups of 16 sequences in flight = 256 generations): no stage has room for a second weight copy next to 141 GB, so every group step is
+    one pass over the stage's RESIDENT layouts with the group's sequences as rows of gemm_stream_kernel (what `bench.py --gpus 8` runs on a rank whose copy does not fit).
+    Sequence 0 of group 0 = the 80-layer ORACLE golden; a spread of the others = the single-process whole-model run."""
+    import pipeline
+    gpath = os.path.join(ROOT, "tests", "golden", "configs4_80layer_tokens.json")
+    if not os.path.exists(gpath):
+        pytest.skip("tests/golden/configs4_80layer_tokens.json not generated yet")
+    gold = json.load(open(gpath))
+    cfg = dict(orc.LLAMA_8B, **{k: gold["model"][k] for k in ("dim", "n_layers", "n_heads", "n_kv_heads", "multiple_of")})
+    world, P, n_decode, n = 8, gold["prompt_len"], 6, 16
+    G = 2 * world
+    cuts = [3 * 10 * r for r in range(world + 1)]
+    try:
+        stages = [lnb.LlamaTransformer(part_begin=a, part_end=b, **cfg).fill_synthetic(gold["weights_seed"]).finalize() for a, b in zip(cuts[:-1], cuts[1:])]
+    except lnb.LnbError as e:
+        pytest.skip("the eight stages do not fit: %s" % str(e)[:120])
+    assert all(st.batch_bytes() == 0 for st in stages)
+    ctxs = [[[lnb.InferenceContext(st, P + n_decode + 2) for _ in range(n)] for _ in range(G)] for st in stages]            # [rank][group][seq]
+    pipes = [lnb.Pipeline(stages[r], r, world, loopback_group="cfg4b") for r in range(world)]
+    prompts = [[lnb.synth_tokens(gold["prompt_seed"] + n * g + s, P, cfg["vocab_size"]) for s in range(n)] for g in range(G)]
+    first_slots = {}
+    for g in range(G):
+        for s in range(n):
+            for r in range(world):
+                slot = pipeline.prefill_through_pipeline(r, world, pipes[r], ctxs[r][g][s], prompts[g][s])
+            first_slots[(g, s)] = slot
+    batches = [[lnb.Batch(ctxs[r][g]).set_state(None, [P] * n) for g in range(G)] for r in range(world)]
+    n_ticks = n_decode * G + 2 * (world - 1)
+    state = [None] * world
+    for t in range(n_ticks):
+        for r in range(world):
+            state[r] = pipeline.run_ticks_native_batched(r, world, pipes[r], batches[r], n_decode, t, t + 1, state[r])
+    for p_ in pipes:
+        p_.sync()
+    got = {}
+    for g in range(G):
+        steps = [pipes[-1].read_tokens(q, n) for q in state[-1]["slots"][g]]          # [step][seq]
+        for s in range(n):
+            got[(g, s)] = [int(pipes[-1].read_tokens(first_slots[(g, s)], 1)[0])] + [int(st_[s]) for st_ in steps]
+    for r in range(world):
+        for b in batches[r]:
+            b.check_error(); b.close()
+        pipes[r].close()
+        for grp_ in ctxs[r]:
+            for c in grp_:
+                c.close()
+        stages[r].close()
+    assert got[(0, 0)] == gold["tokens"][:1 + n_decode]
+    whole = lnb.LlamaTransformer(**cfg).fill_synthetic(gold["weights_seed"]).finalize()
+    for g, s in [(0, s_) for s_ in range(n)] + [(g_, (5 * g_) % n) for g_ in range(1, G)]:
+        wc = lnb.InferenceContext(whole, P + n_decode + 2)
+        _, first = wc.Forward(prompts[g][s], 0, want_logits=False)
+        more, _ = wc.decode_greedy(first, P, n_decode)
+        assert got[(g, s)] == [first] + [int(t) for t in more], (g, s)
+        wc.close()
+    whole.close()
+
+
 @pytest.mark.parametrize("copy", [False, True])
 def test_sequences_of_a_128_batch_on_the_full_model_are_their_oracle_continuations(lnb, copy):
     """Batched exact decode at FULL depth (llamatransformer.go:215-254 for 128 generations at once): 128 prompts of 128 tokens on the 32-layer 8B shape, one pass over the
