@@ -335,6 +335,19 @@ def test_device_exp_against_the_host_libm_exp_on_every_possible_softmax_input(ln
         assert int((ulps != 0).sum()) <= 400, (divisor, int((ulps != 0).sum()))                                        # measured: 231 at divisor 1
         with np.errstate(all="ignore"):
             assert (dev[ok].astype(np.float32).view(np.uint32) == ref[ok].astype(np.float32).view(np.uint32)).all()   # identical once narrowed to f32
+        # ... and against the THIRD implementation, Go's portable math.Exp restated (oracle/go_exp.py; tests/test_exp_implementations.py ties it to the host libm):
+        # the device is no further from what the reference calls than the reference's own platforms are from each other
+        from oracle.go_exp import go_exp
+        bits = (np.arange(65536, dtype=np.uint32) << 16).view(np.float32)
+        with np.errstate(all="ignore"):
+            q = (bits / np.float32(divisor)).astype(np.float32)
+        s16 = (q.view(np.uint32) & np.uint32(0xFFFF0000)).view(np.float32).astype(np.float64)
+        gox = np.array([go_exp(float(v)) for v in s16])
+        ulps_go = np.abs(dev.view(np.int64)[ok] - gox.view(np.int64)[ok])
+        assert ulps_go.max() <= 1 and int((ulps_go != 0).sum()) <= 1000, (divisor, int(ulps_go.max()), int((ulps_go != 0).sum()))
+        with np.errstate(all="ignore"):
+            assert (dev[ok].astype(np.float32).view(np.uint32) == gox[ok].astype(np.float32).view(np.uint32)).all()
+        print("exp over 65536 bf16 inputs, divisor %g: device vs host libm %d differ, device vs Go's portable exp %d differ (all by one f64 ulp, none as f32)" % (divisor, int((ulps != 0).sum()), int((ulps_go != 0).sum())))
 
 
 def test_rope_table_matches_oracle(lnb, tiny_pair):
