@@ -182,11 +182,37 @@ void orc_mean_f32(const float* in, float* out, int groups, int last) {   /* :219
         out[g] = s / (float)last;
     }
 }
+/* Which float64 exp the oracle calls (test infrastructure: tests/test_exp_implementations.py).  0 (default): the host libm's.  1: Go's PORTABLE math.Exp restated
+ * (src/math/exp.go = FreeBSD msun e_exp.c: two-part ln2 reduction, degree-5 polynomial in r^2, ldexp) -- the reference's softmax and SiLU table call math.Exp
+ * (operations_impl.go:498/506, activations.go:24); the two differ by one ulp on ~0.75 % of the bf16 inputs, and the switch exists to show that NOT ONE logit bit of a whole
+ * model run depends on which one is used (compiled with -ffp-contract=off like the rest: no fused operations). */
+static int g_exp_impl = 0;
+static double exp_go(double x) {
+    static const double Ln2Hi = 6.93147180369123816490e-01, Ln2Lo = 1.90821492927058770002e-10, Log2e = 1.44269504088896338700e+00,
+        Overflow = 7.09782712893383973096e+02, Underflow = -7.45133219101941108420e+02, NearZero = 1.0 / (1 << 28),
+        P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05, P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x || x == INFINITY) return x;
+    if (x == -INFINITY) return 0.0;
+    if (x > Overflow) return INFINITY;
+    if (x < Underflow) return 0.0;
+    if (-NearZero < x && x < NearZero) return 1.0 + x;
+    int k = 0;
+    if (x < 0) k = (int)(Log2e * x - 0.5); else if (x > 0) k = (int)(Log2e * x + 0.5);
+    const double hi = x - (double)k * Ln2Hi, lo = (double)k * Ln2Lo;
+    const double r = hi - lo, t = r * r;
+    const double c = r - t * (P1 + t * (P2 + t * (P3 + t * (P4 + t * P5))));
+    const double y = 1.0 - ((lo - (r * c) / (2.0 - c)) - hi);
+    return ldexp(y, k);
+}
+static inline double orc_exp(double x) { return g_exp_impl ? exp_go(x) : exp(x); }
+static int g_silu_init;                                     /* (defined below; the table is rebuilt after a switch) */
+void orc_set_exp_impl(int which) { g_exp_impl = which ? 1 : 0; g_silu_init = 0; }
+double orc_exp_f64(double x) { return orc_exp(x); }
 void orc_softmax_f32(const float* in, float* out, int rows, int cols) {   /* :478-511 */
     for (int r = 0; r < rows; r++) {
         double z = 0.0;
-        for (int j = 0; j < cols; j++) z += exp((double)in[(size_t)r * cols + j]);
-        for (int j = 0; j < cols; j++) out[(size_t)r * cols + j] = (float)(exp((double)in[(size_t)r * cols + j]) / z);
+        for (int j = 0; j < cols; j++) z += orc_exp((double)in[(size_t)r * cols + j]);
+        for (int j = 0; j < cols; j++) out[(size_t)r * cols + j] = (float)(orc_exp((double)in[(size_t)r * cols + j]) / z);
     }
 }
 int32_t orc_argmax_f32(const float* in, int n) {   /* :529-541 */
@@ -194,13 +220,13 @@ int32_t orc_argmax_f32(const float* in, int n) {   /* :529-541 */
     for (int i = 0; i < n; i++) if (mx < in[i]) { mx = in[i]; mi = i; }
     return mi;
 }
-static float g_silu[1 << 16]; static int g_silu_init = 0;
+static float g_silu[1 << 16];
 const float* orc_silu_table(void) {   /* activations.go:15-25 */
     if (!g_silu_init) {
 #pragma omp critical
         {
             if (!g_silu_init) {
-                for (int i = 0; i < (1 << 16); i++) { double x = (double)wide((uint16_t)i); g_silu[i] = (float)(x / (1.0 + exp(-x))); }
+                for (int i = 0; i < (1 << 16); i++) { double x = (double)wide((uint16_t)i); g_silu[i] = (float)(x / (1.0 + orc_exp(-x))); }
                 g_silu_init = 1;
             }
         }
@@ -473,8 +499,8 @@ static int attention_forward(orc_ctx* c, int layer, const uint16_t* x, int S, in
         }
         /* :484-495 ToFloat32 -> Softmax (f64) -> ToBFloat16 */
         double z = 0.0;
-        for (int j = 0; j < T; j++) z += exp((double)wide(s16[j]));
-        for (int j = 0; j < T; j++) s16[j] = trunc16((float)(exp((double)wide(s16[j])) / z));
+        for (int j = 0; j < T; j++) z += orc_exp((double)wide(s16[j]));
+        for (int j = 0; j < T; j++) s16[j] = trunc16((float)(orc_exp((double)wide(s16[j])) / z));
         if (scores_dump) memcpy(scores_dump + ((size_t)h * S + i) * T, s16, (size_t)T * 2);
         /* :504 MatMul(scores, values) */
         for (int d = 0; d < hd; d++) {

@@ -60,6 +60,8 @@ void orc_pow_bf16(const uint16_t* in, float* out, int n, double power);
 void orc_mean_f32(const float* in, float* out, int groups, int last);
 /* operations_impl.go:478-511 (f32 in/out, f64 exp and sum, no max subtraction) */
 void orc_softmax_f32(const float* in, float* out, int rows, int cols);
+void orc_set_exp_impl(int which);      /* 0: host libm exp (default); 1: Go's portable math.Exp restated (fdlibm e_exp) -- softmax and the SiLU table */
+double orc_exp_f64(double x);           /* the exp in effect */
 /* operations_impl.go:513-548 */
 int32_t orc_argmax_f32(const float* in, int n);
 /* activations.go:10-25 */

@@ -70,6 +70,8 @@ def lib():
         "orc_ctx_create": (vp, [vp, C.c_int]),
         "orc_ctx_destroy": (None, [vp]),
         "orc_ctx_set_threads": (None, [vp, C.c_int]),
+        "orc_set_exp_impl": (None, [C.c_int]),
+        "orc_exp_f64": (C.c_double, [C.c_double]),
         "orc_ctx_cache": (u16p, [vp, C.c_int, C.c_int]),
         "orc_ctx_set_dump": (None, [vp, vp, vp]),
         "orc_forward": (C.c_int, [vp, vp, C.c_int, C.c_int, vp, i32p]),

@@ -43,3 +43,45 @@ def test_special_cases_of_exp_go():
     assert go_exp(0.0) == 1.0 and go_exp(-0.0) == 1.0 and go_exp(math.inf) == math.inf and go_exp(-math.inf) == 0.0
     assert go_exp(710.0) == math.inf and go_exp(-746.0) == 0.0 and go_exp(1e-10) == 1.0 + 1e-10
     assert abs(int(np.float64(go_exp(1.0)).view(np.int64)) - int(np.float64(math.e).view(np.int64))) <= 1      # (fdlibm's exp(1) is the float64 above math.E)
+
+
+def test_the_c_restatement_in_the_oracle_is_the_python_one_bit_for_bit():
+    """oracle/lnb_oracle.c: exp_go (behind orc_set_exp_impl(1)) against oracle/go_exp.py on all 65536 inputs"""
+    from oracle import oracle as orc
+    L = orc.lib()
+    L.orc_set_exp_impl(1)
+    try:
+        for v in _inputs():
+            v = float(v)
+            a, b = L.orc_exp_f64(v), go_exp(v)
+            assert (a != a and b != b) or np.float64(a).view(np.int64) == np.float64(b).view(np.int64), v
+    finally:
+        L.orc_set_exp_impl(0)
+    assert L.orc_exp_f64(1.0) == math.exp(1.0)
+
+
+def test_not_one_logit_bit_of_a_model_run_depends_on_which_exp_the_oracle_calls():
+    """The whole point of measuring the implementations against each other: run the ORACLE with the host libm's exp and again with Go's portable math.Exp restated
+    (softmax numerators and denominators, operations_impl.go:498/506, and the SiLU table, activations.go:24) -- every logit of every row of the prompt's Forward and of the
+    following greedy steps must have the same bits, on several shapes and seeds (~1.5 million softmax elements and the whole 65536-entry SiLU table go through the other exp)."""
+    from oracle import oracle as orc
+    L = orc.lib()
+    shapes = [dict(orc.TINY), dict(orc.TINY, dim=512, n_heads=8, n_kv_heads=2, n_layers=4, vocab_size=2048), dict(orc.TINY, dim=384, n_heads=6, n_kv_heads=6, n_layers=3)]
+    try:
+        for k, cfg in enumerate(shapes):
+            runs = []
+            for impl in (0, 1):
+                L.orc_set_exp_impl(impl)
+                om = orc.Model(**cfg).fill_synthetic(70 + k).finalize()
+                oc = orc.Context(om, 160)
+                lg, tok = oc.forward(orc.synth_tokens(5 + k, 96, cfg["vocab_size"]), 0)
+                rows, toks = [lg.view(np.uint32).copy()], [tok]
+                for i in range(24):
+                    lg, tok = oc.forward(np.array([toks[-1]], dtype=np.int32), 96 + i)
+                    rows.append(lg.view(np.uint32).copy()); toks.append(tok)
+                runs.append((rows, toks))
+                oc.close(); om.close()
+            assert runs[0][1] == runs[1][1], k
+            assert all((a == b).all() for a, b in zip(runs[0][0], runs[1][0])), k
+    finally:
+        L.orc_set_exp_impl(0)
